@@ -1,0 +1,331 @@
+/*
+ * ythip.h — C ABI of libythip.so, the MI355X (gfx950) path-tracing core that
+ * sits behind Yocto/GL's `trace_samples` boundary.
+ *
+ * Everything crossing this boundary is plain-old-data: pointers, sizes and
+ * fixed-width scalars.  No STL, no torch types.  Error convention: every entry
+ * point returns 0 on success and a non-zero YTHIP_ERR_* code otherwise;
+ * `ythip_last_error()` returns a human-readable message.  The C++ shim
+ * (yocto-gl_amd/host/yocto_hiptrace.cpp) turns non-zero codes into
+ * std::runtime_error, mirroring the reference's exception behaviour
+ * (libs/yocto/yocto_trace.cpp:1437,1454,1682-1690).
+ *
+ * Each declaration cites the reference interface (file:line under
+ * /root/reference) that it replaces or mirrors.
+ */
+#ifndef YTHIP_H
+#define YTHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YTHIP_OK 0
+#define YTHIP_ERR_INVALID 1  /* bad argument (std::invalid_argument in the reference) */
+#define YTHIP_ERR_HIP 2      /* a HIP runtime call failed                             */
+#define YTHIP_ERR_STATE 3    /* call order violated (e.g. trace before upload)        */
+#define YTHIP_ERR_SAMPLER 4  /* "sampler unknown" (yocto_trace.cpp:1437)              */
+#define YTHIP_ERR_CANCELLED 5 /* stop flag observed (yocto_trace.cpp:1637)            */
+
+#define YTHIP_INVALIDID (-1) /* yocto_math.h `invalidid` */
+
+/* ------------------------------------------------------------------------- */
+/* Flat scene: POD mirrors of the reference's data model                      */
+/* ------------------------------------------------------------------------- */
+
+/* frame3f, column-major {x, y, z, o} — libs/yocto/yocto_math.h:770-777 */
+typedef struct ythip_frame {
+  float x[3], y[3], z[3], o[3];
+} ythip_frame;
+
+/* camera_data — libs/yocto/yocto_scene.h:83-91 (72 B, bool widened to int32) */
+typedef struct ythip_camera {
+  ythip_frame frame;
+  int32_t     orthographic;
+  float       lens, film, aspect, focus, aperture;
+} ythip_camera;
+
+/* instance_data — libs/yocto/yocto_scene.h:144-149 (56 B) */
+typedef struct ythip_instance {
+  ythip_frame frame;
+  int32_t     shape, material;
+} ythip_instance;
+
+/* material_type — libs/yocto/yocto_scene.h:106-111 */
+enum {
+  YTHIP_MATTE = 0, YTHIP_GLOSSY, YTHIP_REFLECTIVE, YTHIP_TRANSPARENT,
+  YTHIP_REFRACTIVE, YTHIP_SUBSURFACE, YTHIP_VOLUMETRIC, YTHIP_GLTFPBR
+};
+
+/* material_data — libs/yocto/yocto_scene.h:122-141 (84 B, same field order) */
+typedef struct ythip_material {
+  int32_t type;
+  float   emission[3];
+  float   color[3];
+  float   roughness, metallic, ior;
+  float   scattering[3];
+  float   scanisotropy, trdepth, opacity;
+  int32_t emission_tex, color_tex, roughness_tex, scattering_tex, normal_tex;
+} ythip_material;
+
+/* environment_data — libs/yocto/yocto_scene.h:152-157 (64 B) */
+typedef struct ythip_environment {
+  ythip_frame frame;
+  float       emission[3];
+  int32_t     emission_tex;
+} ythip_environment;
+
+/* texture_data — libs/yocto/yocto_scene.h:95-103.  Texels live in one of the
+ * two concatenated pools of ythip_scene (`pixelsf` vec4f / `pixelsb` vec4b);
+ * `offset` is in texels. */
+typedef struct ythip_texture {
+  int32_t width, height, linear, nearest, clamp, is_float;
+  int64_t offset;
+} ythip_texture;
+
+/* shape_data — libs/yocto/yocto_shape.h:74-88.  All shapes share concatenated
+ * element / vertex pools; offsets are in elements (resp. vertices) and are -1
+ * for an absent attribute.  Element indices stay shape-local, as in the
+ * reference. */
+typedef struct ythip_shape {
+  int64_t points_offset, lines_offset, triangles_offset, quads_offset;
+  int64_t positions_offset, normals_offset, texcoords_offset, colors_offset,
+      radius_offset;
+  int32_t num_points, num_lines, num_triangles, num_quads;
+  int32_t num_positions, num_normals, num_texcoords, num_colors, num_radius;
+  int32_t pad_;
+} ythip_shape;
+
+/* scene_data — libs/yocto/yocto_scene.h:191-213 (the subset trace_samples
+ * reads: cameras, instances, environments, shapes, textures, materials). */
+typedef struct ythip_scene {
+  int32_t num_cameras, num_instances, num_environments, num_shapes,
+      num_textures, num_materials;
+  const ythip_camera*      cameras;
+  const ythip_instance*    instances;
+  const ythip_environment* environments;
+  const ythip_shape*       shapes;
+  const ythip_texture*     textures;
+  const ythip_material*    materials;
+  /* element pools */
+  int64_t        num_points, num_lines, num_triangles, num_quads;
+  const int32_t* points;    /* 1 int / point    */
+  const int32_t* lines;     /* 2 int / line     */
+  const int32_t* triangles; /* 3 int / triangle */
+  const int32_t* quads;     /* 4 int / quad     */
+  /* vertex pools */
+  int64_t      num_positions, num_normals, num_texcoords, num_colors,
+      num_radius;
+  const float* positions; /* 3 float */
+  const float* normals;   /* 3 float */
+  const float* texcoords; /* 2 float */
+  const float* colors;    /* 4 float */
+  const float* radius;    /* 1 float */
+  /* texel pools */
+  int64_t        num_pixelsf, num_pixelsb;
+  const float*   pixelsf; /* 4 float / texel */
+  const uint8_t* pixelsb; /* 4 byte  / texel */
+} ythip_scene;
+
+/* bvh_node — libs/yocto/yocto_shape.h:474-480 (32 B, identical layout) */
+typedef struct ythip_bvh_node {
+  float   bbox_min[3], bbox_max[3];
+  int32_t start;
+  int16_t num;
+  int8_t  axis;
+  uint8_t internal;
+} ythip_bvh_node;
+
+/* scene_bvh — libs/yocto/yocto_bvh.h:70-79.  `num_trees` = num_shapes + 1;
+ * tree t < num_shapes is shape t's bvh_tree, tree num_shapes is the instance
+ * tree.  node_offset/prim_offset have num_trees + 1 entries. */
+typedef struct ythip_bvh {
+  int32_t               num_trees;
+  const int64_t*        node_offset;
+  const int64_t*        prim_offset;
+  const ythip_bvh_node* nodes;
+  const int32_t*        primitives;
+} ythip_bvh;
+
+/* trace_light / trace_lights — libs/yocto/yocto_trace.h:126-135 */
+typedef struct ythip_light {
+  int32_t instance, environment;
+  int64_t cdf_offset;
+  int32_t cdf_count, pad_;
+} ythip_light;
+typedef struct ythip_lights {
+  int32_t            num_lights;
+  const ythip_light* lights;
+  int64_t            num_cdf;
+  const float*       cdf;
+} ythip_lights;
+
+/* trace_sampler_type / trace_falsecolor_type — yocto_trace.h:71-90 */
+enum {
+  YTHIP_SAMPLER_PATH = 0, YTHIP_SAMPLER_PATHDIRECT, YTHIP_SAMPLER_PATHMIS,
+  YTHIP_SAMPLER_PATHTEST, YTHIP_SAMPLER_NAIVE, YTHIP_SAMPLER_EYELIGHT,
+  YTHIP_SAMPLER_DIAGRAM, YTHIP_SAMPLER_FURNACE, YTHIP_SAMPLER_FALSECOLOR
+};
+enum {
+  YTHIP_FC_POSITION = 0, YTHIP_FC_NORMAL, YTHIP_FC_FRONTFACING,
+  YTHIP_FC_GNORMAL, YTHIP_FC_GFRONTFACING, YTHIP_FC_TEXCOORD, YTHIP_FC_MTYPE,
+  YTHIP_FC_COLOR, YTHIP_FC_EMISSION, YTHIP_FC_ROUGHNESS, YTHIP_FC_OPACITY,
+  YTHIP_FC_METALLIC, YTHIP_FC_DELTA, YTHIP_FC_INSTANCE, YTHIP_FC_SHAPE,
+  YTHIP_FC_MATERIAL, YTHIP_FC_ELEMENT, YTHIP_FC_HIGHLIGHT
+};
+
+/* trace_params — libs/yocto/yocto_trace.h:95-113 (same fields, bools as int32) */
+typedef struct ythip_params {
+  int32_t  camera, resolution, sampler, falsecolor, samples, bounces;
+  float    clamp;
+  int32_t  nocaustics, envhidden, tentfilter;
+  uint64_t seed;
+  int32_t  embreebvh, highqualitybvh, noparallel, pratio, denoise, batch;
+} ythip_params;
+
+/* scene_intersection — libs/yocto/yocto_bvh.h:96-102 (24 B) */
+typedef struct ythip_hit {
+  int32_t instance, element;
+  float   u, v, distance;
+  int32_t hit;
+} ythip_hit;
+
+/* ray3f — libs/yocto/yocto_geometry.h:135-140 (32 B) */
+typedef struct ythip_ray {
+  float o[3], d[3], tmin, tmax;
+} ythip_ray;
+
+/* Measurement record filled by ythip_get_stats (no reference equivalent; the
+ * reference only prints wall-clock, yocto_cli.h:128-140). */
+typedef struct ythip_stats {
+  /* traversal kernel (k_extend), measured with hipEvents on the launch stream
+   * while profiling is enabled */
+  int64_t extend_launches;
+  double  extend_ms;
+  int64_t shade_launches;
+  double  shade_ms;
+  /* traversal work counters (valid after a run with counting enabled) */
+  int64_t rays;        /* intersect_scene_bvh calls        (yocto_bvh.cpp:554) */
+  int64_t nodes;       /* BVH node pops, TLAS+BLAS         (:487,:581)         */
+  int64_t triangles;   /* leaf triangle tests              (:526-533)          */
+  int64_t quads;       /* leaf quad tests                  (:536-544)          */
+  int64_t lines;       /* leaf line tests                  (:516-524)          */
+  int64_t points;      /* leaf point tests                 (:506-514)          */
+  int64_t instances;   /* TLAS leaf entries                (:600-604)          */
+  int64_t shades;      /* surface interactions shaded      (yocto_trace.cpp:494-496) */
+  int64_t samples;     /* trace_sample calls               (yocto_trace.cpp:1461)    */
+} ythip_stats;
+
+typedef struct ythip_ctx ythip_ctx;
+
+/* ------------------------------------------------------------------------- */
+/* Context                                                                     */
+/* ------------------------------------------------------------------------- */
+
+/* One context per process/GPU.  Mirrors make_cutrace_context
+ * (libs/yocto/yocto_cutrace.h:88, yocto_cutrace.cpp:385-520). */
+int         ythip_create(int device, ythip_ctx** out);
+void        ythip_destroy(ythip_ctx* ctx);
+const char* ythip_last_error(const ythip_ctx* ctx); /* ctx may be NULL */
+/* Launch stream (a hipStream_t); NULL = the context's own stream. */
+int ythip_set_stream(ythip_ctx* ctx, void* hip_stream);
+int ythip_sync(ythip_ctx* ctx);
+
+/* ------------------------------------------------------------------------- */
+/* Scene / BVH / lights residency                                              */
+/* ------------------------------------------------------------------------- */
+
+/* Flatten-and-upload of scene_data; mirrors make_cutrace_scene
+ * (yocto_cutrace.cpp:564-702).  Host pointers; copied. */
+int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* scene);
+
+/* make_trace_bvh → make_scene_bvh (yocto_trace.cpp:88-96,
+ * yocto_bvh.cpp:238-302,321-396): host-side build that reproduces the
+ * reference's node order bit-for-bit, then upload. */
+int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* scene, int highquality);
+/* Upload a tree built elsewhere (e.g. by the reference's make_trace_bvh). */
+int ythip_upload_bvh(ythip_ctx* ctx, const ythip_bvh* bvh);
+/* Read back the resident tree (for tree-identity tests). */
+int ythip_bvh_sizes(ythip_ctx* ctx, int32_t* num_trees, int64_t* num_nodes,
+    int64_t* num_prims);
+int ythip_bvh_download(ythip_ctx* ctx, int64_t* node_offset,
+    int64_t* prim_offset, ythip_bvh_node* nodes, int32_t* primitives);
+
+/* make_trace_lights (yocto_trace.cpp:1528-1581): host-side CDF build + upload. */
+int ythip_build_lights(ythip_ctx* ctx, const ythip_scene* scene);
+int ythip_upload_lights(ythip_ctx* ctx, const ythip_lights* lights);
+int ythip_lights_sizes(ythip_ctx* ctx, int32_t* num_lights, int64_t* num_cdf);
+int ythip_lights_download(ythip_ctx* ctx, ythip_light* lights, float* cdf);
+
+/* ------------------------------------------------------------------------- */
+/* trace_state                                                                 */
+/* ------------------------------------------------------------------------- */
+
+/* Image size rule of make_trace_state (yocto_trace.cpp:1499-1505). */
+int ythip_state_size(const ythip_camera* camera, int resolution, int* width,
+    int* height);
+/* Per-pixel PCG seeding of make_trace_state (yocto_trace.cpp:1512-1515):
+ * a serial master stream; fills 2*n uint64 {state, inc}.  Host only. */
+int ythip_make_rngs(uint64_t seed, int64_t n, uint64_t* rngs);
+
+/* Device-resident mirror of trace_state (yocto_trace.h:147-157) for the rows
+ * [row_begin, row_end) of a width x height image (row sharding, §8e).
+ * Arrays hold width*(row_end-row_begin) pixels.  Zero-initialises
+ * image/albedo/normal/hits; rngs must be uploaded. */
+int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin,
+    int row_end);
+/* Any pointer may be NULL to skip that array. */
+int ythip_state_upload(ythip_ctx* ctx, const float* image, const float* albedo,
+    const float* normal, const int32_t* hits, const uint64_t* rngs,
+    int samples);
+int ythip_state_download(ythip_ctx* ctx, float* image, float* albedo,
+    float* normal, int32_t* hits, uint64_t* rngs, int* samples);
+/* Use caller-owned DEVICE buffers (e.g. torch tensors) for the state arrays,
+ * so that the framebuffer gather can run on them directly (RCCL). */
+int ythip_state_bind_device(ythip_ctx* ctx, void* image, void* albedo,
+    void* normal, void* hits, void* rngs);
+int ythip_state_set_samples(ythip_ctx* ctx, int samples);
+
+/* ------------------------------------------------------------------------- */
+/* The hot path                                                                */
+/* ------------------------------------------------------------------------- */
+
+/* trace_samples (yocto_trace.h:171-173, yocto_trace.cpp:1595-1619): renders
+ * `params->batch` more samples for every pixel of the resident state slice and
+ * bumps state.samples.  Returns immediately (no-op) when
+ * state.samples >= params->samples.  `stop` (may be NULL) is polled between
+ * samples like trace_start does (yocto_trace.cpp:1637).  Synchronous. */
+int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params,
+    const volatile int32_t* stop);
+/* Same, but only enqueues the work on the stream (pair with ythip_sync). */
+int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params);
+
+/* intersect_scene_bvh for a batch of rays (yocto_bvh.h:105-106,
+ * yocto_bvh.cpp:554-617); parity/test entry using the same device function as
+ * the extend kernel.  Host pointers. */
+int ythip_intersect_batch(ythip_ctx* ctx, const ythip_ray* rays, int64_t n,
+    int find_any, ythip_hit* hits);
+/* intersect_instance_bvh for a batch (yocto_bvh.cpp:619-628). */
+int ythip_intersect_instance_batch(ythip_ctx* ctx, const int32_t* instances,
+    const ythip_ray* rays, int64_t n, int find_any, ythip_hit* hits);
+/* sample_camera for the next sample of every resident pixel
+ * (yocto_trace.cpp:338-358,1467-1468) WITHOUT advancing the resident rngs;
+ * writes width*(rows) rays.  Test entry. */
+int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params,
+    ythip_ray* rays);
+
+/* ------------------------------------------------------------------------- */
+/* Measurement                                                                 */
+/* ------------------------------------------------------------------------- */
+/* mode bit 0: time extend/shade launches with hipEvents on the launch stream;
+ * mode bit 1: count traversal work (nodes/prims/instances) in-kernel. */
+int ythip_set_profiling(ythip_ctx* ctx, int mode);
+int ythip_reset_stats(ythip_ctx* ctx);
+int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YTHIP_H */
