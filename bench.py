@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+
+  metric   Msamples/s (whole job) on the procedural 1M-triangle plane + constant
+           environment, 1280x720, 64 spp, sampler=path, 8 bounces, clamp 10,
+           default seed  (configs[1]; SURVEY.md §8d recipe cfg2)
+  step     one trace_samples call rendering `--spp` (64) more samples for every
+           pixel = 1280*720*64 = 58,982,400 camera paths
+  N > 1    image rows sharded across ranks (configs[2]); every rank holds a full
+           replica of scene+BVH and its slice of trace_state; one RCCL all-gather
+           of the framebuffer per step (inside the timed region).  Total work is
+           fixed → "strong" scaling.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+                --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "yocto-gl_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def shard_rows(height, world, rank):
+    """Contiguous row blocks, the reference's own unit of work (yocto_trace.cpp:66-69)."""
+    base, rem = divmod(height, world)
+    r0 = rank * base + min(rank, rem)
+    return r0, r0 + base + (1 if rank < rem else 0)
+
+
+def cpu_baseline(flat, params_kw, budget_s=15.0):
+    """The reference itself (oracle/_ref, g++ -O3, all host cores) timed on a
+    bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import refyocto as ry
+    import ythip as yt
+    if not ry.available():
+        return None
+    scene = ry.RefScene.from_flat(flat)
+    bvh, lights = ry.RefBvh(scene), ry.RefLights(scene)
+    cores = ry.hardware_concurrency()
+    # warm-up + rate probe with 1 spp, then size the sample to ~budget_s
+    p = yt.trace_params(samples=1 << 20, batch=1, **params_kw)
+    st = ry.RefState(scene, p)
+    ry.trace_samples(st, scene, bvh, lights, p)
+    t1 = ry.trace_samples(st, scene, bvh, lights, p)
+    spp = int(max(1, min(64, budget_s / max(t1, 1e-3))))
+    p = yt.trace_params(samples=1 << 20, batch=spp, **params_kw)
+    t = ry.trace_samples(st, scene, bvh, lights, p)
+    n = st.width * st.height * spp
+    return {"value": round(n / t / 1e6, 3), "unit": "Msamples/s", "cores": cores,
+            "kind": "reference",
+            "sample": f"{st.width}x{st.height}x{spp}spp of the same scene/params "
+                      f"({n} samples, {t:.2f} s, after a 2-pass warm-up), "
+                      f"reference trace_samples via oracle/_ref (g++ -O3, std::async x{cores})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--resolution", type=int, default=1280)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ythip as yt
+    import scenes as ysc
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    # ---- workload: BASELINE.json configs[1] --------------------------------
+    flat = ysc.plane_scene()  # 1,000,000 triangles, 501,501 vertices
+    params_kw = dict(sampler="path", resolution=args.resolution, bounces=8, clamp=10.0)
+    params = yt.trace_params(samples=1 << 30, batch=args.spp, **params_kw)
+    t0 = time.time()
+    ctx = yt.Context(local)
+    ctx.upload_scene(flat)
+    ctx.make_trace_bvh(flat)
+    ctx.make_trace_lights(flat)
+    setup_s = time.time() - t0
+    w, h = yt.state_size(flat.cameras[0], params.resolution)
+    r0, r1 = shard_rows(h, world, rank)
+    rngs = yt.make_rngs(params.seed, w * h)
+    ctx.make_trace_state(flat, params, rows=(r0, r1), rngs=rngs)
+    npix = w * (r1 - r0)
+
+    # state arrays live in torch tensors so the RCCL gather runs on them directly
+    dev = torch.device("cuda", local)
+    image = torch.zeros(npix, 4, device=dev)
+    albedo = torch.zeros(npix, 3, device=dev)
+    normal = torch.zeros(npix, 3, device=dev)
+    hits = torch.zeros(npix, dtype=torch.int32, device=dev)
+    trng = torch.from_numpy(rngs[r0 * w:r1 * w].view(np.int64).copy()).to(dev)
+    ctx.bind_device_state(image.data_ptr(), albedo.data_ptr(), normal.data_ptr(),
+                          hits.data_ptr(), trng.data_ptr())
+    stream = torch.cuda.Stream(device=dev)  # non-null: kernels and the RCCL gather share it
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    full = torch.empty(world * npix, 4, device=dev) if world > 1 else None
+    even = all(shard_rows(h, world, r)[1] - shard_rows(h, world, r)[0] == r1 - r0 for r in range(world))
+    if world > 1 and not even:
+        raise SystemExit("row count must divide evenly across ranks for the all-gather")
+
+    def step():
+        ctx.trace_samples_async(params)
+        if world > 1:  # framebuffer gather over RCCL/xGMI (§8e), once per batch
+            dist.all_gather_into_tensor(full, image)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- algorithmic work of one step (counting pass, untimed) --------------
+    stats_count = None
+    if not args.no_roofline:
+        ctx.set_profiling(2)
+        ctx.reset_stats()
+        step()
+        fence()
+        stats_count = ctx.get_stats()
+        ctx.set_profiling(0)
+    for _ in range(args.warmup):
+        step()
+    fence()
+
+    # ---- timed region: exactly K steps --------------------------------------
+    ctx.set_profiling(0 if args.no_roofline else 1)  # hipEvents around extend/shade launches
+    ctx.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    stats_time = ctx.get_stats()
+    ctx.set_profiling(0)
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    total_samples = w * h * args.spp * args.steps
+    value = total_samples / dt / 1e6
+
+    out = {
+        "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"1M-triangle plane + constant env, {w}x{h}x{args.spp}spp, "
+                               "sampler=path bounces=8 clamp=10 (BASELINE configs[1]"
+                               + ("/[2] row-sharded" if world > 1 else "") + ")",
+                   "triangles": int(flat.shapes[0]["num_triangles"]),
+                   "resolution": [w, h], "spp": args.spp, "rows_per_rank": r1 - r0,
+                   "sharding": f"rows/{world}" if world > 1 else "none",
+                   "setup_s": round(setup_s, 3)},
+    }
+    if rank == 0 and stats_count is not None and stats_time["extend_launches"] > 0:
+        # algorithmic bytes of the traversal kernel: SURVEY.md §8(d) per-unit
+        # figures x the units counted in one step, per k_extend launch
+        launches_per_step = stats_time["extend_launches"] / args.steps
+        trav_bytes_step = yt.traversal_bytes(stats_count)
+        ext_ms = stats_time["extend_ms"] / stats_time["extend_launches"]
+        bytes_per_launch = trav_bytes_step / launches_per_step
+        achieved = bytes_per_launch / (ext_ms * 1e-3) / 1e9
+        nsamp = max(stats_count["samples"], 1)
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None,
+            "launch_ms_avg": round(ext_ms, 5), "launches_per_step": launches_per_step,
+            "bytes_per_launch": int(bytes_per_launch),
+            "extend_ms_per_step": round(stats_time["extend_ms"] / args.steps, 3),
+            "shade_ms_per_step": round(stats_time["shade_ms"] / args.steps, 3),
+            "per_sample": {"rays": round(stats_count["rays"] / nsamp, 3),
+                           "nodes": round(stats_count["nodes"] / nsamp, 3),
+                           "triangles": round(stats_count["triangles"] / nsamp, 3),
+                           "instances": round(stats_count["instances"] / nsamp, 3),
+                           "shades": round(stats_count["shades"] / nsamp, 3),
+                           "bytes_all_stages": round(yt.algorithmic_bytes(stats_count) / nsamp, 1)},
+            "whole_job_GBs": round(yt.algorithmic_bytes(stats_count) / nsamp * value * 1e6 / 1e9, 2),
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(flat, params_kw)
+        except Exception as e:  # the baseline is reported, never required
+            out["cpu_baseline"] = {"error": str(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

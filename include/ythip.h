@@ -253,9 +253,21 @@ int ythip_bvh_sizes(ythip_ctx* ctx, int32_t* num_trees, int64_t* num_nodes,
 int ythip_bvh_download(ythip_ctx* ctx, int64_t* node_offset,
     int64_t* prim_offset, ythip_bvh_node* nodes, int32_t* primitives);
 
+/* The same builder without a GPU context (host-only; lets the `-m "not gpu"`
+ * tests pin the tree against the reference's make_scene_bvh node-for-node). */
+typedef struct ythip_hostbvh ythip_hostbvh;
+int  ythip_host_bvh_build(const ythip_scene* scene, int highquality,
+     ythip_hostbvh** out);
+int  ythip_host_bvh_view(const ythip_hostbvh* bvh, ythip_bvh* view);
+void ythip_host_bvh_free(ythip_hostbvh* bvh);
+
 /* make_trace_lights (yocto_trace.cpp:1528-1581): host-side CDF build + upload. */
 int ythip_build_lights(ythip_ctx* ctx, const ythip_scene* scene);
 int ythip_upload_lights(ythip_ctx* ctx, const ythip_lights* lights);
+typedef struct ythip_hostlights ythip_hostlights;
+int  ythip_host_lights_build(const ythip_scene* scene, ythip_hostlights** out);
+int  ythip_host_lights_view(const ythip_hostlights* lights, ythip_lights* view);
+void ythip_host_lights_free(ythip_hostlights* lights);
 int ythip_lights_sizes(ythip_ctx* ctx, int32_t* num_lights, int64_t* num_cdf);
 int ythip_lights_download(ythip_ctx* ctx, ythip_light* lights, float* cdf);
 

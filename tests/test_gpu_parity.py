@@ -1,0 +1,320 @@
+"""GPU parity tests (`-m gpu`): the HIP path, called through the C ABI, against
+  (a) the compiled reference live (oracle/_ref, when it travelled with the repo), and
+  (b) the committed golden fixtures generated from it (tests/golden/).
+
+Bars:  bit-exact for integer/index work (PCG streams, hit records, BVH, hits
+counters) and for every float stage that involves no libm transcendental
+(camera rays with aperture 0, traversal uv/distance, eyelight images on
+polygonal matte scenes); radiance of the Monte Carlo integrators within the
+float tolerances written in each test (device libm sin/cos/pow/exp/log differ
+from glibc in the last ulp, and one ulp in a bounce direction can flip a hit)."""
+import os
+
+import numpy as np
+import pytest
+
+import parity as P
+from parity import ry, yt
+
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not P.have_ref(), reason="oracle/_ref did not travel")
+
+ALL_SCENES = list(P.SCENES)
+
+
+@pytest.fixture(scope="module")
+def bundles():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            flat = P.SCENES[name]()
+            cache[name] = (flat, P.gpu_context(flat), P.RefBundle(flat) if P.have_ref() else None)
+        return cache[name]
+
+    yield get
+    for _, ctx, _ in cache.values():
+        ctx.close()
+
+
+def test_native_library_is_loaded_and_no_fallback():
+    lib = yt.load_library()
+    assert lib._name.endswith("libythip.so")
+    ctx = yt.Context(0)
+    # trace before residency must fail loudly
+    with pytest.raises(yt.YthipError):
+        ctx.trace_samples(yt.trace_params())
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# BVH residency
+# ---------------------------------------------------------------------------
+@needs_ref
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_resident_bvh_equals_reference_tree(bundles, name):
+    flat, ctx, rb = bundles(name)
+    assert ctx.download_bvh().same_as(rb.bvh.flat())
+    lights = ctx.download_lights()
+    rl = rb.lights.flat()
+    assert lights.lights.tobytes() == rl.lights.tobytes() and lights.cdf.tobytes() == rl.cdf.tobytes()
+
+
+@needs_ref
+def test_uploaded_reference_bvh_gives_same_hits(bundles):
+    """Drop-in path: trees built by the reference's make_trace_bvh and uploaded."""
+    flat, ctx, rb = bundles("materials")
+    ctx2 = yt.Context(0)
+    ctx2.upload_scene(flat)
+    ctx2.upload_bvh(rb.bvh.flat())
+    rays = P.random_rays(flat, 4096, seed=5)
+    assert P.hits_equal(ctx2.intersect_batch(rays), ctx.intersect_batch(rays))
+    ctx2.close()
+
+
+# ---------------------------------------------------------------------------
+# traversal: bit-exact hit records
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_intersect_batch_golden(bundles, name):
+    flat, ctx, _ = bundles(name)
+    g = np.load(os.path.join(P.GOLDEN, f"hits_{name}.npz"))
+    rays = P.random_rays(flat, 2048)
+    assert P.hits_equal(ctx.intersect_batch(rays), g["hits"])
+    assert P.hits_equal(ctx.intersect_batch(rays, find_any=True), g["hits_any"])
+    assert P.hits_equal(ctx.intersect_instance_batch(g["inst"], rays), g["hits_inst"])
+    assert g["hits"]["hit"].sum() > 50  # the batch is not vacuous
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_intersect_batch_live_large(bundles, name):
+    flat, ctx, rb = bundles(name)
+    rays = P.random_rays(flat, 100_000, seed=17)
+    a = ctx.intersect_batch(rays)
+    b = ry.intersect_batch(rb.bvh, rb.scene, rays)
+    assert P.hits_equal(a, b)
+    inst = (np.arange(len(rays)) * 7 % len(flat.instances)).astype("i4")
+    assert P.hits_equal(ctx.intersect_instance_batch(inst, rays),
+                        ry.intersect_instance_batch(rb.bvh, rb.scene, inst, rays))
+    assert P.hits_equal(ctx.intersect_batch(rays, find_any=True),
+                        ry.intersect_batch(rb.bvh, rb.scene, rays, find_any=True))
+
+
+def test_cornell_hit_index_known_answer():
+    """Cornell 256², sample-0 primary rays: FNV-1a-64 over
+    (instance, element) = e32777791f766a25, Σdistance = 264850.978779."""
+    flat = P.SCENES["cornellbox"]()
+    ctx = P.gpu_context(flat)
+    p = yt.trace_params(resolution=256, samples=1)
+    ctx.make_trace_state(flat, p)
+    rays = ctx.camera_rays(p)
+    hits = ctx.intersect_batch(rays)
+    pairs = np.stack([hits["instance"], hits["element"]], 1).astype("<i4")
+    assert hits["hit"].sum() == 65536
+    assert ry.fnv1a64(pairs.tobytes()) == 0xE32777791F766A25
+    assert abs(hits["distance"].astype("f8").sum() - 264850.978779) < 1e-3
+    ctx.close()
+
+
+def test_empty_and_degenerate_inputs():
+    flat = P.SCENES["cornellbox"]()
+    ctx = P.gpu_context(flat)
+    assert len(ctx.intersect_batch(np.zeros(0, yt.ray_dt))) == 0
+    rays = np.zeros(4, yt.ray_dt)  # zero direction: 1/0 = inf, NaNs in the slab test
+    rays["tmin"], rays["tmax"] = 1e-4, np.finfo("f4").max
+    rays["o"] = [0, 1, 0]
+    h = ctx.intersect_batch(rays)
+    if P.have_ref():
+        rb = P.RefBundle(flat)
+        assert P.hits_equal(h, ry.intersect_batch(rb.bvh, rb.scene, rays))
+    # a scene whose only instance has no elements, and an empty scene
+    sc = yt.FlatScene()
+    sc.add_camera(yt.IDENTITY_FRAME)
+    sc.add_material("matte", color=(1, 1, 1))
+    s = sc.add_shape(np.zeros((3, 3), "f4"))
+    sc.add_instance(s, 0)
+    c2 = P.gpu_context(sc)
+    r = P.random_rays(flat, 64)
+    assert c2.intersect_batch(r)["hit"].sum() == 0
+    c2.close()
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# camera + PCG: bit-exact
+# ---------------------------------------------------------------------------
+@needs_ref
+@pytest.mark.parametrize("name,tent", [("cornellbox", False), ("cornellbox", True),
+                                       ("plane", False), ("lines_points", True)])
+def test_camera_rays_bit_exact(bundles, name, tent):
+    flat, ctx, rb = bundles(name)
+    p = yt.trace_params(resolution=96, samples=1, tentfilter=int(tent))
+    ctx.make_trace_state(flat, p)
+    st = ry.RefState(rb.scene, p)
+    a = ctx.camera_rays(p)
+    b = ry.camera_rays(st, rb.scene, p)
+    assert a.tobytes() == b.tobytes()
+
+
+# ---------------------------------------------------------------------------
+# images
+# ---------------------------------------------------------------------------
+def _render_gpu(ctx, flat, **kw):
+    params = yt.trace_params(**kw)
+    return P.gpu_render(ctx, flat, params), params
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "plane", "instances"])
+def test_eyelight_image_bit_exact_golden(bundles, name):
+    """eyelight on polygonal matte/glossy-free scenes involves no libm call →
+    the whole trace_state (image, albedo, normal, hits, rngs) must be bit-identical."""
+    flat, ctx, _ = bundles(name)
+    g = np.load(os.path.join(P.GOLDEN, f"render_{name}_eyelight.npz"))
+    st, _ = _render_gpu(ctx, flat, sampler="eyelight", resolution=32, samples=4, batch=4,
+                        falsecolor="normal")
+    assert st["rngs"].tobytes() == g["rngs"].tobytes()
+    assert np.array_equal(st["hits"], g["hits"])
+    if name == "instances":  # glossy instances: fresnel/microfacet are libm-free too
+        pass
+    assert st["image"].tobytes() == g["image"].tobytes()
+    assert st["albedo"].tobytes() == g["albedo"].tobytes()
+    assert st["normal"].tobytes() == g["normal"].tobytes()
+
+
+@pytest.mark.parametrize("name,sampler", [(n, s) for n, ss in {
+    "cornellbox": ["path", "pathdirect", "pathmis", "pathtest", "naive", "eyelight",
+                   "diagram", "furnace", "falsecolor"],
+    "materials": ["path", "pathdirect", "pathmis", "naive", "eyelight", "falsecolor"],
+    "plane": ["path", "eyelight"],
+    "instances": ["path", "eyelight", "falsecolor"],
+    "lines_points": ["path", "eyelight", "falsecolor"]}.items() for s in ss])
+def test_render_vs_golden(bundles, name, sampler):
+    """Same scene, seed, spp as the fixture.  Tolerances (float32 radiance):
+    >= 97 % of pixels within 1e-4 relative of the reference pixel; the rng state
+    (i.e. the number of draws = the path structure) identical for >= 97 % of pixels;
+    image mean within 2 %."""
+    flat, ctx, _ = bundles(name)
+    g = np.load(os.path.join(P.GOLDEN, f"render_{name}_{sampler}.npz"))
+    st, _ = _render_gpu(ctx, flat, sampler=sampler, resolution=32, samples=4, batch=4,
+                        falsecolor="normal")
+    s = P.image_stats(st["image"], g["image"])
+    same_rng = float((st["rngs"] == g["rngs"]).all(axis=1).mean())
+    assert np.isfinite(st["image"]).all()
+    assert same_rng >= 0.97, (same_rng, s)
+    assert s["frac_1e4"] >= 0.97, s
+    assert s["mean_rel"] <= 0.02, s
+    assert (st["hits"] == g["hits"]).mean() >= 0.99
+
+
+@needs_ref
+@pytest.mark.parametrize("name,sampler,res,spp", [
+    ("cornellbox", "path", 128, 16), ("cornellbox", "pathmis", 64, 8),
+    ("materials", "path", 96, 16), ("materials", "pathdirect", 64, 8),
+    ("plane", "path", 128, 8), ("instances", "path", 96, 8),
+    ("lines_points", "path", 96, 8), ("materials", "naive", 64, 8),
+    ("materials", "furnace", 64, 4), ("materials", "pathtest", 64, 4),
+])
+def test_render_vs_live_reference(bundles, name, sampler, res, spp):
+    """Larger live comparison against the compiled reference, progressive
+    (batch < samples, so state carries across trace_samples calls)."""
+    flat, ctx, rb = bundles(name)
+    params = yt.trace_params(sampler=sampler, resolution=res, samples=spp, batch=max(spp // 4, 1))
+    gpu = P.gpu_render(ctx, flat, params)
+    ref = rb.render(params)
+    s = P.image_stats(gpu["image"], ref["image"])
+    same_rng = float((gpu["rngs"] == ref["rngs"]).all(axis=1).mean())
+    assert gpu["samples"] == ref["samples"] == spp
+    assert same_rng >= 0.95, (same_rng, s)
+    assert s["frac_1e4"] >= 0.95 and s["mean_rel"] <= 0.01, s
+    assert np.abs(gpu["albedo"] - ref["albedo"]).mean() < 1e-3
+    assert np.abs(gpu["normal"] - ref["normal"]).mean() < 1e-3
+
+
+@needs_ref
+@pytest.mark.parametrize("fc", ["position", "normal", "frontfacing", "gnormal", "gfrontfacing",
+                                "texcoord", "color", "emission", "roughness", "opacity",
+                                "metallic", "delta", "mtype", "instance", "shape", "material",
+                                "element", "highlight"])
+def test_falsecolor_modes(bundles, fc):
+    """Every falsecolor mode (yocto_trace.cpp:1366-1415); the only libm call is
+    the final srgb_to_rgb powf → 2e-6 relative."""
+    flat, ctx, rb = bundles("materials")
+    params = yt.trace_params(sampler="falsecolor", falsecolor=fc, resolution=64, samples=1)
+    gpu = P.gpu_render(ctx, flat, params)
+    ref = rb.render(params)
+    assert gpu["rngs"].tobytes() == ref["rngs"].tobytes()
+    assert np.array_equal(gpu["hits"], ref["hits"])
+    assert np.allclose(gpu["image"], ref["image"], rtol=5e-6, atol=1e-7)
+
+
+@needs_ref
+def test_params_variants(bundles):
+    """envhidden / nocaustics / clamp / bounces / seed / second camera-less edge."""
+    flat, ctx, rb = bundles("materials")
+    for kw in [dict(envhidden=1), dict(nocaustics=1), dict(clamp=0.5), dict(bounces=2),
+               dict(bounces=1), dict(seed=12345), dict(tentfilter=1)]:
+        params = yt.trace_params(sampler="path", resolution=48, samples=4, batch=2, **kw)
+        gpu = P.gpu_render(ctx, flat, params)
+        ref = rb.render(params)
+        s = P.image_stats(gpu["image"], ref["image"])
+        same_rng = float((gpu["rngs"] == ref["rngs"]).all(axis=1).mean())
+        assert same_rng >= 0.95 and s["frac_1e4"] >= 0.95 and s["mean_rel"] <= 0.02, (kw, same_rng, s)
+
+
+@needs_ref
+def test_resume_cpu_state_on_gpu_and_back(bundles):
+    """trace_state is the checkpoint: a render started on the CPU
+    reference continues on the GPU and vice versa (eyelight → bit-exact)."""
+    flat, ctx, rb = bundles("cornellbox")
+    params = yt.trace_params(sampler="eyelight", resolution=48, samples=4, batch=2)
+    st = ry.RefState(rb.scene, params)
+    ry.trace_samples(st, rb.scene, rb.bvh, rb.lights, params)  # samples 0-1 on the CPU
+    half = st.get()
+    ctx.make_trace_state(flat, params)
+    ctx.upload_state(half["image"], half["albedo"], half["normal"], half["hits"], half["rngs"],
+                     samples=half["samples"])
+    ctx.trace_samples(params)  # samples 2-3 on the GPU
+    ctx.trace_samples(params)  # no-op: samples >= params.samples (yocto_trace.cpp:1598)
+    gpu = ctx.download_state()
+    ry.trace_samples(st, rb.scene, rb.bvh, rb.lights, params)
+    ref = st.get()
+    assert gpu["samples"] == 4
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert gpu[k].tobytes() == ref[k].tobytes(), k
+
+
+def test_row_sharding_equals_full_frame(bundles):
+    """§8e: rendering rows [a,b) with the sliced seeds gives exactly the rows of
+    the full-frame render (no cross-pixel data flow)."""
+    flat, ctx, _ = bundles("materials")
+    params = yt.trace_params(sampler="path", resolution=64, samples=2, batch=2)
+    full = P.gpu_render(ctx, flat, params)
+    w, h = full["width"], full["height"]
+    rngs = yt.make_rngs(params.seed, w * h)
+    parts = []
+    for r0, r1 in [(0, 5), (5, h // 2), (h // 2, h)]:
+        parts.append(P.gpu_render(ctx, flat, params, rows=(r0, r1), rngs=rngs))
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert np.concatenate([p[k] for p in parts]).tobytes() == full[k].tobytes(), k
+
+
+def test_work_counters_and_cancel(bundles):
+    flat, ctx, _ = bundles("cornellbox")
+    params = yt.trace_params(sampler="path", resolution=64, samples=2, batch=2)
+    ctx.set_profiling(3)
+    ctx.reset_stats()
+    P.gpu_render(ctx, flat, params)
+    s = ctx.get_stats()
+    ctx.set_profiling(0)
+    assert s["samples"] == 64 * 64 * 2 and s["rays"] >= s["samples"]
+    assert s["nodes"] > s["rays"] and s["triangles"] > 0 and s["instances"] > 0
+    assert s["extend_launches"] > 0 and s["extend_ms"] > 0
+    assert yt.algorithmic_bytes(s) > 0
+    # cancellation (trace_start's stop flag, yocto_trace.cpp:1637)
+    ctx.make_trace_state(flat, params)
+    stop = np.ones(1, "i4")
+    with pytest.raises(yt.YthipError):
+        ctx.trace_samples(params, stop=stop)
+    with pytest.raises(yt.YthipError):
+        ctx.trace_samples(yt.trace_params(sampler=42))  # "sampler unknown"

@@ -1,0 +1,473 @@
+// yt_scene.h — device-resident scene view and the eval_* subset of
+// libs/yocto/yocto_scene.cpp used by trace_samples (camera, texture, material,
+// position/normal/texcoord/color interpolation, environment).
+#pragma once
+
+#include "../../include/ythip.h"
+#include "yt_math.h"
+
+namespace yt {
+
+// element kinds, in the reference's two dispatch orders
+enum { KIND_NONE = 0, KIND_POINTS = 1, KIND_LINES = 2, KIND_TRIANGLES = 3, KIND_QUADS = 4 };
+
+// Per-shape record (device).  Offsets index the shared pools.
+struct DShape {
+  int kind_bvh;   // points→lines→triangles→quads  (yocto_bvh.cpp:505-545)
+  int kind_eval;  // triangles→quads→lines→points  (yocto_scene.cpp:288-311)
+  int elem_bvh;   // element pool offset for kind_bvh
+  int elem_eval;  // element pool offset for kind_eval
+  int positions, normals, texcoords, colors, radius;  // vertex pool offsets, -1 absent
+  int pad_[3];
+};
+
+// Per-instance record for traversal: inverse(frame, non_rigid=true) computed on
+// the host with the reference's operation order (yocto_math.h:2114-2118), plus
+// the shape's BLAS root and element kind so a TLAS leaf visit is one 64-B fetch.
+struct DInstanceT {
+  float inv[12];
+  int   root;   // global node index of the shape's BLAS root, -1 if empty
+  int   kind;   // kind_bvh of the shape
+  int   shape;
+  int   pad_;
+};
+
+struct DLight {
+  int instance, environment, cdf_offset, cdf_count;
+};
+
+struct DScene {
+  // scene_data
+  const ythip_camera*      cameras;
+  const ythip_instance*    instances;
+  const ythip_environment* environments;
+  const float*             env_inv;  // 12 floats per environment: inverse(frame) rigid
+  const ythip_material*    materials;
+  const ythip_texture*     textures;
+  const DShape*            shapes;
+  int num_instances, num_environments, num_shapes, num_materials, num_textures;
+  // pools
+  const int*   points;
+  const int*   lines;
+  const int*   triangles;
+  const int*   quads;
+  const float* positions;
+  const float* normals;
+  const float* texcoords;
+  const float* colors;
+  const float* radius;
+  const float*   pixelsf;
+  const uint8_t* pixelsb;
+  // bvh
+  const ythip_bvh_node* nodes;      // all trees, indices baked to global
+  const float4*         leafdata;   // pre-gathered leaf primitives
+  const int*            tlas_prims; // instance ids in TLAS leaf order
+  const DInstanceT*     tinst;      // per instance
+  int                   tlas_root;  // global node index, -1 if empty
+  // lights
+  const DLight* lights;
+  const float*  cdf;
+  int           num_lights;
+};
+
+YT_FN vec3f ld3(const float* p, int i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+YT_FN vec2f ld2(const float* p, int i) { return {p[2 * i], p[2 * i + 1]}; }
+YT_FN vec4f ld4(const float* p, int i) {
+  auto v = reinterpret_cast<const float4*>(p)[i];
+  return {v.x, v.y, v.z, v.w};
+}
+YT_FN frame3f ldframe(const float* f) {
+  return {{f[0], f[1], f[2]}, {f[3], f[4], f[5]}, {f[6], f[7], f[8]}, {f[9], f[10], f[11]}};
+}
+YT_FN frame3f ldframe(const ythip_frame& f) { return ldframe(f.x); }
+
+struct ray3f {
+  vec3f o, d;
+  float tmin, tmax;
+};
+YT_FN ray3f make_ray(vec3f o, vec3f d) { return {o, d, ray_eps, flt_max}; }
+
+// ---------------------------------------------------------------------------
+// eval_camera — yocto_scene.cpp:66-101
+// ---------------------------------------------------------------------------
+YT_FN ray3f eval_camera(const ythip_camera& camera, vec2f image_uv, vec2f lens_uv) {
+  auto film = camera.aspect >= 1 ? vec2f{camera.film, camera.film / camera.aspect}
+                                 : vec2f{camera.film * camera.aspect, camera.film};
+  auto frame = ldframe(camera.frame);
+  if (!camera.orthographic) {
+    auto q  = vec3f{film.x * (0.5f - image_uv.x), film.y * (image_uv.y - 0.5f), camera.lens};
+    auto dc = -normalize(q);
+    auto e  = vec3f{lens_uv.x * camera.aperture / 2, lens_uv.y * camera.aperture / 2, 0};
+    auto p  = dc * camera.focus / fabs_(dc.z);
+    auto d  = normalize(p - e);
+    return make_ray(transform_point(frame, e), transform_direction(frame, d));
+  } else {
+    auto scale = 1 / camera.lens;
+    auto q     = vec3f{film.x * (0.5f - image_uv.x) * scale,
+        film.y * (image_uv.y - 0.5f) * scale, camera.lens};
+    auto e     = vec3f{-q.x, -q.y, 0} +
+             vec3f{lens_uv.x * camera.aperture / 2, lens_uv.y * camera.aperture / 2, 0};
+    auto p = vec3f{-q.x, -q.y, -camera.focus};
+    auto d = normalize(p - e);
+    return make_ray(transform_point(frame, e), transform_direction(frame, d));
+  }
+}
+
+// sample_camera — yocto_trace.cpp:338-358
+YT_FN ray3f sample_camera(const ythip_camera& camera, int i, int j, int width, int height,
+    vec2f puv, vec2f luv, bool tent) {
+  if (!tent) {
+    auto uv = vec2f{(i + puv.x) / width, (j + puv.y) / height};
+    return eval_camera(camera, uv, sample_disk(luv));
+  } else {
+    const auto width_ = 2.0f;
+    const auto offset = 0.5f;
+    auto       fuv    = vec2f{puv.x < 0.5f ? sqrt_(2 * puv.x) - 1 : 1 - sqrt_(2 - 2 * puv.x),
+                     puv.y < 0.5f ? sqrt_(2 * puv.y) - 1 : 1 - sqrt_(2 - 2 * puv.y)};
+    fuv = {width_ * fuv.x + offset, width_ * fuv.y + offset};
+    auto uv = vec2f{(i + fuv.x) / width, (j + fuv.y) / height};
+    return eval_camera(camera, uv, sample_disk(luv));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// textures — yocto_scene.cpp:111-178, yocto_color.h:223-249
+// ---------------------------------------------------------------------------
+YT_FN float srgb_to_rgb(float srgb) {  // yocto_color.h:235 (double-typed threshold)
+  return ((double)srgb <= 0.04045) ? srgb / 12.92f
+                                   : powf((srgb + 0.055f) / (1.0f + 0.055f), 2.4f);
+}
+YT_FN vec3f srgb_to_rgb(vec3f c) { return {srgb_to_rgb(c.x), srgb_to_rgb(c.y), srgb_to_rgb(c.z)}; }
+YT_FN vec4f lookup_texture(const DScene& sc, const ythip_texture& t, int i, int j, bool as_linear) {
+  vec4f color;
+  auto  idx = t.offset + (int64_t)j * t.width + i;
+  if (t.is_float) {
+    auto v = reinterpret_cast<const float4*>(sc.pixelsf)[idx];
+    color  = {v.x, v.y, v.z, v.w};
+  } else {
+    auto b = reinterpret_cast<const uchar4*>(sc.pixelsb)[idx];
+    color  = {b.x / 255.0f, b.y / 255.0f, b.z / 255.0f, b.w / 255.0f};
+  }
+  if (as_linear && !t.linear) {
+    return {srgb_to_rgb(color.x), srgb_to_rgb(color.y), srgb_to_rgb(color.z), color.w};
+  }
+  return color;
+}
+YT_FN vec4f eval_texture(const DScene& sc, int texture, vec2f uv, bool as_linear) {
+  if (texture == YTHIP_INVALIDID) return {1, 1, 1, 1};
+  const auto& t = sc.textures[texture];
+  if (t.width == 0 || t.height == 0) return {0, 0, 0, 0};
+  auto sx = t.width, sy = t.height;
+  auto s = 0.0f, tt = 0.0f;
+  if (t.clamp) {
+    s  = clamp_(uv.x, 0.0f, 1.0f) * sx;
+    tt = clamp_(uv.y, 0.0f, 1.0f) * sy;
+  } else {
+    s = fmodf(uv.x, 1.0f) * sx;
+    if (s < 0) s += sx;
+    tt = fmodf(uv.y, 1.0f) * sy;
+    if (tt < 0) tt += sy;
+  }
+  auto i = clamp_((int)s, 0, sx - 1), j = clamp_((int)tt, 0, sy - 1);
+  auto ii = (i + 1) % sx, jj = (j + 1) % sy;
+  auto u = s - i, v = tt - j;
+  if (t.nearest) {
+    return lookup_texture(sc, t, i, j, as_linear);
+  } else {
+    return lookup_texture(sc, t, i, j, as_linear) * (1 - u) * (1 - v) +
+           lookup_texture(sc, t, i, jj, as_linear) * (1 - u) * v +
+           lookup_texture(sc, t, ii, j, as_linear) * u * (1 - v) +
+           lookup_texture(sc, t, ii, jj, as_linear) * u * v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// interpolation — yocto_geometry.h:535-556
+// ---------------------------------------------------------------------------
+template <typename T>
+YT_FN T interpolate_line(T p0, T p1, float u) {
+  return p0 * (1 - u) + p1 * u;
+}
+template <typename T>
+YT_FN T interpolate_triangle(T p0, T p1, T p2, vec2f uv) {
+  return p0 * (1 - uv.x - uv.y) + p1 * uv.x + p2 * uv.y;
+}
+template <typename T>
+YT_FN T interpolate_quad(T p0, T p1, T p2, T p3, vec2f uv) {
+  if (uv.x + uv.y <= 1) {
+    return interpolate_triangle(p0, p1, p3, uv);
+  } else {
+    return interpolate_triangle(p2, p3, p1, 1 - uv);
+  }
+}
+YT_FN vec3f triangle_normal(vec3f p0, vec3f p1, vec3f p2) {  // yocto_geometry.h:512
+  return normalize(cross(p1 - p0, p2 - p0));
+}
+YT_FN vec3f quad_normal(vec3f p0, vec3f p1, vec3f p2, vec3f p3) {  // :522
+  return normalize(triangle_normal(p0, p1, p3) + triangle_normal(p2, p3, p1));
+}
+
+// ---------------------------------------------------------------------------
+// instance properties — yocto_scene.cpp:288-528
+// ---------------------------------------------------------------------------
+struct elem4 {
+  int x, y, z, w;
+};
+YT_FN elem4 load_element(const DScene& sc, const DShape& sh, int element) {
+  switch (sh.kind_eval) {
+    case KIND_TRIANGLES: {
+      auto p = sc.triangles + 3 * (sh.elem_eval + (int64_t)element);
+      return {p[0], p[1], p[2], 0};
+    }
+    case KIND_QUADS: {
+      auto p = sc.quads + 4 * (sh.elem_eval + (int64_t)element);
+      return {p[0], p[1], p[2], p[3]};
+    }
+    case KIND_LINES: {
+      auto p = sc.lines + 2 * (sh.elem_eval + (int64_t)element);
+      return {p[0], p[1], 0, 0};
+    }
+    case KIND_POINTS: return {sc.points[sh.elem_eval + (int64_t)element], 0, 0, 0};
+    default: return {0, 0, 0, 0};
+  }
+}
+
+// shape-local position (yocto_shape.cpp:63-82 for points; interpolation otherwise)
+YT_FN vec3f eval_position_local(const DScene& sc, const DShape& sh, elem4 e, vec2f uv) {
+  auto P = sc.positions + 3 * (int64_t)sh.positions;
+  switch (sh.kind_eval) {
+    case KIND_TRIANGLES: return interpolate_triangle(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z), uv);
+    case KIND_QUADS:
+      return interpolate_quad(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z), ld3(P, e.w), uv);
+    case KIND_LINES: return interpolate_line(ld3(P, e.x), ld3(P, e.y), uv.x);
+    case KIND_POINTS: return ld3(P, e.x);
+    default: return {0, 0, 0};
+  }
+}
+// eval_position — yocto_scene.cpp:288-311
+YT_FN vec3f eval_position(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e, vec2f uv) {
+  if (sh.kind_eval == KIND_NONE) return {0, 0, 0};
+  return transform_point(frame, eval_position_local(sc, sh, e, uv));
+}
+// eval_element_normal — yocto_scene.cpp:314-336
+YT_FN vec3f eval_element_normal(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e) {
+  auto P = sc.positions + 3 * (int64_t)sh.positions;
+  switch (sh.kind_eval) {
+    case KIND_TRIANGLES:
+      return transform_normal(frame, triangle_normal(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z)));
+    case KIND_QUADS:
+      return transform_normal(frame, quad_normal(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z), ld3(P, e.w)));
+    case KIND_LINES: return transform_normal(frame, normalize(ld3(P, e.y) - ld3(P, e.x)));
+    case KIND_POINTS: return {0, 0, 1};
+    default: return {0, 0, 0};
+  }
+}
+// eval_normal — yocto_scene.cpp:339-366
+YT_FN vec3f eval_normal(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e, vec2f uv) {
+  if (sh.normals < 0) return eval_element_normal(sc, frame, sh, e);
+  auto N = sc.normals + 3 * (int64_t)sh.normals;
+  switch (sh.kind_eval) {
+    case KIND_TRIANGLES:
+      return transform_normal(
+          frame, normalize(interpolate_triangle(ld3(N, e.x), ld3(N, e.y), ld3(N, e.z), uv)));
+    case KIND_QUADS:
+      return transform_normal(frame,
+          normalize(interpolate_quad(ld3(N, e.x), ld3(N, e.y), ld3(N, e.z), ld3(N, e.w), uv)));
+    case KIND_LINES:
+      return transform_normal(frame, normalize(interpolate_line(ld3(N, e.x), ld3(N, e.y), uv.x)));
+    case KIND_POINTS: return transform_normal(frame, normalize(ld3(N, e.x)));
+    default: return {0, 0, 0};
+  }
+}
+// eval_texcoord — yocto_scene.cpp:369-389
+YT_FN vec2f eval_texcoord(const DScene& sc, const DShape& sh, elem4 e, vec2f uv) {
+  if (sh.texcoords < 0) return uv;
+  auto T = sc.texcoords + 2 * (int64_t)sh.texcoords;
+  switch (sh.kind_eval) {
+    case KIND_TRIANGLES: return interpolate_triangle(ld2(T, e.x), ld2(T, e.y), ld2(T, e.z), uv);
+    case KIND_QUADS: return interpolate_quad(ld2(T, e.x), ld2(T, e.y), ld2(T, e.z), ld2(T, e.w), uv);
+    case KIND_LINES: return interpolate_line(ld2(T, e.x), ld2(T, e.y), uv.x);
+    case KIND_POINTS: return ld2(T, e.x);
+    default: return {0, 0};
+  }
+}
+// eval_color — yocto_scene.cpp:508-528
+YT_FN vec4f eval_color(const DScene& sc, const DShape& sh, elem4 e, vec2f uv) {
+  if (sh.colors < 0) return {1, 1, 1, 1};
+  auto Cc = sc.colors + 4 * (int64_t)sh.colors;
+  switch (sh.kind_eval) {
+    case KIND_TRIANGLES: return interpolate_triangle(ld4(Cc, e.x), ld4(Cc, e.y), ld4(Cc, e.z), uv);
+    case KIND_QUADS:
+      return interpolate_quad(ld4(Cc, e.x), ld4(Cc, e.y), ld4(Cc, e.z), ld4(Cc, e.w), uv);
+    case KIND_LINES: return interpolate_line(ld4(Cc, e.x), ld4(Cc, e.y), uv.x);
+    case KIND_POINTS: return ld4(Cc, e.x);
+    default: return {0, 0, 0, 0};
+  }
+}
+
+// triangle_tangents_fromuv — yocto_geometry.h:610-627
+YT_FN void triangle_tangents_fromuv(vec3f p0, vec3f p1, vec3f p2, vec2f uv0, vec2f uv1, vec2f uv2,
+    vec3f& tu, vec3f& tv) {
+  auto p = p1 - p0, q = p2 - p0;
+  auto s = vec2f{uv1.x - uv0.x, uv2.x - uv0.x};
+  auto t = vec2f{uv1.y - uv0.y, uv2.y - uv0.y};
+  auto div = s.x * t.y - s.y * t.x;
+  if (div != 0) {
+    tu = vec3f{t.y * p.x - t.x * q.x, t.y * p.y - t.x * q.y, t.y * p.z - t.x * q.z} / div;
+    tv = vec3f{s.x * q.x - s.y * p.x, s.x * q.y - s.y * p.y, s.x * q.z - s.y * p.z} / div;
+  } else {
+    tu = {1, 0, 0};
+    tv = {0, 1, 0};
+  }
+}
+
+// eval_normalmap — yocto_scene.cpp:446-466 (+ eval_element_tangents :424-444)
+YT_FN vec3f eval_normalmap(const DScene& sc, const frame3f& frame, const DShape& sh,
+    const ythip_material& material, elem4 e, vec2f uv) {
+  auto normal   = eval_normal(sc, frame, sh, e, uv);
+  auto texcoord = eval_texcoord(sc, sh, e, uv);
+  if (material.normal_tex != YTHIP_INVALIDID &&
+      (sh.kind_eval == KIND_TRIANGLES || sh.kind_eval == KIND_QUADS)) {
+    const auto& ntex = sc.textures[material.normal_tex];
+    // eval_texture(normal_tex, texcoord, false) → texture's own nearest/clamp
+    auto normalmap = -1 + 2 * xyz(eval_texture(sc, material.normal_tex, texcoord, false));
+    (void)ntex;
+    vec3f tu = {0, 0, 0}, tv = {0, 0, 0};
+    if (sh.texcoords >= 0) {
+      auto P = sc.positions + 3 * (int64_t)sh.positions;
+      auto T = sc.texcoords + 2 * (int64_t)sh.texcoords;
+      vec3f ltu, ltv;
+      if (sh.kind_eval == KIND_TRIANGLES) {
+        triangle_tangents_fromuv(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z), ld2(T, e.x), ld2(T, e.y),
+            ld2(T, e.z), ltu, ltv);
+      } else {
+        // quad_tangents_fromuv(..., current_uv = {0,0}) → first triangle (p0,p1,p3)
+        triangle_tangents_fromuv(ld3(P, e.x), ld3(P, e.y), ld3(P, e.w), ld2(T, e.x), ld2(T, e.y),
+            ld2(T, e.w), ltu, ltv);
+      }
+      tu = transform_direction(frame, ltu);
+      tv = transform_direction(frame, ltv);
+    }
+    auto fx     = orthonormalize(tu, normal);
+    auto fy     = normalize(cross(normal, fx));
+    auto flip_v = dot(fy, tv) < 0;
+    normalmap.y *= flip_v ? 1 : -1;
+    // transform_normal(frame{fx,fy,normal,0}, normalmap) rigid → normalize(transform_vector)
+    normal = normalize(fx * normalmap.x + fy * normalmap.y + normal * normalmap.z);
+  }
+  return normal;
+}
+
+// eval_shading_position — yocto_scene.cpp:469-482 (points: shape-local, a
+// reference quirk kept for parity)
+YT_FN vec3f eval_shading_position(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e,
+    vec2f uv) {
+  if (sh.kind_eval == KIND_TRIANGLES || sh.kind_eval == KIND_QUADS || sh.kind_eval == KIND_LINES) {
+    return eval_position(sc, frame, sh, e, uv);
+  } else if (sh.kind_eval == KIND_POINTS) {
+    return eval_position_local(sc, sh, e, uv);
+  }
+  return {0, 0, 0};
+}
+// eval_shading_normal — yocto_scene.cpp:485-505
+YT_FN vec3f eval_shading_normal(const DScene& sc, const frame3f& frame, const DShape& sh,
+    const ythip_material& material, elem4 e, vec2f uv, vec3f outgoing) {
+  if (sh.kind_eval == KIND_TRIANGLES || sh.kind_eval == KIND_QUADS) {
+    auto normal = eval_normal(sc, frame, sh, e, uv);
+    if (material.normal_tex != YTHIP_INVALIDID) normal = eval_normalmap(sc, frame, sh, material, e, uv);
+    if (material.type == YTHIP_REFRACTIVE) return normal;
+    return dot(normal, outgoing) >= 0 ? normal : -normal;
+  } else if (sh.kind_eval == KIND_LINES) {
+    auto normal = eval_normal(sc, frame, sh, e, uv);
+    return orthonormalize(outgoing, normal);
+  } else if (sh.kind_eval == KIND_POINTS) {
+    return outgoing;
+  }
+  return {0, 0, 0};
+}
+
+// ---------------------------------------------------------------------------
+// material_point / eval_material — yocto_scene.h:258-270, yocto_scene.cpp:531-581
+// ---------------------------------------------------------------------------
+struct material_point {
+  int   type;
+  vec3f emission, color;
+  float opacity, roughness, metallic, ior;
+  vec3f density, scattering;
+  float scanisotropy, trdepth;
+};
+constexpr float min_roughness = 0.03f * 0.03f;
+
+YT_FN material_point eval_material(const DScene& sc, const DShape& sh, const ythip_material& material,
+    elem4 e, vec2f uv) {
+  auto texcoord       = eval_texcoord(sc, sh, e, uv);
+  auto emission_tex   = eval_texture(sc, material.emission_tex, texcoord, true);
+  auto color_shp      = eval_color(sc, sh, e, uv);
+  auto color_tex      = eval_texture(sc, material.color_tex, texcoord, true);
+  auto roughness_tex  = eval_texture(sc, material.roughness_tex, texcoord, false);
+  auto scattering_tex = eval_texture(sc, material.scattering_tex, texcoord, true);
+
+  material_point point;
+  point.type     = material.type;
+  auto memission = vec3f{material.emission[0], material.emission[1], material.emission[2]};
+  auto mcolor    = vec3f{material.color[0], material.color[1], material.color[2]};
+  auto mscatter  = vec3f{material.scattering[0], material.scattering[1], material.scattering[2]};
+  point.emission = memission * xyz(emission_tex) * xyz(color_shp);
+  point.color    = mcolor * xyz(color_tex) * xyz(color_shp);
+  point.opacity  = material.opacity * color_tex.w * color_shp.w;
+  point.metallic = material.metallic * roughness_tex.z;
+  point.roughness    = material.roughness * roughness_tex.y;
+  point.roughness    = point.roughness * point.roughness;
+  point.ior          = material.ior;
+  point.scattering   = mscatter * xyz(scattering_tex);
+  point.scanisotropy = material.scanisotropy;
+  point.trdepth      = material.trdepth;
+
+  if (material.type == YTHIP_REFRACTIVE || material.type == YTHIP_VOLUMETRIC ||
+      material.type == YTHIP_SUBSURFACE) {
+    point.density = -log_(clamp_(point.color, 0.0001f, 1.0f)) / point.trdepth;
+  } else {
+    point.density = {0, 0, 0};
+  }
+
+  if (point.type == YTHIP_MATTE || point.type == YTHIP_GLTFPBR || point.type == YTHIP_GLOSSY) {
+    point.roughness = clamp_(point.roughness, min_roughness, 1.0f);
+  } else if (material.type == YTHIP_VOLUMETRIC) {
+    point.roughness = 0;
+  } else {
+    if (point.roughness < min_roughness) point.roughness = 0;
+  }
+  return point;
+}
+YT_FN bool is_delta(const material_point& m) {  // yocto_scene.cpp:265-273
+  return (m.type == YTHIP_REFLECTIVE && m.roughness == 0) ||
+         (m.type == YTHIP_REFRACTIVE && m.roughness == 0) ||
+         (m.type == YTHIP_TRANSPARENT && m.roughness == 0) || (m.type == YTHIP_VOLUMETRIC);
+}
+YT_FN bool is_volumetric(const ythip_material& m) {  // yocto_scene.cpp:258-262
+  return m.type == YTHIP_REFRACTIVE || m.type == YTHIP_VOLUMETRIC || m.type == YTHIP_SUBSURFACE;
+}
+
+// ---------------------------------------------------------------------------
+// eval_environment — yocto_scene.cpp:596-613
+// ---------------------------------------------------------------------------
+YT_FN vec3f eval_environment(const DScene& sc, int env, vec3f direction) {
+  const auto& environment = sc.environments[env];
+  auto        emission = vec3f{environment.emission[0], environment.emission[1], environment.emission[2]};
+  if (environment.emission_tex == YTHIP_INVALIDID) {
+    // eval_texture(invalidid) = {1,1,1,1}: the lat-long lookup does not influence the result
+    return emission * vec3f{1, 1, 1};
+  }
+  auto inv      = ldframe(sc.env_inv + 12 * env);
+  auto wl       = transform_direction(inv, direction);
+  auto texcoord = vec2f{atan2f(wl.z, wl.x) / (2 * pif), acosf(clamp_(wl.y, -1.0f, 1.0f)) / pif};
+  if (texcoord.x < 0) texcoord.x += 1;
+  return emission * xyz(eval_texture(sc, environment.emission_tex, texcoord, false));
+}
+YT_FN vec3f eval_environment(const DScene& sc, vec3f direction) {
+  auto emission = vec3f{0, 0, 0};
+  for (auto env = 0; env < sc.num_environments; env++) emission += eval_environment(sc, env, direction);
+  return emission;
+}
+
+}  // namespace yt

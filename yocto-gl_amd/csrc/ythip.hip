@@ -1,0 +1,881 @@
+// ythip.hip — libythip.so: the C ABI of include/ythip.h over the gfx950 kernels
+// of yt_kernels.h.  Host side mirrors the reference's cutrace split
+// (context / scene / bvh / lights / state — libs/yocto/yocto_cutrace.cpp:385-996)
+// but is written for HIP directly.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// (-ffp-contract=off is REQUIRED: bit parity with the g++-built reference, which
+// has no FMA contraction on baseline x86-64).
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/ythip.h"
+#include "yt_build.h"
+#include "yt_kernels.h"
+
+using namespace yt;
+
+namespace {
+
+thread_local std::string g_error;
+
+struct DevBuf {
+  void*  p = nullptr;
+  size_t n = 0;
+};
+
+}  // namespace
+
+struct ythip_ctx {
+  int         device     = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream     = nullptr;
+  std::string err;
+
+  std::vector<void*> scene_allocs, bvh_allocs, light_allocs, state_allocs;
+
+  // host copies kept for BVH baking / light building
+  std::vector<ythip_shape>    h_shapes;
+  std::vector<ythip_instance> h_instances;
+  std::vector<int32_t>        h_points, h_lines, h_triangles, h_quads;
+  std::vector<float>          h_positions, h_radius;
+  bool                        may_retry = false;  // opacity < 1 possible → bounce loop may exceed `bounces`
+  bool                        has_volumes = false;
+  int                         num_cameras = 0;
+
+  ythost::flat_bvh    h_bvh;     // as uploaded/built (reference layout) for download
+  ythost::flat_lights h_lights;
+
+  DScene ds = {};
+  DState st = {};
+  bool   have_scene = false, have_bvh = false, have_lights = false, have_state = false;
+  bool   state_bound = false;
+  int    samples     = 0;
+
+  // measurement
+  int                                          prof_mode = 0;
+  unsigned long long*                          d_counters = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<std::pair<int, int>>             ev_used;  // (pool index, kind 0 extend / 1 shade)
+  size_t                                       ev_next = 0;
+  ythip_stats                                  stats   = {};
+  int*                                         h_qcount = nullptr;  // pinned
+};
+
+namespace {
+
+int fail(ythip_ctx* ctx, int code, const char* fmt, ...) {
+  char    buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  g_error = buf;
+  return code;
+}
+
+#define HIPCHECK(ctx, call)                                                                        \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(ctx, YTHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+          __LINE__);                                                                               \
+  } while (0)
+
+void free_all(std::vector<void*>& v) {
+  for (auto p : v)
+    if (p) (void)hipFree(p);
+  v.clear();
+}
+
+template <typename T>
+int dalloc(ythip_ctx* ctx, std::vector<void*>& pool, T** out, size_t count) {
+  *out = nullptr;
+  if (count == 0) count = 1;  // keep pointers valid
+  void* p = nullptr;
+  HIPCHECK(ctx, hipMalloc(&p, count * sizeof(T)));
+  pool.push_back(p);
+  *out = (T*)p;
+  return YTHIP_OK;
+}
+template <typename T>
+int dupload(ythip_ctx* ctx, std::vector<void*>& pool, const T** out, const T* src, size_t count) {
+  T*  d  = nullptr;
+  int rc = dalloc(ctx, pool, &d, count);
+  if (rc) return rc;
+  if (count && src) HIPCHECK(ctx, hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  *out = d;
+  return YTHIP_OK;
+}
+
+int grid_for(long long n) { return (int)((n + YT_BLOCK - 1) / YT_BLOCK); }
+
+KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
+  KParams k;
+  k.camera     = p->camera;
+  k.sampler    = p->sampler;
+  k.falsecolor = p->falsecolor;
+  k.bounces    = p->bounces;
+  k.clamp      = p->clamp;
+  k.nocaustics = p->nocaustics;
+  k.envhidden  = p->envhidden;
+  k.tentfilter = p->tentfilter;
+  k.has_env    = ctx->ds.num_environments > 0;
+  return k;
+}
+
+// Bake the reference-layout trees into the device layout:
+//   * internal `start` → global node index; BLAS-leaf `start` → float4 index into
+//     leafdata; TLAS-leaf `start` → index into tlas_prims
+//   * leafdata: primitives pre-gathered in leaf order (ids come from
+//     `primitives[]`, so hit indices are unaffected)
+int bake_bvh(ythip_ctx* ctx) {
+  auto& b        = ctx->h_bvh;
+  int   nshapes  = (int)ctx->h_shapes.size();
+  int   ntrees   = (int)b.node_offset.size() - 1;
+  if (ntrees != nshapes + 1)
+    return fail(ctx, YTHIP_ERR_INVALID, "bvh has %d trees, scene has %d shapes (+1 expected)", ntrees, nshapes);
+  free_all(ctx->bvh_allocs);
+
+  auto nodes = b.nodes;  // copy to bake
+  std::vector<int64_t> leaf_base(nshapes, 0);
+  int64_t              nleaf4 = 0;
+  for (int s = 0; s < nshapes; s++) {
+    leaf_base[s] = nleaf4;
+    int kind     = ythost::kind_bvh(ctx->h_shapes[s]);
+    int stride   = kind == KIND_TRIANGLES ? 3 : (kind == KIND_QUADS ? 4 : (kind == KIND_LINES ? 3 : 2));
+    nleaf4 += (b.prim_offset[s + 1] - b.prim_offset[s]) * stride;
+  }
+  if (nleaf4 > 0x7fffffffll || (int64_t)nodes.size() > 0x7fffffffll)
+    return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit indices");
+  std::vector<float4> leaf((size_t)nleaf4);
+  for (int s = 0; s < nshapes; s++) {
+    const auto& sh     = ctx->h_shapes[s];
+    int         kind   = ythost::kind_bvh(sh);
+    int         stride = kind == KIND_TRIANGLES ? 3 : (kind == KIND_QUADS ? 4 : (kind == KIND_LINES ? 3 : 2));
+    const float* P     = ctx->h_positions.data() + 3 * sh.positions_offset;
+    const float* R     = sh.radius_offset >= 0 ? ctx->h_radius.data() + sh.radius_offset : nullptr;
+    int64_t      np    = b.prim_offset[s + 1] - b.prim_offset[s];
+    auto         pos   = [&](int v) { return float3{P[3 * v], P[3 * v + 1], P[3 * v + 2]}; };
+    for (int64_t k = 0; k < np; k++) {
+      int     id = b.prims[b.prim_offset[s] + k];
+      float4* L  = leaf.data() + leaf_base[s] + k * stride;
+      if (kind == KIND_TRIANGLES) {
+        const int* t  = ctx->h_triangles.data() + 3 * (sh.triangles_offset + id);
+        auto       p0 = pos(t[0]), p1 = pos(t[1]), p2 = pos(t[2]);
+        L[0] = {p0.x, p0.y, p0.z, p1.x};
+        L[1] = {p1.y, p1.z, p2.x, p2.y};
+        L[2] = {p2.z, __builtin_bit_cast(float, id), 0, 0};
+      } else if (kind == KIND_QUADS) {
+        const int* q  = ctx->h_quads.data() + 4 * (sh.quads_offset + id);
+        auto       p0 = pos(q[0]), p1 = pos(q[1]), p2 = pos(q[2]), p3 = pos(q[3]);
+        L[0] = {p0.x, p0.y, p0.z, p1.x};
+        L[1] = {p1.y, p1.z, p2.x, p2.y};
+        L[2] = {p2.z, p3.x, p3.y, p3.z};
+        L[3] = {__builtin_bit_cast(float, id), 0, 0, 0};
+      } else if (kind == KIND_LINES) {
+        const int* l  = ctx->h_lines.data() + 2 * (sh.lines_offset + id);
+        auto       p0 = pos(l[0]), p1 = pos(l[1]);
+        L[0] = {p0.x, p0.y, p0.z, p1.x};
+        L[1] = {p1.y, p1.z, R ? R[l[0]] : 0.0f, R ? R[l[1]] : 0.0f};
+        L[2] = {__builtin_bit_cast(float, id), 0, 0, 0};
+      } else if (kind == KIND_POINTS) {
+        int  v = ctx->h_points[sh.points_offset + id];
+        auto p = pos(v);
+        L[0]   = {p.x, p.y, p.z, R ? R[v] : 0.0f};
+        L[1]   = {__builtin_bit_cast(float, id), 0, 0, 0};
+      }
+    }
+    // bake this tree's nodes
+    int kstride = stride;
+    for (int64_t n = b.node_offset[s]; n < b.node_offset[s + 1]; n++) {
+      auto& node = nodes[n];
+      if (node.internal)
+        node.start += (int32_t)b.node_offset[s];
+      else
+        node.start = (int32_t)(leaf_base[s] + (int64_t)node.start * kstride);
+    }
+  }
+  for (int64_t n = b.node_offset[nshapes]; n < b.node_offset[nshapes + 1]; n++) {
+    auto& node = nodes[n];
+    if (node.internal) node.start += (int32_t)b.node_offset[nshapes];
+    // TLAS leaf: start indexes tlas_prims directly
+  }
+  // per-instance traversal records
+  std::vector<DInstanceT> tinst(ctx->h_instances.size());
+  for (size_t k = 0; k < tinst.size(); k++) {
+    const auto& inst = ctx->h_instances[k];
+    ythost::inverse_frame_nonrigid(inst.frame, tinst[k].inv);
+    int s         = inst.shape;
+    tinst[k].root = (b.node_offset[s + 1] > b.node_offset[s]) ? (int)b.node_offset[s] : -1;
+    tinst[k].kind = ythost::kind_bvh(ctx->h_shapes[s]);
+    tinst[k].shape = s;
+    tinst[k].pad_  = 0;
+  }
+  int rc;
+  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.nodes, nodes.data(), nodes.size()))) return rc;
+  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.leafdata, leaf.data(), leaf.size()))) return rc;
+  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tlas_prims, b.prims.data() + b.prim_offset[nshapes],
+           (size_t)(b.prim_offset[nshapes + 1] - b.prim_offset[nshapes]))))
+    return rc;
+  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tinst, tinst.data(), tinst.size()))) return rc;
+  ctx->ds.tlas_root =
+      (b.node_offset[nshapes + 1] > b.node_offset[nshapes]) ? (int)b.node_offset[nshapes] : -1;
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
+  ctx->have_bvh = true;
+  return YTHIP_OK;
+}
+
+int upload_lights_impl(ythip_ctx* ctx) {
+  free_all(ctx->light_allocs);
+  auto&               L = ctx->h_lights;
+  std::vector<DLight> dl(L.lights.size());
+  for (size_t k = 0; k < dl.size(); k++)
+    dl[k] = {L.lights[k].instance, L.lights[k].environment, (int)L.lights[k].cdf_offset, L.lights[k].cdf_count};
+  int rc;
+  if ((rc = dupload(ctx, ctx->light_allocs, &ctx->ds.lights, dl.data(), dl.size()))) return rc;
+  if ((rc = dupload(ctx, ctx->light_allocs, &ctx->ds.cdf, L.cdf.data(), L.cdf.size()))) return rc;
+  ctx->ds.num_lights = (int)dl.size();
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_lights = true;
+  return YTHIP_OK;
+}
+
+template <int S>
+void launch_shade(ythip_ctx* ctx, const KParams& kp, int q, int grid) {
+  hipLaunchKernelGGL((k_shade<S, true>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, kp, q);
+}
+
+int launch_shade_any(ythip_ctx* ctx, const KParams& kp, int q, int grid) {
+  switch (kp.sampler) {
+    case YTHIP_SAMPLER_PATH: launch_shade<YTHIP_SAMPLER_PATH>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_PATHDIRECT: launch_shade<YTHIP_SAMPLER_PATHDIRECT>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_PATHMIS: launch_shade<YTHIP_SAMPLER_PATHMIS>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_PATHTEST: launch_shade<YTHIP_SAMPLER_PATHTEST>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_NAIVE: launch_shade<YTHIP_SAMPLER_NAIVE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_EYELIGHT: launch_shade<YTHIP_SAMPLER_EYELIGHT>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_DIAGRAM: launch_shade<YTHIP_SAMPLER_DIAGRAM>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_FURNACE: launch_shade<YTHIP_SAMPLER_FURNACE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_FALSECOLOR: launch_shade<YTHIP_SAMPLER_FALSECOLOR>(ctx, kp, q, grid); break;
+    default: return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
+  }
+  return YTHIP_OK;
+}
+
+// hipEvent bracketing of one launch (profiling mode bit 0)
+struct EvScope {
+  ythip_ctx* ctx;
+  int        idx = -1;
+  EvScope(ythip_ctx* c, int kind) : ctx(c) {
+    if (!(c->prof_mode & 1)) return;
+    if (c->ev_next == c->ev_pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      c->ev_pool.push_back({a, b});
+    }
+    idx = (int)c->ev_next++;
+    c->ev_used.push_back({idx, kind});
+    (void)hipEventRecord(c->ev_pool[idx].first, c->stream);
+  }
+  ~EvScope() {
+    if (idx >= 0) (void)hipEventRecord(ctx->ev_pool[idx].second, ctx->stream);
+  }
+};
+
+void harvest_events(ythip_ctx* ctx) {
+  for (auto [idx, kind] : ctx->ev_used) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev_pool[idx].first, ctx->ev_pool[idx].second) != hipSuccess) continue;
+    if (kind == 0) {
+      ctx->stats.extend_launches++;
+      ctx->stats.extend_ms += ms;
+    } else {
+      ctx->stats.shade_launches++;
+      ctx->stats.shade_ms += ms;
+    }
+  }
+  ctx->ev_used.clear();
+  ctx->ev_next = 0;
+}
+
+int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop) {
+  if (!ctx->have_scene || !ctx->have_bvh || !ctx->have_lights || !ctx->have_state)
+    return fail(ctx, YTHIP_ERR_STATE, "trace_samples needs scene, bvh, lights and state resident");
+  if (params->sampler < 0 || params->sampler > YTHIP_SAMPLER_FALSECOLOR)
+    return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
+  if (params->camera < 0 || params->camera >= ctx->num_cameras)
+    return fail(ctx, YTHIP_ERR_INVALID, "camera index %d out of range [0,%d)", params->camera, ctx->num_cameras);
+  if (ctx->samples >= params->samples) return YTHIP_OK;  // yocto_trace.cpp:1598
+
+  auto kp      = to_kparams(ctx, params);
+  bool count   = (ctx->prof_mode & 2) != 0;
+  ctx->st.counters = count ? ctx->d_counters : nullptr;
+  int  npix    = ctx->st.npix;
+  int  grid    = grid_for(npix);
+  bool mis     = params->sampler == YTHIP_SAMPLER_PATHMIS;
+  if (mis && !ctx->st.nhit_a) {
+    int rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->st.nhit_a, (size_t)npix))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->st.nhit_e, (size_t)npix))) return rc;
+  }
+  DState st_launch = ctx->st;
+  if (!mis) st_launch.nhit_a = nullptr;
+  ctx->st = st_launch;
+
+  int nb = params->bounces;
+  if (params->sampler == YTHIP_SAMPLER_EYELIGHT || params->sampler == YTHIP_SAMPLER_DIAGRAM)
+    nb = params->bounces > 4 ? params->bounces : 4;
+  if (params->sampler == YTHIP_SAMPLER_FALSECOLOR) nb = 1;
+
+  for (int s = 0; s < params->batch; s++) {
+    if (stop && *stop) {
+      HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+      return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
+    }
+    int sample = ctx->samples + s;
+    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, kp);
+    int q = 0;
+    for (int it = 0;; it++) {
+      if (it >= nb) {
+        // Only opacity retries (`bounce -= 1; continue`, yocto_trace.cpp:505-510)
+        // can keep paths alive past `bounces` iterations.
+        if (!ctx->may_retry || it >= nb + 130) break;
+        HIPCHECK(ctx, hipMemcpyAsync(ctx->h_qcount, ctx->st.qcount + q, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_qcount == 0) break;
+      }
+      {
+        EvScope ev(ctx, 0);
+        if (count)
+          hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, q);
+        else
+          hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, q);
+      }
+      {
+        EvScope ev(ctx, 1);
+        int     rc = launch_shade_any(ctx, kp, q, grid);
+        if (rc) return rc;
+      }
+      q ^= 1;
+    }
+    if (count)
+      hipLaunchKernelGGL((k_accumulate<true>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->st, kp, sample);
+    else
+      hipLaunchKernelGGL((k_accumulate<false>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->st, kp, sample);
+  }
+  HIPCHECK(ctx, hipGetLastError());
+  ctx->samples += params->batch;  // yocto_trace.cpp:1614
+  return YTHIP_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int ythip_create(int device, ythip_ctx** out) {
+  if (!out) return fail(nullptr, YTHIP_ERR_INVALID, "out is null");
+  *out       = nullptr;
+  int ndev   = 0;
+  auto e     = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, YTHIP_ERR_HIP, "no HIP device available (%s): libythip has no CPU fallback",
+        hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(nullptr, YTHIP_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+  auto ctx    = new ythip_ctx{};
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, YTHIP_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
+  }
+  ctx->stream = ctx->own_stream;
+  if (hipMalloc((void**)&ctx->d_counters, CNT_NUM * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->h_qcount, 64) != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, YTHIP_ERR_HIP, "context allocation failed");
+  }
+  *out = ctx;
+  return YTHIP_OK;
+}
+
+void ythip_destroy(ythip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_all(ctx->scene_allocs);
+  free_all(ctx->bvh_allocs);
+  free_all(ctx->light_allocs);
+  free_all(ctx->state_allocs);
+  for (auto& ev : ctx->ev_pool) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->h_qcount) (void)hipHostFree(ctx->h_qcount);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* ythip_last_error(const ythip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_error.c_str(); }
+
+int ythip_set_stream(ythip_ctx* ctx, void* hip_stream) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return YTHIP_OK;
+}
+
+int ythip_sync(ythip_ctx* ctx) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  harvest_events(ctx);
+  return YTHIP_OK;
+}
+
+int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* sc) {
+  if (!ctx || !sc) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  // validation (the reference would index out of bounds)
+  for (int k = 0; k < sc->num_instances; k++) {
+    auto& i = sc->instances[k];
+    if (i.shape < 0 || i.shape >= sc->num_shapes || i.material < 0 || i.material >= sc->num_materials)
+      return fail(ctx, YTHIP_ERR_INVALID, "instance %d references shape %d / material %d out of range", k, i.shape, i.material);
+  }
+  if (sc->num_positions > 0x7fffffffll / 4 || sc->num_triangles > 0x7fffffffll / 4 ||
+      sc->num_quads > 0x7fffffffll / 4 || sc->num_lines > 0x7fffffffll / 4)
+    return fail(ctx, YTHIP_ERR_INVALID, "scene pools exceed 32-bit device indexing");
+  free_all(ctx->scene_allocs);
+  ctx->have_scene = ctx->have_bvh = ctx->have_lights = false;
+  auto& ds = ctx->ds;
+  ds       = DScene{};
+  int rc;
+#define UP(field, src, count) \
+  if ((rc = dupload(ctx, ctx->scene_allocs, &ds.field, src, (size_t)(count)))) return rc;
+  UP(cameras, sc->cameras, sc->num_cameras);
+  UP(instances, sc->instances, sc->num_instances);
+  UP(environments, sc->environments, sc->num_environments);
+  UP(materials, sc->materials, sc->num_materials);
+  UP(textures, sc->textures, sc->num_textures);
+  UP(points, sc->points, sc->num_points);
+  UP(lines, sc->lines, sc->num_lines * 2);
+  UP(triangles, sc->triangles, sc->num_triangles * 3);
+  UP(quads, sc->quads, sc->num_quads * 4);
+  UP(positions, sc->positions, sc->num_positions * 3);
+  UP(normals, sc->normals, sc->num_normals * 3);
+  UP(texcoords, sc->texcoords, sc->num_texcoords * 2);
+  UP(colors, sc->colors, sc->num_colors * 4);
+  UP(radius, sc->radius, sc->num_radius);
+  UP(pixelsf, sc->pixelsf, sc->num_pixelsf * 4);
+  UP(pixelsb, sc->pixelsb, sc->num_pixelsb * 4);
+  std::vector<DShape> shapes(sc->num_shapes);
+  for (int k = 0; k < sc->num_shapes; k++) {
+    auto& s  = sc->shapes[k];
+    auto& d  = shapes[k];
+    d        = DShape{};
+    d.kind_bvh  = ythost::kind_bvh(s);
+    d.kind_eval = ythost::kind_eval(s);
+    auto off    = [&](int kind) -> int {
+      switch (kind) {
+        case KIND_POINTS: return (int)s.points_offset;
+        case KIND_LINES: return (int)s.lines_offset;
+        case KIND_TRIANGLES: return (int)s.triangles_offset;
+        case KIND_QUADS: return (int)s.quads_offset;
+        default: return 0;
+      }
+    };
+    d.elem_bvh  = off(d.kind_bvh);
+    d.elem_eval = off(d.kind_eval);
+    d.positions = (int)s.positions_offset;
+    d.normals   = s.num_normals ? (int)s.normals_offset : -1;
+    d.texcoords = s.num_texcoords ? (int)s.texcoords_offset : -1;
+    d.colors    = s.num_colors ? (int)s.colors_offset : -1;
+    d.radius    = s.num_radius ? (int)s.radius_offset : -1;
+  }
+  UP(shapes, shapes.data(), shapes.size());
+  std::vector<float> env_inv((size_t)sc->num_environments * 12);
+  for (int k = 0; k < sc->num_environments; k++)
+    ythost::inverse_frame_rigid(sc->environments[k].frame, env_inv.data() + 12 * k);
+  UP(env_inv, env_inv.data(), env_inv.size());
+#undef UP
+  ctx->num_cameras    = sc->num_cameras;
+  ds.num_instances    = sc->num_instances;
+  ds.num_environments = sc->num_environments;
+  ds.num_shapes       = sc->num_shapes;
+  ds.num_materials    = sc->num_materials;
+  ds.num_textures     = sc->num_textures;
+  // host copies for BVH baking
+  ctx->h_shapes.assign(sc->shapes, sc->shapes + sc->num_shapes);
+  ctx->h_instances.assign(sc->instances, sc->instances + sc->num_instances);
+  ctx->h_points.assign(sc->points, sc->points + sc->num_points);
+  ctx->h_lines.assign(sc->lines, sc->lines + sc->num_lines * 2);
+  ctx->h_triangles.assign(sc->triangles, sc->triangles + sc->num_triangles * 3);
+  ctx->h_quads.assign(sc->quads, sc->quads + sc->num_quads * 4);
+  ctx->h_positions.assign(sc->positions, sc->positions + sc->num_positions * 3);
+  ctx->h_radius.assign(sc->radius, sc->radius + sc->num_radius);
+  ctx->may_retry = false;
+  for (int k = 0; k < sc->num_materials; k++)
+    if (sc->materials[k].opacity < 1 || sc->materials[k].color_tex != YTHIP_INVALIDID) ctx->may_retry = true;
+  for (int k = 0; k < sc->num_shapes; k++)
+    if (sc->shapes[k].num_colors) ctx->may_retry = true;
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_scene = true;
+  return YTHIP_OK;
+}
+
+int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* sc, int highquality) {
+  if (!ctx || !sc) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  ctx->h_bvh = ythost::make_scene_bvh(*sc, highquality != 0);
+  return bake_bvh(ctx);
+}
+
+int ythip_upload_bvh(ythip_ctx* ctx, const ythip_bvh* bvh) {
+  if (!ctx || !bvh) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  auto& b = ctx->h_bvh;
+  int   n = bvh->num_trees;
+  b.node_offset.assign(bvh->node_offset, bvh->node_offset + n + 1);
+  b.prim_offset.assign(bvh->prim_offset, bvh->prim_offset + n + 1);
+  b.nodes.assign(bvh->nodes, bvh->nodes + b.node_offset[n]);
+  b.prims.assign(bvh->primitives, bvh->primitives + b.prim_offset[n]);
+  return bake_bvh(ctx);
+}
+
+int ythip_bvh_sizes(ythip_ctx* ctx, int32_t* num_trees, int64_t* num_nodes, int64_t* num_prims) {
+  if (!ctx || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "no bvh resident");
+  *num_trees = (int32_t)ctx->h_bvh.node_offset.size() - 1;
+  *num_nodes = (int64_t)ctx->h_bvh.nodes.size();
+  *num_prims = (int64_t)ctx->h_bvh.prims.size();
+  return YTHIP_OK;
+}
+
+int ythip_bvh_download(ythip_ctx* ctx, int64_t* node_offset, int64_t* prim_offset, ythip_bvh_node* nodes,
+    int32_t* primitives) {
+  if (!ctx || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "no bvh resident");
+  auto& b = ctx->h_bvh;
+  std::memcpy(node_offset, b.node_offset.data(), b.node_offset.size() * sizeof(int64_t));
+  std::memcpy(prim_offset, b.prim_offset.data(), b.prim_offset.size() * sizeof(int64_t));
+  if (nodes && !b.nodes.empty()) std::memcpy(nodes, b.nodes.data(), b.nodes.size() * sizeof(ythip_bvh_node));
+  if (primitives && !b.prims.empty()) std::memcpy(primitives, b.prims.data(), b.prims.size() * sizeof(int32_t));
+  return YTHIP_OK;
+}
+
+int ythip_host_bvh_build(const ythip_scene* sc, int highquality, ythip_hostbvh** out) {
+  if (!sc || !out) return fail(nullptr, YTHIP_ERR_INVALID, "null argument");
+  auto b = new ythost::flat_bvh(ythost::make_scene_bvh(*sc, highquality != 0));
+  *out   = reinterpret_cast<ythip_hostbvh*>(b);
+  return YTHIP_OK;
+}
+int ythip_host_bvh_view(const ythip_hostbvh* bvh, ythip_bvh* view) {
+  if (!bvh || !view) return YTHIP_ERR_INVALID;
+  auto b            = reinterpret_cast<const ythost::flat_bvh*>(bvh);
+  view->num_trees   = (int)b->node_offset.size() - 1;
+  view->node_offset = b->node_offset.data();
+  view->prim_offset = b->prim_offset.data();
+  view->nodes       = b->nodes.data();
+  view->primitives  = b->prims.data();
+  return YTHIP_OK;
+}
+void ythip_host_bvh_free(ythip_hostbvh* bvh) { delete reinterpret_cast<ythost::flat_bvh*>(bvh); }
+
+int ythip_host_lights_build(const ythip_scene* sc, ythip_hostlights** out) {
+  if (!sc || !out) return fail(nullptr, YTHIP_ERR_INVALID, "null argument");
+  auto l = new ythost::flat_lights(ythost::make_trace_lights(*sc));
+  *out   = reinterpret_cast<ythip_hostlights*>(l);
+  return YTHIP_OK;
+}
+int ythip_host_lights_view(const ythip_hostlights* lights, ythip_lights* view) {
+  if (!lights || !view) return YTHIP_ERR_INVALID;
+  auto l           = reinterpret_cast<const ythost::flat_lights*>(lights);
+  view->num_lights = (int)l->lights.size();
+  view->lights     = l->lights.data();
+  view->num_cdf    = (int64_t)l->cdf.size();
+  view->cdf        = l->cdf.data();
+  return YTHIP_OK;
+}
+void ythip_host_lights_free(ythip_hostlights* lights) { delete reinterpret_cast<ythost::flat_lights*>(lights); }
+
+int ythip_build_lights(ythip_ctx* ctx, const ythip_scene* sc) {
+  if (!ctx || !sc) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  ctx->h_lights = ythost::make_trace_lights(*sc);
+  return upload_lights_impl(ctx);
+}
+
+int ythip_upload_lights(ythip_ctx* ctx, const ythip_lights* lights) {
+  if (!ctx || !lights) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  ctx->h_lights.lights.assign(lights->lights, lights->lights + lights->num_lights);
+  ctx->h_lights.cdf.assign(lights->cdf, lights->cdf + lights->num_cdf);
+  return upload_lights_impl(ctx);
+}
+
+int ythip_lights_sizes(ythip_ctx* ctx, int32_t* num_lights, int64_t* num_cdf) {
+  if (!ctx || !ctx->have_lights) return fail(ctx, YTHIP_ERR_STATE, "no lights resident");
+  *num_lights = (int32_t)ctx->h_lights.lights.size();
+  *num_cdf    = (int64_t)ctx->h_lights.cdf.size();
+  return YTHIP_OK;
+}
+
+int ythip_lights_download(ythip_ctx* ctx, ythip_light* lights, float* cdf) {
+  if (!ctx || !ctx->have_lights) return fail(ctx, YTHIP_ERR_STATE, "no lights resident");
+  auto& L = ctx->h_lights;
+  if (lights && !L.lights.empty()) std::memcpy(lights, L.lights.data(), L.lights.size() * sizeof(ythip_light));
+  if (cdf && !L.cdf.empty()) std::memcpy(cdf, L.cdf.data(), L.cdf.size() * sizeof(float));
+  return YTHIP_OK;
+}
+
+// make_trace_state size rule — yocto_trace.cpp:1499-1505
+int ythip_state_size(const ythip_camera* camera, int resolution, int* width, int* height) {
+  if (!camera || !width || !height) return YTHIP_ERR_INVALID;
+  if (camera->aspect >= 1) {
+    *width  = resolution;
+    *height = (int)std::round(resolution / camera->aspect);
+  } else {
+    *height = resolution;
+    *width  = (int)std::round(resolution * camera->aspect);
+  }
+  return YTHIP_OK;
+}
+
+int ythip_make_rngs(uint64_t seed, int64_t n, uint64_t* rngs) {
+  if (!rngs || n < 0) return YTHIP_ERR_INVALID;
+  ythost::make_rngs(seed, n, rngs);
+  return YTHIP_OK;
+}
+
+int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int row_end) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  if (width <= 0 || height <= 0 || row_begin < 0 || row_end > height || row_begin >= row_end)
+    return fail(ctx, YTHIP_ERR_INVALID, "bad state geometry %dx%d rows [%d,%d)", width, height, row_begin, row_end);
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  free_all(ctx->state_allocs);
+  ctx->have_state  = false;
+  ctx->state_bound = false;
+  auto& st         = ctx->st;
+  st               = DState{};
+  st.width         = width;
+  st.height        = height;
+  st.row_begin     = row_begin;
+  st.rows          = row_end - row_begin;
+  long long npix   = (long long)width * st.rows;
+  if (npix > 0x7fffffffll / 4) return fail(ctx, YTHIP_ERR_INVALID, "state too large");
+  st.npix = (int)npix;
+  size_t n = (size_t)npix;
+  int    rc;
+#define AL(field, count) \
+  if ((rc = dalloc(ctx, ctx->state_allocs, &st.field, (size_t)(count)))) return rc;
+  AL(image, n);
+  AL(albedo, 3 * n);
+  AL(normal, 3 * n);
+  AL(hits, n);
+  AL(rngs, n);
+  AL(ray_a, n);
+  AL(ray_b, n);
+  AL(hit_a, n);
+  AL(hit_e, n);
+  AL(wgt, n);
+  AL(rad, n);
+  AL(first_a, n);
+  AL(first_b, n);
+  AL(vol_a, n);
+  AL(vol_b, n);
+  AL(queue[0], n);
+  AL(queue[1], n);
+  AL(qcount, 2);
+#undef AL
+  HIPCHECK(ctx, hipMemsetAsync(st.image, 0, n * sizeof(float4), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(st.albedo, 0, 3 * n * sizeof(float), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(st.normal, 0, 3 * n * sizeof(float), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(st.hits, 0, n * sizeof(int), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(st.rngs, 0, n * sizeof(ulonglong2), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(st.qcount, 0, 2 * sizeof(int), ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->samples    = 0;
+  ctx->have_state = true;
+  return YTHIP_OK;
+}
+
+int ythip_state_upload(ythip_ctx* ctx, const float* image, const float* albedo, const float* normal,
+    const int32_t* hits, const uint64_t* rngs, int samples) {
+  if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  size_t n = (size_t)ctx->st.npix;
+  if (image) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.image, image, n * 16, hipMemcpyHostToDevice, ctx->stream));
+  if (albedo) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.albedo, albedo, n * 12, hipMemcpyHostToDevice, ctx->stream));
+  if (normal) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.normal, normal, n * 12, hipMemcpyHostToDevice, ctx->stream));
+  if (hits) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.hits, hits, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (rngs) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.rngs, rngs, n * 16, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->samples = samples;
+  return YTHIP_OK;
+}
+
+int ythip_state_download(ythip_ctx* ctx, float* image, float* albedo, float* normal, int32_t* hits,
+    uint64_t* rngs, int* samples) {
+  if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  size_t n = (size_t)ctx->st.npix;
+  if (image) HIPCHECK(ctx, hipMemcpyAsync(image, ctx->st.image, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (albedo) HIPCHECK(ctx, hipMemcpyAsync(albedo, ctx->st.albedo, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  if (normal) HIPCHECK(ctx, hipMemcpyAsync(normal, ctx->st.normal, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  if (hits) HIPCHECK(ctx, hipMemcpyAsync(hits, ctx->st.hits, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (rngs) HIPCHECK(ctx, hipMemcpyAsync(rngs, ctx->st.rngs, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (samples) *samples = ctx->samples;
+  return YTHIP_OK;
+}
+
+int ythip_state_bind_device(ythip_ctx* ctx, void* image, void* albedo, void* normal, void* hits, void* rngs) {
+  if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  if (!image || !albedo || !normal || !hits || !rngs) return fail(ctx, YTHIP_ERR_INVALID, "null device pointer");
+  ctx->st.image    = (float4*)image;
+  ctx->st.albedo   = (float*)albedo;
+  ctx->st.normal   = (float*)normal;
+  ctx->st.hits     = (int*)hits;
+  ctx->st.rngs     = (ulonglong2*)rngs;
+  ctx->state_bound = true;
+  return YTHIP_OK;
+}
+
+int ythip_state_set_samples(ythip_ctx* ctx, int samples) {
+  if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  ctx->samples = samples;
+  return YTHIP_OK;
+}
+
+int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop) {
+  if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  int rc = enqueue_samples(ctx, params, stop);
+  if (rc) return rc;
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  harvest_events(ctx);
+  return YTHIP_OK;
+}
+
+int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params) {
+  if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  return enqueue_samples(ctx, params, nullptr);
+}
+
+static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_ray* rays, int64_t n,
+    int find_any, ythip_hit* hits) {
+  if (!ctx || (n > 0 && (!rays || !hits))) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "scene and bvh must be resident");
+  if (n == 0) return YTHIP_OK;
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  if (instances)
+    for (int64_t k = 0; k < n; k++)
+      if (instances[k] < 0 || instances[k] >= ctx->ds.num_instances)
+        return fail(ctx, YTHIP_ERR_INVALID, "instance id %d out of range", instances[k]);
+  ythip_ray* d_rays = nullptr;
+  ythip_hit* d_hits = nullptr;
+  int*       d_inst = nullptr;
+  std::vector<void*> tmp;
+  int                rc;
+  if ((rc = dalloc(ctx, tmp, &d_rays, (size_t)n)) || (rc = dalloc(ctx, tmp, &d_hits, (size_t)n)) ||
+      (instances && (rc = dalloc(ctx, tmp, &d_inst, (size_t)n)))) {
+    free_all(tmp);
+    return rc;
+  }
+  auto cleanup = [&](int code) {
+    free_all(tmp);
+    return code;
+  };
+  if (hipMemcpyAsync(d_rays, rays, n * sizeof(ythip_ray), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    return cleanup(fail(ctx, YTHIP_ERR_HIP, "ray upload failed"));
+  if (instances &&
+      hipMemcpyAsync(d_inst, instances, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    return cleanup(fail(ctx, YTHIP_ERR_HIP, "instance upload failed"));
+  bool count = (ctx->prof_mode & 2) != 0;
+  if (count)
+    hipLaunchKernelGGL((k_intersect_batch<true>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
+        d_rays, d_inst, (long long)n, find_any, d_hits, ctx->d_counters);
+  else
+    hipLaunchKernelGGL((k_intersect_batch<false>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
+        d_rays, d_inst, (long long)n, find_any, d_hits, (unsigned long long*)nullptr);
+  if (hipMemcpyAsync(hits, d_hits, n * sizeof(ythip_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return cleanup(fail(ctx, YTHIP_ERR_HIP, "intersect batch failed: %s", hipGetErrorString(hipGetLastError())));
+  return cleanup(YTHIP_OK);
+}
+
+int ythip_intersect_batch(ythip_ctx* ctx, const ythip_ray* rays, int64_t n, int find_any, ythip_hit* hits) {
+  return intersect_impl(ctx, nullptr, rays, n, find_any, hits);
+}
+int ythip_intersect_instance_batch(ythip_ctx* ctx, const int32_t* instances, const ythip_ray* rays, int64_t n,
+    int find_any, ythip_hit* hits) {
+  if (!instances && n > 0) return fail(ctx, YTHIP_ERR_INVALID, "null instances");
+  return intersect_impl(ctx, instances, rays, n, find_any, hits);
+}
+
+int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params, ythip_ray* rays) {
+  if (!ctx || !params || !rays) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "scene and state must be resident");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  ythip_ray*         d_rays = nullptr;
+  std::vector<void*> tmp;
+  int                rc = dalloc(ctx, tmp, &d_rays, (size_t)ctx->st.npix);
+  if (rc) return rc;
+  auto kp = to_kparams(ctx, params);
+  hipLaunchKernelGGL(k_camera_rays, dim3(grid_for(ctx->st.npix)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st,
+      kp, d_rays);
+  auto e1 = hipMemcpyAsync(rays, d_rays, (size_t)ctx->st.npix * sizeof(ythip_ray), hipMemcpyDeviceToHost, ctx->stream);
+  auto e2 = hipStreamSynchronize(ctx->stream);
+  free_all(tmp);
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "camera_rays failed");
+  return YTHIP_OK;
+}
+
+int ythip_set_profiling(ythip_ctx* ctx, int mode) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  ctx->prof_mode = mode;
+  return YTHIP_OK;
+}
+
+int ythip_reset_stats(ythip_ctx* ctx) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  harvest_events(ctx);
+  ctx->stats = ythip_stats{};
+  HIPCHECK(ctx, hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long)));
+  return YTHIP_OK;
+}
+
+int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
+  if (!ctx || !stats) return YTHIP_ERR_INVALID;
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  harvest_events(ctx);
+  unsigned long long c[CNT_NUM];
+  HIPCHECK(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  *stats           = ctx->stats;
+  stats->rays      = (int64_t)c[CNT_RAYS];
+  stats->nodes     = (int64_t)c[CNT_NODES];
+  stats->triangles = (int64_t)c[CNT_TRIS];
+  stats->quads     = (int64_t)c[CNT_QUADS];
+  stats->lines     = (int64_t)c[CNT_LINES];
+  stats->points    = (int64_t)c[CNT_POINTS];
+  stats->instances = (int64_t)c[CNT_INST];
+  stats->shades    = (int64_t)c[CNT_SHADES];
+  stats->samples   = (int64_t)c[CNT_SAMPLES];
+  return YTHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""Synthetic scene generators (host side, numpy float32) for the BASELINE.json
+configs and the parity tests.  They restate the few reference generators the
+configs are defined with, in float32 with the reference's operation order, so
+that e.g. the 1M-triangle plane is bit-identical to
+`make_recty({1000,500},{10,10})` + `quads_to_triangles` (checked in
+tests/test_host.py against the compiled reference).
+
+  make_quads / make_rect / make_recty   libs/yocto/yocto_shape.cpp:546-627
+  quads_to_triangles                    libs/yocto/yocto_shape.cpp:2535-2543
+  make_uvsphere                         libs/yocto/yocto_shape.cpp:783-796
+  lookat_frame                          libs/yocto/yocto_math.h:2348-2358
+"""
+import numpy as np
+
+from ythip import FlatScene, IDENTITY_FRAME
+
+f32 = np.float32
+
+
+def _normalize(v):
+    v = np.asarray(v, f32)
+    l = np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2], dtype=f32)
+    return (v / l).astype(f32) if l != 0 else v
+
+
+def _cross(a, b):
+    return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2],
+                     a[0] * b[1] - a[1] * b[0]], f32)
+
+
+def lookat_frame(eye, center, up=(0, 1, 0)):
+    eye, center, up = (np.asarray(x, f32) for x in (eye, center, up))
+    w = _normalize(eye - center)
+    u = _normalize(_cross(up, w))
+    v = _normalize(_cross(w, u))
+    return np.concatenate([u, v, w, eye]).astype(f32)
+
+
+def make_quads(steps, scale, uvscale=(1, 1)):
+    sx, sy = int(steps[0]), int(steps[1])
+    i = np.arange(sx + 1, dtype=f32)
+    j = np.arange(sy + 1, dtype=f32)
+    u = (i / f32(sx)).astype(f32)
+    v = (j / f32(sy)).astype(f32)
+    uu, vv = np.meshgrid(u, v)  # [sy+1, sx+1], index j*(sx+1)+i
+    px = ((f32(2) * uu - f32(1)) * f32(scale[0])).astype(f32)
+    py = ((f32(2) * vv - f32(1)) * f32(scale[1])).astype(f32)
+    positions = np.stack([px, py, np.zeros_like(px)], -1).reshape(-1, 3)
+    normals = np.tile(np.array([0, 0, 1], f32), (len(positions), 1))
+    texcoords = np.stack([uu * f32(uvscale[0]), (f32(1) - vv) * f32(uvscale[1])],
+                         -1).reshape(-1, 2).astype(f32)
+    ii, jj = np.meshgrid(np.arange(sx, dtype=np.int32), np.arange(sy, dtype=np.int32))
+    a = jj * (sx + 1) + ii
+    quads = np.stack([a, a + 1, a + (sx + 1) + 1, a + (sx + 1)], -1).reshape(-1, 4)
+    return dict(positions=positions, normals=normals, texcoords=texcoords,
+                quads=quads.astype(np.int32))
+
+
+def make_rect(steps, scale, uvscale=(1, 1)):
+    return make_quads(steps, scale, uvscale)
+
+
+def make_recty(steps, scale, uvscale=(1, 1)):
+    s = make_quads(steps, scale, uvscale)
+    p, n = s["positions"], s["normals"]
+    s["positions"] = np.stack([p[:, 0], p[:, 2], -p[:, 1]], -1).astype(f32)
+    s["normals"] = np.stack([n[:, 0], n[:, 2], n[:, 1]], -1).astype(f32)
+    return s
+
+
+def quads_to_triangles(quads):
+    q = np.asarray(quads, np.int32)
+    t1 = q[:, [0, 1, 3]]
+    t2 = q[:, [2, 3, 1]]
+    keep = q[:, 2] != q[:, 3]
+    out = np.empty((len(q) * 2, 3), np.int32)
+    out[0::2] = t1
+    out[1::2] = t2
+    mask = np.ones(len(q) * 2, bool)
+    mask[1::2] = keep
+    return out[mask]
+
+
+def triangulated(shape):
+    s = dict(shape)
+    s["triangles"] = quads_to_triangles(s.pop("quads"))
+    return s
+
+
+def make_uvsphere(steps, scale):
+    s = make_quads(steps, (1, 1))
+    uv = s["texcoords"]
+    ax = (f32(2) * f32(np.pi) * uv[:, 0]).astype(f32)
+    ay = (f32(np.pi) * (f32(1) - uv[:, 1])).astype(f32)
+    p = np.stack([np.cos(ax) * np.sin(ay), np.sin(ax) * np.sin(ay), np.cos(ay)],
+                 -1).astype(f32) * f32(scale)
+    n = p / np.linalg.norm(p, axis=1, keepdims=True)
+    s["positions"], s["normals"] = p.astype(f32), n.astype(f32)
+    return s
+
+
+def add_shape(scene, shape):
+    return scene.add_shape(shape["positions"], triangles=shape.get("triangles"),
+                           quads=shape.get("quads"), lines=shape.get("lines"),
+                           points=shape.get("points"), normals=shape.get("normals"),
+                           texcoords=shape.get("texcoords"), colors=shape.get("colors"),
+                           radius=shape.get("radius"))
+
+
+# ----------------------------------------------------------------------------
+# BASELINE.json configs (SURVEY.md §8d recipes)
+# ----------------------------------------------------------------------------
+def plane_scene(steps=(1000, 500), scale=(10, 10)):
+    """cfg2: make_recty(steps, scale) triangulated (1,000,000 triangles at the
+    default steps), matte 0.7, identity instance, constant white environment,
+    16:9 camera at (0,3,8) looking at the origin."""
+    sc = FlatScene()
+    eye, center = (0, 3, 8), (0, 0, 0)
+    focus = float(np.sqrt(f32(0 * 0 + 3 * 3 + 8 * 8), dtype=f32))
+    sc.add_camera(lookat_frame(eye, center), lens=0.035, film=0.036, aspect=16 / 9,
+                  focus=focus, aperture=0.0)
+    sh = add_shape(sc, triangulated(make_recty(steps, scale)))
+    m = sc.add_material("matte", color=(0.7, 0.7, 0.7))
+    sc.add_instance(sh, m)
+    sc.add_environment((1, 1, 1))
+    return sc
+
+
+def instanced_scene(grid=100, sphere_steps=(32, 16), radius=0.04):
+    """cfg4: grid x grid instances of one triangulated uv-sphere (1024 triangles
+    at 32x16) on a 0.1-spaced lattice, same environment / camera as cfg2."""
+    sc = FlatScene()
+    focus = float(np.sqrt(f32(73), dtype=f32))
+    sc.add_camera(lookat_frame((0, 3, 8), (0, 0, 0)), lens=0.035, film=0.036,
+                  aspect=16 / 9, focus=focus, aperture=0.0)
+    sh = add_shape(sc, triangulated(make_uvsphere(sphere_steps, radius)))
+    m = sc.add_material("matte", color=(0.7, 0.7, 0.7))
+    k = np.arange(grid * grid)
+    frames = np.tile(IDENTITY_FRAME, (grid * grid, 1))
+    frames[:, 9] = ((k % grid - grid // 2) * 0.1).astype(f32)
+    frames[:, 10] = f32(radius)
+    frames[:, 11] = ((k // grid - grid // 2) * 0.1).astype(f32)
+    sc.add_instances(frames, sh, m)
+    sc.add_environment((1, 1, 1))
+    return sc

@@ -400,6 +400,13 @@ _SIGNATURES = {
     "ythip_bvh_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ythip_bvh_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
+    "ythip_host_bvh_build": (C.c_int, [C.POINTER(CScene), C.c_int,
+                                       C.POINTER(C.c_void_p)]),
+    "ythip_host_bvh_view": (C.c_int, [C.c_void_p, C.POINTER(CBvh)]),
+    "ythip_host_bvh_free": (None, [C.c_void_p]),
+    "ythip_host_lights_build": (C.c_int, [C.POINTER(CScene), C.POINTER(C.c_void_p)]),
+    "ythip_host_lights_view": (C.c_int, [C.c_void_p, C.POINTER(CLights)]),
+    "ythip_host_lights_free": (None, [C.c_void_p]),
     "ythip_build_lights": (C.c_int, [C.c_void_p, C.POINTER(CScene)]),
     "ythip_upload_lights": (C.c_int, [C.c_void_p, C.POINTER(CLights)]),
     "ythip_lights_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
@@ -467,6 +474,34 @@ def make_rngs(seed, n):
     out = np.zeros((n, 2), "u8")
     if lib.ythip_make_rngs(seed, n, out.ctypes.data):
         raise YthipError("ythip_make_rngs failed")
+    return out
+
+
+def host_make_bvh(scene, highquality=False):
+    """make_scene_bvh (yocto_bvh.cpp:364-396) on the host, no GPU needed."""
+    lib = load_library()
+    cs = scene.c_struct()
+    h = C.c_void_p()
+    if lib.ythip_host_bvh_build(C.byref(cs), int(highquality), C.byref(h)):
+        raise YthipError("ythip_host_bvh_build failed")
+    cb = CBvh()
+    lib.ythip_host_bvh_view(h, C.byref(cb))
+    out = FlatBvh.from_c(cb)
+    lib.ythip_host_bvh_free(h)
+    return out
+
+
+def host_make_lights(scene):
+    """make_trace_lights (yocto_trace.cpp:1528-1581) on the host, no GPU needed."""
+    lib = load_library()
+    cs = scene.c_struct()
+    h = C.c_void_p()
+    if lib.ythip_host_lights_build(C.byref(cs), C.byref(h)):
+        raise YthipError("ythip_host_lights_build failed")
+    cl = CLights()
+    lib.ythip_host_lights_view(h, C.byref(cl))
+    out = FlatLights.from_c(cl)
+    lib.ythip_host_lights_free(h)
     return out
 
 
