@@ -638,11 +638,14 @@ template <bool COUNT>
 __global__ void __launch_bounds__(YT_BLOCK) k_extend(DScene sc, DState st, int q) {
   __shared__ int s_stack[YT_LDS_DEPTH][YT_BLOCK];
   int            idx = blockIdx.x * YT_BLOCK + threadIdx.x;
+  // The other queue was fully consumed by the previous k_shade: reset its counter
+  // before this iteration's k_shade appends to it (must happen even when the
+  // live queue is empty, or a stale count would resurrect dead paths).
+  if (idx == 0) st.qcount[q ^ 1] = 0;
   if (idx >= st.qcount[q]) return;
   int    slot = st.queue[q][idx];
   float4 a = st.ray_a[slot], b = st.ray_b[slot];
   int    flags = __float_as_int(b.w);
-  if (idx == 0) st.qcount[q ^ 1] = 0;  // the other queue was fully consumed by the previous k_shade
   if (flags & PF_SKIPEXTEND) {         // pathmis: intersection = next_intersection
     st.hit_a[slot] = st.nhit_a[slot];
     st.hit_e[slot] = st.nhit_e[slot];
