@@ -206,6 +206,8 @@ typedef struct ythip_stats {
   double  extend_ms;
   int64_t shade_launches;
   double  shade_ms;
+  int64_t lightpdf_launches; /* k_lightpdf (deferred area-light pdf walks) */
+  double  lightpdf_ms;
   /* traversal work counters (valid after a run with counting enabled) */
   int64_t rays;        /* intersect_scene_bvh calls        (yocto_bvh.cpp:554) */
   int64_t nodes;       /* BVH node pops, TLAS+BLAS         (:487,:581)         */

@@ -1,8 +1,29 @@
-// yt_kernels.h — the wavefront (streaming) path tracer: SoA path state in HBM,
-// one live path per pixel, and per bounce two kernels over the compacted queue
-// of live paths:  k_extend (BVH traversal)  →  k_shade (one iteration of the
-// integrator loop body, wave-ballot compaction of survivors into the next
-// queue).  k_generate / k_accumulate are the head and tail of trace_sample.
+// yt_kernels.h — the wavefront (streaming) path tracer.
+//
+// One persistent path slot per pixel, SoA path state in HBM.  Per iteration:
+//
+//   k_extend    BVH traversal of every queued ray (the traversal kernel)
+//   k_shade     ONE iteration of the integrator's bounce-loop body for every
+//               queued path.  A path that ends is accumulated into the image
+//               right there (tail of trace_sample) and, if its pixel still owes
+//               samples to this batch, REGENERATED with the pixel's next camera
+//               ray (head of trace_sample).  Samples of one pixel stay strictly
+//               sequential (the per-pixel PCG stream and the running-mean lerp
+//               are order-dependent), pixels are independent.
+//   k_lightpdf  only for scenes with area lights: the nested instance walks of
+//               sample_lights_pdf (up to 100 per light), deferred out of k_shade
+//               so that kernel carries no traversal, then the rest of the loop
+//               body (weight update, termination tests, russian roulette).
+//
+// Compaction is BLOCK-LOCAL and atomic-free: workgroup b owns the 256 pixel
+// slots [256 b, 256 b + 256) for the whole batch and, after every iteration,
+// partitions them (wave ballots + an LDS prefix over its 4 waves) into its own
+// double-ended queue segment: regenerated (primary) rays from the front,
+// continuing (bounce) rays from the back, dead slots dropped.  Waves of the next
+// k_extend therefore stay homogeneous (primary rays of neighbouring pixels /
+// bounce rays), there is no global counter to contend on (one device-scope
+// atomic word saturates at ~88 ops/us on MI355X — measured 280 us per launch
+// with per-wave atomics), and the order is deterministic.
 //
 // Restates libs/yocto/yocto_trace.cpp:338-1492 (sample_camera, sample_lights,
 // sample_lights_pdf, the nine integrators, trace_sample).  The rng draw order at
@@ -24,9 +45,18 @@ enum {
   PF_INVOL      = 16,  // furnace: in_volume
 };
 
+// How sample_lights_pdf's instance walks are executed
+enum {
+  LP_NONE   = 0,  // scene has no area lights: no traversal needed
+  LP_INLINE = 1,  // walks (and NEE rays) inline in k_shade   (pathdirect / pathmis)
+  LP_DEFER  = 2,  // walks deferred to k_lightpdf             (path / pathtest with area lights)
+};
+
 // Device mirror of trace_state (yocto_trace.h:147-157) + wavefront path state.
 struct DState {
   int width, height, row_begin, rows, npix;
+  int sample_base;  // state.samples at the start of this batch
+  int batch;        // samples to add per pixel in this batch
   // trace_state
   float4*     image;   // vec4f
   float*      albedo;  // vec3f
@@ -39,16 +69,20 @@ struct DState {
   float4* hit_a;    // u, v, distance, instance (-1 = miss)
   int*    hit_e;    // element
   float4* wgt;      // weight.xyz, max_roughness
-  float4* rad;      // radiance.xyz, -
+  float4* rad;      // radiance.xyz, samples done in this batch (int)
   float4* first_a;  // hit_albedo.xyz, hit_normal.x
   float2* first_b;  // hit_normal.yz          (before the first hit: -camera_ray.d)
   float4* vol_a;    // volume: density.xyz, scattering.x
   float4* vol_b;    // volume: scattering.yz, scanisotropy, -
   float4* nhit_a;   // pathmis next_intersection: u, v, distance, instance
   int*    nhit_e;   // pathmis next_intersection: element
-  // queues of live pixel slots
-  int* queue[2];
-  int* qcount;  // [2]
+  float4* pend;     // deferred light pdf: bsdfcos.xyz (or scattering), bsdf pdf
+  // per-workgroup double-ended queue segments (256 entries each) + counts
+  int*  queue[2];   // [nblocks*256]
+  int2* bcount[2];  // [nblocks] {primaries (front), bounces (back)}
+  int*  lqueue;     // [nblocks*256] deferred light-pdf slots
+  int*  lcount;     // [nblocks]
+  int*  alive;      // [1] last iteration tag in which any path survived
   // work counters (ythip_stats), may be null
   unsigned long long* counters;
 };
@@ -73,13 +107,11 @@ YT_FN void flush_counters(unsigned long long* c, const Counters& cnt) {
   atomicAdd(&c[CNT_INST], (unsigned long long)cnt.instances);
 }
 
-// Out-of-line traversal used from the shading kernel (light-pdf walks and the
-// NEE rays of pathdirect/pathmis) so the big kernel carries one copy.
-template <bool COUNT>
+// Out-of-line traversal for LP_INLINE shading (several call sites, one copy).
 __device__ __noinline__ Hit trace_ray(const DScene& sc, vec3f o, vec3f d, int only_instance, Stack& st,
     Counters& cnt) {
   ray3f ray = make_ray(o, d);
-  return traverse<COUNT>(sc, ray, only_instance, false, st, cnt);
+  return traverse<true>(sc, ray, only_instance, false, st, cnt);
 }
 
 // ---------------------------------------------------------------------------
@@ -131,29 +163,38 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
   return {0, 0, 0};
 }
 
-// sample_lights_pdf — yocto_trace.cpp:391-443
-template <bool COUNT>
-YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack& st, Counters& cnt) {
+// sample_lights_pdf — yocto_trace.cpp:391-443.  WALK: 0 = no instance lights in
+// the scene, 1 = walks through the out-of-line trace_ray, 2 = walks inline.
+template <int WALK>
+YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt) {
   auto pdf = 0.0f;
   for (int l = 0; l < sc.num_lights; l++) {
     const auto& light = sc.lights[l];
     if (light.instance != YTHIP_INVALIDID) {
-      const auto& inst          = sc.instances[light.instance];
-      const auto& sh            = sc.shapes[inst.shape];
-      auto        frame         = ldframe(inst.frame);
-      auto        lpdf          = 0.0f;
-      auto        next_position = position;
-      for (auto bounce = 0; bounce < 100; bounce++) {
-        auto isec = trace_ray<COUNT>(sc, next_position, direction, light.instance, st, cnt);
-        if (!isec.hit) break;
-        auto e         = load_element(sc, sh, isec.element);
-        auto lposition = eval_position(sc, frame, sh, e, {isec.u, isec.v});
-        auto lnormal   = eval_element_normal(sc, frame, sh, e);
-        auto area      = sc.cdf[light.cdf_offset + light.cdf_count - 1];
-        lpdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
-        next_position = lposition + direction * 1e-3f;
+      if constexpr (WALK != 0) {
+        const auto& inst          = sc.instances[light.instance];
+        const auto& sh            = sc.shapes[inst.shape];
+        auto        frame         = ldframe(inst.frame);
+        auto        lpdf          = 0.0f;
+        auto        next_position = position;
+        auto        area          = sc.cdf[light.cdf_offset + light.cdf_count - 1];
+        for (auto bounce = 0; bounce < 100; bounce++) {
+          Hit isec;
+          if constexpr (WALK == 1) {
+            isec = trace_ray(sc, next_position, direction, light.instance, *st, *cnt);
+          } else {
+            ray3f ray = make_ray(next_position, direction);
+            isec      = traverse<true>(sc, ray, light.instance, false, *st, *cnt);
+          }
+          if (!isec.hit) break;
+          auto e         = load_element(sc, sh, isec.element);
+          auto lposition = eval_position(sc, frame, sh, e, {isec.u, isec.v});
+          auto lnormal   = eval_element_normal(sc, frame, sh, e);
+          lpdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
+          next_position = lposition + direction * 1e-3f;
+        }
+        pdf += lpdf;
       }
-      pdf += lpdf;
     } else if (light.environment != YTHIP_INVALIDID) {
       const auto& environment = sc.environments[light.environment];
       if (environment.emission_tex != YTHIP_INVALIDID) {
@@ -184,19 +225,24 @@ struct Path {
   Hit       isec;         // intersection for this iteration
   vec3f     weight, radiance;
   float     max_roughness;
-  int       bounce, opbounce, flags;
+  int       bounce, opbounce, flags, sidx;
   rng_state rng;
 };
 
 // What the loop body decided
-enum { STEP_END = 0, STEP_NEXT = 1 /* bounce++ */, STEP_RETRY = 2 /* opacity: same bounce */ };
+enum {
+  STEP_END   = 0,
+  STEP_NEXT  = 1,  // bounce++
+  STEP_RETRY = 2,  // opacity: same bounce
+  STEP_DEFER = 3,  // light pdf pending: k_lightpdf finishes the iteration
+};
 
 struct ShadeEnv {
   const DScene&  sc;
   const DState&  st;
   const KParams& kp;
-  Stack&         stack;
-  Counters&      cnt;
+  Stack*         stack;  // LP_INLINE only
+  Counters*      cnt;    // LP_INLINE only
   int            slot;
 };
 
@@ -212,6 +258,9 @@ YT_FN void set_first_hit(const DState& s, int slot, vec3f albedo, vec3f normal) 
   s.first_a[slot] = {albedo.x, albedo.y, albedo.z, normal.x};
   s.first_b[slot] = {normal.y, normal.z};
 }
+YT_FN void count_shade(const DState& s) {
+  if (s.counters) atomicAdd(&s.counters[CNT_SHADES], 1ull);
+}
 
 // emission seen along `incoming` from a NEE ray's intersection
 // (yocto_trace.cpp:678-687, 873-884)
@@ -223,11 +272,23 @@ YT_FN vec3f nee_emission(const DScene& sc, const Hit& isec, vec3f incoming) {
   return eval_emission(material, normal, -incoming);
 }
 
+// The end of one loop-body iteration, after the weight update:
+// weight check + russian roulette (yocto_trace.cpp:584-592).
+YT_FN int step_tail(Path& P) {
+  if (P.weight == vec3f{0, 0, 0} || !isfinite_(P.weight)) return STEP_END;
+  if (P.bounce > 3) {
+    auto rr_prob = min_((float)0.99, max_(P.weight));
+    if (rand1f(P.rng) >= rr_prob) return STEP_END;
+    P.weight *= 1 / rr_prob;
+  }
+  return STEP_NEXT;
+}
+
 // ---------------------------------------------------------------------------
 // trace_path / trace_pathdirect / trace_pathmis / trace_pathtest — one iteration
 // of the bounce loop after the intersection (yocto_trace.cpp:453-1029)
 // ---------------------------------------------------------------------------
-template <int SAMPLER, bool COUNT>
+template <int SAMPLER, int LP>
 YT_FN int step_path(ShadeEnv& E, Path& P) {
   const auto& sc = E.sc;
   const auto& kp = E.kp;
@@ -235,6 +296,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
   constexpr bool MIS     = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   constexpr bool TEST    = SAMPLER == YTHIP_SAMPLER_PATHTEST;
   constexpr bool VOLUMES = !TEST;
+  static_assert(!(DIRECT || MIS) || LP == LP_INLINE, "NEE samplers trace inline");
   const bool next_emission = !(P.flags & PF_NOEMIT);
 
   auto& isec = P.isec;
@@ -265,7 +327,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     auto position = eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
     auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
     auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
-    if (COUNT && E.st.counters) atomicAdd(&E.st.counters[CNT_SHADES], 1ull);
+    count_shade(E.st);
     if (TEST) material.type = YTHIP_MATTE;
 
     // correct roughness
@@ -291,16 +353,16 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     if ((!DIRECT && !MIS) || next_emission) P.radiance += P.weight * eval_emission(material, normal, outgoing);
 
     // direct (pathdirect) — yocto_trace.cpp:670-693
-    if (DIRECT) {
+    if constexpr (DIRECT) {
       if (!is_delta(material)) {
         auto ruv      = rand2f(P.rng);  // g++ order: ruv, rel, rl
         auto rel      = rand1f(P.rng);
         auto rl       = rand1f(P.rng);
         auto incoming = sample_lights(sc, position, rl, rel, ruv);
-        auto pdf      = sample_lights_pdf<COUNT>(sc, position, incoming, E.stack, E.cnt);
+        auto pdf      = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt);
         auto bsdfcos  = eval_bsdfcos(material, normal, outgoing, incoming);
         if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
-          auto nisec    = trace_ray<COUNT>(sc, position, incoming, -1, E.stack, E.cnt);
+          auto nisec    = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt);
           auto emission = nee_emission(sc, nisec, incoming);
           P.radiance += P.weight * bsdfcos * emission / pdf;
         }
@@ -312,8 +374,9 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
 
     // next direction
     auto incoming = vec3f{0, 0, 0};
+    bool deferred = false;
     if (!is_delta(material)) {
-      if (MIS) {
+      if constexpr (MIS) {
         // direct with MIS — yocto_trace.cpp:853-892
         for (int pass = 0; pass < 2; pass++) {
           const bool sample_light = pass == 0;
@@ -329,7 +392,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           }
           if (incoming == vec3f{0, 0, 0}) break;
           auto bsdfcos    = eval_bsdfcos(material, normal, outgoing, incoming);
-          auto light_pdf  = sample_lights_pdf<COUNT>(sc, position, incoming, E.stack, E.cnt);
+          auto light_pdf  = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt);
           auto bsdf_pdf   = sample_bsdfcos_pdf(material, normal, outgoing, incoming);
           auto heur       = [](float this_pdf, float other_pdf) {
             return (this_pdf * this_pdf) / (this_pdf * this_pdf + other_pdf * other_pdf);
@@ -337,7 +400,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           auto mis_weight = sample_light ? heur(light_pdf, bsdf_pdf) / light_pdf
                                          : heur(bsdf_pdf, light_pdf) / bsdf_pdf;
           if (bsdfcos != vec3f{0, 0, 0} && mis_weight != 0) {
-            auto nisec = trace_ray<COUNT>(sc, position, incoming, -1, E.stack, E.cnt);
+            auto nisec = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt);
             if (!sample_light) {
               // next_intersection = intersection (persists across bounces)
               E.st.nhit_a[E.slot] = {nisec.u, nisec.v, nisec.distance, __int_as_float(nisec.hit ? nisec.instance : -1)};
@@ -363,9 +426,15 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           incoming = sample_lights(sc, position, rl, rel, ruv);
         }
         if (incoming == vec3f{0, 0, 0}) return STEP_END;
-        P.weight *= eval_bsdfcos(material, normal, outgoing, incoming) /
-                    (0.5f * sample_bsdfcos_pdf(material, normal, outgoing, incoming) +
-                        0.5f * sample_lights_pdf<COUNT>(sc, position, incoming, E.stack, E.cnt));
+        auto f     = eval_bsdfcos(material, normal, outgoing, incoming);
+        auto pdf_a = sample_bsdfcos_pdf(material, normal, outgoing, incoming);
+        if constexpr (LP == LP_DEFER) {
+          E.st.pend[E.slot] = {f.x, f.y, f.z, pdf_a};
+          deferred          = true;
+        } else {
+          P.weight *= f / (0.5f * pdf_a + 0.5f * sample_lights_pdf<LP == LP_INLINE ? 1 : 0>(
+                                                     sc, position, incoming, E.stack, E.cnt));
+        }
       }
     } else {
       incoming = sample_delta(material, normal, outgoing, rand1f(P.rng));
@@ -389,6 +458,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     // setup next iteration
     P.o = position;
     P.d = incoming;
+    if (deferred) return STEP_DEFER;
   } else {
     // volume scattering event
     auto outgoing = -P.d;
@@ -407,29 +477,25 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
       if (MIS) P.flags &= ~PF_NOEMIT;
     }
     if (!MIS && incoming == vec3f{0, 0, 0}) return STEP_END;
-    P.weight *= eval_scattering(vsdf, outgoing, incoming) /
-                (0.5f * sample_scattering_pdf(vsdf, outgoing, incoming) +
-                    0.5f * sample_lights_pdf<COUNT>(sc, position, incoming, E.stack, E.cnt));
-    P.o = position;
-    P.d = incoming;
+    auto f     = eval_scattering(vsdf, outgoing, incoming);
+    auto pdf_a = sample_scattering_pdf(vsdf, outgoing, incoming);
+    P.o        = position;
+    P.d        = incoming;
+    if constexpr (LP == LP_DEFER) {
+      E.st.pend[E.slot] = {f.x, f.y, f.z, pdf_a};
+      return STEP_DEFER;
+    } else {
+      P.weight *= f / (0.5f * pdf_a + 0.5f * sample_lights_pdf<LP == LP_INLINE ? 1 : 0>(
+                                                 sc, position, incoming, E.stack, E.cnt));
+    }
   }
-
-  // check weight
-  if (P.weight == vec3f{0, 0, 0} || !isfinite_(P.weight)) return STEP_END;
-
-  // russian roulette
-  if (P.bounce > 3) {
-    auto rr_prob = min_((float)0.99, max_(P.weight));
-    if (rand1f(P.rng) >= rr_prob) return STEP_END;
-    P.weight *= 1 / rr_prob;
-  }
-  return STEP_NEXT;
+  return step_tail(P);
 }
 
 // ---------------------------------------------------------------------------
 // trace_naive / trace_furnace — yocto_trace.cpp:1032-1108, 1247-1338
 // ---------------------------------------------------------------------------
-template <int SAMPLER, bool COUNT>
+template <int SAMPLER>
 YT_FN int step_naive(ShadeEnv& E, Path& P) {
   const auto& sc = E.sc;
   const auto& kp = E.kp;
@@ -446,7 +512,7 @@ YT_FN int step_naive(ShadeEnv& E, Path& P) {
                           : eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
   auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
   auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
-  if (COUNT && E.st.counters) atomicAdd(&E.st.counters[CNT_SHADES], 1ull);
+  count_shade(E.st);
 
   if (material.opacity < 1 && rand1f(P.rng) >= material.opacity) {
     if (P.opbounce++ > 128) return STEP_END;
@@ -473,12 +539,8 @@ YT_FN int step_naive(ShadeEnv& E, Path& P) {
     P.weight *= eval_delta(material, normal, outgoing, incoming) /
                 sample_delta_pdf(material, normal, outgoing, incoming);
   }
-  if (P.weight == vec3f{0, 0, 0} || !isfinite_(P.weight)) return STEP_END;
-  if (P.bounce > 3) {
-    auto rr_prob = min_((float)0.99, max_(P.weight));
-    if (rand1f(P.rng) >= rr_prob) return STEP_END;
-    P.weight *= 1 / rr_prob;
-  }
+  int tail = step_tail(P);
+  if (tail == STEP_END) return STEP_END;
   if (FURNACE) {
     if (dot(normal, outgoing) * dot(normal, incoming) < 0) P.flags ^= PF_INVOL;
   }
@@ -490,7 +552,7 @@ YT_FN int step_naive(ShadeEnv& E, Path& P) {
 // ---------------------------------------------------------------------------
 // trace_eyelight / trace_diagram — yocto_trace.cpp:1111-1244
 // ---------------------------------------------------------------------------
-template <int SAMPLER, bool COUNT>
+template <int SAMPLER>
 YT_FN int step_eyelight(ShadeEnv& E, Path& P) {
   const auto& sc = E.sc;
   const auto& kp = E.kp;
@@ -499,12 +561,9 @@ YT_FN int step_eyelight(ShadeEnv& E, Path& P) {
   if (!isec.hit) {
     if (DIAGRAM) {
       P.radiance += P.weight * vec3f{1, 1, 1};
+      // hit = true; albedo/normal stay as recorded at bounce 0 (zero if never hit)
+      if (!(P.flags & PF_HIT)) set_first_hit(E.st, E.slot, {0, 0, 0}, {0, 0, 0});
       P.flags |= PF_HIT;
-      if (P.bounce != 0) {
-        // hit=true with the albedo/normal recorded at bounce 0
-      } else {
-        set_first_hit(E.st, E.slot, {0, 0, 0}, {0, 0, 0});
-      }
     } else if (P.bounce > 0 || !kp.envhidden) {
       P.radiance += P.weight * eval_environment(sc, P.d);
     }
@@ -515,7 +574,7 @@ YT_FN int step_eyelight(ShadeEnv& E, Path& P) {
   auto position = eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
   auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
   auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
-  if (COUNT && E.st.counters) atomicAdd(&E.st.counters[CNT_SHADES], 1ull);
+  count_shade(E.st);
 
   if (material.opacity < 1 && rand1f(P.rng) >= material.opacity) {
     if (P.opbounce++ > 128) return STEP_END;
@@ -552,11 +611,10 @@ YT_FN vec3f hashed_color(int id) {
   auto c      = 0.5f + 0.5f * r;
   return {powf(c.x, 2.2f), powf(c.y, 2.2f), powf(c.z, 2.2f)};
 }
-template <bool COUNT>
 YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
   const auto& sc   = E.sc;
   auto&       isec = P.isec;
-  if (!isec.hit) return STEP_END;  // trace_result{}: radiance 0, hit false, albedo 0, normal 0
+  if (!isec.hit) return STEP_END;  // trace_result{}: radiance 0, hit false
   auto outgoing = -P.d;
   auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
   auto position = eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
@@ -565,7 +623,7 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
   auto texcoord = eval_texcoord(sc, *s.sh, s.e, s.uv);
   auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
   auto delta    = is_delta(material) ? 1.0f : 0.0f;
-  if (COUNT && E.st.counters) atomicAdd(&E.st.counters[CNT_SHADES], 1ull);
+  count_shade(E.st);
   const auto& inst = sc.instances[isec.instance];
 
   auto result = vec3f{0, 0, 0};
@@ -600,174 +658,67 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
 }
 
 // ===========================================================================
-// Kernels
+// Path slot I/O, accumulation, regeneration, compaction
 // ===========================================================================
 
-// k_generate: head of trace_sample (yocto_trace.cpp:1464-1468) for every pixel
-// of the slice; initialises the path and enqueues it.
-__global__ void __launch_bounds__(YT_BLOCK) k_generate(DScene sc, DState st, KParams kp) {
-  int slot = blockIdx.x * YT_BLOCK + threadIdx.x;
-  if (slot >= st.npix) return;
-  int  i = slot % st.width, j = st.row_begin + slot / st.width;
-  auto r = st.rngs[slot];
-  rng_state rng = {r.x, r.y};
+YT_FN void load_path(const DState& st, int slot, Path& P, bool with_hit) {
+  float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+  float4 w = st.wgt[slot], r = st.rad[slot];
+  auto   g = st.rngs[slot];
+  P.o             = {ra.x, ra.y, ra.z};
+  P.d             = {ra.w, rb.x, rb.y};
+  P.bounce        = __float_as_int(rb.z);
+  int fw          = __float_as_int(rb.w);
+  P.flags         = fw & 0xff;
+  P.opbounce      = fw >> 8;
+  P.weight        = {w.x, w.y, w.z};
+  P.max_roughness = w.w;
+  P.radiance      = {r.x, r.y, r.z};
+  P.sidx          = __float_as_int(r.w);
+  P.rng           = {g.x, g.y};
+  if (with_hit) {
+    float4 ha   = st.hit_a[slot];
+    int    inst = __float_as_int(ha.w);
+    P.isec      = {inst, st.hit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
+  }
+}
+
+YT_FN void store_path(const DState& st, int slot, const Path& P) {
+  st.rngs[slot]  = {P.rng.state, P.rng.inc};
+  st.ray_a[slot] = {P.o.x, P.o.y, P.o.z, P.d.x};
+  st.ray_b[slot] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
+  st.wgt[slot]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
+  st.rad[slot]   = {P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)};
+}
+
+// Head of trace_sample (yocto_trace.cpp:1464-1468): the pixel's next camera ray.
+YT_FN void start_sample(const DScene& sc, const DState& st, const KParams& kp, int slot, Path& P) {
+  int i = slot % st.width, j = st.row_begin + slot / st.width;
   // sample_camera(camera, ij, size, puv = rand2f, luv = rand2f, tent): g++ draws luv first
-  auto luv = rand2f(rng);
-  auto puv = rand2f(rng);
+  auto luv = rand2f(P.rng);
+  auto puv = rand2f(P.rng);
   auto ray = sample_camera(sc.cameras[kp.camera], i, j, st.width, st.height, puv, luv, kp.tentfilter != 0);
-  st.rngs[slot]    = {rng.state, rng.inc};
-  st.ray_a[slot]   = {ray.o.x, ray.o.y, ray.o.z, ray.d.x};
-  st.ray_b[slot]   = {ray.d.y, ray.d.z, __int_as_float(0), __int_as_float(0)};
-  st.wgt[slot]     = {1, 1, 1, 0};
-  st.rad[slot]     = {0, 0, 0, 0};
+  P.o = ray.o, P.d = ray.d;
+  P.weight        = {1, 1, 1};
+  P.radiance      = {0, 0, 0};
+  P.max_roughness = 0;
+  P.bounce = 0, P.opbounce = 0, P.flags = 0;
   st.first_a[slot] = {0, 0, 0, -ray.d.x};
   st.first_b[slot] = {-ray.d.y, -ray.d.z};
   if (st.nhit_a) {
     st.nhit_a[slot] = {0, 0, 0, __int_as_float(-1)};
     st.nhit_e[slot] = -1;
   }
-  st.queue[0][slot] = slot;
-  if (slot == 0) {
-    st.qcount[0] = st.npix;
-    st.qcount[1] = 0;
-  }
 }
 
-// k_extend: intersect_scene_bvh for every live path (the traversal kernel).
-template <bool COUNT>
-__global__ void __launch_bounds__(YT_BLOCK) k_extend(DScene sc, DState st, int q) {
-  __shared__ int s_stack[YT_LDS_DEPTH][YT_BLOCK];
-  int            idx = blockIdx.x * YT_BLOCK + threadIdx.x;
-  // The other queue was fully consumed by the previous k_shade: reset its counter
-  // before this iteration's k_shade appends to it (must happen even when the
-  // live queue is empty, or a stale count would resurrect dead paths).
-  if (idx == 0) st.qcount[q ^ 1] = 0;
-  if (idx >= st.qcount[q]) return;
-  int    slot = st.queue[q][idx];
-  float4 a = st.ray_a[slot], b = st.ray_b[slot];
-  int    flags = __float_as_int(b.w);
-  if (flags & PF_SKIPEXTEND) {         // pathmis: intersection = next_intersection
-    st.hit_a[slot] = st.nhit_a[slot];
-    st.hit_e[slot] = st.nhit_e[slot];
-    return;
-  }
-  Stack stack;
-  stack.lds = &s_stack[0][threadIdx.x];
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0};
-  // furnace: `if (bounce > 0 && !in_volume) { env; break; }` happens BEFORE the
-  // intersection (yocto_trace.cpp:1263-1266); handled in k_shade by a flag check.
-  ray3f ray = make_ray({a.x, a.y, a.z}, {a.w, b.x, b.y});
-  Hit   h   = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
-  st.hit_a[slot] = {h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)};
-  st.hit_e[slot] = h.element;
-  if (COUNT) flush_counters(st.counters, cnt);
-}
-
-// k_shade: one iteration of the integrator's bounce loop for every live path,
-// then wave-ballot compaction of the survivors into the other queue.
-template <int SAMPLER, bool COUNT>
-__global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParams kp, int q) {
-  __shared__ int s_stack[YT_LDS_DEPTH][YT_BLOCK];
-  int            idx   = blockIdx.x * YT_BLOCK + threadIdx.x;
-  bool           alive = false;
-  int            slot  = -1;
-  if (idx < st.qcount[q]) {
-    slot = st.queue[q][idx];
-    Path   P;
-    float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
-    float4 ha = st.hit_a[slot];
-    float4 w = st.wgt[slot], r = st.rad[slot];
-    auto   g = st.rngs[slot];
-    P.o             = {ra.x, ra.y, ra.z};
-    P.d             = {ra.w, rb.x, rb.y};
-    P.bounce        = __float_as_int(rb.z);
-    int fw          = __float_as_int(rb.w);
-    P.flags         = fw & 0xff;
-    P.opbounce      = fw >> 8;
-    int inst        = __float_as_int(ha.w);
-    P.isec          = {inst, st.hit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
-    P.weight        = {w.x, w.y, w.z};
-    P.max_roughness = w.w;
-    P.radiance      = {r.x, r.y, r.z};
-    P.rng           = {g.x, g.y};
-    P.flags &= ~PF_SKIPEXTEND;
-
-    Stack stack;
-    stack.lds    = &s_stack[0][threadIdx.x];
-    Counters cnt = {0, 0, 0, 0, 0, 0, 0};
-    ShadeEnv E   = {sc, st, kp, stack, cnt, slot};
-
-    int step;
-    if (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHDIRECT ||
-        SAMPLER == YTHIP_SAMPLER_PATHMIS || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
-      step = step_path<SAMPLER, COUNT>(E, P);
-    } else if (SAMPLER == YTHIP_SAMPLER_NAIVE) {
-      step = step_naive<SAMPLER, COUNT>(E, P);
-    } else if (SAMPLER == YTHIP_SAMPLER_FURNACE) {
-      // exit test at the top of the loop body — yocto_trace.cpp:1263-1266
-      if (P.bounce > 0 && !(P.flags & PF_INVOL)) {
-        P.radiance += P.weight * eval_environment(sc, P.d);
-        step = STEP_END;
-      } else {
-        step = step_naive<SAMPLER, COUNT>(E, P);
-      }
-    } else if (SAMPLER == YTHIP_SAMPLER_EYELIGHT || SAMPLER == YTHIP_SAMPLER_DIAGRAM) {
-      step = step_eyelight<SAMPLER, COUNT>(E, P);
-    } else {
-      step = step_falsecolor<COUNT>(E, P);
-    }
-
-    if (SAMPLER == YTHIP_SAMPLER_PATHMIS && (P.flags & PF_NOEMIT)) P.flags |= PF_SKIPEXTEND;
-    int max_bounces = (SAMPLER == YTHIP_SAMPLER_EYELIGHT || SAMPLER == YTHIP_SAMPLER_DIAGRAM)
-                          ? max_(kp.bounces, 4)
-                          : kp.bounces;
-    if (step == STEP_NEXT) {
-      P.bounce += 1;
-      alive = P.bounce < max_bounces;
-    } else if (step == STEP_RETRY) {
-      alive = true;
-    }
-
-    st.rngs[slot] = {P.rng.state, P.rng.inc};
-    st.rad[slot]  = {P.radiance.x, P.radiance.y, P.radiance.z, 0};
-    if (alive) {
-      st.ray_a[slot] = {P.o.x, P.o.y, P.o.z, P.d.x};
-      st.ray_b[slot] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
-      st.wgt[slot]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
-    } else {
-      // keep the hit flag for k_accumulate
-      st.ray_b[slot].w = __int_as_float(P.flags | (P.opbounce << 8));
-    }
-    if (COUNT) flush_counters(st.counters, cnt);
-  }
-  // stream compaction: wave ballot + one atomic per wave
-  unsigned long long mask = __ballot(alive);
-  if (mask) {
-    int lane   = threadIdx.x & 63;
-    int leader = __ffsll((long long)mask) - 1;
-    int base   = 0;
-    if (lane == leader) base = atomicAdd(&st.qcount[q ^ 1], __popcll(mask));
-    base = __shfl(base, leader);
-    if (alive) {
-      int rank = __popcll(mask & ((1ull << lane) - 1ull));
-      st.queue[q ^ 1][base + rank] = slot;
-    }
-  }
-}
-
-
-// k_accumulate: tail of trace_sample (yocto_trace.cpp:1471-1491).
-template <bool COUNT>
-__global__ void __launch_bounds__(YT_BLOCK) k_accumulate(DState st, KParams kp, int sample) {
-  int slot = blockIdx.x * YT_BLOCK + threadIdx.x;
-  if (slot >= st.npix) return;
-  float4 r  = st.rad[slot];
-  int    fl = __float_as_int(st.ray_b[slot].w);
-  float4 fa = st.first_a[slot];
-  float2 fb = st.first_b[slot];
-  vec3f  radiance = {r.x, r.y, r.z};
-  bool   hit      = (fl & PF_HIT) != 0;
-  vec3f  albedo = {fa.x, fa.y, fa.z}, normal = {fa.w, fb.x, fb.y};
+// Tail of trace_sample (yocto_trace.cpp:1471-1491).
+YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Path& P) {
+  int    sample = st.sample_base + P.sidx;
+  float4 fa     = st.first_a[slot];
+  float2 fb     = st.first_b[slot];
+  vec3f  radiance = P.radiance;
+  bool   hit      = (P.flags & PF_HIT) != 0;
+  vec3f  albedo = {fa.x, fa.y, fa.z}, normal = {fa.w, fb.x, fb.y};  // normal = -camera_ray.d before a hit
   if (!isfinite_(radiance)) radiance = {0, 0, 0};
   if (max_(radiance) > kp.clamp) radiance = radiance * (kp.clamp / max_(radiance));
   auto   weight = 1.0f / (sample + 1);
@@ -775,7 +726,6 @@ __global__ void __launch_bounds__(YT_BLOCK) k_accumulate(DState st, KParams kp, 
   vec4f  image  = {im.x, im.y, im.z, im.w};
   vec3f  alb    = ld3(st.albedo, slot);
   vec3f  nrm    = ld3(st.normal, slot);
-  // before the first hit `normal` holds -camera_ray.d
   if (hit) {
     image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
     alb   = lerp_(alb, albedo, weight);
@@ -798,7 +748,212 @@ __global__ void __launch_bounds__(YT_BLOCK) k_accumulate(DState st, KParams kp, 
   st.normal[3 * slot]     = nrm.x;
   st.normal[3 * slot + 1] = nrm.y;
   st.normal[3 * slot + 2] = nrm.z;
-  if (COUNT && st.counters && slot == 0) atomicAdd(&st.counters[CNT_SAMPLES], (unsigned long long)st.npix);
+  if (st.counters) atomicAdd(&st.counters[CNT_SAMPLES], 1ull);
+}
+
+// Path outcome classes for the compaction
+enum { OUT_DEAD = 0, OUT_PRIMARY = 1, OUT_BOUNCE = 2, OUT_DEFER = 3 };
+
+// Applies a step decision: bounce bookkeeping, end-of-sample accumulation and
+// regeneration.  Returns the queue class of the slot.
+YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, int slot, Path& P, int step,
+    int max_bounces) {
+  if (step == STEP_DEFER) return OUT_DEFER;
+  bool alive = false;
+  if (step == STEP_NEXT) {
+    P.bounce += 1;
+    alive = P.bounce < max_bounces;
+  } else if (step == STEP_RETRY) {
+    alive = true;
+  }
+  if (alive) return OUT_BOUNCE;
+  finish_sample(st, kp, slot, P);
+  P.sidx += 1;
+  if (P.sidx < st.batch) {
+    start_sample(sc, st, kp, slot, P);
+    return OUT_PRIMARY;
+  }
+  return OUT_DEAD;
+}
+
+// Block-local partition of this workgroup's slots into its segment of queue
+// `qn`: class OUT_PRIMARY from the front, OUT_BOUNCE from the back, starting
+// after the `base` entries already there; OUT_DEFER into the lqueue segment.
+// Every thread of the workgroup must call it.  Returns the new counts.
+YT_FN int2 block_partition(const DState& st, int qn, int slot, int cls, int2 base, bool defer_class, int iter) {
+  __shared__ int s_cnt[YT_BLOCK / 64][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg  = blockIdx.x * YT_BLOCK;
+  unsigned long long mp = __ballot(cls == OUT_PRIMARY);
+  unsigned long long mb = __ballot(cls == OUT_BOUNCE);
+  unsigned long long md = defer_class ? __ballot(cls == OUT_DEFER) : 0ull;
+  if (lane == 0) {
+    s_cnt[wave][0] = __popcll(mp);
+    s_cnt[wave][1] = __popcll(mb);
+    s_cnt[wave][2] = __popcll(md);
+  }
+  __syncthreads();
+  int offp = base.x, offb = base.y, offd = 0, totp = base.x, totb = base.y, totd = 0;
+#pragma unroll
+  for (int w = 0; w < YT_BLOCK / 64; w++) {
+    if (w < wave) {
+      offp += s_cnt[w][0];
+      offb += s_cnt[w][1];
+      offd += s_cnt[w][2];
+    }
+    totp += s_cnt[w][0];
+    totb += s_cnt[w][1];
+    totd += s_cnt[w][2];
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (cls == OUT_PRIMARY) st.queue[qn][seg + offp + __popcll(mp & below)] = slot;
+  if (cls == OUT_BOUNCE) st.queue[qn][seg + YT_BLOCK - 1 - (offb + __popcll(mb & below))] = slot;
+  if (defer_class && cls == OUT_DEFER) st.lqueue[seg + offd + __popcll(md & below)] = slot;
+  if (threadIdx.x == 0) {
+    st.bcount[qn][blockIdx.x] = {totp, totb};
+    if (defer_class) st.lcount[blockIdx.x] = totd;
+    if (totp + totb + totd > 0) *st.alive = iter;  // benign race: every writer stores the same tag
+  }
+  return {totp, totb};
+}
+
+// Slot handled by this thread: entry threadIdx.x of the workgroup's segment
+// (front entries, then back entries), -1 past the end.
+YT_FN int queue_slot(const DState& st, int q) {
+  int2 n   = st.bcount[q][blockIdx.x];
+  int  seg = blockIdx.x * YT_BLOCK, t = threadIdx.x;
+  if (t < n.x) return st.queue[q][seg + t];
+  if (t < n.x + n.y) return st.queue[q][seg + YT_BLOCK - 1 - (t - n.x)];
+  return -1;
+}
+
+// ===========================================================================
+// Kernels
+// ===========================================================================
+
+// k_generate: first camera ray of the batch for every pixel of the slice.
+__global__ void __launch_bounds__(YT_BLOCK) k_generate(DScene sc, DState st, KParams kp) {
+  int slot = blockIdx.x * YT_BLOCK + threadIdx.x;
+  if (threadIdx.x == 0) {
+    int n                    = min_(YT_BLOCK, st.npix - blockIdx.x * YT_BLOCK);
+    st.bcount[0][blockIdx.x] = {n, 0};
+    st.bcount[1][blockIdx.x] = {0, 0};
+    st.lcount[blockIdx.x]    = 0;
+    if (blockIdx.x == 0) *st.alive = -1;
+  }
+  if (slot >= st.npix) return;
+  Path P;
+  auto r = st.rngs[slot];
+  P.rng  = {r.x, r.y};
+  P.sidx = 0;
+  P.isec = {-1, -1, 0, 0, 0, false};
+  start_sample(sc, st, kp, slot, P);
+  store_path(st, slot, P);
+  st.queue[0][slot] = slot;
+}
+
+// k_extend: intersect_scene_bvh for every live path (the traversal kernel).
+template <bool COUNT>
+__global__ void __launch_bounds__(YT_BLOCK) k_extend(DScene sc, DState st, int q) {
+  __shared__ int s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  int slot = queue_slot(st, q);
+  if (slot < 0) return;
+  float4 a = st.ray_a[slot], b = st.ray_b[slot];
+  int    flags = __float_as_int(b.w);
+  if (flags & PF_SKIPEXTEND) {  // pathmis: intersection = next_intersection
+    st.hit_a[slot] = st.nhit_a[slot];
+    st.hit_e[slot] = st.nhit_e[slot];
+    return;
+  }
+  Stack stack;
+  stack.lds    = &s_stack[0][threadIdx.x];
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0};
+  ray3f    ray = make_ray({a.x, a.y, a.z}, {a.w, b.x, b.y});
+  Hit      h   = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
+  st.hit_a[slot] = {h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)};
+  st.hit_e[slot] = h.element;
+  if (COUNT) flush_counters(st.counters, cnt);
+}
+
+template <int SAMPLER>
+YT_FN int max_bounces_of(const KParams& kp) {
+  return (SAMPLER == YTHIP_SAMPLER_EYELIGHT || SAMPLER == YTHIP_SAMPLER_DIAGRAM) ? max_(kp.bounces, 4)
+                                                                              : kp.bounces;
+}
+
+// k_shade: one iteration of the integrator's bounce loop for every live path.
+template <int SAMPLER, int LP>
+__global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParams kp, int q, int iter) {
+  constexpr bool INLINE = LP == LP_INLINE;
+  __shared__ int s_stack[INLINE ? YT_LDS_DEPTH : 1][INLINE ? YT_BLOCK : 1];
+  int            slot = queue_slot(st, q);
+  int            cls  = OUT_DEAD;
+  if (slot >= 0) {
+    Path P;
+    load_path(st, slot, P, true);
+    P.flags &= ~PF_SKIPEXTEND;
+
+    int step;
+    if constexpr (INLINE) {
+      Stack stack;
+      stack.lds    = &s_stack[0][threadIdx.x];
+      Counters cnt = {0, 0, 0, 0, 0, 0, 0};
+      ShadeEnv E   = {sc, st, kp, &stack, &cnt, slot};
+      step         = step_path<SAMPLER, LP>(E, P);
+      flush_counters(st.counters, cnt);
+    } else {
+      ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
+      if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
+        step = step_path<SAMPLER, LP>(E, P);
+      } else if constexpr (SAMPLER == YTHIP_SAMPLER_NAIVE) {
+        step = step_naive<SAMPLER>(E, P);
+      } else if constexpr (SAMPLER == YTHIP_SAMPLER_FURNACE) {
+        // exit test at the top of the loop body — yocto_trace.cpp:1263-1266
+        if (P.bounce > 0 && !(P.flags & PF_INVOL)) {
+          P.radiance += P.weight * eval_environment(sc, P.d);
+          step = STEP_END;
+        } else {
+          step = step_naive<SAMPLER>(E, P);
+        }
+      } else if constexpr (SAMPLER == YTHIP_SAMPLER_EYELIGHT || SAMPLER == YTHIP_SAMPLER_DIAGRAM) {
+        step = step_eyelight<SAMPLER>(E, P);
+      } else {
+        step = step_falsecolor(E, P);
+      }
+    }
+    if (SAMPLER == YTHIP_SAMPLER_PATHMIS && step != STEP_END && (P.flags & PF_NOEMIT)) P.flags |= PF_SKIPEXTEND;
+    cls = resolve_step(sc, st, kp, slot, P, step, max_bounces_of<SAMPLER>(kp));
+    store_path(st, slot, P);
+  }
+  block_partition(st, q ^ 1, slot, cls, {0, 0}, LP == LP_DEFER, iter);
+}
+
+// k_lightpdf: the deferred sample_lights_pdf walks + the rest of the loop body.
+template <int SAMPLER>
+__global__ void __launch_bounds__(YT_BLOCK) k_lightpdf(DScene sc, DState st, KParams kp, int q, int iter) {
+  __shared__ int s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  int            slot = -1;
+  int            cls  = OUT_DEAD;
+  const int      nl   = st.lcount[blockIdx.x];
+  if (nl == 0) return;  // workgroup-uniform: nothing deferred here
+  if ((int)threadIdx.x < nl) {
+    slot = st.lqueue[blockIdx.x * YT_BLOCK + threadIdx.x];
+    Path P;
+    load_path(st, slot, P, false);
+    Stack stack;
+    stack.lds    = &s_stack[0][threadIdx.x];
+    Counters cnt = {0, 0, 0, 0, 0, 0, 0};
+    float4   pd  = st.pend[slot];
+    // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
+    auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
+    P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
+    flush_counters(st.counters, cnt);
+    int step = step_tail(P);
+    cls      = resolve_step(sc, st, kp, slot, P, step, max_bounces_of<SAMPLER>(kp));
+    store_path(st, slot, P);
+  }
+  // append behind what k_shade already queued for this workgroup
+  block_partition(st, q ^ 1, slot, cls, st.bcount[q ^ 1][blockIdx.x], false, iter);
 }
 
 // Test/parity entries ---------------------------------------------------------

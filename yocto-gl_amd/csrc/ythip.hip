@@ -65,6 +65,10 @@ struct ythip_ctx {
   size_t                                       ev_next = 0;
   ythip_stats                                  stats   = {};
   int*                                         h_qcount = nullptr;  // pinned
+  hipEvent_t                                   ev_count = nullptr;
+  int                                          iter_tag = 0;
+  float4*                                      nhit_a   = nullptr;
+  int*                                         nhit_e   = nullptr;
 };
 
 namespace {
@@ -247,25 +251,47 @@ int upload_lights_impl(ythip_ctx* ctx) {
   return YTHIP_OK;
 }
 
-template <int S>
+template <int S, int LP>
 void launch_shade(ythip_ctx* ctx, const KParams& kp, int q, int grid) {
-  hipLaunchKernelGGL((k_shade<S, true>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, kp, q);
+  hipLaunchKernelGGL((k_shade<S, LP>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, kp, q,
+      ctx->iter_tag);
 }
 
-int launch_shade_any(ythip_ctx* ctx, const KParams& kp, int q, int grid) {
+// lp: LP_NONE / LP_DEFER for path & pathtest (area lights absent / present);
+// pathdirect & pathmis always trace inline; the rest never need a light pdf.
+int launch_shade_any(ythip_ctx* ctx, const KParams& kp, int lp, int q, int grid) {
   switch (kp.sampler) {
-    case YTHIP_SAMPLER_PATH: launch_shade<YTHIP_SAMPLER_PATH>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_PATHDIRECT: launch_shade<YTHIP_SAMPLER_PATHDIRECT>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_PATHMIS: launch_shade<YTHIP_SAMPLER_PATHMIS>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_PATHTEST: launch_shade<YTHIP_SAMPLER_PATHTEST>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_NAIVE: launch_shade<YTHIP_SAMPLER_NAIVE>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_EYELIGHT: launch_shade<YTHIP_SAMPLER_EYELIGHT>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_DIAGRAM: launch_shade<YTHIP_SAMPLER_DIAGRAM>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_FURNACE: launch_shade<YTHIP_SAMPLER_FURNACE>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_FALSECOLOR: launch_shade<YTHIP_SAMPLER_FALSECOLOR>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_PATH:
+      if (lp == LP_DEFER)
+        launch_shade<YTHIP_SAMPLER_PATH, LP_DEFER>(ctx, kp, q, grid);
+      else
+        launch_shade<YTHIP_SAMPLER_PATH, LP_NONE>(ctx, kp, q, grid);
+      break;
+    case YTHIP_SAMPLER_PATHTEST:
+      if (lp == LP_DEFER)
+        launch_shade<YTHIP_SAMPLER_PATHTEST, LP_DEFER>(ctx, kp, q, grid);
+      else
+        launch_shade<YTHIP_SAMPLER_PATHTEST, LP_NONE>(ctx, kp, q, grid);
+      break;
+    case YTHIP_SAMPLER_PATHDIRECT: launch_shade<YTHIP_SAMPLER_PATHDIRECT, LP_INLINE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_PATHMIS: launch_shade<YTHIP_SAMPLER_PATHMIS, LP_INLINE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_NAIVE: launch_shade<YTHIP_SAMPLER_NAIVE, LP_NONE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_EYELIGHT: launch_shade<YTHIP_SAMPLER_EYELIGHT, LP_NONE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_DIAGRAM: launch_shade<YTHIP_SAMPLER_DIAGRAM, LP_NONE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_FURNACE: launch_shade<YTHIP_SAMPLER_FURNACE, LP_NONE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_FALSECOLOR: launch_shade<YTHIP_SAMPLER_FALSECOLOR, LP_NONE>(ctx, kp, q, grid); break;
     default: return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
   }
   return YTHIP_OK;
+}
+
+void launch_lightpdf(ythip_ctx* ctx, const KParams& kp, int q, int grid) {
+  if (kp.sampler == YTHIP_SAMPLER_PATHTEST)
+    hipLaunchKernelGGL((k_lightpdf<YTHIP_SAMPLER_PATHTEST>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
+        ctx->st, kp, q, ctx->iter_tag);
+  else
+    hipLaunchKernelGGL((k_lightpdf<YTHIP_SAMPLER_PATH>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
+        ctx->st, kp, q, ctx->iter_tag);
 }
 
 // hipEvent bracketing of one launch (profiling mode bit 0)
@@ -295,6 +321,9 @@ void harvest_events(ythip_ctx* ctx) {
     if (kind == 0) {
       ctx->stats.extend_launches++;
       ctx->stats.extend_ms += ms;
+    } else if (kind == 2) {
+      ctx->stats.lightpdf_launches++;
+      ctx->stats.lightpdf_ms += ms;
     } else {
       ctx->stats.shade_launches++;
       ctx->stats.shade_ms += ms;
@@ -311,63 +340,79 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
     return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
   if (params->camera < 0 || params->camera >= ctx->num_cameras)
     return fail(ctx, YTHIP_ERR_INVALID, "camera index %d out of range [0,%d)", params->camera, ctx->num_cameras);
+  if (params->batch < 1) return fail(ctx, YTHIP_ERR_INVALID, "batch must be >= 1");
   if (ctx->samples >= params->samples) return YTHIP_OK;  // yocto_trace.cpp:1598
+  if (stop && *stop) return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
 
-  auto kp      = to_kparams(ctx, params);
-  bool count   = (ctx->prof_mode & 2) != 0;
+  auto kp          = to_kparams(ctx, params);
+  bool count       = (ctx->prof_mode & 2) != 0;
   ctx->st.counters = count ? ctx->d_counters : nullptr;
-  int  npix    = ctx->st.npix;
-  int  grid    = grid_for(npix);
-  bool mis     = params->sampler == YTHIP_SAMPLER_PATHMIS;
-  if (mis && !ctx->st.nhit_a) {
+  int  npix        = ctx->st.npix;
+  int  grid        = grid_for(npix);
+  bool mis         = params->sampler == YTHIP_SAMPLER_PATHMIS;
+  if (mis && !ctx->nhit_a) {
     int rc;
-    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->st.nhit_a, (size_t)npix))) return rc;
-    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->st.nhit_e, (size_t)npix))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nhit_a, (size_t)npix))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nhit_e, (size_t)npix))) return rc;
   }
-  DState st_launch = ctx->st;
-  if (!mis) st_launch.nhit_a = nullptr;
-  ctx->st = st_launch;
+  ctx->st.nhit_a      = mis ? ctx->nhit_a : nullptr;
+  ctx->st.nhit_e      = mis ? ctx->nhit_e : nullptr;
+  ctx->st.sample_base = ctx->samples;
+  ctx->st.batch       = params->batch;
 
+  // how sample_lights_pdf's instance walks run
+  int lp = LP_NONE;
+  if (params->sampler == YTHIP_SAMPLER_PATH || params->sampler == YTHIP_SAMPLER_PATHTEST) {
+    for (auto& l : ctx->h_lights.lights)
+      if (l.instance != YTHIP_INVALIDID) lp = LP_DEFER;
+  }
+
+  // iterations: every sample needs >= 1; afterwards poll the live-path count
+  // (pipelined by one chunk so the stream never drains).
   int nb = params->bounces;
   if (params->sampler == YTHIP_SAMPLER_EYELIGHT || params->sampler == YTHIP_SAMPLER_DIAGRAM)
     nb = params->bounces > 4 ? params->bounces : 4;
   if (params->sampler == YTHIP_SAMPLER_FALSECOLOR) nb = 1;
+  if (nb < 1) nb = 1;
+  const long long max_iters = (long long)params->batch * (nb + (ctx->may_retry ? 130 : 0)) + 1;
+  const int       CHUNK     = 4;
 
-  for (int s = 0; s < params->batch; s++) {
-    if (stop && *stop) {
-      HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-      return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
+  hipLaunchKernelGGL(k_generate, dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, kp);
+  int       q         = 0;
+  long long poll_iter = -1;  // iteration whose survivor tag is being read back
+  for (long long it = 0; it < max_iters; it++) {
+    ctx->iter_tag = (int)it;
+    {
+      EvScope ev(ctx, 0);
+      if (count)
+        hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, q);
+      else
+        hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, q);
     }
-    int sample = ctx->samples + s;
-    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, kp);
-    int q = 0;
-    for (int it = 0;; it++) {
-      if (it >= nb) {
-        // Only opacity retries (`bounce -= 1; continue`, yocto_trace.cpp:505-510)
-        // can keep paths alive past `bounces` iterations.
-        if (!ctx->may_retry || it >= nb + 130) break;
-        HIPCHECK(ctx, hipMemcpyAsync(ctx->h_qcount, ctx->st.qcount + q, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (*ctx->h_qcount == 0) break;
-      }
-      {
-        EvScope ev(ctx, 0);
-        if (count)
-          hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, q);
-        else
-          hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, q);
-      }
-      {
-        EvScope ev(ctx, 1);
-        int     rc = launch_shade_any(ctx, kp, q, grid);
-        if (rc) return rc;
-      }
-      q ^= 1;
+    {
+      EvScope ev(ctx, 1);
+      int     rc = launch_shade_any(ctx, kp, lp, q, grid);
+      if (rc) return rc;
     }
-    if (count)
-      hipLaunchKernelGGL((k_accumulate<true>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->st, kp, sample);
-    else
-      hipLaunchKernelGGL((k_accumulate<false>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->st, kp, sample);
+    if (lp == LP_DEFER) {
+      EvScope ev(ctx, 2);
+      launch_lightpdf(ctx, kp, q, grid);
+    }
+    q ^= 1;
+    if (it + 1 >= params->batch && (it + 1 - params->batch) % CHUNK == 0) {
+      if (poll_iter >= 0) {
+        HIPCHECK(ctx, hipEventSynchronize(ctx->ev_count));
+        // `alive` holds the tag of the last iteration in which any path survived
+        if (ctx->h_qcount[0] < (int)poll_iter) break;
+        if (stop && *stop) {
+          HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+          return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
+        }
+      }
+      HIPCHECK(ctx, hipMemcpyAsync(ctx->h_qcount, ctx->st.alive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHECK(ctx, hipEventRecord(ctx->ev_count, ctx->stream));
+      poll_iter = it;
+    }
   }
   HIPCHECK(ctx, hipGetLastError());
   ctx->samples += params->batch;  // yocto_trace.cpp:1614
@@ -399,7 +444,8 @@ int ythip_create(int device, ythip_ctx** out) {
   ctx->stream = ctx->own_stream;
   if (hipMalloc((void**)&ctx->d_counters, CNT_NUM * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc((void**)&ctx->h_qcount, 64) != hipSuccess) {
+      hipHostMalloc((void**)&ctx->h_qcount, 64) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_count, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return fail(nullptr, YTHIP_ERR_HIP, "context allocation failed");
   }
@@ -421,6 +467,7 @@ void ythip_destroy(ythip_ctx* ctx) {
   }
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->h_qcount) (void)hipHostFree(ctx->h_qcount);
+  if (ctx->ev_count) (void)hipEventDestroy(ctx->ev_count);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -693,17 +740,24 @@ int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int
   AL(first_b, n);
   AL(vol_a, n);
   AL(vol_b, n);
-  AL(queue[0], n);
-  AL(queue[1], n);
-  AL(qcount, 2);
+  AL(pend, n);
+  size_t nblk = (size_t)grid_for(npix);
+  AL(queue[0], nblk * YT_BLOCK);
+  AL(queue[1], nblk * YT_BLOCK);
+  AL(lqueue, nblk * YT_BLOCK);
+  AL(bcount[0], nblk);
+  AL(bcount[1], nblk);
+  AL(lcount, nblk);
+  AL(alive, 1);
 #undef AL
   HIPCHECK(ctx, hipMemsetAsync(st.image, 0, n * sizeof(float4), ctx->stream));
   HIPCHECK(ctx, hipMemsetAsync(st.albedo, 0, 3 * n * sizeof(float), ctx->stream));
   HIPCHECK(ctx, hipMemsetAsync(st.normal, 0, 3 * n * sizeof(float), ctx->stream));
   HIPCHECK(ctx, hipMemsetAsync(st.hits, 0, n * sizeof(int), ctx->stream));
   HIPCHECK(ctx, hipMemsetAsync(st.rngs, 0, n * sizeof(ulonglong2), ctx->stream));
-  HIPCHECK(ctx, hipMemsetAsync(st.qcount, 0, 2 * sizeof(int), ctx->stream));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->nhit_a     = nullptr;
+  ctx->nhit_e     = nullptr;
   ctx->samples    = 0;
   ctx->have_state = true;
   return YTHIP_OK;
