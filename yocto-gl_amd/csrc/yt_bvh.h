@@ -4,8 +4,22 @@
 // plus the ray-primitive intersectors of libs/yocto/yocto_geometry.h:697-864.
 //
 // Bit-exact contract: identical tree, identical
-// push order (ray_dsign[node.axis]), bbox test at POP time, `t > tmax` reject
-// (a later equal-t primitive replaces an earlier one), ternary min/max, no FMA.
+// visit order (ray_dsign[node.axis]), the slab test of a node decided with the
+// ray.tmax current when the reference would POP it, `t > tmax` reject (a later
+// equal-t primitive replaces an earlier one), ternary min/max, no FMA.
+//
+// What is different from the reference is only WHEN the memory is touched:
+//   * the tree is baked into 64-B "sibling pair" records (both children of an
+//     internal node: 2 x {bbox, ref}), so one dependent fetch serves the two
+//     nodes the reference pops one after the other;
+//   * a child's slab interval [t0, far] is computed when its parent is
+//     processed; the child is pushed as (ref, t0) and the tmax-dependent half
+//     of the reference's test, t0 <= tmax * 1.00000024f, is re-evaluated when
+//     it is popped.  Because  min(far, tmax) * k == min(far * k, tmax * k)
+//     (rounding is monotonic, k > 0), this is the reference's
+//     `t0 <= min(far, tmax) * k` exactly (NaN cases spelled out at slab());
+//   * "while-while" control flow: a lane that reaches a leaf waits for the
+//     rest of its wavefront to reach one, so primitive tests run convergent.
 #pragma once
 
 #include "yt_scene.h"
@@ -13,27 +27,35 @@
 namespace yt {
 
 constexpr int YT_BLOCK      = 256;  // threads per workgroup (4 waves)
-constexpr int YT_LDS_DEPTH  = 32;   // stack entries per lane kept in LDS
-constexpr int YT_SPILL      = 96;   // further entries in scratch (total 128 = reference)
+constexpr int YT_LDS_DEPTH  = 16;   // stack entries (8 B) per lane kept in LDS: 32 KB / workgroup
+constexpr int YT_SPILL      = 112;  // further entries in scratch (total 128 = reference)
 
-// Per-lane traversal stack.  LDS layout [level][thread]: lane l at any level
-// hits bank l%32, i.e. conflict-free for ds_read/write_b32.
-constexpr int ENTRY_DROPPED = -1;  // == ENTRY_EXIT: unwinds safely
+// Node references of the baked tree
+constexpr int REF_INST = 0x40000000;  // [REF_INST, REF_NONE): TLAS-leaf continuation | (tlas_prim << 1 | last)
+constexpr int REF_NONE = 0x7ffffffe;  // nothing / empty tree
+constexpr int REF_EXIT = 0x7fffffff;  // end of the current instance's BLAS entries
+// ref <  0          leaf:  bit 31 | num << 28 | first primitive (leaf order, global)
+// ref in [0, 2^30)  internal: index of its children's sibling-pair record
+
+// Per-lane traversal stack of (ref, t0) entries.  LDS layout [level][thread] of
+// 8-B entries: ds_read/write_b64, lane l at any level hits banks 2l, 2l+1 mod 64
+// → conflict-free within each 32-lane group.
 struct Stack {
-  int* lds;  // &s_stack[0][threadIdx.x]
-  int  sp;
-  int  spill[YT_SPILL];
-  YT_FN void push(int v) {
+  int2* lds;  // &s_stack[0][threadIdx.x]
+  int   sp;
+  int2  spill[YT_SPILL];
+  YT_FN void push(int ref, float t0) {
+    int2 v = {ref, __float_as_int(t0)};
     if (sp < YT_LDS_DEPTH)
       lds[sp * YT_BLOCK] = v;
     else if (sp < YT_LDS_DEPTH + YT_SPILL)
       spill[sp - YT_LDS_DEPTH] = v;
     sp++;  // entries beyond 128 are dropped (the reference's array<int,128> would overflow)
   }
-  YT_FN int pop() {
+  YT_FN int2 pop() {
     sp--;
     if (sp < YT_LDS_DEPTH) return lds[sp * YT_BLOCK];
-    return (sp < YT_LDS_DEPTH + YT_SPILL) ? spill[sp - YT_LDS_DEPTH] : ENTRY_DROPPED;
+    return (sp < YT_LDS_DEPTH + YT_SPILL) ? spill[sp - YT_LDS_DEPTH] : int2{REF_EXIT, 0};
   }
 };
 
@@ -129,11 +151,28 @@ YT_FN bool intersect_bbox(vec3f o, vec3f dinv, float tmin, float tmax, vec3f bmi
   return t0 <= t1;
 }
 
-constexpr int ENTRY_EXIT = -1;  // end of the current instance's BLAS entries
-
 // Leaf-data strides in float4 units, by kind_bvh.
 YT_FN int leaf_stride(int kind) {
   return kind == KIND_TRIANGLES ? 3 : (kind == KIND_QUADS ? 4 : (kind == KIND_LINES ? 3 : 2));
+}
+
+constexpr float BBOX_K = 1.00000024f;  // yocto_geometry.h:862
+
+// Slab interval of one box for the ray (o, dinv): the tmax-independent part of
+// intersect_bbox (yocto_geometry.h:854-864).  The reference's verdict is
+//     t0 <= min_(far, tmax) * k          with min_(a, b) = (a < b) ? a : b
+//   far NaN            → min_ = tmax            → t0 <= tmax*k
+//   far < tmax         → t0 <= far*k  (and then t0 <= far*k <= tmax*k)
+//   otherwise (incl. tmax NaN) → t0 <= tmax*k (and far*k >= tmax*k, or false)
+// i.e. exactly  farok && t0 <= tmax*k  with farok = isnan(far) || t0 <= far*k.
+YT_FN bool slab(vec3f o, vec3f dinv, float tmin, vec3f bmin, vec3f bmax, float& t0) {
+  auto it_min = (bmin - o) * dinv;
+  auto it_max = (bmax - o) * dinv;
+  auto tmn    = min3_(it_min, it_max);
+  auto tmx    = max3_(it_min, it_max);
+  t0          = max_(max_(tmn), tmin);
+  auto far    = min_(tmx);
+  return (far != far) || (t0 <= far * BBOX_K);
 }
 
 // The traversal.  `only_instance` < 0: intersect_scene_bvh (yocto_bvh.cpp:554-617);
@@ -147,35 +186,51 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   const vec3f wo = wray.o, wd = wray.d;
   const float tmin  = wray.tmin;
   float       tmax  = wray.tmax;
+  float       tmaxk = tmax * BBOX_K;
+  // tmax only shrinks while hit distances are numbers; a NaN distance (only
+  // possible with non-finite rays or vertices) is accepted by the reference's
+  // `t < tmin || t > tmax` test and breaks that, so push-time culling against
+  // tmax is switched off from then on (pop-time tests stay exact).
+  bool        weird = tmax != tmax;
   const vec3f wdinv = {1 / wd.x, 1 / wd.y, 1 / wd.z};
   const int   wsign = ((wdinv.x < 0) ? 1 : 0) | ((wdinv.y < 0) ? 2 : 0) | ((wdinv.z < 0) ? 4 : 0);
   vec3f o = wo, d = wd, dinv = wdinv;
   int   sign     = wsign;
   int   cur_inst = -1;   // instance whose BLAS is being walked, -1 at TLAS level
   int   kind     = KIND_NONE;
+  int   leafbias = 0;    // float4 index of the shape's leaf data minus first_prim * stride
   bool  cur_last = false, blas_hit = false;
 
   if (COUNT && only_instance < 0) cnt.rays++;  // intersect_scene_bvh call (yocto_bvh.cpp:554)
-  const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
-  st.sp               = 0;
+  st.sp = 0;
 
-  auto enter = [&](int inst) -> bool {
-    const float4* ti  = reinterpret_cast<const float4*>(sc.tinst + inst);
-    float4        m0 = ti[0], m1 = ti[1], m2 = ti[2];
-    int4          m3 = reinterpret_cast<const int4*>(ti)[3];
-    if (m3.x < 0) return false;  // empty shape BVH → miss (yocto_bvh.cpp:466)
+  // intersect_shape_bvh prologue for instance `inst`: transform_ray(inverse(frame,
+  // true), ray) (yocto_geometry.h:441-443) and the pop + slab test of the BLAS
+  // root, whose bbox travels in the instance record.  Returns the root's ref
+  // when the walk goes on, REF_NONE (level state untouched) when the shape BVH
+  // is empty (yocto_bvh.cpp:466) or the root is culled.
+  auto enter = [&](int inst) -> int {
+    const float4* ti = reinterpret_cast<const float4*>(sc.tinst + inst);
+    float4        m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
+    int4          m5 = reinterpret_cast<const int4*>(ti)[5];
+    int           root = __float_as_int(m4.z);
+    if (root == REF_NONE) return REF_NONE;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
-    // transform_ray(inverse(frame, true), ray) — yocto_geometry.h:441-443
-    o        = transform_point(inv, wo);
-    d        = transform_vector(inv, wd);
-    dinv     = {1 / d.x, 1 / d.y, 1 / d.z};
+    vec3f   io   = transform_point(inv, wo);
+    vec3f   id   = transform_vector(inv, wd);
+    vec3f   idin = {1 / id.x, 1 / id.y, 1 / id.z};
+    if (COUNT) cnt.nodes++;
+    float t0;
+    bool  ok = slab(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
+    if (!ok) return REF_NONE;
+    o = io, d = id, dinv = idin;
     sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
     cur_inst = inst;
-    kind     = m3.y;
+    kind     = __float_as_int(m4.w);
+    leafbias = m5.x;
     blas_hit = false;
-    st.push(ENTRY_EXIT);
-    st.push(m3.x);
-    return true;
+    st.push(REF_EXIT, 0);
+    return root;
   };
 
   // back to the TLAS level: restore the world ray.  Returns true when the
@@ -187,99 +242,136 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     return find_any && cur_last && best.hit;
   };
 
+  int cur = REF_NONE;  // node to process next, REF_NONE = pop one
   if (only_instance >= 0) {
     cur_last = true;
-    if (!enter(only_instance)) return best;
+    cur      = enter(only_instance);
+    if (cur_inst < 0) return best;
   } else {
-    if (sc.tlas_root < 0) return best;
-    st.push(sc.tlas_root);
+    if (sc.tlas_ref == REF_NONE) return best;
+    if (COUNT) cnt.nodes++;
+    float t0;
+    if (!(slab(o, dinv, tmin, sc.tlas_bmin, sc.tlas_bmax, t0) && t0 <= tmaxk)) return best;
+    cur = sc.tlas_ref;
   }
 
-  while (st.sp > 0) {
-    int e = st.pop();
-    if (e >= 0) {
-      float4 na = nodes4[2 * (int64_t)e], nb = nodes4[2 * (int64_t)e + 1];
-      if (COUNT) cnt.nodes++;
-      if (!intersect_bbox(o, dinv, tmin, tmax, {na.x, na.y, na.z}, {na.w, nb.x, nb.y})) continue;
-      int      start    = __float_as_int(nb.z);
-      unsigned packed   = (unsigned)__float_as_int(nb.w);
-      int      num      = (int)(short)(packed & 0xffffu);
-      int      axis     = (int)((packed >> 16) & 0xffu);
-      bool     internal = (packed >> 24) != 0;
-      if (internal) {
-        // near-first along the split axis — yocto_bvh.cpp:498-504
-        if ((sign >> axis) & 1) {
-          st.push(start + 0);
-          st.push(start + 1);
-        } else {
-          st.push(start + 1);
-          st.push(start + 0);
+  auto accept = [&](int element, const PrimHit& h) {
+    best     = {cur_inst, element, h.u, h.v, h.t, true};
+    tmax     = h.t;
+    tmaxk    = h.t * BBOX_K;
+    weird    = weird || (h.t != h.t);
+    blas_hit = true;
+  };
+
+  const float4* pairs = sc.pairs;
+  bool          done  = false;
+  while (!done) {
+    // ---- (1) descend: until this lane holds a leaf / instance entry ----------
+    while (true) {
+      if (cur == REF_NONE) {
+        if (st.sp == 0) {
+          done = true;
+          break;
         }
-      } else if (cur_inst < 0) {
-        // TLAS leaf: instances must be walked in order, each to completion
-        // (yocto_bvh.cpp:600-609) → push continuation entries in reverse.
-        for (int k = num - 1; k >= 0; k--) st.push(-2 - (((start + k) << 1) | (k == num - 1 ? 1 : 0)));
-      } else {
-        // BLAS leaf — yocto_bvh.cpp:505-545
-        const float4* L = sc.leafdata + start;
-        if (kind == KIND_TRIANGLES) {
-          for (int k = 0; k < num; k++) {
-            float4 a = L[3 * k], b = L[3 * k + 1], c = L[3 * k + 2];
-            if (COUNT) cnt.triangles++;
-            auto   h = intersect_triangle(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x});
-            if (!h.hit) continue;
-            best     = {cur_inst, __float_as_int(c.y), h.u, h.v, h.t, true};
-            tmax     = h.t;
-            blas_hit = true;
-          }
-        } else if (kind == KIND_QUADS) {
-          for (int k = 0; k < num; k++) {
-            float4 a = L[4 * k], b = L[4 * k + 1], c = L[4 * k + 2], e4 = L[4 * k + 3];
-            if (COUNT) cnt.quads++;
-            auto   h = intersect_quad(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x},
-                  {c.y, c.z, c.w});
-            if (!h.hit) continue;
-            best     = {cur_inst, __float_as_int(e4.x), h.u, h.v, h.t, true};
-            tmax     = h.t;
-            blas_hit = true;
-          }
-        } else if (kind == KIND_LINES) {
-          for (int k = 0; k < num; k++) {
-            float4 a = L[3 * k], b = L[3 * k + 1], c = L[3 * k + 2];
-            if (COUNT) cnt.lines++;
-            auto   h = intersect_line(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
-            if (!h.hit) continue;
-            best     = {cur_inst, __float_as_int(c.x), h.u, h.v, h.t, true};
-            tmax     = h.t;
-            blas_hit = true;
-          }
-        } else if (kind == KIND_POINTS) {
-          for (int k = 0; k < num; k++) {
-            float4 a = L[2 * k], b = L[2 * k + 1];
-            if (COUNT) cnt.points++;
-            auto   h = intersect_point(o, d, tmin, tmax, {a.x, a.y, a.z}, a.w);
-            if (!h.hit) continue;
-            best     = {cur_inst, __float_as_int(b.x), h.u, h.v, h.t, true};
-            tmax     = h.t;
-            blas_hit = true;
-          }
-        }
-        // find_any early-out of intersect_shape_bvh — yocto_bvh.cpp:548
-        if (find_any && blas_hit) {
-          while (st.sp > 0 && st.pop() != ENTRY_EXIT) {
-          }
-          if (exit_instance()) return best;
-        }
+        int2 e = st.pop();
+        cur    = e.x;
+        if (e.x < REF_INST && !(__int_as_float(e.y) <= tmaxk)) cur = REF_NONE;  // culled at pop time
+        if (cur == REF_NONE) continue;
       }
-    } else if (e == ENTRY_EXIT) {
-      if (exit_instance()) return best;
-    } else {
-      int code = -2 - e;
+      if ((unsigned)cur >= (unsigned)REF_INST) break;  // leaf, instance entry or exit → phase 2
+      // internal node: its two children in the reference's visit order
+      // (near-first along the split axis — yocto_bvh.cpp:498-504, 592-598)
+      const float4* P  = pairs + 4 * (int64_t)cur;
+      float4        q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3];
+      if (COUNT) cnt.nodes += 2;
+      float t0a, t0b;
+      bool  fa   = slab(o, dinv, tmin, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, t0a);
+      bool  fb   = slab(o, dinv, tmin, {q2.x, q2.y, q2.z}, {q2.w, q3.x, q3.y}, t0b);
+      int   axis = __float_as_int(q1.w);
+      bool  swp  = ((sign >> axis) & 1) != 0;  // ray_dsign[axis]: child 1 is popped first
+      int   r1 = swp ? __float_as_int(q3.z) : __float_as_int(q1.z);
+      int   r2 = swp ? __float_as_int(q1.z) : __float_as_int(q3.z);
+      float t1 = swp ? t0b : t0a, t2 = swp ? t0a : t0b;
+      bool  f1 = swp ? fb : fa, f2 = swp ? fa : fb;
+      bool  n1 = f1 && t1 <= tmaxk, n2 = f2 && t2 <= tmaxk;
+      if (n1) {
+        cur = r1;
+        if (weird ? f2 : n2) st.push(r2, t2);
+      } else {
+        cur = n2 ? r2 : REF_NONE;
+      }
+    }
+    if (done) break;
+
+    // ---- (2) leaves, instance entries ----------------------------------------
+    if (cur >= REF_INST) {
+      if (cur == REF_EXIT) {
+        cur = REF_NONE;
+        if (exit_instance()) done = true;
+        continue;
+      }
+      int code = cur - REF_INST;
       cur_last = (code & 1) != 0;
       if (COUNT) cnt.instances++;  // TLAS leaf entry (yocto_bvh.cpp:600-604)
-      if (!enter(sc.tlas_prims[code >> 1])) {
-        if (find_any && cur_last && best.hit) return best;
+      cur = enter(sc.tlas_prims[code >> 1]);
+      if (cur_inst < 0 && find_any && cur_last && best.hit) done = true;
+      continue;
+    }
+    const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+    if (cur_inst < 0) {
+      // TLAS leaf: instances are walked in order, each to completion
+      // (yocto_bvh.cpp:600-609) → continuation entries in reverse, first one now.
+      for (int k = num - 1; k >= 1; k--) st.push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
+      cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
+      continue;
+    }
+    cur = REF_NONE;
+    // BLAS leaf — yocto_bvh.cpp:505-545
+    if (kind == KIND_TRIANGLES) {
+      const float4* L = sc.leafdata + (leafbias + first * 3);
+      // two triangles per round trip (the pool is padded, over-reads are ignored)
+      for (int k0 = 0; k0 < num; k0 += 2) {
+        float4 a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
+        float4 a1 = L[3 * k0 + 3], b1 = L[3 * k0 + 4], c1 = L[3 * k0 + 5];
+        if (COUNT) cnt.triangles++;
+        auto h = intersect_triangle(o, d, tmin, tmax, {a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x});
+        if (h.hit) accept(__float_as_int(c0.y), h);
+        if (k0 + 1 < num) {
+          if (COUNT) cnt.triangles++;
+          h = intersect_triangle(o, d, tmin, tmax, {a1.x, a1.y, a1.z}, {a1.w, b1.x, b1.y}, {b1.z, b1.w, c1.x});
+          if (h.hit) accept(__float_as_int(c1.y), h);
+        }
       }
+    } else if (kind == KIND_QUADS) {
+      const float4* L = sc.leafdata + (leafbias + first * 4);
+      for (int k = 0; k < num; k++) {
+        float4 a = L[4 * k], b = L[4 * k + 1], c = L[4 * k + 2], e4 = L[4 * k + 3];
+        if (COUNT) cnt.quads++;
+        auto h = intersect_quad(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, {c.y, c.z, c.w});
+        if (h.hit) accept(__float_as_int(e4.x), h);
+      }
+    } else if (kind == KIND_LINES) {
+      const float4* L = sc.leafdata + (leafbias + first * 3);
+      for (int k = 0; k < num; k++) {
+        float4 a = L[3 * k], b = L[3 * k + 1], c = L[3 * k + 2];
+        if (COUNT) cnt.lines++;
+        auto h = intersect_line(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
+        if (h.hit) accept(__float_as_int(c.x), h);
+      }
+    } else if (kind == KIND_POINTS) {
+      const float4* L = sc.leafdata + (leafbias + first * 2);
+      for (int k = 0; k < num; k++) {
+        float4 a = L[2 * k], b = L[2 * k + 1];
+        if (COUNT) cnt.points++;
+        auto h = intersect_point(o, d, tmin, tmax, {a.x, a.y, a.z}, a.w);
+        if (h.hit) accept(__float_as_int(b.x), h);
+      }
+    }
+    // find_any early-out of intersect_shape_bvh — yocto_bvh.cpp:548
+    if (find_any && blas_hit) {
+      while (st.sp > 0 && st.pop().x != REF_EXIT) {
+      }
+      if (exit_instance()) done = true;
     }
   }
   return best;

@@ -855,7 +855,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_generate(DScene sc, DState st, KPa
 // k_extend: intersect_scene_bvh for every live path (the traversal kernel).
 template <bool COUNT>
 __global__ void __launch_bounds__(YT_BLOCK) k_extend(DScene sc, DState st, int q) {
-  __shared__ int s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  __shared__ int2 s_stack[YT_LDS_DEPTH][YT_BLOCK];
   int slot = queue_slot(st, q);
   if (slot < 0) return;
   float4 a = st.ray_a[slot], b = st.ray_b[slot];
@@ -885,7 +885,7 @@ YT_FN int max_bounces_of(const KParams& kp) {
 template <int SAMPLER, int LP>
 __global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParams kp, int q, int iter) {
   constexpr bool INLINE = LP == LP_INLINE;
-  __shared__ int s_stack[INLINE ? YT_LDS_DEPTH : 1][INLINE ? YT_BLOCK : 1];
+  __shared__ int2 s_stack[INLINE ? YT_LDS_DEPTH : 1][INLINE ? YT_BLOCK : 1];
   int            slot = queue_slot(st, q);
   int            cls  = OUT_DEAD;
   if (slot >= 0) {
@@ -931,7 +931,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParam
 // k_lightpdf: the deferred sample_lights_pdf walks + the rest of the loop body.
 template <int SAMPLER>
 __global__ void __launch_bounds__(YT_BLOCK) k_lightpdf(DScene sc, DState st, KParams kp, int q, int iter) {
-  __shared__ int s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  __shared__ int2 s_stack[YT_LDS_DEPTH][YT_BLOCK];
   int            slot = -1;
   int            cls  = OUT_DEAD;
   const int      nl   = st.lcount[blockIdx.x];
@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_lightpdf(DScene sc, DState st, KPa
 template <bool COUNT>
 __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const ythip_ray* rays,
     const int* instances, long long n, int find_any, ythip_hit* hits, unsigned long long* counters) {
-  __shared__ int s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  __shared__ int2 s_stack[YT_LDS_DEPTH][YT_BLOCK];
   long long      idx = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
   if (idx >= n) return;
   Stack stack;

@@ -21,16 +21,21 @@ struct DShape {
   int pad_[3];
 };
 
-// Per-instance record for traversal: inverse(frame, non_rigid=true) computed on
-// the host with the reference's operation order (yocto_math.h:2114-2118), plus
-// the shape's BLAS root and element kind so a TLAS leaf visit is one 64-B fetch.
+// Per-instance record for traversal (96 B, one fetch per TLAS leaf entry):
+// inverse(frame, non_rigid=true) computed on the host with the reference's
+// operation order (yocto_math.h:2114-2118), the bbox and ref of the shape's BLAS
+// root (so entering an instance needs no dependent node fetch), the shape's
+// element kind and where its leaf data lives.
 struct DInstanceT {
   float inv[12];
-  int   root;   // global node index of the shape's BLAS root, -1 if empty
-  int   kind;   // kind_bvh of the shape
+  float root_bmin[3], root_bmax[3];
+  int   root_ref;   // ref of the BLAS root (yt_bvh.h), REF_NONE if the tree is empty
+  int   kind;       // kind_bvh of the shape
+  int   leaf_bias;  // float4 index: leafdata of global primitive p starts at leaf_bias + p * stride
   int   shape;
-  int   pad_;
+  int   pad_[2];
 };
+static_assert(sizeof(DInstanceT) == 96, "DInstanceT is fetched as 6 float4");
 
 struct DLight {
   int instance, environment, cdf_offset, cdf_count;
@@ -59,11 +64,12 @@ struct DScene {
   const float*   pixelsf;
   const uint8_t* pixelsb;
   // bvh
-  const ythip_bvh_node* nodes;      // all trees, indices baked to global
-  const float4*         leafdata;   // pre-gathered leaf primitives
-  const int*            tlas_prims; // instance ids in TLAS leaf order
-  const DInstanceT*     tinst;      // per instance
-  int                   tlas_root;  // global node index, -1 if empty
+  const float4*     pairs;      // sibling-pair records (4 float4 each), all trees
+  const float4*     leafdata;   // pre-gathered leaf primitives in leaf order
+  const int*        tlas_prims; // instance ids in TLAS leaf order
+  const DInstanceT* tinst;      // per instance
+  int               tlas_ref;   // ref of the TLAS root, REF_NONE if empty
+  vec3f             tlas_bmin, tlas_bmax;
   // lights
   const DLight* lights;
   const float*  cdf;

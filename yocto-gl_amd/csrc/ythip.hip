@@ -134,11 +134,14 @@ KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
   return k;
 }
 
-// Bake the reference-layout trees into the device layout:
-//   * internal `start` → global node index; BLAS-leaf `start` → float4 index into
-//     leafdata; TLAS-leaf `start` → index into tlas_prims
+// Bake the reference-layout trees (ctx->h_bvh, kept verbatim for download) into
+// the device layout of yt_bvh.h:
+//   * pairs:    one 64-B record per internal node holding BOTH children
+//               {bbox, ref} (+ the parent's split axis) — the two nodes the
+//               reference pops one after the other arrive in one fetch
 //   * leafdata: primitives pre-gathered in leaf order (ids come from
-//     `primitives[]`, so hit indices are unaffected)
+//               `primitives[]`, so hit indices are unaffected)
+//   * tinst:    per-instance inverse frame + BLAS root {bbox, ref}
 int bake_bvh(ythip_ctx* ctx) {
   auto& b        = ctx->h_bvh;
   int   nshapes  = (int)ctx->h_shapes.size();
@@ -147,22 +150,24 @@ int bake_bvh(ythip_ctx* ctx) {
     return fail(ctx, YTHIP_ERR_INVALID, "bvh has %d trees, scene has %d shapes (+1 expected)", ntrees, nshapes);
   free_all(ctx->bvh_allocs);
 
-  auto nodes = b.nodes;  // copy to bake
+  const auto&          nodes = b.nodes;
   std::vector<int64_t> leaf_base(nshapes, 0);
+  std::vector<int>     strides(nshapes, 0);
   int64_t              nleaf4 = 0;
   for (int s = 0; s < nshapes; s++) {
     leaf_base[s] = nleaf4;
     int kind     = ythost::kind_bvh(ctx->h_shapes[s]);
-    int stride   = kind == KIND_TRIANGLES ? 3 : (kind == KIND_QUADS ? 4 : (kind == KIND_LINES ? 3 : 2));
-    nleaf4 += (b.prim_offset[s + 1] - b.prim_offset[s]) * stride;
+    strides[s]   = kind == KIND_TRIANGLES ? 3 : (kind == KIND_QUADS ? 4 : (kind == KIND_LINES ? 3 : 2));
+    nleaf4 += (b.prim_offset[s + 1] - b.prim_offset[s]) * strides[s];
   }
-  if (nleaf4 > 0x7fffffffll || (int64_t)nodes.size() > 0x7fffffffll)
-    return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit indices");
-  std::vector<float4> leaf((size_t)nleaf4);
+  if (nleaf4 > 0x7fffff00ll || (int64_t)nodes.size() > 0x7fffffffll || b.prim_offset[ntrees] > 0x0fffffffll)
+    return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit device references");
+  const int           LEAF_PAD = 8;  // the triangle loop fetches two primitives per round trip
+  std::vector<float4> leaf((size_t)nleaf4 + LEAF_PAD, float4{0, 0, 0, 0});
   for (int s = 0; s < nshapes; s++) {
     const auto& sh     = ctx->h_shapes[s];
     int         kind   = ythost::kind_bvh(sh);
-    int         stride = kind == KIND_TRIANGLES ? 3 : (kind == KIND_QUADS ? 4 : (kind == KIND_LINES ? 3 : 2));
+    int         stride = strides[s];
     const float* P     = ctx->h_positions.data() + 3 * sh.positions_offset;
     const float* R     = sh.radius_offset >= 0 ? ctx->h_radius.data() + sh.radius_offset : nullptr;
     int64_t      np    = b.prim_offset[s + 1] - b.prim_offset[s];
@@ -196,41 +201,71 @@ int bake_bvh(ythip_ctx* ctx) {
         L[1]   = {__builtin_bit_cast(float, id), 0, 0, 0};
       }
     }
-    // bake this tree's nodes
-    int kstride = stride;
-    for (int64_t n = b.node_offset[s]; n < b.node_offset[s + 1]; n++) {
-      auto& node = nodes[n];
-      if (node.internal)
-        node.start += (int32_t)b.node_offset[s];
-      else
-        node.start = (int32_t)(leaf_base[s] + (int64_t)node.start * kstride);
-    }
   }
-  for (int64_t n = b.node_offset[nshapes]; n < b.node_offset[nshapes + 1]; n++) {
-    auto& node = nodes[n];
-    if (node.internal) node.start += (int32_t)b.node_offset[nshapes];
-    // TLAS leaf: start indexes tlas_prims directly
+
+  // sibling-pair records: pair ids in node order, per tree
+  std::vector<int32_t> pair_id(nodes.size(), -1);
+  int64_t              npairs = 0;
+  for (size_t n = 0; n < nodes.size(); n++)
+    if (nodes[n].internal) pair_id[n] = (int32_t)npairs++;
+  if (npairs >= (int64_t)REF_INST) return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit device references");
+  bool bad_leaf = false;
+  auto ref_of   = [&](int64_t gn, int tree) -> int32_t {
+    const auto& node = nodes[gn];
+    if (node.internal) return pair_id[gn];
+    if (node.num < 0 || node.num > 7) bad_leaf = true;
+    // BLAS leaves address leaf data by global primitive index, TLAS leaves index tlas_prims
+    int64_t first = (tree < nshapes ? b.prim_offset[tree] : 0) + node.start;
+    return (int32_t)(0x80000000u | ((uint32_t)(node.num & 7) << 28) | (uint32_t)first);
+  };
+  std::vector<float4> pairs((size_t)npairs * 4 + 4, float4{0, 0, 0, 0});
+  for (int t = 0; t < ntrees; t++) {
+    for (int64_t n = b.node_offset[t]; n < b.node_offset[t + 1]; n++) {
+      const auto& node = nodes[n];
+      if (!node.internal) continue;
+      float4* P = pairs.data() + 4 * (size_t)pair_id[n];
+      for (int c = 0; c < 2; c++) {
+        int64_t     gc = b.node_offset[t] + node.start + c;
+        const auto& ch = nodes[gc];
+        P[2 * c]       = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_min[2], ch.bbox_max[0]};
+        P[2 * c + 1]   = {ch.bbox_max[1], ch.bbox_max[2], __builtin_bit_cast(float, ref_of(gc, t)),
+              __builtin_bit_cast(float, (int32_t)node.axis)};
+      }
+    }
   }
   // per-instance traversal records
   std::vector<DInstanceT> tinst(ctx->h_instances.size());
   for (size_t k = 0; k < tinst.size(); k++) {
     const auto& inst = ctx->h_instances[k];
-    ythost::inverse_frame_nonrigid(inst.frame, tinst[k].inv);
-    int s         = inst.shape;
-    tinst[k].root = (b.node_offset[s + 1] > b.node_offset[s]) ? (int)b.node_offset[s] : -1;
-    tinst[k].kind = ythost::kind_bvh(ctx->h_shapes[s]);
-    tinst[k].shape = s;
-    tinst[k].pad_  = 0;
+    auto&       ti   = tinst[k];
+    ti               = DInstanceT{};
+    ythost::inverse_frame_nonrigid(inst.frame, ti.inv);
+    int s       = inst.shape;
+    ti.root_ref = REF_NONE;
+    if (b.node_offset[s + 1] > b.node_offset[s]) {
+      const auto& root = nodes[b.node_offset[s]];
+      ti.root_ref      = ref_of(b.node_offset[s], s);
+      for (int c = 0; c < 3; c++) ti.root_bmin[c] = root.bbox_min[c], ti.root_bmax[c] = root.bbox_max[c];
+    }
+    ti.kind      = ythost::kind_bvh(ctx->h_shapes[s]);
+    ti.leaf_bias = (int)(leaf_base[s] - b.prim_offset[s] * strides[s]);
+    ti.shape     = s;
   }
+  ctx->ds.tlas_ref = REF_NONE;
+  if (b.node_offset[nshapes + 1] > b.node_offset[nshapes]) {
+    const auto& root  = nodes[b.node_offset[nshapes]];
+    ctx->ds.tlas_ref  = ref_of(b.node_offset[nshapes], nshapes);
+    ctx->ds.tlas_bmin = {root.bbox_min[0], root.bbox_min[1], root.bbox_min[2]};
+    ctx->ds.tlas_bmax = {root.bbox_max[0], root.bbox_max[1], root.bbox_max[2]};
+  }
+  if (bad_leaf) return fail(ctx, YTHIP_ERR_INVALID, "bvh leaf with more than 7 primitives (reference builds <= 4)");
   int rc;
-  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.nodes, nodes.data(), nodes.size()))) return rc;
+  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.pairs, pairs.data(), pairs.size()))) return rc;
   if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.leafdata, leaf.data(), leaf.size()))) return rc;
   if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tlas_prims, b.prims.data() + b.prim_offset[nshapes],
            (size_t)(b.prim_offset[nshapes + 1] - b.prim_offset[nshapes]))))
     return rc;
   if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tinst, tinst.data(), tinst.size()))) return rc;
-  ctx->ds.tlas_root =
-      (b.node_offset[nshapes + 1] > b.node_offset[nshapes]) ? (int)b.node_offset[nshapes] : -1;
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   ctx->have_bvh = true;
   return YTHIP_OK;

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libythip.so")
+LIB_PATH = os.environ.get("YTHIP_LIB") or os.path.join(_HERE, "csrc", "libythip.so")  # YTHIP_LIB: A/B builds of the same HIP library
 
 # ----------------------------------------------------------------------------
 # numpy dtypes == C structs of include/ythip.h
