@@ -39,25 +39,19 @@ constexpr int REF_EXIT = 0x7fffffff;  // end of the current instance's BLAS entr
 
 // Per-lane traversal stack of (ref, t0) entries.  LDS layout [level][thread] of
 // 8-B entries: ds_read/write_b64, lane l at any level hits banks 2l, 2l+1 mod 64
-// → conflict-free within each 32-lane group.
-struct Stack {
-  int2* lds;  // &s_stack[0][threadIdx.x]
-  int   sp;
-  int2  spill[YT_SPILL];
-  YT_FN void push(int ref, float t0) {
-    int2 v = {ref, __float_as_int(t0)};
-    if (sp < YT_LDS_DEPTH)
-      lds[sp * YT_BLOCK] = v;
-    else if (sp < YT_LDS_DEPTH + YT_SPILL)
-      spill[sp - YT_LDS_DEPTH] = v;
-    sp++;  // entries beyond 128 are dropped (the reference's array<int,128> would overflow)
-  }
-  YT_FN int2 pop() {
-    sp--;
-    if (sp < YT_LDS_DEPTH) return lds[sp * YT_BLOCK];
-    return (sp < YT_LDS_DEPTH + YT_SPILL) ? spill[sp - YT_LDS_DEPTH] : int2{REF_EXIT, 0};
-  }
+// → conflict-free within each 32-lane group.  The pointer is typed address
+// space 3 so the accesses are ds_* instructions (a generic pointer would make
+// them flat_*), and `sp` / the scratch overflow array are plain locals of
+// traverse() so `sp` lives in a register (inside one struct with the array the
+// whole struct was demoted to scratch).
+struct alignas(8) StackEntry {
+  int ref, t0;
 };
+typedef __attribute__((address_space(3))) StackEntry lds_entry;
+struct Stack {
+  lds_entry* lds;  // &s_stack[0][threadIdx.x]
+};
+#define YT_STACK_INIT(stack, s_stack) (stack).lds = (lds_entry*)&(s_stack)[0][threadIdx.x]
 
 struct Hit {
   int   instance, element;
@@ -202,7 +196,26 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   bool  cur_last = false, blas_hit = false;
 
   if (COUNT && only_instance < 0) cnt.rays++;  // intersect_scene_bvh call (yocto_bvh.cpp:554)
-  st.sp = 0;
+  lds_entry* const lds = st.lds;
+  int             sp  = 0;
+  StackEntry      spill[YT_SPILL];
+  auto push = [&](int ref, float t0) {
+    StackEntry v = {ref, __float_as_int(t0)};
+    if (sp < YT_LDS_DEPTH)
+      lds[sp * YT_BLOCK].ref = v.ref, lds[sp * YT_BLOCK].t0 = v.t0;
+    else if (sp < YT_LDS_DEPTH + YT_SPILL)
+      spill[sp - YT_LDS_DEPTH] = v;
+    sp++;  // entries beyond 128 are dropped (the reference's array<int,128> would overflow)
+  };
+  auto pop = [&]() -> StackEntry {
+    sp--;
+    if (sp < YT_LDS_DEPTH) {
+      StackEntry v;
+      v.ref = lds[sp * YT_BLOCK].ref, v.t0 = lds[sp * YT_BLOCK].t0;
+      return v;
+    }
+    return (sp < YT_LDS_DEPTH + YT_SPILL) ? spill[sp - YT_LDS_DEPTH] : StackEntry{REF_EXIT, 0};
+  };
 
   // intersect_shape_bvh prologue for instance `inst`: transform_ray(inverse(frame,
   // true), ray) (yocto_geometry.h:441-443) and the pop + slab test of the BLAS
@@ -229,7 +242,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     kind     = __float_as_int(m4.w);
     leafbias = m5.x;
     blas_hit = false;
-    st.push(REF_EXIT, 0);
+    push(REF_EXIT, 0);
     return root;
   };
 
@@ -269,13 +282,13 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     // ---- (1) descend: until this lane holds a leaf / instance entry ----------
     while (true) {
       if (cur == REF_NONE) {
-        if (st.sp == 0) {
+        if (sp == 0) {
           done = true;
           break;
         }
-        int2 e = st.pop();
-        cur    = e.x;
-        if (e.x < REF_INST && !(__int_as_float(e.y) <= tmaxk)) cur = REF_NONE;  // culled at pop time
+        StackEntry e = pop();
+        cur          = e.ref;
+        if (e.ref < REF_INST && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;  // culled at pop time
         if (cur == REF_NONE) continue;
       }
       if ((unsigned)cur >= (unsigned)REF_INST) break;  // leaf, instance entry or exit → phase 2
@@ -296,7 +309,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       bool  n1 = f1 && t1 <= tmaxk, n2 = f2 && t2 <= tmaxk;
       if (n1) {
         cur = r1;
-        if (weird ? f2 : n2) st.push(r2, t2);
+        if (weird ? f2 : n2) push(r2, t2);
       } else {
         cur = n2 ? r2 : REF_NONE;
       }
@@ -321,7 +334,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     if (cur_inst < 0) {
       // TLAS leaf: instances are walked in order, each to completion
       // (yocto_bvh.cpp:600-609) → continuation entries in reverse, first one now.
-      for (int k = num - 1; k >= 1; k--) st.push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
+      for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
       cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
       continue;
     }
@@ -369,7 +382,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     }
     // find_any early-out of intersect_shape_bvh — yocto_bvh.cpp:548
     if (find_any && blas_hit) {
-      while (st.sp > 0 && st.pop().x != REF_EXIT) {
+      while (sp > 0 && pop().ref != REF_EXIT) {
       }
       if (exit_instance()) done = true;
     }

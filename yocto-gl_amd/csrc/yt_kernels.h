@@ -55,6 +55,10 @@ enum {
 // Device mirror of trace_state (yocto_trace.h:147-157) + wavefront path state.
 struct DState {
   int width, height, row_begin, rows, npix;
+  // path slots: the slice is cut into 16x16-pixel tiles; workgroup (logical
+  // block) t owns the 256 slots of tile t for the whole batch.  Slots whose
+  // pixel falls outside the slice are never queued.
+  int tiles_x, tiles_y, nblocks, nslots;
   int sample_base;  // state.samples at the start of this batch
   int batch;        // samples to add per pixel in this batch
   // trace_state
@@ -95,6 +99,32 @@ struct KParams {
   int   nocaustics, envhidden, tentfilter;
   int   has_env;  // !scene.environments.empty()
 };
+
+constexpr int YT_TILE = 16;  // 16 x 16 pixels = YT_BLOCK slots
+static_assert(YT_TILE * YT_TILE == YT_BLOCK, "one tile per workgroup");
+
+// Block → tile mapping.  Hardware block b runs on XCD b % 8 (each XCD has its own
+// 4 MB L2), so with the identity mapping each XCD serves every 8th tile of a
+// tile row.  XCD-aware alternatives were measured on the 1M-triangle plane
+// (k_extend per launch): identity 68 us; one contiguous band of tile rows per
+// XCD 78 us (the sky band idles); tile rows ty = x (mod 8) per XCD 73 us (45
+// tile rows do not divide by 8).  The tree's leaf level dominates the L2
+// footprint and is private to a pixel neighbourhood under any mapping, so
+// balance wins; the hook stays here in case a scene says otherwise.
+YT_FN int logical_block(const DState& st) { return blockIdx.x < st.nblocks ? (int)blockIdx.x : -1; }
+
+// Pixel of a path slot: index into the slice's trace_state arrays (row-major,
+// as the reference lays them out), -1 when outside.  A wave covers 16 x 4
+// pixels: 256-B runs of the image rows (8 x 8 quadrants traced 1 % faster but
+// shaded 6 % slower: trace_state rows are touched in 128-B pieces).
+YT_FN int slot_pixel(const DState& st, int slot, int& i, int& j) {
+  int tile = slot >> 8, w = slot & 255;
+  int ty = tile / st.tiles_x, tx = tile - ty * st.tiles_x;
+  i      = tx * YT_TILE + (w & 15);
+  int jl = ty * YT_TILE + (w >> 4);
+  j      = st.row_begin + jl;
+  return (i < st.width && jl < st.rows) ? jl * st.width + i : -1;
+}
 
 YT_FN void flush_counters(unsigned long long* c, const Counters& cnt) {
   if (!c) return;
@@ -226,6 +256,7 @@ struct Path {
   vec3f     weight, radiance;
   float     max_roughness;
   int       bounce, opbounce, flags, sidx;
+  int       pix;  // pixel index of the slot in the slice's trace_state arrays
   rng_state rng;
 };
 
@@ -664,7 +695,9 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
 YT_FN void load_path(const DState& st, int slot, Path& P, bool with_hit) {
   float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
   float4 w = st.wgt[slot], r = st.rad[slot];
-  auto   g = st.rngs[slot];
+  int    pi, pj;
+  P.pix    = slot_pixel(st, slot, pi, pj);
+  auto   g = st.rngs[P.pix];
   P.o             = {ra.x, ra.y, ra.z};
   P.d             = {ra.w, rb.x, rb.y};
   P.bounce        = __float_as_int(rb.z);
@@ -684,7 +717,7 @@ YT_FN void load_path(const DState& st, int slot, Path& P, bool with_hit) {
 }
 
 YT_FN void store_path(const DState& st, int slot, const Path& P) {
-  st.rngs[slot]  = {P.rng.state, P.rng.inc};
+  st.rngs[P.pix] = {P.rng.state, P.rng.inc};
   st.ray_a[slot] = {P.o.x, P.o.y, P.o.z, P.d.x};
   st.ray_b[slot] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
   st.wgt[slot]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
@@ -693,7 +726,8 @@ YT_FN void store_path(const DState& st, int slot, const Path& P) {
 
 // Head of trace_sample (yocto_trace.cpp:1464-1468): the pixel's next camera ray.
 YT_FN void start_sample(const DScene& sc, const DState& st, const KParams& kp, int slot, Path& P) {
-  int i = slot % st.width, j = st.row_begin + slot / st.width;
+  int i, j;
+  slot_pixel(st, slot, i, j);
   // sample_camera(camera, ij, size, puv = rand2f, luv = rand2f, tent): g++ draws luv first
   auto luv = rand2f(P.rng);
   auto puv = rand2f(P.rng);
@@ -722,32 +756,33 @@ YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Pa
   if (!isfinite_(radiance)) radiance = {0, 0, 0};
   if (max_(radiance) > kp.clamp) radiance = radiance * (kp.clamp / max_(radiance));
   auto   weight = 1.0f / (sample + 1);
-  float4 im     = st.image[slot];
+  const int pix = P.pix;
+  float4 im     = st.image[pix];
   vec4f  image  = {im.x, im.y, im.z, im.w};
-  vec3f  alb    = ld3(st.albedo, slot);
-  vec3f  nrm    = ld3(st.normal, slot);
+  vec3f  alb    = ld3(st.albedo, pix);
+  vec3f  nrm    = ld3(st.normal, pix);
   if (hit) {
     image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
     alb   = lerp_(alb, albedo, weight);
     nrm   = lerp_(nrm, normal, weight);
-    st.hits[slot] += 1;
+    st.hits[pix] += 1;
   } else if (!kp.envhidden && kp.has_env) {
     image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
     alb   = lerp_(alb, vec3f{1, 1, 1}, weight);
     nrm   = lerp_(nrm, normal, weight);
-    st.hits[slot] += 1;
+    st.hits[pix] += 1;
   } else {
     image = lerp_(image, vec4f{0, 0, 0, 0}, weight);
     alb   = lerp_(alb, vec3f{0, 0, 0}, weight);
     nrm   = lerp_(nrm, normal, weight);
   }
-  st.image[slot]          = {image.x, image.y, image.z, image.w};
-  st.albedo[3 * slot]     = alb.x;
-  st.albedo[3 * slot + 1] = alb.y;
-  st.albedo[3 * slot + 2] = alb.z;
-  st.normal[3 * slot]     = nrm.x;
-  st.normal[3 * slot + 1] = nrm.y;
-  st.normal[3 * slot + 2] = nrm.z;
+  st.image[pix]          = {image.x, image.y, image.z, image.w};
+  st.albedo[3 * pix]     = alb.x;
+  st.albedo[3 * pix + 1] = alb.y;
+  st.albedo[3 * pix + 2] = alb.z;
+  st.normal[3 * pix]     = nrm.x;
+  st.normal[3 * pix + 1] = nrm.y;
+  st.normal[3 * pix + 2] = nrm.z;
   if (st.counters) atomicAdd(&st.counters[CNT_SAMPLES], 1ull);
 }
 
@@ -780,10 +815,11 @@ YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, in
 // `qn`: class OUT_PRIMARY from the front, OUT_BOUNCE from the back, starting
 // after the `base` entries already there; OUT_DEFER into the lqueue segment.
 // Every thread of the workgroup must call it.  Returns the new counts.
-YT_FN int2 block_partition(const DState& st, int qn, int slot, int cls, int2 base, bool defer_class, int iter) {
+YT_FN int2 block_partition(const DState& st, int lb, int qn, int slot, int cls, int2 base, bool defer_class,
+    int iter) {
   __shared__ int s_cnt[YT_BLOCK / 64][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int seg  = blockIdx.x * YT_BLOCK;
+  const int seg  = lb * YT_BLOCK;
   unsigned long long mp = __ballot(cls == OUT_PRIMARY);
   unsigned long long mb = __ballot(cls == OUT_BOUNCE);
   unsigned long long md = defer_class ? __ballot(cls == OUT_DEFER) : 0ull;
@@ -810,18 +846,18 @@ YT_FN int2 block_partition(const DState& st, int qn, int slot, int cls, int2 bas
   if (cls == OUT_BOUNCE) st.queue[qn][seg + YT_BLOCK - 1 - (offb + __popcll(mb & below))] = slot;
   if (defer_class && cls == OUT_DEFER) st.lqueue[seg + offd + __popcll(md & below)] = slot;
   if (threadIdx.x == 0) {
-    st.bcount[qn][blockIdx.x] = {totp, totb};
-    if (defer_class) st.lcount[blockIdx.x] = totd;
-    if (totp + totb + totd > 0) *st.alive = iter;  // benign race: every writer stores the same tag
+    st.bcount[qn][lb] = {totp, totb};
+    if (defer_class) st.lcount[lb] = totd;
+    if (iter >= 0 && totp + totb + totd > 0) *st.alive = iter;  // benign race: every writer stores the same tag
   }
   return {totp, totb};
 }
 
 // Slot handled by this thread: entry threadIdx.x of the workgroup's segment
 // (front entries, then back entries), -1 past the end.
-YT_FN int queue_slot(const DState& st, int q) {
-  int2 n   = st.bcount[q][blockIdx.x];
-  int  seg = blockIdx.x * YT_BLOCK, t = threadIdx.x;
+YT_FN int queue_slot(const DState& st, int lb, int q) {
+  int2 n   = st.bcount[q][lb];
+  int  seg = lb * YT_BLOCK, t = threadIdx.x;
   if (t < n.x) return st.queue[q][seg + t];
   if (t < n.x + n.y) return st.queue[q][seg + YT_BLOCK - 1 - (t - n.x)];
   return -1;
@@ -833,30 +869,37 @@ YT_FN int queue_slot(const DState& st, int q) {
 
 // k_generate: first camera ray of the batch for every pixel of the slice.
 __global__ void __launch_bounds__(YT_BLOCK) k_generate(DScene sc, DState st, KParams kp) {
-  int slot = blockIdx.x * YT_BLOCK + threadIdx.x;
+  const int lb = logical_block(st);
+  if (lb < 0) return;
+  int slot = lb * YT_BLOCK + threadIdx.x;
   if (threadIdx.x == 0) {
-    int n                    = min_(YT_BLOCK, st.npix - blockIdx.x * YT_BLOCK);
-    st.bcount[0][blockIdx.x] = {n, 0};
-    st.bcount[1][blockIdx.x] = {0, 0};
-    st.lcount[blockIdx.x]    = 0;
-    if (blockIdx.x == 0) *st.alive = -1;
+    st.bcount[1][lb] = {0, 0};
+    st.lcount[lb]    = 0;
+    if (lb == 0) *st.alive = -1;
   }
-  if (slot >= st.npix) return;
-  Path P;
-  auto r = st.rngs[slot];
-  P.rng  = {r.x, r.y};
-  P.sidx = 0;
-  P.isec = {-1, -1, 0, 0, 0, false};
-  start_sample(sc, st, kp, slot, P);
-  store_path(st, slot, P);
-  st.queue[0][slot] = slot;
+  int  i, j;
+  int  pix = slot_pixel(st, slot, i, j);
+  if (pix >= 0) {
+    Path P;
+    auto r = st.rngs[pix];
+    P.rng  = {r.x, r.y};
+    P.sidx = 0;
+    P.pix  = pix;
+    P.isec = {-1, -1, 0, 0, 0, false};
+    start_sample(sc, st, kp, slot, P);
+    store_path(st, slot, P);
+  }
+  // iteration tag -1: keeps `alive` untouched (the host polls tags >= 0)
+  block_partition(st, lb, 0, slot, pix >= 0 ? OUT_PRIMARY : OUT_DEAD, {0, 0}, false, -1);
 }
 
 // k_extend: intersect_scene_bvh for every live path (the traversal kernel).
 template <bool COUNT>
 __global__ void __launch_bounds__(YT_BLOCK) k_extend(DScene sc, DState st, int q) {
-  __shared__ int2 s_stack[YT_LDS_DEPTH][YT_BLOCK];
-  int slot = queue_slot(st, q);
+  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  const int lb = logical_block(st);
+  if (lb < 0) return;
+  int slot = queue_slot(st, lb, q);
   if (slot < 0) return;
   float4 a = st.ray_a[slot], b = st.ray_b[slot];
   int    flags = __float_as_int(b.w);
@@ -866,7 +909,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_extend(DScene sc, DState st, int q
     return;
   }
   Stack stack;
-  stack.lds    = &s_stack[0][threadIdx.x];
+  YT_STACK_INIT(stack, s_stack);
   Counters cnt = {0, 0, 0, 0, 0, 0, 0};
   ray3f    ray = make_ray({a.x, a.y, a.z}, {a.w, b.x, b.y});
   Hit      h   = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
@@ -885,8 +928,10 @@ YT_FN int max_bounces_of(const KParams& kp) {
 template <int SAMPLER, int LP>
 __global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParams kp, int q, int iter) {
   constexpr bool INLINE = LP == LP_INLINE;
-  __shared__ int2 s_stack[INLINE ? YT_LDS_DEPTH : 1][INLINE ? YT_BLOCK : 1];
-  int            slot = queue_slot(st, q);
+  __shared__ StackEntry s_stack[INLINE ? YT_LDS_DEPTH : 1][INLINE ? YT_BLOCK : 1];
+  const int      lb   = logical_block(st);
+  if (lb < 0) return;
+  int            slot = queue_slot(st, lb, q);
   int            cls  = OUT_DEAD;
   if (slot >= 0) {
     Path P;
@@ -896,7 +941,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParam
     int step;
     if constexpr (INLINE) {
       Stack stack;
-      stack.lds    = &s_stack[0][threadIdx.x];
+      YT_STACK_INIT(stack, s_stack);
       Counters cnt = {0, 0, 0, 0, 0, 0, 0};
       ShadeEnv E   = {sc, st, kp, &stack, &cnt, slot};
       step         = step_path<SAMPLER, LP>(E, P);
@@ -925,23 +970,25 @@ __global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParam
     cls = resolve_step(sc, st, kp, slot, P, step, max_bounces_of<SAMPLER>(kp));
     store_path(st, slot, P);
   }
-  block_partition(st, q ^ 1, slot, cls, {0, 0}, LP == LP_DEFER, iter);
+  block_partition(st, lb, q ^ 1, slot, cls, {0, 0}, LP == LP_DEFER, iter);
 }
 
 // k_lightpdf: the deferred sample_lights_pdf walks + the rest of the loop body.
 template <int SAMPLER>
 __global__ void __launch_bounds__(YT_BLOCK) k_lightpdf(DScene sc, DState st, KParams kp, int q, int iter) {
-  __shared__ int2 s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   int            slot = -1;
   int            cls  = OUT_DEAD;
-  const int      nl   = st.lcount[blockIdx.x];
+  const int      lb   = logical_block(st);
+  if (lb < 0) return;
+  const int      nl   = st.lcount[lb];
   if (nl == 0) return;  // workgroup-uniform: nothing deferred here
   if ((int)threadIdx.x < nl) {
-    slot = st.lqueue[blockIdx.x * YT_BLOCK + threadIdx.x];
+    slot = st.lqueue[lb * YT_BLOCK + threadIdx.x];
     Path P;
     load_path(st, slot, P, false);
     Stack stack;
-    stack.lds    = &s_stack[0][threadIdx.x];
+    YT_STACK_INIT(stack, s_stack);
     Counters cnt = {0, 0, 0, 0, 0, 0, 0};
     float4   pd  = st.pend[slot];
     // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
@@ -953,18 +1000,18 @@ __global__ void __launch_bounds__(YT_BLOCK) k_lightpdf(DScene sc, DState st, KPa
     store_path(st, slot, P);
   }
   // append behind what k_shade already queued for this workgroup
-  block_partition(st, q ^ 1, slot, cls, st.bcount[q ^ 1][blockIdx.x], false, iter);
+  block_partition(st, lb, q ^ 1, slot, cls, st.bcount[q ^ 1][lb], false, iter);
 }
 
 // Test/parity entries ---------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const ythip_ray* rays,
     const int* instances, long long n, int find_any, ythip_hit* hits, unsigned long long* counters) {
-  __shared__ int2 s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   long long      idx = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
   if (idx >= n) return;
   Stack stack;
-  stack.lds    = &s_stack[0][threadIdx.x];
+  YT_STACK_INIT(stack, s_stack);
   Counters cnt = {0, 0, 0, 0, 0, 0, 0};
   auto     r   = rays[idx];
   ray3f    ray = {{r.o[0], r.o[1], r.o[2]}, {r.d[0], r.d[1], r.d[2]}, r.tmin, r.tmax};

@@ -11,6 +11,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -382,8 +383,8 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   auto kp          = to_kparams(ctx, params);
   bool count       = (ctx->prof_mode & 2) != 0;
   ctx->st.counters = count ? ctx->d_counters : nullptr;
-  int  npix        = ctx->st.npix;
-  int  grid        = grid_for(npix);
+  int  npix        = ctx->st.nslots;      // path-state arrays are per slot
+  int  grid        = ctx->st.nblocks;     // one workgroup per 16x16 tile (logical_block)
   bool mis         = params->sampler == YTHIP_SAMPLER_PATHMIS;
   if (mis && !ctx->nhit_a) {
     int rc;
@@ -755,8 +756,12 @@ int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int
   st.rows          = row_end - row_begin;
   long long npix   = (long long)width * st.rows;
   if (npix > 0x7fffffffll / 4) return fail(ctx, YTHIP_ERR_INVALID, "state too large");
-  st.npix = (int)npix;
-  size_t n = (size_t)npix;
+  st.npix      = (int)npix;
+  st.tiles_x   = (width + YT_TILE - 1) / YT_TILE;
+  st.tiles_y   = (st.rows + YT_TILE - 1) / YT_TILE;
+  st.nblocks   = st.tiles_x * st.tiles_y;
+  st.nslots    = st.nblocks * YT_BLOCK;
+  size_t n = (size_t)npix, ns = (size_t)st.nslots;
   int    rc;
 #define AL(field, count) \
   if ((rc = dalloc(ctx, ctx->state_allocs, &st.field, (size_t)(count)))) return rc;
@@ -765,18 +770,18 @@ int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int
   AL(normal, 3 * n);
   AL(hits, n);
   AL(rngs, n);
-  AL(ray_a, n);
-  AL(ray_b, n);
-  AL(hit_a, n);
-  AL(hit_e, n);
-  AL(wgt, n);
-  AL(rad, n);
-  AL(first_a, n);
-  AL(first_b, n);
-  AL(vol_a, n);
-  AL(vol_b, n);
-  AL(pend, n);
-  size_t nblk = (size_t)grid_for(npix);
+  AL(ray_a, ns);
+  AL(ray_b, ns);
+  AL(hit_a, ns);
+  AL(hit_e, ns);
+  AL(wgt, ns);
+  AL(rad, ns);
+  AL(first_a, ns);
+  AL(first_b, ns);
+  AL(vol_a, ns);
+  AL(vol_b, ns);
+  AL(pend, ns);
+  size_t nblk = (size_t)st.nblocks;
   AL(queue[0], nblk * YT_BLOCK);
   AL(queue[1], nblk * YT_BLOCK);
   AL(lqueue, nblk * YT_BLOCK);
