@@ -159,14 +159,38 @@ constexpr float BBOX_K = 1.00000024f;  // yocto_geometry.h:862
 //   far < tmax         → t0 <= far*k  (and then t0 <= far*k <= tmax*k)
 //   otherwise (incl. tmax NaN) → t0 <= tmax*k (and far*k >= tmax*k, or false)
 // i.e. exactly  farok && t0 <= tmax*k  with farok = isnan(far) || t0 <= far*k.
+//
+// TAME = the ray cannot produce a NaN slab product (see ray_is_tame): then the
+// ternary min_/max_ chains equal v_min_f32 / v_max3_f32 up to the sign of a
+// zero, which no comparison below can see — 9 instructions instead of 24
+// compare+select pairs per box.
+template <bool TAME>
 YT_FN bool slab(vec3f o, vec3f dinv, float tmin, vec3f bmin, vec3f bmax, float& t0) {
   auto it_min = (bmin - o) * dinv;
   auto it_max = (bmax - o) * dinv;
-  auto tmn    = min3_(it_min, it_max);
-  auto tmx    = max3_(it_min, it_max);
-  t0          = max_(max_(tmn), tmin);
-  auto far    = min_(tmx);
-  return (far != far) || (t0 <= far * BBOX_K);
+  if constexpr (TAME) {
+    float nx = __builtin_fminf(it_min.x, it_max.x), ny = __builtin_fminf(it_min.y, it_max.y),
+          nz = __builtin_fminf(it_min.z, it_max.z);
+    float fx = __builtin_fmaxf(it_min.x, it_max.x), fy = __builtin_fmaxf(it_min.y, it_max.y),
+          fz = __builtin_fmaxf(it_min.z, it_max.z);
+    t0       = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), tmin);
+    auto far = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    return t0 <= far * BBOX_K;
+  } else {
+    auto tmn = min3_(it_min, it_max);
+    auto tmx = max3_(it_min, it_max);
+    t0       = max_(max_(tmn), tmin);
+    auto far = min_(tmx);
+    return (far != far) || (t0 <= far * BBOX_K);
+  }
+}
+// No slab product (b - o) * dinv can be NaN for finite boxes: o finite, every
+// 1/d finite and non-zero (a zero direction component gives inf and 0 * inf on
+// a box face through the origin), tmin a number.
+YT_FN bool ray_is_tame(vec3f o, vec3f dinv, float tmin) {
+  auto ok = [](float x) { return __builtin_isfinite(x); };
+  return ok(o.x) && ok(o.y) && ok(o.z) && ok(dinv.x) && ok(dinv.y) && ok(dinv.z) && dinv.x != 0 && dinv.y != 0 &&
+         dinv.z != 0 && tmin == tmin;
 }
 
 // The traversal.  `only_instance` < 0: intersect_scene_bvh (yocto_bvh.cpp:554-617);
@@ -188,8 +212,10 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   bool        weird = tmax != tmax;
   const vec3f wdinv = {1 / wd.x, 1 / wd.y, 1 / wd.z};
   const int   wsign = ((wdinv.x < 0) ? 1 : 0) | ((wdinv.y < 0) ? 2 : 0) | ((wdinv.z < 0) ? 4 : 0);
+  const bool  wtame = ray_is_tame(wo, wdinv, tmin);
   vec3f o = wo, d = wd, dinv = wdinv;
   int   sign     = wsign;
+  bool  tame     = wtame;
   int   cur_inst = -1;   // instance whose BLAS is being walked, -1 at TLAS level
   int   kind     = KIND_NONE;
   int   leafbias = 0;    // float4 index of the shape's leaf data minus first_prim * stride
@@ -234,9 +260,10 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     vec3f   idin = {1 / id.x, 1 / id.y, 1 / id.z};
     if (COUNT) cnt.nodes++;
     float t0;
-    bool  ok = slab(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
+    bool  ok = slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
     if (!ok) return REF_NONE;
     o = io, d = id, dinv = idin;
+    tame = ray_is_tame(o, dinv, tmin);
     sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
     cur_inst = inst;
     kind     = __float_as_int(m4.w);
@@ -250,7 +277,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   // find_any early-out of intersect_scene_bvh fires (yocto_bvh.cpp:613: checked
   // after the whole TLAS leaf has been processed).
   auto exit_instance = [&]() -> bool {
-    o = wo, d = wd, dinv = wdinv, sign = wsign;
+    o = wo, d = wd, dinv = wdinv, sign = wsign, tame = wtame;
     cur_inst = -1;
     return find_any && cur_last && best.hit;
   };
@@ -264,7 +291,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     if (sc.tlas_ref == REF_NONE) return best;
     if (COUNT) cnt.nodes++;
     float t0;
-    if (!(slab(o, dinv, tmin, sc.tlas_bmin, sc.tlas_bmax, t0) && t0 <= tmaxk)) return best;
+    if (!(slab<false>(o, dinv, tmin, sc.tlas_bmin, sc.tlas_bmax, t0) && t0 <= tmaxk)) return best;
     cur = sc.tlas_ref;
   }
 
@@ -298,8 +325,14 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       float4        q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3];
       if (COUNT) cnt.nodes += 2;
       float t0a, t0b;
-      bool  fa   = slab(o, dinv, tmin, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, t0a);
-      bool  fb   = slab(o, dinv, tmin, {q2.x, q2.y, q2.z}, {q2.w, q3.x, q3.y}, t0b);
+      bool  fa, fb;
+      if (tame) {
+        fa = slab<true>(o, dinv, tmin, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, t0a);
+        fb = slab<true>(o, dinv, tmin, {q2.x, q2.y, q2.z}, {q2.w, q3.x, q3.y}, t0b);
+      } else {
+        fa = slab<false>(o, dinv, tmin, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, t0a);
+        fb = slab<false>(o, dinv, tmin, {q2.x, q2.y, q2.z}, {q2.w, q3.x, q3.y}, t0b);
+      }
       int   axis = __float_as_int(q1.w);
       bool  swp  = ((sign >> axis) & 1) != 0;  // ray_dsign[axis]: child 1 is popped first
       int   r1 = swp ? __float_as_int(q3.z) : __float_as_int(q1.z);

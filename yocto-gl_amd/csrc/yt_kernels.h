@@ -126,15 +126,32 @@ YT_FN int slot_pixel(const DState& st, int slot, int& i, int& j) {
   return (i < st.width && jl < st.rows) ? jl * st.width + i : -1;
 }
 
+// The counters are kept in CNT_BANKS copies (one 128-B line each, chosen by block
+// index) that the host sums: a single device-scope atomic word saturates at
+// ~88 ops/us on MI355X.
+constexpr int CNT_BANKS = 64, CNT_STRIDE = 16;
+YT_FN int     cnt_bank() { return (int)(blockIdx.x & (CNT_BANKS - 1)) * CNT_STRIDE; }
+
+// Counting mode only: per-lane work counters → wavefront sum (butterfly over
+// __shfl_xor) → one global atomic per counter per wave.  Must be called with
+// the whole wavefront converged (idle lanes pass zeros).
 YT_FN void flush_counters(unsigned long long* c, const Counters& cnt) {
   if (!c) return;
-  atomicAdd(&c[CNT_RAYS], (unsigned long long)cnt.rays);
-  atomicAdd(&c[CNT_NODES], (unsigned long long)cnt.nodes);
-  atomicAdd(&c[CNT_TRIS], (unsigned long long)cnt.triangles);
-  atomicAdd(&c[CNT_QUADS], (unsigned long long)cnt.quads);
-  atomicAdd(&c[CNT_LINES], (unsigned long long)cnt.lines);
-  atomicAdd(&c[CNT_POINTS], (unsigned long long)cnt.points);
-  atomicAdd(&c[CNT_INST], (unsigned long long)cnt.instances);
+  unsigned  v[7]   = {cnt.rays, cnt.nodes, cnt.triangles, cnt.quads, cnt.lines, cnt.points, cnt.instances};
+  const int idx[7] = {CNT_RAYS, CNT_NODES, CNT_TRIS, CNT_QUADS, CNT_LINES, CNT_POINTS, CNT_INST};
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    unsigned x = v[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&c[cnt_bank() + idx[k]], (unsigned long long)x);
+  }
+}
+// +1 per active lane of the current (possibly diverged) control flow: one atomic per wave
+YT_FN void count_lanes(unsigned long long* c, int idx) {
+  if (!c) return;
+  unsigned long long m = __ballot(1);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&c[cnt_bank() + idx], (unsigned long long)__popcll(m));
 }
 
 // Out-of-line traversal for LP_INLINE shading (several call sites, one copy).
@@ -289,9 +306,7 @@ YT_FN void set_first_hit(const DState& s, int slot, vec3f albedo, vec3f normal) 
   s.first_a[slot] = {albedo.x, albedo.y, albedo.z, normal.x};
   s.first_b[slot] = {normal.y, normal.z};
 }
-YT_FN void count_shade(const DState& s) {
-  if (s.counters) atomicAdd(&s.counters[CNT_SHADES], 1ull);
-}
+YT_FN void count_shade(const DState& s) { count_lanes(s.counters, CNT_SHADES); }
 
 // emission seen along `incoming` from a NEE ray's intersection
 // (yocto_trace.cpp:678-687, 873-884)
@@ -783,7 +798,7 @@ YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Pa
   st.normal[3 * pix]     = nrm.x;
   st.normal[3 * pix + 1] = nrm.y;
   st.normal[3 * pix + 2] = nrm.z;
-  if (st.counters) atomicAdd(&st.counters[CNT_SAMPLES], 1ull);
+  count_lanes(st.counters, CNT_SAMPLES);
 }
 
 // Path outcome classes for the compaction
@@ -899,22 +914,23 @@ __global__ void __launch_bounds__(YT_BLOCK) k_extend(DScene sc, DState st, int q
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   const int lb = logical_block(st);
   if (lb < 0) return;
-  int slot = queue_slot(st, lb, q);
-  if (slot < 0) return;
-  float4 a = st.ray_a[slot], b = st.ray_b[slot];
-  int    flags = __float_as_int(b.w);
-  if (flags & PF_SKIPEXTEND) {  // pathmis: intersection = next_intersection
-    st.hit_a[slot] = st.nhit_a[slot];
-    st.hit_e[slot] = st.nhit_e[slot];
-    return;
+  int      slot = queue_slot(st, lb, q);
+  Counters cnt  = {0, 0, 0, 0, 0, 0, 0};
+  if (slot >= 0) {
+    float4 a = st.ray_a[slot], b = st.ray_b[slot];
+    int    flags = __float_as_int(b.w);
+    if (flags & PF_SKIPEXTEND) {  // pathmis: intersection = next_intersection
+      st.hit_a[slot] = st.nhit_a[slot];
+      st.hit_e[slot] = st.nhit_e[slot];
+    } else {
+      Stack stack;
+      YT_STACK_INIT(stack, s_stack);
+      ray3f ray = make_ray({a.x, a.y, a.z}, {a.w, b.x, b.y});
+      Hit   h   = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
+      st.hit_a[slot] = {h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)};
+      st.hit_e[slot] = h.element;
+    }
   }
-  Stack stack;
-  YT_STACK_INIT(stack, s_stack);
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0};
-  ray3f    ray = make_ray({a.x, a.y, a.z}, {a.w, b.x, b.y});
-  Hit      h   = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
-  st.hit_a[slot] = {h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)};
-  st.hit_e[slot] = h.element;
   if (COUNT) flush_counters(st.counters, cnt);
 }
 
@@ -933,6 +949,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParam
   if (lb < 0) return;
   int            slot = queue_slot(st, lb, q);
   int            cls  = OUT_DEAD;
+  Counters       cnt  = {0, 0, 0, 0, 0, 0, 0};
   if (slot >= 0) {
     Path P;
     load_path(st, slot, P, true);
@@ -942,10 +959,8 @@ __global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParam
     if constexpr (INLINE) {
       Stack stack;
       YT_STACK_INIT(stack, s_stack);
-      Counters cnt = {0, 0, 0, 0, 0, 0, 0};
-      ShadeEnv E   = {sc, st, kp, &stack, &cnt, slot};
-      step         = step_path<SAMPLER, LP>(E, P);
-      flush_counters(st.counters, cnt);
+      ShadeEnv E = {sc, st, kp, &stack, &cnt, slot};
+      step       = step_path<SAMPLER, LP>(E, P);
     } else {
       ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
       if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
@@ -970,6 +985,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParam
     cls = resolve_step(sc, st, kp, slot, P, step, max_bounces_of<SAMPLER>(kp));
     store_path(st, slot, P);
   }
+  if (INLINE) flush_counters(st.counters, cnt);
   block_partition(st, lb, q ^ 1, slot, cls, {0, 0}, LP == LP_DEFER, iter);
 }
 
@@ -983,22 +999,22 @@ __global__ void __launch_bounds__(YT_BLOCK) k_lightpdf(DScene sc, DState st, KPa
   if (lb < 0) return;
   const int      nl   = st.lcount[lb];
   if (nl == 0) return;  // workgroup-uniform: nothing deferred here
+  Counters cnt = {0, 0, 0, 0, 0, 0, 0};
   if ((int)threadIdx.x < nl) {
     slot = st.lqueue[lb * YT_BLOCK + threadIdx.x];
     Path P;
     load_path(st, slot, P, false);
     Stack stack;
     YT_STACK_INIT(stack, s_stack);
-    Counters cnt = {0, 0, 0, 0, 0, 0, 0};
-    float4   pd  = st.pend[slot];
+    float4 pd = st.pend[slot];
     // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
     auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
     P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
-    flush_counters(st.counters, cnt);
     int step = step_tail(P);
     cls      = resolve_step(sc, st, kp, slot, P, step, max_bounces_of<SAMPLER>(kp));
     store_path(st, slot, P);
   }
+  flush_counters(st.counters, cnt);
   // append behind what k_shade already queued for this workgroup
   block_partition(st, lb, q ^ 1, slot, cls, st.bcount[q ^ 1][lb], false, iter);
 }
@@ -1009,16 +1025,17 @@ __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const y
     const int* instances, long long n, int find_any, ythip_hit* hits, unsigned long long* counters) {
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   long long      idx = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
-  if (idx >= n) return;
-  Stack stack;
-  YT_STACK_INIT(stack, s_stack);
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0};
-  auto     r   = rays[idx];
-  ray3f    ray = {{r.o[0], r.o[1], r.o[2]}, {r.d[0], r.d[1], r.d[2]}, r.tmin, r.tmax};
-  Hit      h   = traverse<COUNT>(sc, ray, instances ? instances[idx] : -1, find_any != 0, stack, cnt);
-  // scene_intersection{} defaults when missed: instance -1, element -1, uv 0, distance 0
-  if (!h.hit) h = {-1, -1, 0, 0, 0, false};
-  hits[idx] = {h.instance, h.element, h.u, h.v, h.distance, h.hit ? 1 : 0};
+  Counters       cnt = {0, 0, 0, 0, 0, 0, 0};
+  if (idx < n) {
+    Stack stack;
+    YT_STACK_INIT(stack, s_stack);
+    auto  r   = rays[idx];
+    ray3f ray = {{r.o[0], r.o[1], r.o[2]}, {r.d[0], r.d[1], r.d[2]}, r.tmin, r.tmax};
+    Hit   h   = traverse<COUNT>(sc, ray, instances ? instances[idx] : -1, find_any != 0, stack, cnt);
+    // scene_intersection{} defaults when missed: instance -1, element -1, uv 0, distance 0
+    if (!h.hit) h = {-1, -1, 0, 0, 0, false};
+    hits[idx] = {h.instance, h.element, h.u, h.v, h.distance, h.hit ? 1 : 0};
+  }
   if (COUNT) flush_counters(counters, cnt);
 }
 

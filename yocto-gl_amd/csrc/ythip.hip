@@ -478,8 +478,8 @@ int ythip_create(int device, ythip_ctx** out) {
     return fail(nullptr, YTHIP_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
   }
   ctx->stream = ctx->own_stream;
-  if (hipMalloc((void**)&ctx->d_counters, CNT_NUM * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_qcount, 64) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_count, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
@@ -948,7 +948,7 @@ int ythip_reset_stats(ythip_ctx* ctx) {
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   harvest_events(ctx);
   ctx->stats = ythip_stats{};
-  HIPCHECK(ctx, hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long)));
+  HIPCHECK(ctx, hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)));
   return YTHIP_OK;
 }
 
@@ -957,8 +957,10 @@ int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   harvest_events(ctx);
-  unsigned long long c[CNT_NUM];
-  HIPCHECK(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  unsigned long long banks[CNT_BANKS * CNT_STRIDE], c[CNT_NUM] = {};
+  HIPCHECK(ctx, hipMemcpy(banks, ctx->d_counters, sizeof(banks), hipMemcpyDeviceToHost));
+  for (int b = 0; b < CNT_BANKS; b++)
+    for (int k = 0; k < CNT_NUM; k++) c[k] += banks[b * CNT_STRIDE + k];
   *stats           = ctx->stats;
   stats->rays      = (int64_t)c[CNT_RAYS];
   stats->nodes     = (int64_t)c[CNT_NODES];
