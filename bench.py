@@ -30,6 +30,19 @@ sys.path.insert(0, os.path.join(ROOT, "yocto-gl_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def measured_traffic():
+    """HBM bytes per k_trace launch from the PMC passes of the same command
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled
+    as MI355X_MICROARCH.md §HBM prescribes for gfx950), as committed by
+    tools/prof.sh in profiles/traffic.json; None when no profile is present.
+    Counters cannot be read from inside the timed run, so this is not live."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)["k_trace"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def shard_rows(height, world, rank):
     """Contiguous row blocks, the reference's own unit of work (yocto_trace.cpp:66-69)."""
     base, rem = divmod(height, world)
@@ -150,7 +163,7 @@ def main():
     fence()
 
     # ---- timed region: exactly K steps --------------------------------------
-    ctx.set_profiling(0 if args.no_roofline else 1)  # hipEvents around extend/shade launches
+    ctx.set_profiling(0 if args.no_roofline else 1)  # hipEvents around the k_trace launches
     ctx.reset_stats()
     fence()
     t0 = time.perf_counter()
@@ -182,30 +195,29 @@ def main():
                    "sharding": f"rows/{world}" if world > 1 else "none",
                    "setup_s": round(setup_s, 3)},
     }
-    if rank == 0 and stats_count is not None and stats_time["extend_launches"] > 0:
-        # algorithmic bytes of the traversal kernel: SURVEY.md §8(d) per-unit
-        # figures x the units counted in one step, per k_extend launch
-        launches_per_step = stats_time["extend_launches"] / args.steps
-        trav_bytes_step = yt.traversal_bytes(stats_count)
-        ext_ms = stats_time["extend_ms"] / stats_time["extend_launches"]
-        bytes_per_launch = trav_bytes_step / launches_per_step
-        achieved = bytes_per_launch / (ext_ms * 1e-3) / 1e9
+    if rank == 0 and stats_count is not None and stats_time["trace_launches"] > 0:
+        # The dominant (only) kernel is k_trace: one launch = one step.  Its
+        # ALGORITHMIC bytes are SURVEY.md §8(d)'s per-unit figures x the units
+        # counted in one step (all stages: traversal + shading + trace_state).
+        launches_per_step = stats_time["trace_launches"] / args.steps
+        bytes_step = yt.algorithmic_bytes(stats_count)
+        k_ms = stats_time["trace_ms"] / stats_time["trace_launches"]
+        bytes_per_launch = bytes_step / launches_per_step
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
         nsamp = max(stats_count["samples"], 1)
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2),
+            "bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
-            "launch_ms_avg": round(ext_ms, 5), "launches_per_step": launches_per_step,
+            "traffic": measured_traffic(),
+            "launch_ms_avg": round(k_ms, 4), "launches_per_step": launches_per_step,
             "bytes_per_launch": int(bytes_per_launch),
-            "extend_ms_per_step": round(stats_time["extend_ms"] / args.steps, 3),
-            "shade_ms_per_step": round(stats_time["shade_ms"] / args.steps, 3),
+            "traversal_bytes_per_launch": int(yt.traversal_bytes(stats_count) / launches_per_step),
             "per_sample": {"rays": round(stats_count["rays"] / nsamp, 3),
                            "nodes": round(stats_count["nodes"] / nsamp, 3),
                            "triangles": round(stats_count["triangles"] / nsamp, 3),
                            "instances": round(stats_count["instances"] / nsamp, 3),
                            "shades": round(stats_count["shades"] / nsamp, 3),
-                           "bytes_all_stages": round(yt.algorithmic_bytes(stats_count) / nsamp, 1)},
-            "whole_job_GBs": round(yt.algorithmic_bytes(stats_count) / nsamp * value * 1e6 / 1e9, 2),
+                           "bytes_all_stages": round(bytes_step / nsamp, 1)},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

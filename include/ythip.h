@@ -200,14 +200,11 @@ typedef struct ythip_ray {
 /* Measurement record filled by ythip_get_stats (no reference equivalent; the
  * reference only prints wall-clock, yocto_cli.h:128-140). */
 typedef struct ythip_stats {
-  /* traversal kernel (k_extend), measured with hipEvents on the launch stream
-   * while profiling is enabled */
-  int64_t extend_launches;
-  double  extend_ms;
-  int64_t shade_launches;
-  double  shade_ms;
-  int64_t lightpdf_launches; /* k_lightpdf (deferred area-light pdf walks) */
-  double  lightpdf_ms;
+  /* k_trace (the persistent extend + shade kernel, one launch per
+   * trace_samples call), measured with hipEvents on the launch stream while
+   * profiling bit 0 is set */
+  int64_t trace_launches;
+  double  trace_ms;
   /* traversal work counters (valid after a run with counting enabled) */
   int64_t rays;        /* intersect_scene_bvh calls        (yocto_bvh.cpp:554) */
   int64_t nodes;       /* BVH node pops, TLAS+BLAS         (:487,:581)         */
@@ -333,7 +330,7 @@ int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params,
 /* ------------------------------------------------------------------------- */
 /* Measurement                                                                 */
 /* ------------------------------------------------------------------------- */
-/* mode bit 0: time extend/shade launches with hipEvents on the launch stream;
+/* mode bit 0: time k_trace launches with hipEvents on the launch stream;
  * mode bit 1: count traversal work (nodes/prims/instances) in-kernel. */
 int ythip_set_profiling(ythip_ctx* ctx, int mode);
 int ythip_reset_stats(ythip_ctx* ctx);

@@ -309,7 +309,7 @@ def test_work_counters_and_cancel(bundles):
     ctx.set_profiling(0)
     assert s["samples"] == 64 * 64 * 2 and s["rays"] >= s["samples"]
     assert s["nodes"] > s["rays"] and s["triangles"] > 0 and s["instances"] > 0
-    assert s["extend_launches"] > 0 and s["extend_ms"] > 0
+    assert s["trace_launches"] > 0 and s["trace_ms"] > 0
     assert yt.algorithmic_bytes(s) > 0
     # cancellation (trace_start's stop flag, yocto_trace.cpp:1637)
     ctx.make_trace_state(flat, params)

@@ -70,8 +70,6 @@ struct DState {
   // path state, one slot per pixel (SoA of 16-B records: coalesced dwordx4)
   float4* ray_a;    // o.xyz, d.x
   float4* ray_b;    // d.y, d.z, bounce, flags|opbounce<<8
-  float4* hit_a;    // u, v, distance, instance (-1 = miss)
-  int*    hit_e;    // element
   float4* wgt;      // weight.xyz, max_roughness
   float4* rad;      // radiance.xyz, samples done in this batch (int)
   float4* first_a;  // hit_albedo.xyz, hit_normal.x
@@ -81,12 +79,6 @@ struct DState {
   float4* nhit_a;   // pathmis next_intersection: u, v, distance, instance
   int*    nhit_e;   // pathmis next_intersection: element
   float4* pend;     // deferred light pdf: bsdfcos.xyz (or scattering), bsdf pdf
-  // per-workgroup double-ended queue segments (256 entries each) + counts
-  int*  queue[2];   // [nblocks*256]
-  int2* bcount[2];  // [nblocks] {primaries (front), bounces (back)}
-  int*  lqueue;     // [nblocks*256] deferred light-pdf slots
-  int*  lcount;     // [nblocks]
-  int*  alive;      // [1] last iteration tag in which any path survived
   // work counters (ythip_stats), may be null
   unsigned long long* counters;
 };
@@ -160,7 +152,6 @@ __device__ __noinline__ Hit trace_ray(const DScene& sc, vec3f o, vec3f d, int on
   ray3f ray = make_ray(o, d);
   return traverse<true>(sc, ray, only_instance, false, st, cnt);
 }
-
 // ---------------------------------------------------------------------------
 // shading-point helpers
 // ---------------------------------------------------------------------------
@@ -707,14 +698,12 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
 // Path slot I/O, accumulation, regeneration, compaction
 // ===========================================================================
 
-YT_FN void load_path(const DState& st, int slot, Path& P, bool with_hit) {
-  float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+// everything but the ray, whose second record `rb` the caller already holds
+YT_FN void load_path_rest(const DState& st, int slot, Path& P, float4 rb) {
   float4 w = st.wgt[slot], r = st.rad[slot];
   int    pi, pj;
   P.pix    = slot_pixel(st, slot, pi, pj);
   auto   g = st.rngs[P.pix];
-  P.o             = {ra.x, ra.y, ra.z};
-  P.d             = {ra.w, rb.x, rb.y};
   P.bounce        = __float_as_int(rb.z);
   int fw          = __float_as_int(rb.w);
   P.flags         = fw & 0xff;
@@ -724,11 +713,12 @@ YT_FN void load_path(const DState& st, int slot, Path& P, bool with_hit) {
   P.radiance      = {r.x, r.y, r.z};
   P.sidx          = __float_as_int(r.w);
   P.rng           = {g.x, g.y};
-  if (with_hit) {
-    float4 ha   = st.hit_a[slot];
-    int    inst = __float_as_int(ha.w);
-    P.isec      = {inst, st.hit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
-  }
+}
+YT_FN void load_path(const DState& st, int slot, Path& P) {
+  float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+  P.o = {ra.x, ra.y, ra.z};
+  P.d = {ra.w, rb.x, rb.y};
+  load_path_rest(st, slot, P, rb);
 }
 
 YT_FN void store_path(const DState& st, int slot, const Path& P) {
@@ -826,112 +816,45 @@ YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, in
   return OUT_DEAD;
 }
 
-// Block-local partition of this workgroup's slots into its segment of queue
-// `qn`: class OUT_PRIMARY from the front, OUT_BOUNCE from the back, starting
-// after the `base` entries already there; OUT_DEFER into the lqueue segment.
-// Every thread of the workgroup must call it.  Returns the new counts.
-YT_FN int2 block_partition(const DState& st, int lb, int qn, int slot, int cls, int2 base, bool defer_class,
-    int iter) {
-  __shared__ int s_cnt[YT_BLOCK / 64][3];
+// Workgroup-local queue of the persistent kernel (LDS).  Partition of the 256
+// slots a workgroup owns: class OUT_PRIMARY from the front of `queue`,
+// OUT_BOUNCE from the back, starting after the `base` entries already there;
+// OUT_DEFER into `lqueue`.  Every thread of the workgroup must call it.
+// Returns {primaries, bounces, deferred} (workgroup-uniform).
+struct WgQueues {
+  int queue[YT_BLOCK];
+  int lqueue[YT_BLOCK];
+  int cnt[YT_BLOCK / 64][3];
+};
+YT_FN int3 block_partition(WgQueues& Q, int slot, int cls, int2 base, bool defer_class) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int seg  = lb * YT_BLOCK;
   unsigned long long mp = __ballot(cls == OUT_PRIMARY);
   unsigned long long mb = __ballot(cls == OUT_BOUNCE);
   unsigned long long md = defer_class ? __ballot(cls == OUT_DEFER) : 0ull;
   if (lane == 0) {
-    s_cnt[wave][0] = __popcll(mp);
-    s_cnt[wave][1] = __popcll(mb);
-    s_cnt[wave][2] = __popcll(md);
+    Q.cnt[wave][0] = __popcll(mp);
+    Q.cnt[wave][1] = __popcll(mb);
+    Q.cnt[wave][2] = __popcll(md);
   }
-  __syncthreads();
+  __syncthreads();  // also: every thread has read its entry of the previous queue
   int offp = base.x, offb = base.y, offd = 0, totp = base.x, totb = base.y, totd = 0;
 #pragma unroll
   for (int w = 0; w < YT_BLOCK / 64; w++) {
     if (w < wave) {
-      offp += s_cnt[w][0];
-      offb += s_cnt[w][1];
-      offd += s_cnt[w][2];
+      offp += Q.cnt[w][0];
+      offb += Q.cnt[w][1];
+      offd += Q.cnt[w][2];
     }
-    totp += s_cnt[w][0];
-    totb += s_cnt[w][1];
-    totd += s_cnt[w][2];
+    totp += Q.cnt[w][0];
+    totb += Q.cnt[w][1];
+    totd += Q.cnt[w][2];
   }
   const unsigned long long below = (1ull << lane) - 1ull;
-  if (cls == OUT_PRIMARY) st.queue[qn][seg + offp + __popcll(mp & below)] = slot;
-  if (cls == OUT_BOUNCE) st.queue[qn][seg + YT_BLOCK - 1 - (offb + __popcll(mb & below))] = slot;
-  if (defer_class && cls == OUT_DEFER) st.lqueue[seg + offd + __popcll(md & below)] = slot;
-  if (threadIdx.x == 0) {
-    st.bcount[qn][lb] = {totp, totb};
-    if (defer_class) st.lcount[lb] = totd;
-    if (iter >= 0 && totp + totb + totd > 0) *st.alive = iter;  // benign race: every writer stores the same tag
-  }
-  return {totp, totb};
-}
-
-// Slot handled by this thread: entry threadIdx.x of the workgroup's segment
-// (front entries, then back entries), -1 past the end.
-YT_FN int queue_slot(const DState& st, int lb, int q) {
-  int2 n   = st.bcount[q][lb];
-  int  seg = lb * YT_BLOCK, t = threadIdx.x;
-  if (t < n.x) return st.queue[q][seg + t];
-  if (t < n.x + n.y) return st.queue[q][seg + YT_BLOCK - 1 - (t - n.x)];
-  return -1;
-}
-
-// ===========================================================================
-// Kernels
-// ===========================================================================
-
-// k_generate: first camera ray of the batch for every pixel of the slice.
-__global__ void __launch_bounds__(YT_BLOCK) k_generate(DScene sc, DState st, KParams kp) {
-  const int lb = logical_block(st);
-  if (lb < 0) return;
-  int slot = lb * YT_BLOCK + threadIdx.x;
-  if (threadIdx.x == 0) {
-    st.bcount[1][lb] = {0, 0};
-    st.lcount[lb]    = 0;
-    if (lb == 0) *st.alive = -1;
-  }
-  int  i, j;
-  int  pix = slot_pixel(st, slot, i, j);
-  if (pix >= 0) {
-    Path P;
-    auto r = st.rngs[pix];
-    P.rng  = {r.x, r.y};
-    P.sidx = 0;
-    P.pix  = pix;
-    P.isec = {-1, -1, 0, 0, 0, false};
-    start_sample(sc, st, kp, slot, P);
-    store_path(st, slot, P);
-  }
-  // iteration tag -1: keeps `alive` untouched (the host polls tags >= 0)
-  block_partition(st, lb, 0, slot, pix >= 0 ? OUT_PRIMARY : OUT_DEAD, {0, 0}, false, -1);
-}
-
-// k_extend: intersect_scene_bvh for every live path (the traversal kernel).
-template <bool COUNT>
-__global__ void __launch_bounds__(YT_BLOCK) k_extend(DScene sc, DState st, int q) {
-  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
-  const int lb = logical_block(st);
-  if (lb < 0) return;
-  int      slot = queue_slot(st, lb, q);
-  Counters cnt  = {0, 0, 0, 0, 0, 0, 0};
-  if (slot >= 0) {
-    float4 a = st.ray_a[slot], b = st.ray_b[slot];
-    int    flags = __float_as_int(b.w);
-    if (flags & PF_SKIPEXTEND) {  // pathmis: intersection = next_intersection
-      st.hit_a[slot] = st.nhit_a[slot];
-      st.hit_e[slot] = st.nhit_e[slot];
-    } else {
-      Stack stack;
-      YT_STACK_INIT(stack, s_stack);
-      ray3f ray = make_ray({a.x, a.y, a.z}, {a.w, b.x, b.y});
-      Hit   h   = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
-      st.hit_a[slot] = {h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)};
-      st.hit_e[slot] = h.element;
-    }
-  }
-  if (COUNT) flush_counters(st.counters, cnt);
+  if (cls == OUT_PRIMARY) Q.queue[offp + __popcll(mp & below)] = slot;
+  if (cls == OUT_BOUNCE) Q.queue[YT_BLOCK - 1 - (offb + __popcll(mb & below))] = slot;
+  if (defer_class && cls == OUT_DEFER) Q.lqueue[offd + __popcll(md & below)] = slot;
+  __syncthreads();  // queue visible; cnt[] free for the next call
+  return {totp, totb, totd};
 }
 
 template <int SAMPLER>
@@ -940,83 +863,121 @@ YT_FN int max_bounces_of(const KParams& kp) {
                                                                               : kp.bounces;
 }
 
-// k_shade: one iteration of the integrator's bounce loop for every live path.
-template <int SAMPLER, int LP>
-__global__ void __launch_bounds__(YT_BLOCK) k_shade(DScene sc, DState st, KParams kp, int q, int iter) {
-  constexpr bool INLINE = LP == LP_INLINE;
-  __shared__ StackEntry s_stack[INLINE ? YT_LDS_DEPTH : 1][INLINE ? YT_BLOCK : 1];
-  const int      lb   = logical_block(st);
+// ===========================================================================
+// k_trace — the whole of trace_samples for one 16x16 tile, one launch per batch.
+//
+// A persistent workgroup owns its tile's 256 path slots and loops
+//     extend (BVH traversal)  →  shade (one bounce-loop body)  →
+//     [deferred light-pdf walks]  →  block-local compaction
+// until every pixel of the tile has taken its `batch` samples.  Workgroups
+// never wait for each other: no per-iteration launch, no grid-wide tail, and the
+// tile's path state (≈40 KB) stays in the XCD's L2 between iterations.  The
+// ray and the hit record never leave registers between extend and shade.
+// ===========================================================================
+template <int SAMPLER, int LP, bool COUNT>
+__global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KParams kp) {
+  constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
+  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  __shared__ WgQueues   Q;
+  const int lb = logical_block(st);
   if (lb < 0) return;
-  int            slot = queue_slot(st, lb, q);
-  int            cls  = OUT_DEAD;
-  Counters       cnt  = {0, 0, 0, 0, 0, 0, 0};
-  if (slot >= 0) {
-    Path P;
-    load_path(st, slot, P, true);
-    P.flags &= ~PF_SKIPEXTEND;
+  const int tid = threadIdx.x;
+  Stack     stack;
+  YT_STACK_INIT(stack, s_stack);
+  Counters  cnt         = {0, 0, 0, 0, 0, 0, 0};
+  const int max_bounces = max_bounces_of<SAMPLER>(kp);
 
-    int step;
-    if constexpr (INLINE) {
-      Stack stack;
-      YT_STACK_INIT(stack, s_stack);
-      ShadeEnv E = {sc, st, kp, &stack, &cnt, slot};
-      step       = step_path<SAMPLER, LP>(E, P);
-    } else {
-      ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
-      if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
-        step = step_path<SAMPLER, LP>(E, P);
-      } else if constexpr (SAMPLER == YTHIP_SAMPLER_NAIVE) {
-        step = step_naive<SAMPLER>(E, P);
-      } else if constexpr (SAMPLER == YTHIP_SAMPLER_FURNACE) {
-        // exit test at the top of the loop body — yocto_trace.cpp:1263-1266
-        if (P.bounce > 0 && !(P.flags & PF_INVOL)) {
-          P.radiance += P.weight * eval_environment(sc, P.d);
-          step = STEP_END;
-        } else {
-          step = step_naive<SAMPLER>(E, P);
-        }
-      } else if constexpr (SAMPLER == YTHIP_SAMPLER_EYELIGHT || SAMPLER == YTHIP_SAMPLER_DIAGRAM) {
-        step = step_eyelight<SAMPLER>(E, P);
+  // head of the batch: the first camera ray of every pixel of the tile
+  int3 n;
+  {
+    int slot = lb * YT_BLOCK + tid, i, j;
+    int pix  = slot_pixel(st, slot, i, j);
+    if (pix >= 0) {
+      Path P;
+      auto r = st.rngs[pix];
+      P.rng  = {r.x, r.y};
+      P.sidx = 0;
+      P.pix  = pix;
+      start_sample(sc, st, kp, slot, P);
+      store_path(st, slot, P);
+    }
+    n = block_partition(Q, slot, pix >= 0 ? OUT_PRIMARY : OUT_DEAD, {0, 0}, false);
+  }
+
+  while (n.x + n.y > 0) {
+    // entry `tid` of the queue: primaries from the front, then bounces from the back
+    int slot = tid < n.x ? Q.queue[tid] : (tid < n.x + n.y ? Q.queue[YT_BLOCK - 1 - (tid - n.x)] : -1);
+    int cls  = OUT_DEAD;
+    if (slot >= 0) {
+      Path   P;
+      float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+      P.o      = {ra.x, ra.y, ra.z};
+      P.d      = {ra.w, rb.x, rb.y};
+      int fw   = __float_as_int(rb.w);
+      // ---- extend: intersect_scene_bvh ------------------------------------
+      if (MIS && (fw & PF_SKIPEXTEND)) {  // pathmis: intersection = next_intersection
+        float4 ha   = st.nhit_a[slot];
+        int    inst = __float_as_int(ha.w);
+        P.isec      = {inst, st.nhit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
       } else {
-        step = step_falsecolor(E, P);
+        ray3f ray = make_ray(P.o, P.d);
+        P.isec    = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
+      }
+      // ---- shade: one iteration of the integrator's bounce loop -------------
+      load_path_rest(st, slot, P, rb);
+      P.flags &= ~PF_SKIPEXTEND;
+      int step;
+      if constexpr (LP == LP_INLINE) {
+        ShadeEnv E = {sc, st, kp, &stack, &cnt, slot};
+        step       = step_path<SAMPLER, LP>(E, P);
+      } else {
+        ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
+        if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
+          step = step_path<SAMPLER, LP>(E, P);
+        } else if constexpr (SAMPLER == YTHIP_SAMPLER_NAIVE) {
+          step = step_naive<SAMPLER>(E, P);
+        } else if constexpr (SAMPLER == YTHIP_SAMPLER_FURNACE) {
+          // exit test at the top of the loop body — yocto_trace.cpp:1263-1266
+          if (P.bounce > 0 && !(P.flags & PF_INVOL)) {
+            P.radiance += P.weight * eval_environment(sc, P.d);
+            step = STEP_END;
+          } else {
+            step = step_naive<SAMPLER>(E, P);
+          }
+        } else if constexpr (SAMPLER == YTHIP_SAMPLER_EYELIGHT || SAMPLER == YTHIP_SAMPLER_DIAGRAM) {
+          step = step_eyelight<SAMPLER>(E, P);
+        } else {
+          step = step_falsecolor(E, P);
+        }
+      }
+      if (MIS && step != STEP_END && (P.flags & PF_NOEMIT)) P.flags |= PF_SKIPEXTEND;
+      cls = resolve_step(sc, st, kp, slot, P, step, max_bounces);
+      store_path(st, slot, P);
+    }
+    n = block_partition(Q, slot, cls, {0, 0}, LP == LP_DEFER);
+
+    // ---- deferred sample_lights_pdf walks + the rest of the loop body -------
+    if constexpr (LP == LP_DEFER) {
+      if (n.z > 0) {  // workgroup-uniform
+        slot = -1, cls = OUT_DEAD;
+        if (tid < n.z) {
+          slot = Q.lqueue[tid];
+          Path P;
+          load_path(st, slot, P);
+          float4 pd = st.pend[slot];
+          // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
+          auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
+          P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
+          int step = step_tail(P);
+          cls      = resolve_step(sc, st, kp, slot, P, step, max_bounces);
+          store_path(st, slot, P);
+        }
+        // append behind what the shade stage queued
+        n = block_partition(Q, slot, cls, {n.x, n.y}, false);
       }
     }
-    if (SAMPLER == YTHIP_SAMPLER_PATHMIS && step != STEP_END && (P.flags & PF_NOEMIT)) P.flags |= PF_SKIPEXTEND;
-    cls = resolve_step(sc, st, kp, slot, P, step, max_bounces_of<SAMPLER>(kp));
-    store_path(st, slot, P);
   }
-  if (INLINE) flush_counters(st.counters, cnt);
-  block_partition(st, lb, q ^ 1, slot, cls, {0, 0}, LP == LP_DEFER, iter);
-}
-
-// k_lightpdf: the deferred sample_lights_pdf walks + the rest of the loop body.
-template <int SAMPLER>
-__global__ void __launch_bounds__(YT_BLOCK) k_lightpdf(DScene sc, DState st, KParams kp, int q, int iter) {
-  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
-  int            slot = -1;
-  int            cls  = OUT_DEAD;
-  const int      lb   = logical_block(st);
-  if (lb < 0) return;
-  const int      nl   = st.lcount[lb];
-  if (nl == 0) return;  // workgroup-uniform: nothing deferred here
-  Counters cnt = {0, 0, 0, 0, 0, 0, 0};
-  if ((int)threadIdx.x < nl) {
-    slot = st.lqueue[lb * YT_BLOCK + threadIdx.x];
-    Path P;
-    load_path(st, slot, P, false);
-    Stack stack;
-    YT_STACK_INIT(stack, s_stack);
-    float4 pd = st.pend[slot];
-    // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
-    auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
-    P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
-    int step = step_tail(P);
-    cls      = resolve_step(sc, st, kp, slot, P, step, max_bounces_of<SAMPLER>(kp));
-    store_path(st, slot, P);
-  }
-  flush_counters(st.counters, cnt);
-  // append behind what k_shade already queued for this workgroup
-  block_partition(st, lb, q ^ 1, slot, cls, st.bcount[q ^ 1][lb], false, iter);
+  if (COUNT || LP != LP_NONE) flush_counters(st.counters, cnt);
 }
 
 // Test/parity entries ---------------------------------------------------------

@@ -65,9 +65,6 @@ struct ythip_ctx {
   std::vector<std::pair<int, int>>             ev_used;  // (pool index, kind 0 extend / 1 shade)
   size_t                                       ev_next = 0;
   ythip_stats                                  stats   = {};
-  int*                                         h_qcount = nullptr;  // pinned
-  hipEvent_t                                   ev_count = nullptr;
-  int                                          iter_tag = 0;
   float4*                                      nhit_a   = nullptr;
   int*                                         nhit_e   = nullptr;
 };
@@ -288,46 +285,40 @@ int upload_lights_impl(ythip_ctx* ctx) {
 }
 
 template <int S, int LP>
-void launch_shade(ythip_ctx* ctx, const KParams& kp, int q, int grid) {
-  hipLaunchKernelGGL((k_shade<S, LP>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, kp, q,
-      ctx->iter_tag);
+void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
+  dim3 grid(ctx->st.nblocks), block(YT_BLOCK);  // one persistent workgroup per 16x16 tile
+  if (count)
+    hipLaunchKernelGGL((k_trace<S, LP, true>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
+  else
+    hipLaunchKernelGGL((k_trace<S, LP, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
 }
 
 // lp: LP_NONE / LP_DEFER for path & pathtest (area lights absent / present);
 // pathdirect & pathmis always trace inline; the rest never need a light pdf.
-int launch_shade_any(ythip_ctx* ctx, const KParams& kp, int lp, int q, int grid) {
+int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
   switch (kp.sampler) {
     case YTHIP_SAMPLER_PATH:
       if (lp == LP_DEFER)
-        launch_shade<YTHIP_SAMPLER_PATH, LP_DEFER>(ctx, kp, q, grid);
+        launch_trace<YTHIP_SAMPLER_PATH, LP_DEFER>(ctx, kp, count);
       else
-        launch_shade<YTHIP_SAMPLER_PATH, LP_NONE>(ctx, kp, q, grid);
+        launch_trace<YTHIP_SAMPLER_PATH, LP_NONE>(ctx, kp, count);
       break;
     case YTHIP_SAMPLER_PATHTEST:
       if (lp == LP_DEFER)
-        launch_shade<YTHIP_SAMPLER_PATHTEST, LP_DEFER>(ctx, kp, q, grid);
+        launch_trace<YTHIP_SAMPLER_PATHTEST, LP_DEFER>(ctx, kp, count);
       else
-        launch_shade<YTHIP_SAMPLER_PATHTEST, LP_NONE>(ctx, kp, q, grid);
+        launch_trace<YTHIP_SAMPLER_PATHTEST, LP_NONE>(ctx, kp, count);
       break;
-    case YTHIP_SAMPLER_PATHDIRECT: launch_shade<YTHIP_SAMPLER_PATHDIRECT, LP_INLINE>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_PATHMIS: launch_shade<YTHIP_SAMPLER_PATHMIS, LP_INLINE>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_NAIVE: launch_shade<YTHIP_SAMPLER_NAIVE, LP_NONE>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_EYELIGHT: launch_shade<YTHIP_SAMPLER_EYELIGHT, LP_NONE>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_DIAGRAM: launch_shade<YTHIP_SAMPLER_DIAGRAM, LP_NONE>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_FURNACE: launch_shade<YTHIP_SAMPLER_FURNACE, LP_NONE>(ctx, kp, q, grid); break;
-    case YTHIP_SAMPLER_FALSECOLOR: launch_shade<YTHIP_SAMPLER_FALSECOLOR, LP_NONE>(ctx, kp, q, grid); break;
+    case YTHIP_SAMPLER_PATHDIRECT: launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_INLINE>(ctx, kp, count); break;
+    case YTHIP_SAMPLER_PATHMIS: launch_trace<YTHIP_SAMPLER_PATHMIS, LP_INLINE>(ctx, kp, count); break;
+    case YTHIP_SAMPLER_NAIVE: launch_trace<YTHIP_SAMPLER_NAIVE, LP_NONE>(ctx, kp, count); break;
+    case YTHIP_SAMPLER_EYELIGHT: launch_trace<YTHIP_SAMPLER_EYELIGHT, LP_NONE>(ctx, kp, count); break;
+    case YTHIP_SAMPLER_DIAGRAM: launch_trace<YTHIP_SAMPLER_DIAGRAM, LP_NONE>(ctx, kp, count); break;
+    case YTHIP_SAMPLER_FURNACE: launch_trace<YTHIP_SAMPLER_FURNACE, LP_NONE>(ctx, kp, count); break;
+    case YTHIP_SAMPLER_FALSECOLOR: launch_trace<YTHIP_SAMPLER_FALSECOLOR, LP_NONE>(ctx, kp, count); break;
     default: return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
   }
   return YTHIP_OK;
-}
-
-void launch_lightpdf(ythip_ctx* ctx, const KParams& kp, int q, int grid) {
-  if (kp.sampler == YTHIP_SAMPLER_PATHTEST)
-    hipLaunchKernelGGL((k_lightpdf<YTHIP_SAMPLER_PATHTEST>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
-        ctx->st, kp, q, ctx->iter_tag);
-  else
-    hipLaunchKernelGGL((k_lightpdf<YTHIP_SAMPLER_PATH>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
-        ctx->st, kp, q, ctx->iter_tag);
 }
 
 // hipEvent bracketing of one launch (profiling mode bit 0)
@@ -354,16 +345,9 @@ void harvest_events(ythip_ctx* ctx) {
   for (auto [idx, kind] : ctx->ev_used) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev_pool[idx].first, ctx->ev_pool[idx].second) != hipSuccess) continue;
-    if (kind == 0) {
-      ctx->stats.extend_launches++;
-      ctx->stats.extend_ms += ms;
-    } else if (kind == 2) {
-      ctx->stats.lightpdf_launches++;
-      ctx->stats.lightpdf_ms += ms;
-    } else {
-      ctx->stats.shade_launches++;
-      ctx->stats.shade_ms += ms;
-    }
+    (void)kind;
+    ctx->stats.trace_launches++;
+    ctx->stats.trace_ms += ms;
   }
   ctx->ev_used.clear();
   ctx->ev_next = 0;
@@ -383,8 +367,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   auto kp          = to_kparams(ctx, params);
   bool count       = (ctx->prof_mode & 2) != 0;
   ctx->st.counters = count ? ctx->d_counters : nullptr;
-  int  npix        = ctx->st.nslots;      // path-state arrays are per slot
-  int  grid        = ctx->st.nblocks;     // one workgroup per 16x16 tile (logical_block)
+  int  npix        = ctx->st.nslots;  // path-state arrays are per slot
   bool mis         = params->sampler == YTHIP_SAMPLER_PATHMIS;
   if (mis && !ctx->nhit_a) {
     int rc;
@@ -403,52 +386,12 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
       if (l.instance != YTHIP_INVALIDID) lp = LP_DEFER;
   }
 
-  // iterations: every sample needs >= 1; afterwards poll the live-path count
-  // (pipelined by one chunk so the stream never drains).
-  int nb = params->bounces;
-  if (params->sampler == YTHIP_SAMPLER_EYELIGHT || params->sampler == YTHIP_SAMPLER_DIAGRAM)
-    nb = params->bounces > 4 ? params->bounces : 4;
-  if (params->sampler == YTHIP_SAMPLER_FALSECOLOR) nb = 1;
-  if (nb < 1) nb = 1;
-  const long long max_iters = (long long)params->batch * (nb + (ctx->may_retry ? 130 : 0)) + 1;
-  const int       CHUNK     = 4;
-
-  hipLaunchKernelGGL(k_generate, dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, kp);
-  int       q         = 0;
-  long long poll_iter = -1;  // iteration whose survivor tag is being read back
-  for (long long it = 0; it < max_iters; it++) {
-    ctx->iter_tag = (int)it;
-    {
-      EvScope ev(ctx, 0);
-      if (count)
-        hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, q);
-      else
-        hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st, q);
-    }
-    {
-      EvScope ev(ctx, 1);
-      int     rc = launch_shade_any(ctx, kp, lp, q, grid);
-      if (rc) return rc;
-    }
-    if (lp == LP_DEFER) {
-      EvScope ev(ctx, 2);
-      launch_lightpdf(ctx, kp, q, grid);
-    }
-    q ^= 1;
-    if (it + 1 >= params->batch && (it + 1 - params->batch) % CHUNK == 0) {
-      if (poll_iter >= 0) {
-        HIPCHECK(ctx, hipEventSynchronize(ctx->ev_count));
-        // `alive` holds the tag of the last iteration in which any path survived
-        if (ctx->h_qcount[0] < (int)poll_iter) break;
-        if (stop && *stop) {
-          HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-          return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
-        }
-      }
-      HIPCHECK(ctx, hipMemcpyAsync(ctx->h_qcount, ctx->st.alive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHECK(ctx, hipEventRecord(ctx->ev_count, ctx->stream));
-      poll_iter = it;
-    }
+  // one launch renders the whole batch: every workgroup loops over its tile
+  // until its pixels have taken `batch` samples (k_trace)
+  {
+    EvScope ev(ctx, 0);
+    int     rc = launch_trace_any(ctx, kp, lp, count);
+    if (rc) return rc;
   }
   HIPCHECK(ctx, hipGetLastError());
   ctx->samples += params->batch;  // yocto_trace.cpp:1614
@@ -480,8 +423,7 @@ int ythip_create(int device, ythip_ctx** out) {
   ctx->stream = ctx->own_stream;
   if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc((void**)&ctx->h_qcount, 64) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_count, hipEventDisableTiming) != hipSuccess) {
+      false) {
     delete ctx;
     return fail(nullptr, YTHIP_ERR_HIP, "context allocation failed");
   }
@@ -502,8 +444,6 @@ void ythip_destroy(ythip_ctx* ctx) {
     (void)hipEventDestroy(ev.second);
   }
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-  if (ctx->h_qcount) (void)hipHostFree(ctx->h_qcount);
-  if (ctx->ev_count) (void)hipEventDestroy(ctx->ev_count);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -772,8 +712,6 @@ int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int
   AL(rngs, n);
   AL(ray_a, ns);
   AL(ray_b, ns);
-  AL(hit_a, ns);
-  AL(hit_e, ns);
   AL(wgt, ns);
   AL(rad, ns);
   AL(first_a, ns);
@@ -781,14 +719,6 @@ int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int
   AL(vol_a, ns);
   AL(vol_b, ns);
   AL(pend, ns);
-  size_t nblk = (size_t)st.nblocks;
-  AL(queue[0], nblk * YT_BLOCK);
-  AL(queue[1], nblk * YT_BLOCK);
-  AL(lqueue, nblk * YT_BLOCK);
-  AL(bcount[0], nblk);
-  AL(bcount[1], nblk);
-  AL(lcount, nblk);
-  AL(alive, 1);
 #undef AL
   HIPCHECK(ctx, hipMemsetAsync(st.image, 0, n * sizeof(float4), ctx->stream));
   HIPCHECK(ctx, hipMemsetAsync(st.albedo, 0, 3 * n * sizeof(float), ctx->stream));

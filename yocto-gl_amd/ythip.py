@@ -142,9 +142,7 @@ def trace_params(**kw):
 
 
 class CStats(C.Structure):
-    _fields_ = [("extend_launches", C.c_int64), ("extend_ms", C.c_double),
-                ("shade_launches", C.c_int64), ("shade_ms", C.c_double),
-                ("lightpdf_launches", C.c_int64), ("lightpdf_ms", C.c_double),
+    _fields_ = [("trace_launches", C.c_int64), ("trace_ms", C.c_double),
                 ("rays", C.c_int64), ("nodes", C.c_int64),
                 ("triangles", C.c_int64), ("quads", C.c_int64),
                 ("lines", C.c_int64), ("points", C.c_int64),
