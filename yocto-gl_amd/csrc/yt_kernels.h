@@ -72,8 +72,6 @@ struct DState {
   float4* ray_b;    // d.y, d.z, bounce, flags|opbounce<<8
   float4* wgt;      // weight.xyz, max_roughness
   float4* rad;      // radiance.xyz, samples done in this batch (int)
-  float4* first_a;  // hit_albedo.xyz, hit_normal.x
-  float2* first_b;  // hit_normal.yz          (before the first hit: -camera_ray.d)
   float4* vol_a;    // volume: density.xyz, scattering.x
   float4* vol_b;    // volume: scattering.yz, scanisotropy, -
   float4* nhit_a;   // pathmis next_intersection: u, v, distance, instance
@@ -293,9 +291,17 @@ YT_FN void store_volume(const DState& s, int slot, const material_point& m) {
   s.vol_a[slot] = {m.density.x, m.density.y, m.density.z, m.scattering.x};
   s.vol_b[slot] = {m.scattering.y, m.scattering.z, m.scanisotropy, 0};
 }
-YT_FN void set_first_hit(const DState& s, int slot, vec3f albedo, vec3f normal) {
-  s.first_a[slot] = {albedo.x, albedo.y, albedo.z, normal.x};
-  s.first_b[slot] = {normal.y, normal.z};
+// trace_result.albedo / .normal of the sample = those of its first surface hit.
+// The running means of trace_state.albedo / .normal (yocto_trace.cpp:1477-1481)
+// take exactly one term per sample, so the term is folded in right here, with
+// the same lerp and weight trace_sample's tail uses, instead of being parked in
+// per-slot arrays until the sample ends (saves 72 B of state traffic per sample).
+YT_FN void set_first_hit(const DState& s, const Path& P, vec3f albedo, vec3f normal) {
+  auto weight = 1.0f / (s.sample_base + P.sidx + 1);
+  auto alb    = lerp_(ld3(s.albedo, P.pix), albedo, weight);
+  auto nrm    = lerp_(ld3(s.normal, P.pix), normal, weight);
+  s.albedo[3 * P.pix] = alb.x, s.albedo[3 * P.pix + 1] = alb.y, s.albedo[3 * P.pix + 2] = alb.z;
+  s.normal[3 * P.pix] = nrm.x, s.normal[3 * P.pix + 1] = nrm.y, s.normal[3 * P.pix + 2] = nrm.z;
 }
 YT_FN void count_shade(const DState& s) { count_lanes(s.counters, CNT_SHADES); }
 
@@ -383,7 +389,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     // set hit variables
     if (P.bounce == 0) {
       P.flags |= PF_HIT;
-      set_first_hit(E.st, E.slot, material.color, normal);
+      set_first_hit(E.st, P, material.color, normal);
     }
 
     // accumulate emission
@@ -558,7 +564,7 @@ YT_FN int step_naive(ShadeEnv& E, Path& P) {
   }
   if (P.bounce == 0) {
     P.flags |= PF_HIT;
-    set_first_hit(E.st, E.slot, material.color, normal);
+    set_first_hit(E.st, P, material.color, normal);
   }
   P.radiance += P.weight * eval_emission(material, normal, outgoing);
 
@@ -599,7 +605,7 @@ YT_FN int step_eyelight(ShadeEnv& E, Path& P) {
     if (DIAGRAM) {
       P.radiance += P.weight * vec3f{1, 1, 1};
       // hit = true; albedo/normal stay as recorded at bounce 0 (zero if never hit)
-      if (!(P.flags & PF_HIT)) set_first_hit(E.st, E.slot, {0, 0, 0}, {0, 0, 0});
+      if (!(P.flags & PF_HIT)) set_first_hit(E.st, P, {0, 0, 0}, {0, 0, 0});
       P.flags |= PF_HIT;
     } else if (P.bounce > 0 || !kp.envhidden) {
       P.radiance += P.weight * eval_environment(sc, P.d);
@@ -620,7 +626,7 @@ YT_FN int step_eyelight(ShadeEnv& E, Path& P) {
   }
   if (P.bounce == 0) {
     P.flags |= PF_HIT;
-    set_first_hit(E.st, E.slot, material.color, normal);
+    set_first_hit(E.st, P, material.color, normal);
   }
   auto incoming = outgoing;
   P.radiance += P.weight * eval_emission(material, normal, outgoing);
@@ -690,7 +696,7 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
   }
   P.radiance = srgb_to_rgb(result);
   P.flags |= PF_HIT;
-  set_first_hit(E.st, E.slot, material.color, normal);
+  set_first_hit(E.st, P, material.color, normal);
   return STEP_END;
 }
 
@@ -742,8 +748,6 @@ YT_FN void start_sample(const DScene& sc, const DState& st, const KParams& kp, i
   P.radiance      = {0, 0, 0};
   P.max_roughness = 0;
   P.bounce = 0, P.opbounce = 0, P.flags = 0;
-  st.first_a[slot] = {0, 0, 0, -ray.d.x};
-  st.first_b[slot] = {-ray.d.y, -ray.d.z};
   if (st.nhit_a) {
     st.nhit_a[slot] = {0, 0, 0, __int_as_float(-1)};
     st.nhit_e[slot] = -1;
@@ -752,42 +756,39 @@ YT_FN void start_sample(const DScene& sc, const DState& st, const KParams& kp, i
 
 // Tail of trace_sample (yocto_trace.cpp:1471-1491).
 YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Path& P) {
-  int    sample = st.sample_base + P.sidx;
-  float4 fa     = st.first_a[slot];
-  float2 fb     = st.first_b[slot];
-  vec3f  radiance = P.radiance;
-  bool   hit      = (P.flags & PF_HIT) != 0;
-  vec3f  albedo = {fa.x, fa.y, fa.z}, normal = {fa.w, fb.x, fb.y};  // normal = -camera_ray.d before a hit
+  int   sample   = st.sample_base + P.sidx;
+  vec3f radiance = P.radiance;
+  bool  hit      = (P.flags & PF_HIT) != 0;
   if (!isfinite_(radiance)) radiance = {0, 0, 0};
   if (max_(radiance) > kp.clamp) radiance = radiance * (kp.clamp / max_(radiance));
-  auto   weight = 1.0f / (sample + 1);
-  const int pix = P.pix;
-  float4 im     = st.image[pix];
-  vec4f  image  = {im.x, im.y, im.z, im.w};
-  vec3f  alb    = ld3(st.albedo, pix);
-  vec3f  nrm    = ld3(st.normal, pix);
+  auto      weight = 1.0f / (sample + 1);
+  const int pix    = P.pix;
+  float4    im     = st.image[pix];
+  vec4f     image  = {im.x, im.y, im.z, im.w};
   if (hit) {
+    // albedo / normal were folded in at the first hit (set_first_hit)
     image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
-    alb   = lerp_(alb, albedo, weight);
-    nrm   = lerp_(nrm, normal, weight);
-    st.hits[pix] += 1;
-  } else if (!kp.envhidden && kp.has_env) {
-    image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
-    alb   = lerp_(alb, vec3f{1, 1, 1}, weight);
-    nrm   = lerp_(nrm, normal, weight);
     st.hits[pix] += 1;
   } else {
-    image = lerp_(image, vec4f{0, 0, 0, 0}, weight);
-    alb   = lerp_(alb, vec3f{0, 0, 0}, weight);
-    nrm   = lerp_(nrm, normal, weight);
+    // no surface was hit: the path never left the camera ray's direction
+    // (opacity skips only move the origin), so -P.d is -camera_ray.d
+    vec3f normal = -P.d;
+    vec3f alb    = ld3(st.albedo, pix);
+    vec3f nrm    = ld3(st.normal, pix);
+    if (!kp.envhidden && kp.has_env) {
+      image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
+      alb   = lerp_(alb, vec3f{1, 1, 1}, weight);
+      nrm   = lerp_(nrm, normal, weight);
+      st.hits[pix] += 1;
+    } else {
+      image = lerp_(image, vec4f{0, 0, 0, 0}, weight);
+      alb   = lerp_(alb, vec3f{0, 0, 0}, weight);
+      nrm   = lerp_(nrm, normal, weight);
+    }
+    st.albedo[3 * pix] = alb.x, st.albedo[3 * pix + 1] = alb.y, st.albedo[3 * pix + 2] = alb.z;
+    st.normal[3 * pix] = nrm.x, st.normal[3 * pix + 1] = nrm.y, st.normal[3 * pix + 2] = nrm.z;
   }
-  st.image[pix]          = {image.x, image.y, image.z, image.w};
-  st.albedo[3 * pix]     = alb.x;
-  st.albedo[3 * pix + 1] = alb.y;
-  st.albedo[3 * pix + 2] = alb.z;
-  st.normal[3 * pix]     = nrm.x;
-  st.normal[3 * pix + 1] = nrm.y;
-  st.normal[3 * pix + 2] = nrm.z;
+  st.image[pix] = {image.x, image.y, image.z, image.w};
   count_lanes(st.counters, CNT_SAMPLES);
 }
 

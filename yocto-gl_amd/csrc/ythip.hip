@@ -714,8 +714,6 @@ int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int
   AL(ray_b, ns);
   AL(wgt, ns);
   AL(rad, ns);
-  AL(first_a, ns);
-  AL(first_b, ns);
   AL(vol_a, ns);
   AL(vol_b, ns);
   AL(pend, ns);
