@@ -27,8 +27,8 @@
 namespace yt {
 
 constexpr int YT_BLOCK      = 256;  // threads per workgroup (4 waves)
-constexpr int YT_LDS_DEPTH  = 16;   // stack entries (8 B) per lane kept in LDS: 32 KB / workgroup
-constexpr int YT_SPILL      = 112;  // further entries in scratch (total 128 = reference)
+constexpr int YT_LDS_DEPTH  = 8;    // stack entries (8 B) per lane kept in LDS: 16 KB / workgroup
+constexpr int YT_SPILL      = 120;  // further entries in scratch (total 128 = reference)
 
 // Node references of the baked tree
 constexpr int REF_INST = 0x40000000;  // [REF_INST, REF_NONE): TLAS-leaf continuation | (tlas_prim << 1 | last)

@@ -67,11 +67,8 @@ struct DState {
   float*      normal;  // vec3f
   int*        hits;
   ulonglong2* rngs;    // rng_state {state, inc}
-  // path state, one slot per pixel (SoA of 16-B records: coalesced dwordx4)
-  float4* ray_a;    // o.xyz, d.x
-  float4* ray_b;    // d.y, d.z, bounce, flags|opbounce<<8
-  float4* wgt;      // weight.xyz, max_roughness
-  float4* rad;      // radiance.xyz, samples done in this batch (int)
+  // rarely-touched path state, one slot per pixel of the tile grid (the hot
+  // path state lives in LDS for the whole batch: WgState)
   float4* vol_a;    // volume: density.xyz, scattering.x
   float4* vol_b;    // volume: scattering.yz, scanisotropy, -
   float4* nhit_a;   // pathmis next_intersection: u, v, distance, instance
@@ -704,12 +701,27 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
 // Path slot I/O, accumulation, regeneration, compaction
 // ===========================================================================
 
+// Path state of the 256 slots of a tile, resident in LDS for the whole batch
+// (SoA of 16-B records: ds_read/write_b128).  Slots change threads at every
+// compaction, so the state cannot stay in registers; keeping it in LDS instead
+// of HBM removes 160 B of global traffic per path per bounce.  The pixel's PCG
+// state travels here too and returns to trace_state.rngs when the pixel has
+// taken its last sample of the batch.
+struct WgState {
+  float4     ray_a[YT_BLOCK];  // o.xyz, d.x
+  float4     ray_b[YT_BLOCK];  // d.y, d.z, bounce, flags|opbounce<<8
+  float4     wgt[YT_BLOCK];    // weight.xyz, max_roughness
+  float4     rad[YT_BLOCK];    // radiance.xyz, samples done in this batch (int)
+  ulonglong2 rng[YT_BLOCK];    // rng_state {state, inc}
+};
+
 // everything but the ray, whose second record `rb` the caller already holds
-YT_FN void load_path_rest(const DState& st, int slot, Path& P, float4 rb) {
-  float4 w = st.wgt[slot], r = st.rad[slot];
-  int    pi, pj;
-  P.pix    = slot_pixel(st, slot, pi, pj);
-  auto   g = st.rngs[P.pix];
+YT_FN void load_path_rest(const DState& st, const WgState& W, int slot, Path& P, float4 rb) {
+  const int l = slot & (YT_BLOCK - 1);
+  float4    w = W.wgt[l], r = W.rad[l];
+  auto      g = W.rng[l];
+  int       pi, pj;
+  P.pix           = slot_pixel(st, slot, pi, pj);
   P.bounce        = __float_as_int(rb.z);
   int fw          = __float_as_int(rb.w);
   P.flags         = fw & 0xff;
@@ -720,19 +732,21 @@ YT_FN void load_path_rest(const DState& st, int slot, Path& P, float4 rb) {
   P.sidx          = __float_as_int(r.w);
   P.rng           = {g.x, g.y};
 }
-YT_FN void load_path(const DState& st, int slot, Path& P) {
-  float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+YT_FN void load_path(const DState& st, const WgState& W, int slot, Path& P) {
+  const int l  = slot & (YT_BLOCK - 1);
+  float4    ra = W.ray_a[l], rb = W.ray_b[l];
   P.o = {ra.x, ra.y, ra.z};
   P.d = {ra.w, rb.x, rb.y};
-  load_path_rest(st, slot, P, rb);
+  load_path_rest(st, W, slot, P, rb);
 }
 
-YT_FN void store_path(const DState& st, int slot, const Path& P) {
-  st.rngs[P.pix] = {P.rng.state, P.rng.inc};
-  st.ray_a[slot] = {P.o.x, P.o.y, P.o.z, P.d.x};
-  st.ray_b[slot] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
-  st.wgt[slot]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
-  st.rad[slot]   = {P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)};
+YT_FN void store_path(WgState& W, int slot, const Path& P) {
+  const int l = slot & (YT_BLOCK - 1);
+  W.rng[l]   = {P.rng.state, P.rng.inc};
+  W.ray_a[l] = {P.o.x, P.o.y, P.o.z, P.d.x};
+  W.ray_b[l] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
+  W.wgt[l]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
+  W.rad[l]   = {P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)};
 }
 
 // Head of trace_sample (yocto_trace.cpp:1464-1468): the pixel's next camera ray.
@@ -814,6 +828,7 @@ YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, in
     start_sample(sc, st, kp, slot, P);
     return OUT_PRIMARY;
   }
+  st.rngs[P.pix] = {P.rng.state, P.rng.inc};  // the pixel's stream goes back to trace_state
   return OUT_DEAD;
 }
 
@@ -880,6 +895,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   __shared__ WgQueues   Q;
+  __shared__ WgState    W;
   const int lb = logical_block(st);
   if (lb < 0) return;
   const int tid = threadIdx.x;
@@ -900,7 +916,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
       P.sidx = 0;
       P.pix  = pix;
       start_sample(sc, st, kp, slot, P);
-      store_path(st, slot, P);
+      store_path(W, slot, P);
     }
     n = block_partition(Q, slot, pix >= 0 ? OUT_PRIMARY : OUT_DEAD, {0, 0}, false);
   }
@@ -911,7 +927,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
     int cls  = OUT_DEAD;
     if (slot >= 0) {
       Path   P;
-      float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+      float4 ra = W.ray_a[slot & (YT_BLOCK - 1)], rb = W.ray_b[slot & (YT_BLOCK - 1)];
       P.o      = {ra.x, ra.y, ra.z};
       P.d      = {ra.w, rb.x, rb.y};
       int fw   = __float_as_int(rb.w);
@@ -925,7 +941,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
         P.isec    = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
       }
       // ---- shade: one iteration of the integrator's bounce loop -------------
-      load_path_rest(st, slot, P, rb);
+      load_path_rest(st, W, slot, P, rb);
       P.flags &= ~PF_SKIPEXTEND;
       int step;
       if constexpr (LP == LP_INLINE) {
@@ -953,7 +969,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
       }
       if (MIS && step != STEP_END && (P.flags & PF_NOEMIT)) P.flags |= PF_SKIPEXTEND;
       cls = resolve_step(sc, st, kp, slot, P, step, max_bounces);
-      store_path(st, slot, P);
+      store_path(W, slot, P);
     }
     n = block_partition(Q, slot, cls, {0, 0}, LP == LP_DEFER);
 
@@ -964,14 +980,14 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
         if (tid < n.z) {
           slot = Q.lqueue[tid];
           Path P;
-          load_path(st, slot, P);
+          load_path(st, W, slot, P);
           float4 pd = st.pend[slot];
           // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
           auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
           P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
           int step = step_tail(P);
           cls      = resolve_step(sc, st, kp, slot, P, step, max_bounces);
-          store_path(st, slot, P);
+          store_path(W, slot, P);
         }
         // append behind what the shade stage queued
         n = block_partition(Q, slot, cls, {n.x, n.y}, false);

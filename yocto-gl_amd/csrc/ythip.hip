@@ -710,10 +710,6 @@ int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int
   AL(normal, 3 * n);
   AL(hits, n);
   AL(rngs, n);
-  AL(ray_a, ns);
-  AL(ray_b, ns);
-  AL(wgt, ns);
-  AL(rad, ns);
   AL(vol_a, ns);
   AL(vol_b, ns);
   AL(pend, ns);
