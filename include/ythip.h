@@ -240,6 +240,12 @@ int ythip_sync(ythip_ctx* ctx);
  * (yocto_cutrace.cpp:564-702).  Host pointers; copied. */
 int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* scene);
 
+/* Re-upload only the cameras of the resident scene (num must equal the resident
+ * count).  The interactive loop edits scene.cameras[params.camera] between
+ * trace_samples calls (apps/ytrace.cpp:189-204, 248-254) without touching the
+ * geometry; everything else stays resident. */
+int ythip_update_cameras(ythip_ctx* ctx, const ythip_camera* cameras, int num);
+
 /* make_trace_bvh → make_scene_bvh (yocto_trace.cpp:88-96,
  * yocto_bvh.cpp:238-302,321-396): host-side build that reproduces the
  * reference's node order bit-for-bit, then upload. */

@@ -318,3 +318,22 @@ def test_work_counters_and_cancel(bundles):
         ctx.trace_samples(params, stop=stop)
     with pytest.raises(yt.YthipError):
         ctx.trace_samples(yt.trace_params(sampler=42))  # "sampler unknown"
+
+
+# ---------------------------------------------------------------------------
+# the C++ drop-in boundary (yocto-gl_amd/host/yocto_hiptrace.h)
+# ---------------------------------------------------------------------------
+DROPIN = os.path.join(os.path.dirname(P.GOLDEN.rstrip("/")), "..", "oracle", "_ref", "dropin_test")
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_test did not travel")
+def test_cpp_dropin_matches_reference_api():
+    """The reference's own scene_data / trace_bvh / trace_lights / trace_state objects
+    through yocto::hip::trace_samples vs yocto::trace_samples, in C++
+    (tests/cpp/dropin_test.cpp): eyelight bit-exact incl. progressive batches,
+    CPU<->GPU resume, camera edits, trace_image, exception behaviour; path within
+    the tolerances stated there."""
+    import subprocess
+    r = subprocess.run([DROPIN], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "dropin_test: OK" in r.stdout

@@ -554,6 +554,18 @@ int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* sc) {
   return YTHIP_OK;
 }
 
+int ythip_update_cameras(ythip_ctx* ctx, const ythip_camera* cameras, int num) {
+  if (!ctx || !cameras) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  if (num != ctx->num_cameras)
+    return fail(ctx, YTHIP_ERR_INVALID, "scene has %d cameras resident, %d given", ctx->num_cameras, num);
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipMemcpyAsync((void*)ctx->ds.cameras, cameras, (size_t)num * sizeof(ythip_camera),
+                    hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return YTHIP_OK;
+}
+
 int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* sc, int highquality) {
   if (!ctx || !sc) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");

@@ -1,0 +1,66 @@
+//
+// yocto_hiptrace.h — the MI355X back-end behind Yocto/GL's lower-level rendering
+// API (libs/yocto/yocto_trace.h:160-190).
+//
+// Every function below has the signature of its namesake in namespace `yocto`
+// and the same observable behaviour: it takes and returns the reference's own
+// value types (scene_data, trace_bvh, trace_lights, trace_state, trace_params,
+// image_data), mutates only `state`, throws std::runtime_error /
+// std::invalid_argument where the reference does, and leaves `state` (image,
+// albedo, normal, hits, rngs, samples) exactly as the CPU tracer would within
+// the float tolerance stated in tests/ (bit-exact for the rng streams, hit
+// counters and every libm-free stage).
+//
+// Only trace_samples runs on the GPU.  make_trace_bvh / make_trace_lights /
+// make_trace_state stay the reference's host functions (SURVEY.md §8a rows
+// 20-22: "host, re-used unchanged"), so a `trace_bvh` built by either side
+// works with either trace_samples.
+//
+// The device mirrors of (scene, bvh, lights, state) are cached between calls by
+// identity + a cheap content stamp, so the progressive loop
+//     for (...) trace_samples(state, scene, bvh, lights, params);
+// of apps/ytrace.cpp:141-158 uploads once.
+//
+#ifndef YOCTO_HIPTRACE_H
+#define YOCTO_HIPTRACE_H
+
+#include <yocto/yocto_image.h>
+#include <yocto/yocto_scene.h>
+#include <yocto/yocto_trace.h>
+
+namespace yocto::hip {
+
+// True when a HIP device and libythip are usable (mirrors embree_supported(),
+// yocto_bvh.h).  Never throws.
+bool hip_supported();
+
+// yocto_trace.h:160-168 — forwarded to the reference's host implementations.
+trace_state  make_trace_state(const scene_data& scene, const trace_params& params);
+trace_lights make_trace_lights(const scene_data& scene, const trace_params& params);
+trace_bvh    make_trace_bvh(const scene_data& scene, const trace_params& params);
+
+// yocto_trace.h:171-173 — the accelerated call.  Synchronous; on return the host
+// vectors of `state` hold the new running means and `state.samples` has grown
+// by params.batch (no-op when state.samples >= params.samples,
+// yocto_trace.cpp:1598).  params.embreebvh is rejected (std::invalid_argument):
+// the Embree half of trace_bvh has no device mirror.
+void trace_samples(trace_state& state, const scene_data& scene, const trace_bvh& bvh,
+    const trace_lights& lights, const trace_params& params);
+
+// Same, but leaves the result on the device: the host vectors of `state` are
+// NOT refreshed until download_state() (or the next trace_samples()).  For
+// loops that only look at the final image.
+void trace_samples_resident(trace_state& state, const scene_data& scene,
+    const trace_bvh& bvh, const trace_lights& lights, const trace_params& params);
+void download_state(trace_state& state);
+
+// yocto_trace.h:116 — make_* + the progressive loop + get_image.
+image_data trace_image(const scene_data& scene, const trace_params& params);
+
+// Drop every cached device mirror and the context (e.g. before the scene's
+// storage is reused for different content of the same sizes).
+void release();
+
+}  // namespace yocto::hip
+
+#endif

@@ -394,6 +394,7 @@ _SIGNATURES = {
     "ythip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_sync": (C.c_int, [C.c_void_p]),
     "ythip_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(CScene)]),
+    "ythip_update_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ythip_build_bvh": (C.c_int, [C.c_void_p, C.POINTER(CScene), C.c_int]),
     "ythip_upload_bvh": (C.c_int, [C.c_void_p, C.POINTER(CBvh)]),
     "ythip_bvh_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
@@ -545,6 +546,12 @@ class Context:
     def upload_scene(self, scene):
         cs = scene.c_struct()
         self._check(self.lib.ythip_upload_scene(self.h, C.byref(cs)), "upload_scene")
+
+    def update_cameras(self, cameras):
+        """Re-upload only the cameras (interactive camera edits, apps/ytrace.cpp:189-204)."""
+        cams = np.ascontiguousarray(cameras, camera_dt)
+        self._check(self.lib.ythip_update_cameras(self.h, cams.ctypes.data, len(cams)),
+                    "update_cameras")
 
     def make_trace_bvh(self, scene, highquality=False):
         cs = scene.c_struct()
