@@ -43,13 +43,6 @@ def measured_traffic():
         return None
 
 
-def shard_rows(height, world, rank):
-    """Contiguous row blocks, the reference's own unit of work (yocto_trace.cpp:66-69)."""
-    base, rem = divmod(height, world)
-    r0 = rank * base + min(rank, rem)
-    return r0, r0 + base + (1 if rank < rem else 0)
-
-
 def cpu_baseline(flat, params_kw, budget_s=15.0):
     """The reference itself (oracle/_ref, g++ -O3, all host cores) timed on a
     bounded sample of the same workload."""
@@ -91,6 +84,7 @@ def main():
     import torch
     import ythip as yt
     import scenes as ysc
+    from sharding import FrameGather, shard_rngs, shard_rows
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,21 +122,18 @@ def main():
     albedo = torch.zeros(npix, 3, device=dev)
     normal = torch.zeros(npix, 3, device=dev)
     hits = torch.zeros(npix, dtype=torch.int32, device=dev)
-    trng = torch.from_numpy(rngs[r0 * w:r1 * w].view(np.int64).copy()).to(dev)
+    trng = torch.from_numpy(shard_rngs(rngs, w, (r0, r1)).view(np.int64).copy()).to(dev)
     ctx.bind_device_state(image.data_ptr(), albedo.data_ptr(), normal.data_ptr(),
                           hits.data_ptr(), trng.data_ptr())
     stream = torch.cuda.Stream(device=dev)  # non-null: kernels and the RCCL gather share it
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
-    full = torch.empty(world * npix, 4, device=dev) if world > 1 else None
-    even = all(shard_rows(h, world, r)[1] - shard_rows(h, world, r)[0] == r1 - r0 for r in range(world))
-    if world > 1 and not even:
-        raise SystemExit("row count must divide evenly across ranks for the all-gather")
+    gather = FrameGather(dist, w, h, 4, dev) if world > 1 else None
 
     def step():
         ctx.trace_samples_async(params)
         if world > 1:  # framebuffer gather over RCCL/xGMI (§8e), once per batch
-            dist.all_gather_into_tensor(full, image)
+            gather.gather(image)
 
     def fence():
         if world > 1:
