@@ -6,10 +6,12 @@
            default seed  (configs[1]; SURVEY.md §8d recipe cfg2)
   step     one trace_samples call rendering `--spp` (64) more samples for every
            pixel = 1280*720*64 = 58,982,400 camera paths
-  N > 1    image rows sharded across ranks (configs[2]); every rank holds a full
-           replica of scene+BVH and its slice of trace_state; one RCCL all-gather
-           of the framebuffer per step (inside the timed region).  Total work is
-           fixed → "strong" scaling.
+  N > 1    the frame's 16-pixel tile columns dealt round-robin across ranks
+           (configs[2]; sharding.py — balanced, unlike contiguous row blocks whose
+           top ranks would only see sky); every rank holds a full replica of
+           scene+BVH and its slice of trace_state; one RCCL all-gather of the
+           framebuffer + un-permute per step (inside the timed region).  Total
+           work is fixed → "strong" scaling.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -79,12 +81,16 @@ def main():
     ap.add_argument("--resolution", type=int, default=1280)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sharding", choices=["columns", "rows"], default="columns")
+    ap.add_argument("--as-rank", default=None, metavar="R/N",
+                    help="single-GPU experiment: render only the slice rank R of N would "
+                         "(no gather); the JSON line then describes that slice")
     args = ap.parse_args()
 
     import torch
     import ythip as yt
     import scenes as ysc
-    from sharding import FrameGather, shard_rngs, shard_rows
+    from sharding import FrameGather, shard_frame
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,10 +117,15 @@ def main():
     ctx.make_trace_lights(flat)
     setup_s = time.time() - t0
     w, h = yt.state_size(flat.cameras[0], params.resolution)
-    r0, r1 = shard_rows(h, world, rank)
+    if args.as_rank:
+        vr, vn = (int(x) for x in args.as_rank.split("/"))
+        shard = shard_frame(w, h, vn, vr, args.sharding)
+    else:
+        shard = shard_frame(w, h, world, rank, args.sharding)
     rngs = yt.make_rngs(params.seed, w * h)
-    ctx.make_trace_state(flat, params, rows=(r0, r1), rngs=rngs)
-    npix = w * (r1 - r0)
+    ctx.make_trace_state(flat, params, rows=shard.rows, cols=shard.cols, rngs=rngs)
+    npix = shard.npixels
+    assert npix == ctx.npixels
 
     # state arrays live in torch tensors so the RCCL gather runs on them directly
     dev = torch.device("cuda", local)
@@ -122,18 +133,18 @@ def main():
     albedo = torch.zeros(npix, 3, device=dev)
     normal = torch.zeros(npix, 3, device=dev)
     hits = torch.zeros(npix, dtype=torch.int32, device=dev)
-    trng = torch.from_numpy(shard_rngs(rngs, w, (r0, r1)).view(np.int64).copy()).to(dev)
+    trng = torch.from_numpy(shard.take(rngs).view(np.int64).copy()).to(dev)
     ctx.bind_device_state(image.data_ptr(), albedo.data_ptr(), normal.data_ptr(),
                           hits.data_ptr(), trng.data_ptr())
     stream = torch.cuda.Stream(device=dev)  # non-null: kernels and the RCCL gather share it
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
-    gather = FrameGather(dist, w, h, 4, dev) if world > 1 else None
+    gather = FrameGather(dist, w, h, 4, dev, mode=args.sharding) if world > 1 else None
 
     def step():
         ctx.trace_samples_async(params)
         if world > 1:  # framebuffer gather over RCCL/xGMI (§8e), once per batch
-            gather.gather(image)
+            gather.frame(image)
 
     def fence():
         if world > 1:
@@ -170,7 +181,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    total_samples = w * h * args.spp * args.steps
+    total_samples = (npix if args.as_rank else w * h) * args.spp * args.steps
     value = total_samples / dt / 1e6
 
     out = {
@@ -180,10 +191,12 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"1M-triangle plane + constant env, {w}x{h}x{args.spp}spp, "
                                "sampler=path bounces=8 clamp=10 (BASELINE configs[1]"
-                               + ("/[2] row-sharded" if world > 1 else "") + ")",
+                               + ("/[2] sharded" if world > 1 else "") + ")"
+                               + (f" — ONLY the slice of rank {args.as_rank}" if args.as_rank else ""),
                    "triangles": int(flat.shapes[0]["num_triangles"]),
-                   "resolution": [w, h], "spp": args.spp, "rows_per_rank": r1 - r0,
-                   "sharding": f"rows/{world}" if world > 1 else "none",
+                   "resolution": [w, h], "spp": args.spp, "pixels_per_rank": npix,
+                   "sharding": (f"{args.sharding}/{world}" if world > 1 else "none")
+                               if not args.as_rank else f"{args.sharding} {args.as_rank}",
                    "setup_s": round(setup_s, 3)},
     }
     if rank == 0 and stats_count is not None and stats_time["trace_launches"] > 0:

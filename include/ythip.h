@@ -293,6 +293,19 @@ int ythip_make_rngs(uint64_t seed, int64_t n, uint64_t* rngs);
  * image/albedo/normal/hits; rngs must be uploaded. */
 int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin,
     int row_end);
+/* The same for a COLUMN-STRIPED slice (multi-GPU load balance, SURVEY.md §8e
+ * "interleaved bands"): of rows [row_begin, row_end) the state holds the
+ * 16-pixel-wide tile columns col_first, col_first + col_stride, ... of the frame,
+ * laid side by side in a row-major local image ythip_state_local_width() pixels
+ * wide.  Rank r of G uses (col_first = r, col_stride = G): every rank sees the
+ * whole vertical extent of the frame (sky and ground alike), which contiguous
+ * row blocks do not.  ythip_state_create == (col_first 0, col_stride 1).  The
+ * reference's unit of parallel work is a pixel (yocto_trace.cpp:1600-1612);
+ * which pixels a worker takes is free. */
+int ythip_state_create_striped(ythip_ctx* ctx, int width, int height,
+    int row_begin, int row_end, int col_first, int col_stride);
+/* Pixels per row of such a slice (-1 on bad arguments).  Host only. */
+int ythip_state_local_width(int width, int col_first, int col_stride);
 /* Any pointer may be NULL to skip that array. */
 int ythip_state_upload(ythip_ctx* ctx, const float* image, const float* albedo,
     const float* normal, const int32_t* hits, const uint64_t* rngs,

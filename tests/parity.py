@@ -219,8 +219,8 @@ def gpu_context(flat, highquality=False, device=0):
     return ctx
 
 
-def gpu_render(ctx, flat, params, rows=None, rngs=None):
-    ctx.make_trace_state(flat, params, rows=rows, rngs=rngs)
+def gpu_render(ctx, flat, params, rows=None, rngs=None, cols=None):
+    ctx.make_trace_state(flat, params, rows=rows, rngs=rngs, cols=cols)
     n = 0
     while n < params.samples:
         ctx.trace_samples(params)

@@ -111,6 +111,11 @@ def test_cfg2_full_size_properties(cfg):
         part = P.gpu_render(ctx, flat, params, rows=(r0, r1), rngs=rngs)
         for k in ["image", "albedo", "normal", "hits", "rngs"]:
             assert part[k].tobytes() == full[k][r0 * w:r1 * w].tobytes(), (k, r0, r1)
+    import sharding
+    sh = sharding.shard_frame(w, h, 8, 5)  # what rank 5 of 8 renders in bench.py
+    part = P.gpu_render(ctx, flat, params, rows=sh.rows, cols=sh.cols, rngs=rngs)
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert part[k].tobytes() == full[k][sh.pixels].tobytes(), (k, "columns 5/8")
     prog = P.gpu_render(ctx, flat, yt.trace_params(sampler="path", resolution=1280, samples=4, batch=2))
     for k in ["image", "albedo", "normal", "hits", "rngs"]:
         assert prog[k].tobytes() == full[k].tobytes(), k

@@ -299,6 +299,36 @@ def test_row_sharding_equals_full_frame(bundles):
         assert np.concatenate([p[k] for p in parts]).tobytes() == full[k].tobytes(), k
 
 
+def test_column_striped_sharding_equals_full_frame(bundles):
+    """§8e, balanced slicing: rank r of G renders tile columns r, r+G, ... (and a
+    row range); put back through the shard's pixel list the slices tile the
+    full-frame render bit for bit, for every state array."""
+    import sharding
+    flat, ctx, _ = bundles("materials")
+    params = yt.trace_params(sampler="path", resolution=72, samples=2, batch=2)
+    full = P.gpu_render(ctx, flat, params)
+    w, h = full["width"], full["height"]
+    rngs = yt.make_rngs(params.seed, w * h)
+    for world in [2, 3]:
+        seen = np.zeros(w * h, bool)
+        for r in range(world):
+            sh = sharding.shard_frame(w, h, world, r, "columns")
+            part = P.gpu_render(ctx, flat, params, rows=sh.rows, cols=sh.cols, rngs=rngs)
+            assert part["width"] == sh.local_width
+            for k in ["image", "albedo", "normal", "hits", "rngs"]:
+                assert part[k].tobytes() == full[k][sh.pixels].tobytes(), (k, world, r)
+            seen[sh.pixels] = True
+        assert seen.all()
+    # rows and columns together, camera rays included
+    sh = sharding.Shard(w, h, (7, 30), (1, 2))
+    part = P.gpu_render(ctx, flat, params, rows=sh.rows, cols=sh.cols, rngs=rngs)
+    assert part["image"].tobytes() == full["image"][sh.pixels].tobytes()
+    ctx.make_trace_state(flat, params, rngs=rngs)
+    rays_full = ctx.camera_rays(params)
+    ctx.make_trace_state(flat, params, rows=sh.rows, cols=sh.cols, rngs=rngs)
+    assert ctx.camera_rays(params).tobytes() == rays_full[sh.pixels].tobytes()
+
+
 def test_work_counters_and_cancel(bundles):
     flat, ctx, _ = bundles("cornellbox")
     params = yt.trace_params(sampler="path", resolution=64, samples=2, batch=2)

@@ -55,6 +55,11 @@ enum {
 // Device mirror of trace_state (yocto_trace.h:147-157) + wavefront path state.
 struct DState {
   int width, height, row_begin, rows, npix;
+  // column striping (multi-GPU load balance): the slice holds the
+  // 16-pixel-wide tile columns col_first, col_first + col_stride, ... of the
+  // frame, side by side in a local image `lwidth` pixels wide (the whole frame:
+  // col_first 0, col_stride 1, lwidth == width)
+  int lwidth, col_first, col_stride;
   // path slots: the slice is cut into 16x16-pixel tiles; workgroup (logical
   // block) t owns the 256 slots of tile t for the whole batch.  Slots whose
   // pixel falls outside the slice are never queued.
@@ -107,10 +112,11 @@ YT_FN int logical_block(const DState& st) { return blockIdx.x < st.nblocks ? (in
 YT_FN int slot_pixel(const DState& st, int slot, int& i, int& j) {
   int tile = slot >> 8, w = slot & 255;
   int ty = tile / st.tiles_x, tx = tile - ty * st.tiles_x;
-  i      = tx * YT_TILE + (w & 15);
+  int il = tx * YT_TILE + (w & 15);
+  i      = (st.col_first + tx * st.col_stride) * YT_TILE + (w & 15);
   int jl = ty * YT_TILE + (w >> 4);
   j      = st.row_begin + jl;
-  return (i < st.width && jl < st.rows) ? jl * st.width + i : -1;
+  return (i < st.width && jl < st.rows) ? jl * st.lwidth + il : -1;
 }
 
 // The counters are kept in CNT_BANKS copies (one 128-B line each, chosen by block
@@ -1020,8 +1026,9 @@ __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const y
 __global__ void __launch_bounds__(YT_BLOCK) k_camera_rays(DScene sc, DState st, KParams kp, ythip_ray* rays) {
   int slot = blockIdx.x * YT_BLOCK + threadIdx.x;
   if (slot >= st.npix) return;
-  int  i = slot % st.width, j = st.row_begin + slot / st.width;
-  auto r = st.rngs[slot];
+  int  il = slot % st.lwidth, j = st.row_begin + slot / st.lwidth;
+  int  i  = (st.col_first + (il / YT_TILE) * st.col_stride) * YT_TILE + il % YT_TILE;
+  auto r  = st.rngs[slot];
   rng_state rng = {r.x, r.y};
   auto luv = rand2f(rng);
   auto puv = rand2f(rng);

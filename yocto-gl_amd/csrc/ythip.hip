@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -693,9 +694,25 @@ int ythip_make_rngs(uint64_t seed, int64_t n, uint64_t* rngs) {
 }
 
 int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int row_end) {
+  return ythip_state_create_striped(ctx, width, height, row_begin, row_end, 0, 1);
+}
+
+int ythip_state_local_width(int width, int col_first, int col_stride) {
+  if (width <= 0 || col_first < 0 || col_stride < 1) return -1;
+  int lw = 0;
+  for (int c = col_first; c * YT_TILE < width; c += col_stride) lw += std::min(YT_TILE, width - c * YT_TILE);
+  return lw;
+}
+
+int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_begin, int row_end, int col_first,
+    int col_stride) {
   if (!ctx) return YTHIP_ERR_INVALID;
   if (width <= 0 || height <= 0 || row_begin < 0 || row_end > height || row_begin >= row_end)
     return fail(ctx, YTHIP_ERR_INVALID, "bad state geometry %dx%d rows [%d,%d)", width, height, row_begin, row_end);
+  int lwidth = ythip_state_local_width(width, col_first, col_stride);
+  if (lwidth <= 0)
+    return fail(ctx, YTHIP_ERR_INVALID, "bad column striping first %d stride %d for width %d (no pixel owned)",
+        col_first, col_stride, width);
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   free_all(ctx->state_allocs);
   ctx->have_state  = false;
@@ -706,10 +723,13 @@ int ythip_state_create(ythip_ctx* ctx, int width, int height, int row_begin, int
   st.height        = height;
   st.row_begin     = row_begin;
   st.rows          = row_end - row_begin;
-  long long npix   = (long long)width * st.rows;
+  st.lwidth        = lwidth;
+  st.col_first     = col_first;
+  st.col_stride    = col_stride;
+  long long npix   = (long long)lwidth * st.rows;
   if (npix > 0x7fffffffll / 4) return fail(ctx, YTHIP_ERR_INVALID, "state too large");
   st.npix      = (int)npix;
-  st.tiles_x   = (width + YT_TILE - 1) / YT_TILE;
+  st.tiles_x   = (lwidth + YT_TILE - 1) / YT_TILE;
   st.tiles_y   = (st.rows + YT_TILE - 1) / YT_TILE;
   st.nblocks   = st.tiles_x * st.tiles_y;
   st.nslots    = st.nblocks * YT_BLOCK;

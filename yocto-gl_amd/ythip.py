@@ -416,6 +416,8 @@ _SIGNATURES = {
                                    C.POINTER(C.c_int)]),
     "ythip_make_rngs": (C.c_int, [C.c_uint64, C.c_int64, C.c_void_p]),
     "ythip_state_create": (C.c_int, [C.c_void_p] + [C.c_int] * 4),
+    "ythip_state_create_striped": (C.c_int, [C.c_void_p] + [C.c_int] * 6),
+    "ythip_state_local_width": (C.c_int, [C.c_int] * 3),
     "ythip_state_upload": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]),
     "ythip_state_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5
                              + [C.POINTER(C.c_int)]),
@@ -466,6 +468,17 @@ def state_size(camera, resolution):
     if rc:
         raise YthipError("ythip_state_size failed")
     return w.value, h.value
+
+
+TILE = 16  # yt_kernels.h YT_TILE: width of a tile column
+
+
+def slice_columns(width, col_first=0, col_stride=1):
+    """Global x of every pixel column of a column-striped slice, in local order
+    (ythip_state_create_striped): tile columns col_first, col_first + col_stride, ..."""
+    cols = [np.arange(c * TILE, min(width, (c + 1) * TILE))
+            for c in range(col_first, (width + TILE - 1) // TILE, col_stride)]
+    return np.concatenate(cols) if cols else np.zeros(0, np.int64)
 
 
 def make_rngs(seed, n):
@@ -594,22 +607,28 @@ class Context:
         return FlatLights(lights, cdf)
 
     # state --------------------------------------------------------------------
-    def make_trace_state(self, scene, params, rows=None, rngs=None):
-        """make_trace_state (yocto_trace.cpp:1495-1520) for rows [r0, r1)."""
+    def make_trace_state(self, scene, params, rows=None, rngs=None, cols=None):
+        """make_trace_state (yocto_trace.cpp:1495-1520) for rows [r0, r1) and,
+        with cols=(first, stride), the 16-pixel tile columns first, first +
+        stride, ... of the frame (ythip_state_create_striped)."""
         w, h = state_size(scene.cameras[params.camera], params.resolution)
         r0, r1 = (0, h) if rows is None else rows
-        self._check(self.lib.ythip_state_create(self.h, w, h, r0, r1), "state_create")
+        c0, cs = (0, 1) if cols is None else cols
+        self._check(self.lib.ythip_state_create_striped(self.h, w, h, r0, r1, c0, cs),
+                    "state_create_striped")
         self.width, self.height, self.row_begin, self.row_end = w, h, r0, r1
+        self.local_width = self.lib.ythip_state_local_width(w, c0, cs)
         if rngs is None:
             rngs = make_rngs(params.seed, w * h)
-        sl = np.ascontiguousarray(rngs[r0 * w:r1 * w])
+        sl = np.ascontiguousarray(
+            np.asarray(rngs).reshape(h, w, 2)[r0:r1, slice_columns(w, c0, cs)].reshape(-1, 2))
         self._check(self.lib.ythip_state_upload(self.h, None, None, None, None,
                                                 sl.ctypes.data, 0), "state_upload")
         return w, h
 
     @property
     def npixels(self):
-        return self.width * (self.row_end - self.row_begin)
+        return self.local_width * (self.row_end - self.row_begin)
 
     def upload_state(self, image=None, albedo=None, normal=None, hits=None,
                      rngs=None, samples=0):
@@ -632,7 +651,7 @@ class Context:
             self.h, image.ctypes.data, albedo.ctypes.data, normal.ctypes.data,
             hits.ctypes.data, rngs.ctypes.data, C.byref(samples)), "state_download")
         return dict(image=image, albedo=albedo, normal=normal, hits=hits, rngs=rngs,
-                    samples=samples.value, width=self.width,
+                    samples=samples.value, width=self.local_width,
                     height=self.row_end - self.row_begin)
 
     def get_image(self):
