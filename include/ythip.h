@@ -250,6 +250,27 @@ int ythip_update_cameras(ythip_ctx* ctx, const ythip_camera* cameras, int num);
  * yocto_bvh.cpp:238-302,321-396): host-side build that reproduces the
  * reference's node order bit-for-bit, then upload. */
 int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* scene, int highquality);
+/* Where make_bvh runs.  mode 1 (default): shapes with >= min_prims primitives
+ * (default 16384; <= 0 keeps the current value) are built ON THE DEVICE by a
+ * level-synchronous restatement of make_bvh + split_middle that reproduces the
+ * reference's node order, `primitives` permutation and boxes bit for bit
+ * (yocto_bvh.cpp:202-302); small shapes, the instance
+ * tree and highquality (SAH) builds use the host builder.  mode 0: host only.
+ * Either way ythip_bvh_download returns the reference's tree. */
+int ythip_set_bvh_builder(ythip_ctx* ctx, int mode, int64_t min_prims);
+/* What the last ythip_build_bvh did (zeroed by ythip_upload_bvh). */
+typedef struct ythip_build_info {
+  int32_t device_trees, host_trees, fallbacks, max_depth;
+  int64_t device_prims;
+  double  device_ms; /* device time inside the builder kernels (hipEvents)        */
+  double  build_ms;  /* wall time of the whole tree construction (all shapes+TLAS) */
+  double  bake_ms;   /* wall time of baking pairs / leaf data / instance records   */
+} ythip_build_info;
+int ythip_bvh_build_info(ythip_ctx* ctx, ythip_build_info* info);
+/* The baked traversal arrays, for tests: pairs are 64-B records,
+ * leaf data 16-B records. */
+int ythip_bvh_baked_sizes(ythip_ctx* ctx, int64_t* num_pairs, int64_t* num_leaf4);
+int ythip_bvh_baked_download(ythip_ctx* ctx, float* pairs, float* leafdata);
 /* Upload a tree built elsewhere (e.g. by the reference's make_trace_bvh). */
 int ythip_upload_bvh(ythip_ctx* ctx, const ythip_bvh* bvh);
 /* Read back the resident tree (for tree-identity tests). */

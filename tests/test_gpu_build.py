@@ -1,0 +1,161 @@
+"""On-device make_bvh (yt_gpubuild.hip), `-m gpu`.
+
+The bar is the same as for the host builder (tests/test_host.py): the tree the
+GPU builds is the reference's tree NODE FOR NODE AND BIT FOR BIT — node order,
+`primitives` permutation, boxes — checked against the host builder (itself pinned
+against the live reference's make_scene_bvh), and against the live reference
+directly when it travelled.  The baked traversal arrays must be byte-identical
+under both builders, so every hit record and image is too."""
+import time
+
+import numpy as np
+import pytest
+
+import parity as P
+from parity import ry, yt, ysc
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def build_both(flat, min_prims=8):
+    """(device-built, host-built) downloads + baked arrays of the same scene."""
+    out = []
+    for mode in ["device", "host"]:
+        ctx = yt.Context(0)
+        ctx.upload_scene(flat)
+        ctx.set_bvh_builder(mode, min_prims)
+        ctx.make_trace_bvh(flat)
+        out.append((ctx.download_bvh(), ctx.download_baked_bvh(), ctx.bvh_build_info()))
+        ctx.close()
+    return out
+
+
+def assert_same(dev, host, what=""):
+    (db, (dp, dl), di), (hb, (hp, hl), hi) = dev, host
+    assert np.array_equal(db.node_offset, hb.node_offset), what
+    assert np.array_equal(db.prim_offset, hb.prim_offset), what
+    assert db.primitives.tobytes() == hb.primitives.tobytes(), what + " primitives"
+    assert db.nodes.tobytes() == hb.nodes.tobytes(), what + " nodes"
+    assert dp.tobytes() == hp.tobytes(), what + " baked pairs"
+    assert dl.tobytes() == hl.tobytes(), what + " baked leaf data"
+
+
+@pytest.mark.parametrize("name", list(P.SCENES))
+def test_device_tree_equals_host_tree_on_test_scenes(name):
+    flat = P.SCENES[name]()
+    dev, host = build_both(flat, min_prims=5)  # force even the tiny shapes through the GPU
+    assert dev[2]["device_trees"] >= 1 and host[2]["device_trees"] == 0
+    assert_same(dev, host, name)
+    if P.have_ref():
+        ref = ry.RefBvh(ry.RefScene.from_flat(flat)).flat()
+        assert dev[0].nodes.tobytes() == ref.nodes.tobytes()
+        assert dev[0].primitives.tobytes() == ref.primitives.tobytes()
+
+
+def _soup(kind, n, seed, clustered=False, dup=False, grid=False):
+    """Random primitive soups that exercise every branch of split_middle."""
+    rng = np.random.default_rng(seed)
+    sc = yt.FlatScene()
+    sc.add_camera(ysc.lookat_frame((0, 0, 5), (0, 0, 0)))
+    if grid:  # many identical centroids along axes: ties in `center < split`
+        c = rng.integers(0, 8, (n, 3)).astype(f32)
+    elif clustered:  # exponentially spaced clusters: very unbalanced middle splits
+        c = (rng.normal(size=(n, 3)) * 0.01 + (2.0 ** rng.integers(-6, 6, (n, 1)))).astype(f32)
+    else:
+        c = (rng.random((n, 3)) * 4 - 2).astype(f32)
+    if dup:  # all primitives identical: csize == 0 → "break in half" path
+        c[:] = c[0]
+    m = sc.add_material("matte", color=(0.5, 0.5, 0.5))
+    if kind == "triangles":
+        d = (rng.normal(size=(n, 3, 3)) * 0.05).astype(f32)
+        if dup:
+            d[:] = d[0]
+        pos = (c[:, None, :] + d).reshape(-1, 3)
+        s = sc.add_shape(pos, triangles=np.arange(3 * n, dtype=np.int32).reshape(-1, 3))
+    elif kind == "quads":
+        d = (rng.normal(size=(n, 4, 3)) * 0.05).astype(f32)
+        pos = (c[:, None, :] + d).reshape(-1, 3)
+        q = np.arange(4 * n, dtype=np.int32).reshape(-1, 4)
+        q[::7, 3] = q[::7, 2]  # degenerate quads (triangles)
+        s = sc.add_shape(pos, quads=q)
+    elif kind == "lines":
+        d = (rng.normal(size=(n, 2, 3)) * 0.05).astype(f32)
+        pos = (c[:, None, :] + d).reshape(-1, 3)
+        s = sc.add_shape(pos, lines=np.arange(2 * n, dtype=np.int32).reshape(-1, 2),
+                         radius=(rng.random(2 * n) * 0.01 + 0.001).astype(f32))
+    else:
+        s = sc.add_shape(c, points=np.arange(n, dtype=np.int32),
+                         radius=(rng.random(n) * 0.02 + 0.001).astype(f32))
+    sc.add_instance(s, m)
+    sc.add_environment((1, 1, 1))
+    return sc
+
+
+@pytest.mark.parametrize("kind", ["triangles", "quads", "lines", "points"])
+@pytest.mark.parametrize("variant", ["uniform", "clustered", "grid"])
+def test_device_tree_equals_host_tree_on_random_soups(kind, variant):
+    flat = _soup(kind, 30011, seed=len(kind) * 7 + len(variant),
+                 clustered=variant == "clustered", grid=variant == "grid")
+    dev, host = build_both(flat)
+    assert dev[2]["device_trees"] == 1 and dev[2]["fallbacks"] == 0
+    assert_same(dev, host, f"{kind}/{variant}")
+
+
+def test_identical_primitives_take_the_break_in_half_path():
+    dev, host = build_both(_soup("triangles", 4099, seed=3, dup=True))
+    assert dev[2]["device_trees"] == 1
+    assert_same(dev, host, "dup")
+
+
+def test_signed_zero_ties_fall_back_to_the_host_builder():
+    """A box face at 0 fed by both +0 and -0: the sign the reference keeps depends on
+    the serial visiting order → the device builder must notice and hand over."""
+    flat = _soup("triangles", 5000, seed=9)
+    pos = flat.positions.copy()
+    pos[:, 1] = 0.0
+    pos[::2, 1] = -0.0
+    flat.positions = pos
+    dev, host = build_both(flat)
+    assert dev[2]["fallbacks"] == 1 and dev[2]["device_trees"] == 0
+    assert_same(dev, host, "signed zero")
+    # a single sign of zero is no tie: stays on the device
+    pos[:, 1] = 0.0
+    flat.positions = pos
+    dev, host = build_both(flat)
+    assert dev[2]["fallbacks"] == 0 and dev[2]["device_trees"] == 1
+    assert_same(dev, host, "plain zero")
+
+
+def test_baseline_cfg2_tree_built_on_device_matches_reference():
+    """1,000,000 triangles: the tree is the reference's; timing printed for DESIGN.md."""
+    flat = ysc.plane_scene()
+    t0 = time.time()
+    dev, host = build_both(flat, min_prims=16384)
+    print("cfg2 build info device:", dev[2], "host:", host[2], "wall", time.time() - t0)
+    assert dev[2]["device_trees"] == 1 and dev[2]["device_prims"] == 1_000_000
+    assert_same(dev, host, "cfg2")
+    assert len(dev[0].nodes) == 503_478
+    if P.have_ref():
+        ref = ry.RefBvh(ry.RefScene.from_flat(flat)).flat()
+        assert dev[0].nodes.tobytes() == ref.nodes.tobytes()
+        assert dev[0].primitives.tobytes() == ref.primitives.tobytes()
+    assert dev[2]["build_ms"] < host[2]["build_ms"]
+
+
+def test_hits_and_images_do_not_depend_on_the_builder():
+    flat = P.SCENES["instances"]()
+    res = []
+    for mode in ["device", "host"]:
+        ctx = yt.Context(0)
+        ctx.upload_scene(flat)
+        ctx.set_bvh_builder(mode, 5)
+        ctx.make_trace_bvh(flat)
+        ctx.make_trace_lights(flat)
+        rays = P.random_rays(flat, 50000, seed=2)
+        p = yt.trace_params(sampler="path", resolution=64, samples=3, batch=3)
+        res.append((ctx.intersect_batch(rays), P.gpu_render(ctx, flat, p)))
+        ctx.close()
+    assert res[0][0].tobytes() == res[1][0].tobytes()
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert res[0][1][k].tobytes() == res[1][1][k].tobytes(), k

@@ -1,0 +1,55 @@
+// yt_gpubuild.h — on-device make_bvh: interface between
+// ythip.hip (the C ABI) and yt_gpubuild.hip (the builder / baker kernels).
+//
+// The builder reproduces the reference's make_bvh + split_middle
+// (libs/yocto/yocto_bvh.cpp:202-302) node for node and bit for bit — same node
+// order, same `primitives` permutation, same boxes — so that every hit record
+// stays identical to the host-built tree's.  See yt_gpubuild.hip for how the
+// serial algorithm (explicit-stack DFS + std::partition) is restated as a
+// level-synchronous parallel one.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/ythip.h"
+
+namespace ytgpu {
+
+// A shape's bvh_tree (yocto_shape.h:486-489) in the reference's layout, resident
+// on the device.
+struct DeviceTree {
+  ythip_bvh_node* nodes      = nullptr;  // num_nodes records, reference node order
+  int32_t*        prims      = nullptr;  // num_prims element ids (bvh_tree::primitives)
+  int64_t         num_nodes  = 0;
+  int64_t         num_prims  = 0;
+  int             depth      = 0;        // levels of the tree
+  float           build_ms   = 0;        // device time of the build (hipEvents)
+};
+
+enum { BUILD_OK = 0, BUILD_FALLBACK = 1, BUILD_ERROR = 2 };
+
+// make_shape_bvh (yocto_bvh.cpp:321-362) for one shape, split_middle only.
+// `elems` / `positions` / `radius` are DEVICE pointers already offset to the
+// shape's first element / vertex; kind is the BVH dispatch kind (1 points,
+// 2 lines, 3 triangles, 4 quads).  Returns BUILD_FALLBACK (nothing allocated)
+// when the tree cannot be reproduced bit for bit on the device (signed-zero
+// ties between box faces — see the .hip) and the caller must use the host
+// builder, BUILD_ERROR on a HIP failure (message in *err).
+int build_shape_tree(hipStream_t stream, int kind, const int32_t* elems, const float* positions,
+    const float* radius, int64_t num_prims, DeviceTree* out, std::string* err);
+void free_tree(DeviceTree* tree);
+
+// Device bake of one BLAS into the traversal layout of yt_bvh.h (what
+// bake_bvh() in ythip.hip does on the host for host-built trees):
+//   pairs    + 4 * pair_base    sibling-pair records of this tree's internal nodes
+//   leafdata + leaf_base        pre-gathered primitives in leaf order
+// prim_base = global index of the tree's first primitive (leaf refs are global).
+// Writes the root's {bbox, ref} to root_out (host pointer, 7 floats: bmin, bmax, ref bits).
+int bake_shape_tree(hipStream_t stream, const DeviceTree& tree, int kind, const int32_t* elems,
+    const float* positions, const float* radius, int64_t pair_base, int64_t prim_base, int64_t leaf_base,
+    float4* pairs, float4* leafdata, float* root_out, std::string* err);
+
+}  // namespace ytgpu

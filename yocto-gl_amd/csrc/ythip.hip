@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -18,6 +19,7 @@
 
 #include "../../include/ythip.h"
 #include "yt_build.h"
+#include "yt_gpubuild.h"
 #include "yt_kernels.h"
 
 using namespace yt;
@@ -51,6 +53,14 @@ struct ythip_ctx {
   int                         num_cameras = 0;
 
   ythost::flat_bvh    h_bvh;     // as uploaded/built (reference layout) for download
+  // shapes whose tree was built on the device (yt_gpubuild.hip); their slice of
+  // h_bvh is downloaded on demand (ensure_host_bvh)
+  std::vector<ytgpu::DeviceTree> d_trees;
+  std::vector<char>              d_tree_on_host;
+  int64_t                        device_build_min_prims = 16384;
+  int                            bvh_builder            = 1;  // 0 host only, 1 device for large shapes
+  ythip_build_info               build_info             = {};
+  int64_t                        num_pairs = 0, num_leaf4 = 0;
   ythost::flat_lights h_lights;
 
   DScene ds = {};
@@ -133,14 +143,18 @@ KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
   return k;
 }
 
-// Bake the reference-layout trees (ctx->h_bvh, kept verbatim for download) into
-// the device layout of yt_bvh.h:
+// Bake the reference-layout trees into the device layout of yt_bvh.h:
 //   * pairs:    one 64-B record per internal node holding BOTH children
 //               {bbox, ref} (+ the parent's split axis) — the two nodes the
 //               reference pops one after the other arrive in one fetch
 //   * leafdata: primitives pre-gathered in leaf order (ids come from
 //               `primitives[]`, so hit indices are unaffected)
 //   * tinst:    per-instance inverse frame + BLAS root {bbox, ref}
+// Trees live either on the host (ctx->h_bvh: uploaded, or built by yt_build.h)
+// or on the device (ctx->d_trees[s], built by yt_gpubuild.hip; their slice of
+// h_bvh is filled lazily by ensure_host_bvh()).  Host trees are baked here and
+// uploaded slice by slice, device trees are baked by kernels; both produce the
+// same bytes (tests/test_gpu_build.py).
 int bake_bvh(ythip_ctx* ctx) {
   auto& b        = ctx->h_bvh;
   int   nshapes  = (int)ctx->h_shapes.size();
@@ -148,6 +162,7 @@ int bake_bvh(ythip_ctx* ctx) {
   if (ntrees != nshapes + 1)
     return fail(ctx, YTHIP_ERR_INVALID, "bvh has %d trees, scene has %d shapes (+1 expected)", ntrees, nshapes);
   free_all(ctx->bvh_allocs);
+  auto on_device = [&](int t) { return t < (int)ctx->d_trees.size() && ctx->d_trees[t].nodes != nullptr; };
 
   const auto&          nodes = b.nodes;
   std::vector<int64_t> leaf_base(nshapes, 0);
@@ -161,75 +176,135 @@ int bake_bvh(ythip_ctx* ctx) {
   }
   if (nleaf4 > 0x7fffff00ll || (int64_t)nodes.size() > 0x7fffffffll || b.prim_offset[ntrees] > 0x0fffffffll)
     return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit device references");
-  const int           LEAF_PAD = 8;  // the triangle loop fetches two primitives per round trip
-  std::vector<float4> leaf((size_t)nleaf4 + LEAF_PAD, float4{0, 0, 0, 0});
-  for (int s = 0; s < nshapes; s++) {
-    const auto& sh     = ctx->h_shapes[s];
-    int         kind   = ythost::kind_bvh(sh);
-    int         stride = strides[s];
-    const float* P     = ctx->h_positions.data() + 3 * sh.positions_offset;
-    const float* R     = sh.radius_offset >= 0 ? ctx->h_radius.data() + sh.radius_offset : nullptr;
-    int64_t      np    = b.prim_offset[s + 1] - b.prim_offset[s];
-    auto         pos   = [&](int v) { return float3{P[3 * v], P[3 * v + 1], P[3 * v + 2]}; };
-    for (int64_t k = 0; k < np; k++) {
-      int     id = b.prims[b.prim_offset[s] + k];
-      float4* L  = leaf.data() + leaf_base[s] + k * stride;
-      if (kind == KIND_TRIANGLES) {
-        const int* t  = ctx->h_triangles.data() + 3 * (sh.triangles_offset + id);
-        auto       p0 = pos(t[0]), p1 = pos(t[1]), p2 = pos(t[2]);
-        L[0] = {p0.x, p0.y, p0.z, p1.x};
-        L[1] = {p1.y, p1.z, p2.x, p2.y};
-        L[2] = {p2.z, __builtin_bit_cast(float, id), 0, 0};
-      } else if (kind == KIND_QUADS) {
-        const int* q  = ctx->h_quads.data() + 4 * (sh.quads_offset + id);
-        auto       p0 = pos(q[0]), p1 = pos(q[1]), p2 = pos(q[2]), p3 = pos(q[3]);
-        L[0] = {p0.x, p0.y, p0.z, p1.x};
-        L[1] = {p1.y, p1.z, p2.x, p2.y};
-        L[2] = {p2.z, p3.x, p3.y, p3.z};
-        L[3] = {__builtin_bit_cast(float, id), 0, 0, 0};
-      } else if (kind == KIND_LINES) {
-        const int* l  = ctx->h_lines.data() + 2 * (sh.lines_offset + id);
-        auto       p0 = pos(l[0]), p1 = pos(l[1]);
-        L[0] = {p0.x, p0.y, p0.z, p1.x};
-        L[1] = {p1.y, p1.z, R ? R[l[0]] : 0.0f, R ? R[l[1]] : 0.0f};
-        L[2] = {__builtin_bit_cast(float, id), 0, 0, 0};
-      } else if (kind == KIND_POINTS) {
-        int  v = ctx->h_points[sh.points_offset + id];
-        auto p = pos(v);
-        L[0]   = {p.x, p.y, p.z, R ? R[v] : 0.0f};
-        L[1]   = {__builtin_bit_cast(float, id), 0, 0, 0};
-      }
-    }
-  }
-
-  // sibling-pair records: pair ids in node order, per tree
-  std::vector<int32_t> pair_id(nodes.size(), -1);
-  int64_t              npairs = 0;
-  for (size_t n = 0; n < nodes.size(); n++)
-    if (nodes[n].internal) pair_id[n] = (int32_t)npairs++;
-  if (npairs >= (int64_t)REF_INST) return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit device references");
-  bool bad_leaf = false;
-  auto ref_of   = [&](int64_t gn, int tree) -> int32_t {
-    const auto& node = nodes[gn];
-    if (node.internal) return pair_id[gn];
-    if (node.num < 0 || node.num > 7) bad_leaf = true;
-    // BLAS leaves address leaf data by global primitive index, TLAS leaves index tlas_prims
-    int64_t first = (tree < nshapes ? b.prim_offset[tree] : 0) + node.start;
-    return (int32_t)(0x80000000u | ((uint32_t)(node.num & 7) << 28) | (uint32_t)first);
-  };
-  std::vector<float4> pairs((size_t)npairs * 4 + 4, float4{0, 0, 0, 0});
+  // sibling-pair ids: one per internal node, in node order, all trees
+  std::vector<int64_t> pair_base(ntrees + 1, 0);
   for (int t = 0; t < ntrees; t++) {
-    for (int64_t n = b.node_offset[t]; n < b.node_offset[t + 1]; n++) {
-      const auto& node = nodes[n];
-      if (!node.internal) continue;
-      float4* P = pairs.data() + 4 * (size_t)pair_id[n];
-      for (int c = 0; c < 2; c++) {
-        int64_t     gc = b.node_offset[t] + node.start + c;
-        const auto& ch = nodes[gc];
-        P[2 * c]       = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_min[2], ch.bbox_max[0]};
-        P[2 * c + 1]   = {ch.bbox_max[1], ch.bbox_max[2], __builtin_bit_cast(float, ref_of(gc, t)),
-              __builtin_bit_cast(float, (int32_t)node.axis)};
+    int64_t n = 0;
+    if (on_device(t)) {
+      n = (ctx->d_trees[t].num_nodes - 1) / 2;  // strictly binary tree
+    } else {
+      for (int64_t k = b.node_offset[t]; k < b.node_offset[t + 1]; k++) n += nodes[k].internal ? 1 : 0;
+    }
+    pair_base[t + 1] = pair_base[t] + n;
+  }
+  const int64_t npairs = pair_base[ntrees];
+  if (npairs >= (int64_t)REF_INST) return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit device references");
+
+  const int LEAF_PAD = 8;  // the triangle loop fetches two primitives per round trip
+  float4 *  d_pairs = nullptr, *d_leaf = nullptr;
+  int       rc;
+  if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_pairs, (size_t)npairs * 4 + 4))) return rc;
+  if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_leaf, (size_t)nleaf4 + LEAF_PAD))) return rc;
+  HIPCHECK(ctx, hipMemsetAsync(d_pairs + 4 * npairs, 0, 4 * sizeof(float4), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(d_leaf + nleaf4, 0, LEAF_PAD * sizeof(float4), ctx->stream));
+
+  struct Root {
+    float bmin[3], bmax[3];
+    int   ref;
+  };
+  std::vector<Root>                roots(ntrees, Root{{0, 0, 0}, {0, 0, 0}, REF_NONE});
+  std::vector<std::vector<float4>> staging;  // host-baked slices, alive until the final sync
+  bool                             bad_leaf = false;
+
+  for (int t = 0; t < ntrees; t++) {
+    const bool    blas  = t < nshapes;
+    const int64_t nn    = b.node_offset[t + 1] - b.node_offset[t];
+    const int64_t np    = b.prim_offset[t + 1] - b.prim_offset[t];
+    if (on_device(t)) {
+      const auto& sh   = ctx->h_shapes[t];
+      int         kind = ythost::kind_bvh(sh);
+      const int*  el   = kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
+                         : kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
+                         : kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
+                                                : ctx->ds.points + sh.points_offset;
+      float       root7[7];
+      std::string err;
+      if (ytgpu::bake_shape_tree(ctx->stream, ctx->d_trees[t], kind, el, ctx->ds.positions + 3 * sh.positions_offset,
+              sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, pair_base[t],
+              b.prim_offset[t], leaf_base[t], d_pairs, d_leaf, root7, &err) != ytgpu::BUILD_OK)
+        return fail(ctx, YTHIP_ERR_HIP, "device bvh bake failed: %s", err.c_str());
+      for (int c = 0; c < 3; c++) roots[t].bmin[c] = root7[c], roots[t].bmax[c] = root7[3 + c];
+      std::memcpy(&roots[t].ref, &root7[6], 4);
+      continue;
+    }
+    // ---- host bake of tree t ------------------------------------------------------
+    if (blas && np > 0) {
+      const auto&  sh     = ctx->h_shapes[t];
+      int          kind   = ythost::kind_bvh(sh);
+      int          stride = strides[t];
+      const float* P      = ctx->h_positions.data() + 3 * sh.positions_offset;
+      const float* R      = sh.radius_offset >= 0 ? ctx->h_radius.data() + sh.radius_offset : nullptr;
+      auto         pos    = [&](int v) { return float3{P[3 * v], P[3 * v + 1], P[3 * v + 2]}; };
+      staging.emplace_back((size_t)np * stride, float4{0, 0, 0, 0});
+      auto& leaf = staging.back();
+      for (int64_t k = 0; k < np; k++) {
+        int     id = b.prims[b.prim_offset[t] + k];
+        float4* L  = leaf.data() + k * stride;
+        if (kind == KIND_TRIANGLES) {
+          const int* tr = ctx->h_triangles.data() + 3 * (sh.triangles_offset + id);
+          auto       p0 = pos(tr[0]), p1 = pos(tr[1]), p2 = pos(tr[2]);
+          L[0] = {p0.x, p0.y, p0.z, p1.x};
+          L[1] = {p1.y, p1.z, p2.x, p2.y};
+          L[2] = {p2.z, __builtin_bit_cast(float, id), 0, 0};
+        } else if (kind == KIND_QUADS) {
+          const int* q  = ctx->h_quads.data() + 4 * (sh.quads_offset + id);
+          auto       p0 = pos(q[0]), p1 = pos(q[1]), p2 = pos(q[2]), p3 = pos(q[3]);
+          L[0] = {p0.x, p0.y, p0.z, p1.x};
+          L[1] = {p1.y, p1.z, p2.x, p2.y};
+          L[2] = {p2.z, p3.x, p3.y, p3.z};
+          L[3] = {__builtin_bit_cast(float, id), 0, 0, 0};
+        } else if (kind == KIND_LINES) {
+          const int* l  = ctx->h_lines.data() + 2 * (sh.lines_offset + id);
+          auto       p0 = pos(l[0]), p1 = pos(l[1]);
+          L[0] = {p0.x, p0.y, p0.z, p1.x};
+          L[1] = {p1.y, p1.z, R ? R[l[0]] : 0.0f, R ? R[l[1]] : 0.0f};
+          L[2] = {__builtin_bit_cast(float, id), 0, 0, 0};
+        } else if (kind == KIND_POINTS) {
+          int  v = ctx->h_points[sh.points_offset + id];
+          auto p = pos(v);
+          L[0]   = {p.x, p.y, p.z, R ? R[v] : 0.0f};
+          L[1]   = {__builtin_bit_cast(float, id), 0, 0, 0};
+        }
       }
+      HIPCHECK(ctx, hipMemcpyAsync(d_leaf + leaf_base[t], leaf.data(), leaf.size() * sizeof(float4),
+                        hipMemcpyHostToDevice, ctx->stream));
+    }
+    // pair ids of this tree, in node order
+    std::vector<int32_t> pair_id((size_t)nn, -1);
+    int64_t              next = pair_base[t];
+    for (int64_t n = 0; n < nn; n++)
+      if (nodes[b.node_offset[t] + n].internal) pair_id[n] = (int32_t)next++;
+    auto ref_of = [&](int64_t ln) -> int32_t {  // ln: tree-local node index
+      const auto& node = nodes[b.node_offset[t] + ln];
+      if (node.internal) return pair_id[ln];
+      if (node.num < 0 || node.num > 7) bad_leaf = true;
+      // BLAS leaves address leaf data by global primitive index, TLAS leaves index tlas_prims
+      int64_t first = (blas ? b.prim_offset[t] : 0) + node.start;
+      return (int32_t)(0x80000000u | ((uint32_t)(node.num & 7) << 28) | (uint32_t)first);
+    };
+    const int64_t np_t = pair_base[t + 1] - pair_base[t];
+    if (np_t > 0) {
+      staging.emplace_back((size_t)np_t * 4, float4{0, 0, 0, 0});
+      auto& pairs = staging.back();
+      for (int64_t n = 0; n < nn; n++) {
+        const auto& node = nodes[b.node_offset[t] + n];
+        if (!node.internal) continue;
+        float4* P = pairs.data() + 4 * (size_t)(pair_id[n] - pair_base[t]);
+        for (int c = 0; c < 2; c++) {
+          int64_t     lc = node.start + c;
+          const auto& ch = nodes[b.node_offset[t] + lc];
+          P[2 * c]       = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_min[2], ch.bbox_max[0]};
+          P[2 * c + 1]   = {ch.bbox_max[1], ch.bbox_max[2], __builtin_bit_cast(float, ref_of(lc)),
+                __builtin_bit_cast(float, (int32_t)node.axis)};
+        }
+      }
+      HIPCHECK(ctx, hipMemcpyAsync(d_pairs + 4 * pair_base[t], pairs.data(), pairs.size() * sizeof(float4),
+                        hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (nn > 0) {
+      const auto& root = nodes[b.node_offset[t]];
+      roots[t].ref     = ref_of(0);
+      for (int c = 0; c < 3; c++) roots[t].bmin[c] = root.bbox_min[c], roots[t].bmax[c] = root.bbox_max[c];
     }
   }
   // per-instance traversal records
@@ -240,27 +315,20 @@ int bake_bvh(ythip_ctx* ctx) {
     ti               = DInstanceT{};
     ythost::inverse_frame_nonrigid(inst.frame, ti.inv);
     int s       = inst.shape;
-    ti.root_ref = REF_NONE;
-    if (b.node_offset[s + 1] > b.node_offset[s]) {
-      const auto& root = nodes[b.node_offset[s]];
-      ti.root_ref      = ref_of(b.node_offset[s], s);
-      for (int c = 0; c < 3; c++) ti.root_bmin[c] = root.bbox_min[c], ti.root_bmax[c] = root.bbox_max[c];
-    }
+    ti.root_ref = roots[s].ref;
+    for (int c = 0; c < 3; c++) ti.root_bmin[c] = roots[s].bmin[c], ti.root_bmax[c] = roots[s].bmax[c];
     ti.kind      = ythost::kind_bvh(ctx->h_shapes[s]);
     ti.leaf_bias = (int)(leaf_base[s] - b.prim_offset[s] * strides[s]);
     ti.shape     = s;
   }
-  ctx->ds.tlas_ref = REF_NONE;
-  if (b.node_offset[nshapes + 1] > b.node_offset[nshapes]) {
-    const auto& root  = nodes[b.node_offset[nshapes]];
-    ctx->ds.tlas_ref  = ref_of(b.node_offset[nshapes], nshapes);
-    ctx->ds.tlas_bmin = {root.bbox_min[0], root.bbox_min[1], root.bbox_min[2]};
-    ctx->ds.tlas_bmax = {root.bbox_max[0], root.bbox_max[1], root.bbox_max[2]};
-  }
+  ctx->ds.tlas_ref  = roots[nshapes].ref;
+  ctx->ds.tlas_bmin = {roots[nshapes].bmin[0], roots[nshapes].bmin[1], roots[nshapes].bmin[2]};
+  ctx->ds.tlas_bmax = {roots[nshapes].bmax[0], roots[nshapes].bmax[1], roots[nshapes].bmax[2]};
   if (bad_leaf) return fail(ctx, YTHIP_ERR_INVALID, "bvh leaf with more than 7 primitives (reference builds <= 4)");
-  int rc;
-  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.pairs, pairs.data(), pairs.size()))) return rc;
-  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.leafdata, leaf.data(), leaf.size()))) return rc;
+  ctx->ds.pairs    = d_pairs;
+  ctx->ds.leafdata = d_leaf;
+  ctx->num_pairs   = npairs;
+  ctx->num_leaf4   = nleaf4;
   if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tlas_prims, b.prims.data() + b.prim_offset[nshapes],
            (size_t)(b.prim_offset[nshapes + 1] - b.prim_offset[nshapes]))))
     return rc;
@@ -268,6 +336,111 @@ int bake_bvh(ythip_ctx* ctx) {
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   ctx->have_bvh = true;
   return YTHIP_OK;
+}
+
+void free_device_trees(ythip_ctx* ctx) {
+  for (auto& t : ctx->d_trees) ytgpu::free_tree(&t);
+  ctx->d_trees.clear();
+}
+
+// Fill the slices of ctx->h_bvh that belong to device-built trees (download).
+int ensure_host_bvh(ythip_ctx* ctx) {
+  auto& b = ctx->h_bvh;
+  for (size_t t = 0; t < ctx->d_trees.size(); t++) {
+    auto& dt = ctx->d_trees[t];
+    if (!dt.nodes || ctx->d_tree_on_host[t]) continue;
+    HIPCHECK(ctx, hipMemcpy(b.nodes.data() + b.node_offset[t], dt.nodes, (size_t)dt.num_nodes * sizeof(ythip_bvh_node),
+                      hipMemcpyDeviceToHost));
+    HIPCHECK(ctx, hipMemcpy(b.prims.data() + b.prim_offset[t], dt.prims, (size_t)dt.num_prims * sizeof(int32_t),
+                      hipMemcpyDeviceToHost));
+    ctx->d_tree_on_host[t] = 1;
+  }
+  return YTHIP_OK;
+}
+
+// make_scene_bvh (yocto_bvh.cpp:364-396) with the large shapes built on the
+// device (yt_gpubuild.hip) and everything else — small shapes, the instance
+// tree — by the host builder of yt_build.h.  Same trees either way.
+int build_bvh_mixed(ythip_ctx* ctx, const ythip_scene& sc, bool highquality, bool use_device) {
+  auto t_start = std::chrono::steady_clock::now();
+  free_device_trees(ctx);
+  auto& out = ctx->h_bvh;
+  out       = ythost::flat_bvh{};
+  ctx->build_info = {};
+  int  nshapes = sc.num_shapes;
+  ctx->d_trees.assign(nshapes, ytgpu::DeviceTree{});
+  ctx->d_tree_on_host.assign(nshapes, 0);
+  auto roots = std::vector<ythost::bbox>(nshapes);
+  auto empty = std::vector<char>(nshapes, 1);
+  for (int k = 0; k < nshapes; k++) {
+    const auto& sh    = sc.shapes[k];
+    int         kind  = ythost::kind_bvh(sh);
+    int64_t     nprim = kind == KIND_POINTS ? sh.num_points : kind == KIND_LINES ? sh.num_lines
+                        : kind == KIND_TRIANGLES ? sh.num_triangles : kind == KIND_QUADS ? sh.num_quads : 0;
+    out.node_offset.push_back((int64_t)out.nodes.size());
+    out.prim_offset.push_back((int64_t)out.prims.size());
+    bool built = false;
+    if (use_device && !highquality && nprim >= ctx->device_build_min_prims) {
+      const int* el = kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
+                      : kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
+                      : kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
+                                             : ctx->ds.points + sh.points_offset;
+      std::string err;
+      int rc = ytgpu::build_shape_tree(ctx->stream, kind, el, ctx->ds.positions + 3 * sh.positions_offset,
+          sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, nprim,
+          &ctx->d_trees[k], &err);
+      if (rc == ytgpu::BUILD_ERROR) return fail(ctx, YTHIP_ERR_HIP, "device bvh build failed: %s", err.c_str());
+      if (rc == ytgpu::BUILD_OK) {
+        auto& dt = ctx->d_trees[k];
+        ythip_bvh_node root;
+        HIPCHECK(ctx, hipMemcpy(&root, dt.nodes, sizeof(root), hipMemcpyDeviceToHost));
+        roots[k].min = {root.bbox_min[0], root.bbox_min[1], root.bbox_min[2]};
+        roots[k].max = {root.bbox_max[0], root.bbox_max[1], root.bbox_max[2]};
+        empty[k]     = 0;
+        out.nodes.resize(out.nodes.size() + (size_t)dt.num_nodes);  // filled by ensure_host_bvh()
+        out.prims.resize(out.prims.size() + (size_t)dt.num_prims);
+        ctx->build_info.device_trees += 1;
+        ctx->build_info.device_prims += nprim;
+        ctx->build_info.device_ms += dt.build_ms;
+        ctx->build_info.max_depth = std::max(ctx->build_info.max_depth, dt.depth);
+        built = true;
+      } else {
+        ctx->build_info.fallbacks += 1;
+      }
+    }
+    if (!built) {
+      auto t = ythost::make_shape_bvh(sc, sh, highquality);
+      if (!t.nodes.empty()) {
+        empty[k]     = 0;
+        auto& n      = t.nodes[0];
+        roots[k].min = {n.bbox_min[0], n.bbox_min[1], n.bbox_min[2]};
+        roots[k].max = {n.bbox_max[0], n.bbox_max[1], n.bbox_max[2]};
+      }
+      out.nodes.insert(out.nodes.end(), t.nodes.begin(), t.nodes.end());
+      out.prims.insert(out.prims.end(), t.prims.begin(), t.prims.end());
+      ctx->build_info.host_trees += 1;
+    }
+  }
+  // the instance tree — yocto_bvh.cpp:381-393
+  auto bboxes = std::vector<ythost::bbox>(sc.num_instances);
+  for (auto k = 0; k < sc.num_instances; k++) {
+    auto& inst = sc.instances[k];
+    bboxes[k]  = empty[inst.shape] ? ythost::bbox{} : ythost::transform_bbox(inst.frame, roots[inst.shape]);
+  }
+  auto tlas = ythost::make_bvh(bboxes, highquality);
+  out.node_offset.push_back((int64_t)out.nodes.size());
+  out.prim_offset.push_back((int64_t)out.prims.size());
+  out.nodes.insert(out.nodes.end(), tlas.nodes.begin(), tlas.nodes.end());
+  out.prims.insert(out.prims.end(), tlas.prims.begin(), tlas.prims.end());
+  out.node_offset.push_back((int64_t)out.nodes.size());
+  out.prim_offset.push_back((int64_t)out.prims.size());
+  ctx->build_info.build_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  auto t_bake = std::chrono::steady_clock::now();
+  int  rc     = bake_bvh(ctx);
+  ctx->build_info.bake_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bake).count();
+  return rc;
 }
 
 int upload_lights_impl(ythip_ctx* ctx) {
@@ -440,6 +613,7 @@ void ythip_destroy(ythip_ctx* ctx) {
   free_all(ctx->bvh_allocs);
   free_all(ctx->light_allocs);
   free_all(ctx->state_allocs);
+  free_device_trees(ctx);
   for (auto& ev : ctx->ev_pool) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -571,14 +745,44 @@ int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* sc, int highquality) {
   if (!ctx || !sc) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
-  ctx->h_bvh = ythost::make_scene_bvh(*sc, highquality != 0);
-  return bake_bvh(ctx);
+  return build_bvh_mixed(ctx, *sc, highquality != 0, ctx->bvh_builder != 0);
+}
+
+int ythip_set_bvh_builder(ythip_ctx* ctx, int mode, int64_t min_prims) {
+  if (!ctx || mode < 0 || mode > 1) return fail(ctx, YTHIP_ERR_INVALID, "bvh builder mode must be 0 (host) or 1 (device)");
+  ctx->bvh_builder = mode;
+  if (min_prims > 0) ctx->device_build_min_prims = min_prims;
+  return YTHIP_OK;
+}
+
+int ythip_bvh_build_info(ythip_ctx* ctx, ythip_build_info* info) {
+  if (!ctx || !info) return YTHIP_ERR_INVALID;
+  *info = ctx->build_info;
+  return YTHIP_OK;
+}
+
+int ythip_bvh_baked_sizes(ythip_ctx* ctx, int64_t* num_pairs, int64_t* num_leaf4) {
+  if (!ctx || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "no bvh resident");
+  *num_pairs = ctx->num_pairs, *num_leaf4 = ctx->num_leaf4;
+  return YTHIP_OK;
+}
+
+int ythip_bvh_baked_download(ythip_ctx* ctx, float* pairs, float* leafdata) {
+  if (!ctx || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "no bvh resident");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  if (pairs && ctx->num_pairs)
+    HIPCHECK(ctx, hipMemcpy(pairs, ctx->ds.pairs, (size_t)ctx->num_pairs * 64, hipMemcpyDeviceToHost));
+  if (leafdata && ctx->num_leaf4)
+    HIPCHECK(ctx, hipMemcpy(leafdata, ctx->ds.leafdata, (size_t)ctx->num_leaf4 * 16, hipMemcpyDeviceToHost));
+  return YTHIP_OK;
 }
 
 int ythip_upload_bvh(ythip_ctx* ctx, const ythip_bvh* bvh) {
   if (!ctx || !bvh) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  free_device_trees(ctx);
+  ctx->build_info = {};
   auto& b = ctx->h_bvh;
   int   n = bvh->num_trees;
   b.node_offset.assign(bvh->node_offset, bvh->node_offset + n + 1);
@@ -599,6 +803,8 @@ int ythip_bvh_sizes(ythip_ctx* ctx, int32_t* num_trees, int64_t* num_nodes, int6
 int ythip_bvh_download(ythip_ctx* ctx, int64_t* node_offset, int64_t* prim_offset, ythip_bvh_node* nodes,
     int32_t* primitives) {
   if (!ctx || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "no bvh resident");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  if (int rc = ensure_host_bvh(ctx)) return rc;
   auto& b = ctx->h_bvh;
   std::memcpy(node_offset, b.node_offset.data(), b.node_offset.size() * sizeof(int64_t));
   std::memcpy(prim_offset, b.prim_offset.data(), b.prim_offset.size() * sizeof(int64_t));

@@ -141,6 +141,12 @@ def trace_params(**kw):
     return p
 
 
+class CBuildInfo(C.Structure):
+    _fields_ = [("device_trees", C.c_int32), ("host_trees", C.c_int32), ("fallbacks", C.c_int32),
+                ("max_depth", C.c_int32), ("device_prims", C.c_int64), ("device_ms", C.c_double),
+                ("build_ms", C.c_double), ("bake_ms", C.c_double)]
+
+
 class CStats(C.Structure):
     _fields_ = [("trace_launches", C.c_int64), ("trace_ms", C.c_double),
                 ("rays", C.c_int64), ("nodes", C.c_int64),
@@ -397,6 +403,10 @@ _SIGNATURES = {
     "ythip_update_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ythip_build_bvh": (C.c_int, [C.c_void_p, C.POINTER(CScene), C.c_int]),
     "ythip_upload_bvh": (C.c_int, [C.c_void_p, C.POINTER(CBvh)]),
+    "ythip_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
+    "ythip_bvh_build_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_bvh_baked_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ythip_bvh_baked_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ythip_bvh_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ythip_bvh_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
@@ -570,6 +580,24 @@ class Context:
         cs = scene.c_struct()
         self._check(self.lib.ythip_build_bvh(self.h, C.byref(cs), int(highquality)),
                     "build_bvh")
+
+    def set_bvh_builder(self, mode, min_prims=0):
+        """mode "device" (default: shapes >= min_prims are built on the GPU) or "host"."""
+        self._check(self.lib.ythip_set_bvh_builder(self.h, {"host": 0, "device": 1}[mode], min_prims),
+                    "set_bvh_builder")
+
+    def bvh_build_info(self):
+        info = CBuildInfo()
+        self._check(self.lib.ythip_bvh_build_info(self.h, C.byref(info)), "bvh_build_info")
+        return {k: getattr(info, k) for k, _ in CBuildInfo._fields_}
+
+    def download_baked_bvh(self):
+        """The traversal layout: pairs [n, 16] f4, leafdata [m, 4] f4."""
+        n, m = C.c_int64(), C.c_int64()
+        self._check(self.lib.ythip_bvh_baked_sizes(self.h, C.byref(n), C.byref(m)), "bvh_baked_sizes")
+        pairs, leaf = np.zeros((n.value, 16), "f4"), np.zeros((m.value, 4), "f4")
+        self._check(self.lib.ythip_bvh_baked_download(self.h, _ptr(pairs), _ptr(leaf)), "bvh_baked_download")
+        return pairs, leaf
 
     def upload_bvh(self, bvh):
         cb = bvh.c_struct()
