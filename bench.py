@@ -116,6 +116,7 @@ def main():
     ctx.make_trace_bvh(flat)
     ctx.make_trace_lights(flat)
     setup_s = time.time() - t0
+    build_info = ctx.bvh_build_info()
     w, h = yt.state_size(flat.cameras[0], params.resolution)
     if args.as_rank:
         vr, vn = (int(x) for x in args.as_rank.split("/"))
@@ -197,7 +198,13 @@ def main():
                    "resolution": [w, h], "spp": args.spp, "pixels_per_rank": npix,
                    "sharding": (f"{args.sharding}/{world}" if world > 1 else "none")
                                if not args.as_rank else f"{args.sharding} {args.as_rank}",
-                   "setup_s": round(setup_s, 3)},
+                   "setup_s": round(setup_s, 3),
+                   # make_trace_bvh: the 1M-triangle tree is built ON THE DEVICE (identical to
+                   # the reference's tree); wall ms of tree construction / baking the traversal layout
+                   "bvh_build": {"builder": "device" if build_info["device_trees"] else "host",
+                                 "device_kernels_ms": round(build_info["device_ms"], 3),
+                                 "build_ms": round(build_info["build_ms"], 3),
+                                 "bake_ms": round(build_info["bake_ms"], 3)}},
     }
     if rank == 0 and stats_count is not None and stats_time["trace_launches"] > 0:
         # The dominant (only) kernel is k_trace: one launch = one step.  Its

@@ -101,6 +101,44 @@ int main() {
     scene.cameras[0].frame.o.x -= 0.25f;
   }
 
+  // 2b. hip::make_trace_bvh builds large shapes ON THE DEVICE: the tree must be the
+  //     reference's, node for node, and usable by the CPU tracer
+  {
+    auto big   = scene_data{};
+    auto& cam  = big.cameras.emplace_back();
+    cam.frame  = lookat_frame(vec3f{0, 3, 8}, vec3f{0, 0, 0}, vec3f{0, 1, 0});
+    cam.aspect = 1.5f, cam.lens = 0.035f, cam.focus = 8.5f;
+    auto& sh   = big.shapes.emplace_back();
+    sh         = make_recty({160, 80}, {10, 10});  // 12,800 quads → 25,600 triangles
+    sh.triangles = quads_to_triangles(sh.quads);
+    sh.quads.clear();
+    big.materials.emplace_back().color = {0.7f, 0.7f, 0.7f};
+    auto& inst = big.instances.emplace_back();
+    inst.shape = 0, inst.material = 0;
+    big.environments.emplace_back().emission = {1, 1, 1};
+    auto params       = trace_params{};
+    params.sampler    = trace_sampler_type::eyelight;
+    params.resolution = 64;
+    params.samples    = 2;
+    params.batch      = 2;
+    auto ref = make_trace_bvh(big, params);
+    auto dev = hip::make_trace_bvh(big, params);
+    EXPECT(dev.bvh.shapes.size() == 1 && dev.bvh.shapes[0].bvh.nodes.size() == ref.bvh.shapes[0].bvh.nodes.size(),
+        "device-built tree has a different node count");
+    EXPECT(std::memcmp(dev.bvh.shapes[0].bvh.nodes.data(), ref.bvh.shapes[0].bvh.nodes.data(),
+               ref.bvh.shapes[0].bvh.nodes.size() * sizeof(bvh_node)) == 0, "device-built BLAS nodes differ");
+    EXPECT(dev.bvh.shapes[0].bvh.primitives == ref.bvh.shapes[0].bvh.primitives, "device-built primitives differ");
+    EXPECT(std::memcmp(dev.bvh.bvh.nodes.data(), ref.bvh.bvh.nodes.data(),
+               ref.bvh.bvh.nodes.size() * sizeof(bvh_node)) == 0, "TLAS nodes differ");
+    auto lights = make_trace_lights(big, params);
+    auto cpu    = make_trace_state(big, params);
+    auto gpu    = make_trace_state(big, params);
+    trace_samples(cpu, big, dev, lights, params);       // the CPU tracer on the device-built tree
+    hip::trace_samples(gpu, big, dev, lights, params);  // no re-upload: the tree is already resident
+    EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.rngs, gpu.rngs), "eyelight on the device-built tree differs");
+    hip::release();
+  }
+
   // 3. trace_image + error behaviour
   {
     auto params       = trace_params{};

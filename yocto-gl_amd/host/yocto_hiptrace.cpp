@@ -222,9 +222,11 @@ stamp stamp_of(const scene_data& s) {
                                         sh.positions.size(), (size_t)(uintptr_t)sh.positions.data()});
   return st;
 }
+// (identified by its node storage, not by the object's address: a trace_bvh is
+// returned by value from make_trace_bvh and moved into the caller's variable)
 stamp stamp_of(const trace_bvh& b) {
-  stamp st{&b, {b.bvh.bvh.nodes.size(), b.bvh.shapes.size()}};
-  for (auto& s : b.bvh.shapes) st.sizes.push_back(s.bvh.nodes.size());
+  stamp st{b.bvh.bvh.nodes.data(), {b.bvh.bvh.nodes.size(), b.bvh.shapes.size()}};
+  for (auto& s : b.bvh.shapes) st.sizes.insert(st.sizes.end(), {s.bvh.nodes.size(), (size_t)(uintptr_t)s.bvh.nodes.data()});
   return st;
 }
 stamp stamp_of(const trace_lights& l) {
@@ -264,15 +266,27 @@ void ensure_context(residency& r) {
   check(nullptr, ythip_create(device, &r.ctx));
 }
 
+// the scene's device mirror (uploads when the stamp changed)
+void ensure_scene(residency& r, const scene_data& scene, flat_scene* keep = nullptr) {
+  ensure_context(r);
+  auto ss = stamp_of(scene);
+  if (ss != r.scene || keep) {
+    flat_scene  local;
+    flat_scene& f = keep ? *keep : local;
+    flatten(scene, f);
+    if (ss != r.scene) {
+      check(r.ctx, ythip_upload_scene(r.ctx, &f.view));
+      r.scene = ss;
+      r.bvh = r.lights = {};
+    }
+  }
+}
+
 void ensure_resident(residency& r, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights) {
   ensure_context(r);
   auto ss = stamp_of(scene);
   if (ss != r.scene) {
-    flat_scene f;
-    flatten(scene, f);
-    check(r.ctx, ythip_upload_scene(r.ctx, &f.view));
-    r.scene = ss;
-    r.bvh = r.lights = {};
+    ensure_scene(r, scene);
   } else {
     std::vector<ythip_camera> cams;
     for (auto& c : scene.cameras) cams.push_back(flat(c));
@@ -356,9 +370,37 @@ trace_state make_trace_state(const scene_data& scene, const trace_params& params
 trace_lights make_trace_lights(const scene_data& scene, const trace_params& params) {
   return yocto::make_trace_lights(scene, params);
 }
+// make_trace_bvh — yocto_trace.cpp:88-96.  Large shapes are built on the device
+// (ythip_build_bvh, yt_gpubuild.hip: the reference's tree node for node), the
+// result stays resident for trace_samples AND comes back as the reference's own
+// value type, so either back-end can use it.  SAH builds stay on the host.
 trace_bvh make_trace_bvh(const scene_data& scene, const trace_params& params) {
   if (params.embreebvh) throw std::invalid_argument("yocto::hip::make_trace_bvh: embreebvh has no device mirror");
-  return yocto::make_trace_bvh(scene, params);
+  if (params.highqualitybvh) return yocto::make_trace_bvh(scene, params);
+  auto&      r    = cache();
+  auto       lock = std::lock_guard{r.mutex};
+  flat_scene f;
+  ensure_scene(r, scene, &f);
+  check(r.ctx, ythip_build_bvh(r.ctx, &f.view, 0));
+  int32_t ntrees = 0;
+  int64_t nnodes = 0, nprims = 0;
+  check(r.ctx, ythip_bvh_sizes(r.ctx, &ntrees, &nnodes, &nprims));
+  auto node_offset = std::vector<int64_t>(ntrees + 1), prim_offset = std::vector<int64_t>(ntrees + 1);
+  auto nodes       = std::vector<ythip_bvh_node>((size_t)nnodes);
+  auto prims       = std::vector<int32_t>((size_t)nprims);
+  check(r.ctx, ythip_bvh_download(r.ctx, node_offset.data(), prim_offset.data(), nodes.data(), prims.data()));
+  static_assert(sizeof(ythip_bvh_node) == sizeof(bvh_node), "bvh_node layout drifted");
+  auto out  = trace_bvh{};
+  auto fill = [&](bvh_tree& t, int k) {
+    t.nodes.resize((size_t)(node_offset[k + 1] - node_offset[k]));
+    if (!t.nodes.empty()) std::memcpy((void*)t.nodes.data(), nodes.data() + node_offset[k], t.nodes.size() * sizeof(bvh_node));
+    t.primitives.assign(prims.begin() + prim_offset[k], prims.begin() + prim_offset[k + 1]);
+  };
+  out.bvh.shapes.resize((size_t)ntrees - 1);
+  for (auto k = 0; k < ntrees - 1; k++) fill(out.bvh.shapes[k].bvh, k);
+  fill(out.bvh.bvh, ntrees - 1);
+  r.bvh = stamp_of(out);  // already resident: trace_samples will not upload it again
+  return out;
 }
 
 void trace_samples(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,

@@ -11,10 +11,11 @@
 // the float tolerance stated in tests/ (bit-exact for the rng streams, hit
 // counters and every libm-free stage).
 //
-// Only trace_samples runs on the GPU.  make_trace_bvh / make_trace_lights /
-// make_trace_state stay the reference's host functions (SURVEY.md §8a rows
-// 20-22: "host, re-used unchanged"), so a `trace_bvh` built by either side
-// works with either trace_samples.
+// trace_samples runs on the GPU, and so does make_trace_bvh for large shapes (the
+// tree it returns is the reference's own tree, node for node — DESIGN.md §7b —
+// as the reference's own value type, so a `trace_bvh` built by either side works
+// with either trace_samples).  make_trace_lights / make_trace_state stay the
+// reference's host functions.
 //
 // The device mirrors of (scene, bvh, lights, state) are cached between calls by
 // identity + a cheap content stamp, so the progressive loop
@@ -34,7 +35,10 @@ namespace yocto::hip {
 // yocto_bvh.h).  Never throws.
 bool hip_supported();
 
-// yocto_trace.h:160-168 — forwarded to the reference's host implementations.
+// yocto_trace.h:160-168.  State and lights: forwarded to the reference's host
+// implementations.  make_trace_bvh: built by libythip (device for shapes >= 16384
+// primitives, host otherwise; params.highqualitybvh → the reference's SAH build),
+// left resident, and returned in the reference's layout.
 trace_state  make_trace_state(const scene_data& scene, const trace_params& params);
 trace_lights make_trace_lights(const scene_data& scene, const trace_params& params);
 trace_bvh    make_trace_bvh(const scene_data& scene, const trace_params& params);
