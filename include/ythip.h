@@ -353,6 +353,14 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params,
 /* Same, but only enqueues the work on the stream (pair with ythip_sync). */
 int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params);
 
+/* Scheduling inside the persistent kernel (no reference equivalent; results do
+ * not depend on it).  adaptive_wait = 1 (default): a workgroup that has measured
+ * its bounce rays to be much cheaper than its camera rays lets regenerated camera
+ * rays wait until the pending bounce rays are done and traces them together
+ * (DESIGN.md §4); 0: every queued ray runs in every iteration.  The environment
+ * variable YTHIP_HOLD=0/1 sets the default of new contexts (A/B measurements). */
+int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait);
+
 /* intersect_scene_bvh for a batch of rays (yocto_bvh.h:105-106,
  * yocto_bvh.cpp:554-617); parity/test entry using the same device function as
  * the extend kernel.  Host pointers. */

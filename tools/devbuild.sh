@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B development builds of libythip (path / pathtest / naive kernels only, ~20 s):
+#   tools/devbuild.sh NAME [-DFLAG ...]   → build/dev/libythip_NAME.so
+# run with  YTHIP_LIB=build/dev/libythip_NAME.so python tools/sampler_times.py
+set -e
+name=$1; shift
+cd "$(dirname "$0")/.."
+mkdir -p build/dev
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DYT_DEV_ONLY_PATH "$@" \
+  -c -o build/dev/ythip_$name.o yocto-gl_amd/csrc/ythip.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/dev/libythip_$name.so build/dev/ythip_$name.o yocto-gl_amd/csrc/yt_gpubuild.o
+echo built build/dev/libythip_$name.so

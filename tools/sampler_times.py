@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Where does a step go?  Times trace_samples on BASELINE configs[1] for several
+samplers (falsecolor = primary ray + minimal shading; eyelight = + material
+evaluation; path = the full loop) and the bare traversal of the frame's primary
+rays (k_intersect_batch).  Diagnostic only."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "yocto-gl_amd"))
+import ythip as yt, scenes as ysc
+
+SCENE = os.environ.get("SCENE", "plane")
+if SCENE == "plane":
+    flat = ysc.plane_scene()
+else:
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import parity as P
+    flat = P.SCENES[SCENE]()
+ctx = yt.Context(0)
+ctx.upload_scene(flat); ctx.make_trace_bvh(flat); ctx.make_trace_lights(flat)
+spp = int(os.environ.get('SPP', '64'))
+RES = int(os.environ.get('RES', '1280'))
+for sampler in (os.environ.get("SAMPLERS") or "falsecolor,eyelight,naive,pathtest,path").split(","):
+    p = yt.trace_params(sampler=sampler, resolution=RES, samples=1 << 30, batch=spp)
+    ctx.make_trace_state(flat, p)
+    ctx.trace_samples(p)
+    ctx.set_profiling(1); ctx.reset_stats()
+    for _ in range(3):
+        ctx.trace_samples(p)
+    s = ctx.get_stats(); ctx.set_profiling(0)
+    ms = s["trace_ms"] / s["trace_launches"]
+    print(f"{SCENE} {sampler:10s} {ms:8.3f} ms/step  {ctx.npixels*spp/ms/1e3:8.1f} Msamples/s", flush=True)

@@ -61,6 +61,7 @@ struct Hit {
 
 struct Counters {
   unsigned nodes, triangles, quads, lines, points, instances, rays;
+  unsigned steps;  // always on: sibling-pair fetches + leaf visits of this lane (k_trace's scheduling signal)
 };
 
 struct PrimHit {
@@ -324,6 +325,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       const float4* P  = pairs + 4 * (int64_t)cur;
       float4        q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3];
       if (COUNT) cnt.nodes += 2;
+      cnt.steps++;
       float t0a, t0b;
       bool  fa, fb;
       if (tame) {
@@ -372,6 +374,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       continue;
     }
     cur = REF_NONE;
+    cnt.steps++;
     // BLAS leaf — yocto_bvh.cpp:505-545
     if (kind == KIND_TRIANGLES) {
       const float4* L = sc.leafdata + (leafbias + first * 3);

@@ -90,9 +90,11 @@ struct KParams {
   float clamp;
   int   nocaustics, envhidden, tentfilter;
   int   has_env;  // !scene.environments.empty()
+  int   hold;     // scheduling policy of k_trace (0 off, 1 hold back partial primary wavefronts)
 };
 
 constexpr int YT_TILE = 16;  // 16 x 16 pixels = YT_BLOCK slots
+constexpr int YT_PROBE_ITERS = 48;  // iterations over which a workgroup measures its per-class traversal work
 static_assert(YT_TILE * YT_TILE == YT_BLOCK, "one tile per workgroup");
 
 // Block → tile mapping.  Hardware block b runs on XCD b % 8 (each XCD has its own
@@ -461,7 +463,11 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
                     sample_bsdfcos_pdf(material, normal, outgoing, incoming);
         P.flags |= PF_NOEMIT;
       } else {
+#ifdef EXP_A
+        if (rand1f(P.rng) < 2.0f) {
+#else
         if (rand1f(P.rng) < 0.5f) {
+#endif
           auto rn  = rand2f(P.rng);
           auto rnl = rand1f(P.rng);
           incoming = sample_bsdfcos(material, normal, outgoing, rnl, rn);
@@ -469,7 +475,13 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           auto ruv = rand2f(P.rng);
           auto rel = rand1f(P.rng);
           auto rl  = rand1f(P.rng);
+#if defined(EXP_B)
+          incoming = sample_sphere(ruv);
+#elif defined(EXP_C)
+          incoming = sample_bsdfcos(material, normal, outgoing, rl, ruv);
+#else
           incoming = sample_lights(sc, position, rl, rel, ruv);
+#endif
         }
         if (incoming == vec3f{0, 0, 0}) return STEP_END;
         auto f     = eval_bsdfcos(material, normal, outgoing, incoming);
@@ -847,6 +859,9 @@ struct WgQueues {
   int queue[YT_BLOCK];
   int lqueue[YT_BLOCK];
   int cnt[YT_BLOCK / 64][3];
+  // traversal work seen so far by this workgroup, per ray class (0 camera rays,
+  // 1 bounce rays): lane-steps and rays — the scheduling signal of k_trace
+  unsigned work[2], rays[2];
 };
 YT_FN int3 block_partition(WgQueues& Q, int slot, int cls, int2 base, bool defer_class) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -907,9 +922,10 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
   const int tid = threadIdx.x;
   Stack     stack;
   YT_STACK_INIT(stack, s_stack);
-  Counters  cnt         = {0, 0, 0, 0, 0, 0, 0};
+  Counters  cnt         = {0, 0, 0, 0, 0, 0, 0, 0};
   const int max_bounces = max_bounces_of<SAMPLER>(kp);
 
+  if (tid < 2) Q.work[tid] = 0, Q.rays[tid] = 0;
   // head of the batch: the first camera ray of every pixel of the tile
   int3 n;
   {
@@ -927,11 +943,36 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
     n = block_partition(Q, slot, pix >= 0 ? OUT_PRIMARY : OUT_DEAD, {0, 0}, false);
   }
 
-  while (n.x + n.y > 0) {
-    // entry `tid` of the queue: primaries from the front, then bounces from the back
-    int slot = tid < n.x ? Q.queue[tid] : (tid < n.x + n.y ? Q.queue[YT_BLOCK - 1 - (tid - n.x)] : -1);
-    int cls  = OUT_DEAD;
-    if (slot >= 0) {
+  for (int iter = 0; n.x + n.y > 0; iter++) {
+    // entry `tid` of the queue: primaries from the front, then bounces from the back.
+    //
+    // Scheduling.  An iteration lasts as long as its slowest wavefront, so one that
+    // traces ANY camera ray costs a full camera-ray traversal.  Where bounce rays
+    // are much cheaper than camera rays (open scenes: most bounce rays leave
+    // through the first box) it pays to let the regenerated camera rays WAIT while
+    // bounce rays are pending and then trace them all together: per sample one
+    // expensive iteration instead of 1 + (bounces) of them.  Where bounce rays cost
+    // as much (interiors) everything runs at once, which keeps the lanes full.  The
+    // workgroup decides from the traversal work it has measured itself; results do
+    // not depend on the decision (pixels are independent).
+    bool wait = false;
+    if (kp.hold && n.y > 0 && n.x > 0) {
+      float wp = (float)Q.work[0], rp = (float)Q.rays[0], wb = (float)Q.work[1], rb_ = (float)Q.rays[1];
+      wait     = rp > 0 && rb_ > 0 && 4.0f * wb * rp < wp * rb_;  // mean bounce work < 1/4 mean camera-ray work
+    }
+    const int held = wait ? n.x : 0;
+    const int np   = n.x - held;
+    int  slot = -1, cls = OUT_DEAD;
+    bool run  = false;
+    if (tid < np) {
+      slot = Q.queue[tid], run = true;
+    } else if (tid < np + n.y) {
+      slot = Q.queue[YT_BLOCK - 1 - (tid - np)], run = true;
+    } else if (tid < n.x + n.y) {
+      slot = Q.queue[np + (tid - np - n.y)], cls = OUT_PRIMARY;  // stays queued
+    }
+    unsigned work = 0;  // traversal steps of this lane's ray in this iteration
+    if (run) {
       Path   P;
       float4 ra = W.ray_a[slot & (YT_BLOCK - 1)], rb = W.ray_b[slot & (YT_BLOCK - 1)];
       P.o      = {ra.x, ra.y, ra.z};
@@ -943,8 +984,10 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
         int    inst = __float_as_int(ha.w);
         P.isec      = {inst, st.nhit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
       } else {
-        ray3f ray = make_ray(P.o, P.d);
-        P.isec    = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
+        ray3f          ray = make_ray(P.o, P.d);
+        const unsigned s0  = cnt.steps;
+        P.isec             = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
+        work               = cnt.steps - s0 + 1;
       }
       // ---- shade: one iteration of the integrator's bounce loop -------------
       load_path_rest(st, W, slot, P, rb);
@@ -976,6 +1019,17 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
       if (MIS && step != STEP_END && (P.flags & PF_NOEMIT)) P.flags |= PF_SKIPEXTEND;
       cls = resolve_step(sc, st, kp, slot, P, step, max_bounces);
       store_path(W, slot, P);
+    }
+    if (kp.hold && iter < YT_PROBE_ITERS) {  // per-class totals: butterflies over the wavefront, one LDS atomic per class per wave
+      const bool               prim = tid < np;
+      const unsigned long long mp = __ballot(run && prim && work > 0), mb = __ballot(run && !prim && work > 0);
+      unsigned                 wp = prim ? work : 0, wb = prim ? 0 : work;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) wp += __shfl_xor(wp, off), wb += __shfl_xor(wb, off);
+      if ((tid & 63) == 0) {
+        if (mp) atomicAdd(&Q.work[0], wp), atomicAdd(&Q.rays[0], (unsigned)__popcll(mp));
+        if (mb) atomicAdd(&Q.work[1], wb), atomicAdd(&Q.rays[1], (unsigned)__popcll(mb));
+      }
     }
     n = block_partition(Q, slot, cls, {0, 0}, LP == LP_DEFER);
 
@@ -1009,7 +1063,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const y
     const int* instances, long long n, int find_any, ythip_hit* hits, unsigned long long* counters) {
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   long long      idx = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
-  Counters       cnt = {0, 0, 0, 0, 0, 0, 0};
+  Counters       cnt = {0, 0, 0, 0, 0, 0, 0, 0};
   if (idx < n) {
     Stack stack;
     YT_STACK_INIT(stack, s_stack);

@@ -406,7 +406,10 @@ constexpr float min_roughness = 0.03f * 0.03f;
 
 YT_FN material_point eval_material(const DScene& sc, const DShape& sh, const ythip_material& material,
     elem4 e, vec2f uv) {
-  auto texcoord       = eval_texcoord(sc, sh, e, uv);
+  // texcoords are only read by texture lookups: skip the three gathers for untextured materials
+  const bool textured = (material.emission_tex & material.color_tex & material.roughness_tex &
+                            material.scattering_tex) != YTHIP_INVALIDID;
+  auto texcoord       = textured ? eval_texcoord(sc, sh, e, uv) : vec2f{0, 0};
   auto emission_tex   = eval_texture(sc, material.emission_tex, texcoord, true);
   auto color_shp      = eval_color(sc, sh, e, uv);
   auto color_tex      = eval_texture(sc, material.color_tex, texcoord, true);

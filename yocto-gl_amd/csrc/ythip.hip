@@ -59,6 +59,7 @@ struct ythip_ctx {
   std::vector<char>              d_tree_on_host;
   int64_t                        device_build_min_prims = 16384;
   int                            bvh_builder            = 1;  // 0 host only, 1 device for large shapes
+  int                            hold_policy            = 1;
   ythip_build_info               build_info             = {};
   int64_t                        num_pairs = 0, num_leaf4 = 0;
   ythost::flat_lights h_lights;
@@ -140,6 +141,7 @@ KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
   k.envhidden  = p->envhidden;
   k.tentfilter = p->tentfilter;
   k.has_env    = ctx->ds.num_environments > 0;
+  k.hold       = ctx->hold_policy;
   return k;
 }
 
@@ -483,13 +485,17 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
       else
         launch_trace<YTHIP_SAMPLER_PATHTEST, LP_NONE>(ctx, kp, count);
       break;
+#ifndef YT_DEV_ONLY_PATH  // development builds: compile the path / pathtest / naive kernels only (10x faster)
     case YTHIP_SAMPLER_PATHDIRECT: launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_INLINE>(ctx, kp, count); break;
     case YTHIP_SAMPLER_PATHMIS: launch_trace<YTHIP_SAMPLER_PATHMIS, LP_INLINE>(ctx, kp, count); break;
+#endif
     case YTHIP_SAMPLER_NAIVE: launch_trace<YTHIP_SAMPLER_NAIVE, LP_NONE>(ctx, kp, count); break;
+#ifndef YT_DEV_ONLY_PATH
     case YTHIP_SAMPLER_EYELIGHT: launch_trace<YTHIP_SAMPLER_EYELIGHT, LP_NONE>(ctx, kp, count); break;
     case YTHIP_SAMPLER_DIAGRAM: launch_trace<YTHIP_SAMPLER_DIAGRAM, LP_NONE>(ctx, kp, count); break;
     case YTHIP_SAMPLER_FURNACE: launch_trace<YTHIP_SAMPLER_FURNACE, LP_NONE>(ctx, kp, count); break;
     case YTHIP_SAMPLER_FALSECOLOR: launch_trace<YTHIP_SAMPLER_FALSECOLOR, LP_NONE>(ctx, kp, count); break;
+#endif
     default: return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
   }
   return YTHIP_OK;
@@ -595,6 +601,7 @@ int ythip_create(int device, ythip_ctx** out) {
     return fail(nullptr, YTHIP_ERR_HIP, "hipSetDevice/hipStreamCreate failed");
   }
   ctx->stream = ctx->own_stream;
+  if (const char* e = std::getenv("YTHIP_HOLD")) ctx->hold_policy = std::atoi(e);
   if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       false) {
@@ -1095,6 +1102,12 @@ int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params, ythip_ray* ray
   auto e2 = hipStreamSynchronize(ctx->stream);
   free_all(tmp);
   if (e1 != hipSuccess || e2 != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "camera_rays failed");
+  return YTHIP_OK;
+}
+
+int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  ctx->hold_policy = adaptive_wait ? 1 : 0;
   return YTHIP_OK;
 }
 
