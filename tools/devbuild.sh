@@ -8,5 +8,7 @@ cd "$(dirname "$0")/.."
 mkdir -p build/dev
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DYT_DEV_ONLY_PATH "$@" \
   -c -o build/dev/ythip_$name.o yocto-gl_amd/csrc/ythip.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/dev/libythip_$name.so build/dev/ythip_$name.o yocto-gl_amd/csrc/yt_gpubuild.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/gpubuild_$name.o yocto-gl_amd/csrc/yt_gpubuild.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/dev/libythip_$name.so build/dev/ythip_$name.o build/dev/gpubuild_$name.o
+rm -f build/dev/ythip_$name.o build/dev/gpubuild_$name.o
 echo built build/dev/libythip_$name.so

@@ -104,7 +104,10 @@ static_assert(YT_TILE * YT_TILE == YT_BLOCK, "one tile per workgroup");
 // XCD 78 us (the sky band idles); tile rows ty = x (mod 8) per XCD 73 us (45
 // tile rows do not divide by 8).  The tree's leaf level dominates the L2
 // footprint and is private to a pixel neighbourhood under any mapping, so
-// balance wins; the hook stays here in case a scene says otherwise.
+// balance wins; the hook stays here in case a scene says otherwise.  (Re-measured
+// with the adaptive-wait scheduler: vertical bands of tile columns per XCD, plain
+// and interleaved in groups of 2 / 4 columns, gain 2-7 % on the plane and the
+// instanced scene and LOSE 15-45 % on the Cornell box, whose column costs differ.)
 YT_FN int logical_block(const DState& st) { return blockIdx.x < st.nblocks ? (int)blockIdx.x : -1; }
 
 // Pixel of a path slot: index into the slice's trace_state arrays (row-major,
@@ -286,6 +289,9 @@ struct ShadeEnv {
   Stack*         stack;  // LP_INLINE only
   Counters*      cnt;    // LP_INLINE only
   int            slot;
+#ifdef YT_TIMING
+  long long t_geo = 0;  // cycle counter after the shading point has been evaluated
+#endif
 };
 
 YT_FN volume_point load_volume(const DState& s, int slot) {
@@ -376,6 +382,10 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
     auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
     count_shade(E.st);
+#ifdef YT_TIMING
+    asm volatile("" ::"v"(position.x), "v"(normal.x), "v"(material.color.x), "v"(material.roughness));
+    E.t_geo = __builtin_readcyclecounter();
+#endif
     if (TEST) material.type = YTHIP_MATTE;
 
     // correct roughness
@@ -463,11 +473,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
                     sample_bsdfcos_pdf(material, normal, outgoing, incoming);
         P.flags |= PF_NOEMIT;
       } else {
-#ifdef EXP_A
-        if (rand1f(P.rng) < 2.0f) {
-#else
         if (rand1f(P.rng) < 0.5f) {
-#endif
           auto rn  = rand2f(P.rng);
           auto rnl = rand1f(P.rng);
           incoming = sample_bsdfcos(material, normal, outgoing, rnl, rn);
@@ -475,13 +481,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           auto ruv = rand2f(P.rng);
           auto rel = rand1f(P.rng);
           auto rl  = rand1f(P.rng);
-#if defined(EXP_B)
-          incoming = sample_sphere(ruv);
-#elif defined(EXP_C)
-          incoming = sample_bsdfcos(material, normal, outgoing, rl, ruv);
-#else
           incoming = sample_lights(sc, position, rl, rel, ruv);
-#endif
         }
         if (incoming == vec3f{0, 0, 0}) return STEP_END;
         auto f     = eval_bsdfcos(material, normal, outgoing, incoming);
@@ -972,6 +972,10 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
       slot = Q.queue[np + (tid - np - n.y)], cls = OUT_PRIMARY;  // stays queued
     }
     unsigned work = 0;  // traversal steps of this lane's ray in this iteration
+#ifdef YT_TIMING  // development builds: per-wave phase times (tools/devbuild.sh NAME -DYT_TIMING)
+    const long long tm0 = __builtin_readcyclecounter();
+    long long       tm1 = tm0, tm2 = tm0, tmS = tm0, tmG = 0;
+#endif
     if (run) {
       Path   P;
       float4 ra = W.ray_a[slot & (YT_BLOCK - 1)], rb = W.ray_b[slot & (YT_BLOCK - 1)];
@@ -989,6 +993,9 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
         P.isec             = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
         work               = cnt.steps - s0 + 1;
       }
+#ifdef YT_TIMING
+      tm1 = __builtin_readcyclecounter();
+#endif
       // ---- shade: one iteration of the integrator's bounce loop -------------
       load_path_rest(st, W, slot, P, rb);
       P.flags &= ~PF_SKIPEXTEND;
@@ -1000,6 +1007,9 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
         ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
         if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
           step = step_path<SAMPLER, LP>(E, P);
+#ifdef YT_TIMING
+          tmG = E.t_geo;
+#endif
         } else if constexpr (SAMPLER == YTHIP_SAMPLER_NAIVE) {
           step = step_naive<SAMPLER>(E, P);
         } else if constexpr (SAMPLER == YTHIP_SAMPLER_FURNACE) {
@@ -1017,9 +1027,15 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
         }
       }
       if (MIS && step != STEP_END && (P.flags & PF_NOEMIT)) P.flags |= PF_SKIPEXTEND;
+#ifdef YT_TIMING
+      tmS = __builtin_readcyclecounter();
+#endif
       cls = resolve_step(sc, st, kp, slot, P, step, max_bounces);
       store_path(W, slot, P);
     }
+#ifdef YT_TIMING
+    tm2 = __builtin_readcyclecounter();
+#endif
     if (kp.hold && iter < YT_PROBE_ITERS) {  // per-class totals: butterflies over the wavefront, one LDS atomic per class per wave
       const bool               prim = tid < np;
       const unsigned long long mp = __ballot(run && prim && work > 0), mb = __ballot(run && !prim && work > 0);
@@ -1032,6 +1048,26 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
       }
     }
     n = block_partition(Q, slot, cls, {0, 0}, LP == LP_DEFER);
+#ifdef YT_TIMING
+    {  // extend | shade | probe + partition (incl. waiting for the workgroup's slower waves)
+      const long long tm3     = __builtin_readcyclecounter();
+      const bool      any_run = __ballot(run) != 0;
+      if ((tid & 63) == 0 && st.counters) {
+        unsigned long long* c = st.counters + cnt_bank();
+        atomicAdd(&c[9], (unsigned long long)(any_run ? tm1 - tm0 : 0));
+        atomicAdd(&c[10], (unsigned long long)(any_run ? tm2 - tm1 : 0));
+        atomicAdd(&c[11], (unsigned long long)(tm3 - tm2));
+        atomicAdd(&c[12], (unsigned long long)(any_run ? 0 : tm2 - tm0));
+        atomicAdd(&c[13], 1ull);
+        // shade split (waves whose lane 0 shaded a hit): shading point | bsdf + sampling | finish + regenerate
+        if (any_run && tmG) {
+          atomicAdd(&c[14], (unsigned long long)(tmG - tm1));
+          atomicAdd(&c[15], (unsigned long long)(tmS - tmG));
+        }
+        if (any_run) atomicAdd(&c[8], (unsigned long long)(tm2 - tmS));
+      }
+    }
+#endif
 
     // ---- deferred sample_lights_pdf walks + the rest of the loop body -------
     if constexpr (LP == LP_DEFER) {

@@ -547,6 +547,9 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   auto kp          = to_kparams(ctx, params);
   bool count       = (ctx->prof_mode & 2) != 0;
   ctx->st.counters = count ? ctx->d_counters : nullptr;
+#ifdef YT_TIMING
+  ctx->st.counters = ctx->d_counters;
+#endif
   int  npix        = ctx->st.nslots;  // path-state arrays are per slot
   bool mis         = params->sampler == YTHIP_SAMPLER_PATHMIS;
   if (mis && !ctx->nhit_a) {
@@ -1136,6 +1139,20 @@ int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
   HIPCHECK(ctx, hipMemcpy(banks, ctx->d_counters, sizeof(banks), hipMemcpyDeviceToHost));
   for (int b = 0; b < CNT_BANKS; b++)
     for (int k = 0; k < CNT_NUM; k++) c[k] += banks[b * CNT_STRIDE + k];
+#ifdef YT_TIMING
+  {
+    unsigned long long t[16] = {};
+    for (int b = 0; b < CNT_BANKS; b++)
+      for (int k = 8; k < 16; k++) t[k] += banks[b * CNT_STRIDE + k];
+    double tot = (double)(t[9] + t[10] + t[11] + t[12]);
+    std::fprintf(stderr, "[timing] wave-iterations %llu | extend %.1f%% shade %.1f%% partition+wait %.1f%% "
+                         "idle-wave %.1f%% | cycles/wave-iteration %.0f\n",
+        t[13], 100 * t[9] / tot, 100 * t[10] / tot, 100 * t[11] / tot, 100 * t[12] / tot, t[13] ? tot / t[13] : 0.0);
+    std::fprintf(stderr, "[timing] of all wave time: hit shading point %.1f%% | bsdf+sampling after it %.1f%% | "
+                         "finish+regenerate (resolve_step) %.1f%%\n",
+        100 * t[14] / tot, 100 * t[15] / tot, 100 * t[8] / tot);
+  }
+#endif
   *stats           = ctx->stats;
   stats->rays      = (int64_t)c[CNT_RAYS];
   stats->nodes     = (int64_t)c[CNT_NODES];
