@@ -333,6 +333,17 @@ int ythip_state_upload(ythip_ctx* ctx, const float* image, const float* albedo,
     int samples);
 int ythip_state_download(ythip_ctx* ctx, float* image, float* albedo,
     float* normal, int32_t* hits, uint64_t* rngs, int* samples);
+/* get_image (yocto_trace.cpp:1694-1708): only trace_state.image, width*rows vec4f,
+ * linear.  The download point of a viewer (16 B/pixel instead of the 60 B/pixel
+ * of ythip_state_download). */
+int ythip_get_image(ythip_ctx* ctx, float* image);
+/* tonemap_image (yocto_image.cpp:911-922; tonemap yocto_color.h:355-364) of the
+ * resident image ON THE DEVICE: exposure in stops, optional filmic curve, optional
+ * sRGB encoding.  `ldr` (vec4f per pixel) and/or `ldr_bytes` (vec4b per pixel,
+ * float_to_byte) receive the result; either may be NULL.  A display loop
+ * (apps/ytrace.cpp:206-216) then moves 4 B/pixel per refresh. */
+int ythip_tonemap_image(ythip_ctx* ctx, float exposure, int filmic, int srgb,
+    float* ldr, uint8_t* ldr_bytes);
 /* Use caller-owned DEVICE buffers (e.g. torch tensors) for the state arrays,
  * so that the framebuffer gather can run on them directly (RCCL). */
 int ythip_state_bind_device(ythip_ctx* ctx, void* image, void* albedo,

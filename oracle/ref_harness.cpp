@@ -612,6 +612,17 @@ void ref_eval_environment(const ref_scene* rs, const float* dirs, int64_t n,
 }
 
 // PCG32 known answers (yocto_sampling.h:187-232)
+// tonemap_image (yocto_image.cpp:911-922) of n vec4f pixels: float and byte results
+void ref_tonemap(const float* hdr, int64_t n, float exposure, int filmic, int srgb, float* ldr, uint8_t* ldrb) {
+  auto h = std::vector<vec4f>((const vec4f*)hdr, (const vec4f*)hdr + n);
+  auto f = std::vector<vec4f>{};
+  auto b = std::vector<vec4b>{};
+  tonemap_image(f, h, exposure, filmic != 0, srgb != 0);
+  tonemap_image(b, h, exposure, filmic != 0, srgb != 0);
+  std::memcpy(ldr, f.data(), (size_t)n * sizeof(vec4f));
+  std::memcpy(ldrb, b.data(), (size_t)n * sizeof(vec4b));
+}
+
 void ref_make_rng(uint64_t seed, uint64_t seq, uint64_t* out) {
   auto rng = make_rng(seed, seq);
   out[0]   = rng.state;

@@ -67,6 +67,7 @@ def lib():
             "ref_camera_rays": (None, [vp, vp, C.POINTER(yt.CParams), vp]),
             "ref_eval_shading": (None, [vp, vp, vp, C.c_int64, vp]),
             "ref_eval_environment": (None, [vp, vp, C.c_int64, vp]),
+            "ref_tonemap": (None, [vp, C.c_int64, C.c_float, C.c_int, C.c_int, vp, vp]),
             "ref_make_rng": (None, [C.c_uint64, C.c_uint64, vp]),
             "ref_rand1f": (None, [vp, C.c_int, vp]),
             "ref_hardware_concurrency": (C.c_int, []),
@@ -278,6 +279,15 @@ def eval_environment(scene, dirs):
     out = np.zeros((len(dirs), 3), "f4")
     lib().ref_eval_environment(scene.h, dirs.ctypes.data, len(dirs), out.ctypes.data)
     return out
+
+
+def tonemap(hdr, exposure=0.0, filmic=False, srgb=True):
+    """The reference's tonemap_image on [n, 4] floats: (float [n, 4], bytes [n, 4])."""
+    hdr = np.ascontiguousarray(hdr, "f4").reshape(-1, 4)
+    ldr, ldrb = np.zeros_like(hdr), np.zeros(hdr.shape, "u1")
+    lib().ref_tonemap(hdr.ctypes.data, len(hdr), exposure, int(filmic), int(srgb), ldr.ctypes.data,
+                      ldrb.ctypes.data)
+    return ldr, ldrb
 
 
 def make_rng(seed, seq):

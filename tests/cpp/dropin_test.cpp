@@ -4,6 +4,7 @@
 // one yocto::trace_samples (the CPU reference, linked from oracle/_ref) produces.
 // TEST INFRASTRUCTURE: built by oracle/Makefile (`make dropin`) when the
 // reference sources are present; run by tests/test_gpu_parity.py on the GPU box.
+#include <yocto/yocto_image.h>
 #include <yocto/yocto_scene.h>
 #include <yocto/yocto_trace.h>
 
@@ -11,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
 
 #include "../../yocto-gl_amd/host/yocto_hiptrace.h"
 
@@ -136,6 +138,56 @@ int main() {
     trace_samples(cpu, big, dev, lights, params);       // the CPU tracer on the device-built tree
     hip::trace_samples(gpu, big, dev, lights, params);  // no re-upload: the tree is already resident
     EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.rngs, gpu.rngs), "eyelight on the device-built tree differs");
+    hip::release();
+  }
+
+  // 2c. the interactive protocol of apps/ytrace.cpp:183-216 on the GPU: preview, start / done /
+  //     get_image / start ..., cancel; get_image moves only the image; tonemap on the device
+  {
+    auto params       = trace_params{};
+    params.sampler    = trace_sampler_type::eyelight;
+    params.resolution = 120;
+    params.samples    = 3;
+    params.batch      = 1;
+    params.pratio     = 8;
+    auto bvh          = make_trace_bvh(scene, params);
+    auto lights       = make_trace_lights(scene, params);
+    auto cpu          = make_trace_state(scene, params);
+    auto gpu          = make_trace_state(scene, params);
+    auto image_c = make_image(cpu.width, cpu.height, true), image_g = make_image(gpu.width, gpu.height, true);
+    auto ctx_c = make_trace_context(params), ctx_g = make_trace_context(params);
+    trace_preview(image_c, ctx_c, cpu, scene, bvh, lights, params);
+    hip::trace_preview(image_g, ctx_g, gpu, scene, bvh, lights, params);
+    EXPECT(same_bytes(image_c.pixels, image_g.pixels), "trace_preview differs");
+    for (auto k = 0; k < params.samples; k++) {
+      trace_start(ctx_c, cpu, scene, bvh, lights, params);
+      hip::trace_start(ctx_g, gpu, scene, bvh, lights, params);
+      while (!ctx_c.done || !ctx_g.done) std::this_thread::yield();  // render_update's `if (context.done)`
+      trace_cancel(ctx_c);  // joins the (finished) workers, as render_next does before the next start
+      hip::trace_cancel(ctx_g);
+      get_image(image_c, cpu);
+      hip::get_image(image_g, gpu);  // device → host: image only
+      EXPECT(same_bytes(image_c.pixels, image_g.pixels), "progressive image differs after batch %d", k);
+    }
+    EXPECT(gpu.samples == 3 && cpu.samples == 3, "samples %d / %d", gpu.samples, cpu.samples);
+    // tonemap on the device vs the reference's tonemap_image: floats within 2 ulp-ish, bytes equal almost everywhere
+    for (auto filmic : {false, true}) {
+      auto ldr_c = tonemap_image(image_c, 0.5f, filmic);
+      auto ldr_g = hip::tonemap_image(gpu, 0.5f, filmic);
+      auto bytes = hip::tonemap_image_bytes(gpu, 0.5f, filmic);
+      auto worst = 0.0f;
+      auto bdiff = 0;
+      for (size_t k = 0; k < ldr_c.pixels.size(); k++) {
+        auto a = ldr_c.pixels[k], b = ldr_g.pixels[k];
+        worst  = std::max(worst, std::max(std::fabs(a.x - b.x), std::max(std::fabs(a.y - b.y), std::fabs(a.z - b.z))));
+        auto rb = float_to_byte(a);
+        bdiff += rb.x != bytes[k].x || rb.y != bytes[k].y || rb.z != bytes[k].z || rb.w != bytes[k].w;
+      }
+      EXPECT(ldr_g.linear == false && worst <= 1e-6f, "device tonemap differs by %g", worst);
+      EXPECT(bdiff <= (int)(ldr_c.pixels.size() / 1000), "device tonemap bytes differ in %d pixels", bdiff);
+    }
+    hip::download_state(gpu);
+    EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.rngs, gpu.rngs), "state after the async loop differs");
     hip::release();
   }
 

@@ -383,6 +383,29 @@ def test_results_do_not_depend_on_the_scheduling_policy(bundles, name, sampler):
         assert out[0][k].tobytes() == out[1][k].tobytes(), k
 
 
+def test_get_image_and_device_tonemap(bundles):
+    """§8(f) rank 2, the display path: ythip_get_image returns exactly
+    trace_state.image; ythip_tonemap_image (device) vs the reference's tonemap_image
+    on the same pixels — float tolerance 1e-6 absolute (device exp2f / powf differ
+    from glibc in the last ulp), bytes identical for >= 99.9 % of the pixels, and
+    byte-identical where the curve is piecewise linear (srgb off, no exposure)."""
+    flat, ctx, _ = bundles("materials")
+    p = yt.trace_params(sampler="path", resolution=128, samples=4, batch=4)
+    st = P.gpu_render(ctx, flat, p)
+    img = ctx.get_image()
+    assert img.reshape(-1, 4).tobytes() == st["image"].tobytes()
+    ldr, ldrb = ctx.tonemap_image(exposure=0.0, filmic=False, srgb=False)
+    assert ldr.tobytes() == img.tobytes()  # identity curve: bit-exact
+    assert np.array_equal(ldrb.reshape(-1, 4), np.clip((img.reshape(-1, 4) * 256).astype(np.int64), 0, 255))
+    if not P.have_ref():
+        pytest.skip("oracle/_ref did not travel")
+    for exposure, filmic in [(0.0, False), (1.5, False), (-0.75, True)]:
+        ldr, ldrb = ctx.tonemap_image(exposure=exposure, filmic=filmic, srgb=True)
+        ref, refb = ry.tonemap(img, exposure, filmic, True)
+        assert np.abs(ldr.reshape(-1, 4) - ref).max() <= 1e-6, (exposure, filmic)
+        assert (ldrb.reshape(-1, 4) == refb).all(1).mean() >= 0.999, (exposure, filmic)
+
+
 def test_work_counters_and_cancel(bundles):
     flat, ctx, _ = bundles("cornellbox")
     params = yt.trace_params(sampler="path", resolution=64, samples=2, batch=2)

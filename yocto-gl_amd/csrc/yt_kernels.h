@@ -1113,6 +1113,37 @@ __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const y
   if (COUNT) flush_counters(counters, cnt);
 }
 
+// ---------------------------------------------------------------------------
+// Display path: tonemap(trace_state.image) on the device, so
+// a viewer downloads 4 B/pixel instead of 16 — yocto_color.h:322-364 (tonemap,
+// tonemap_filmic, rgb_to_srgb) and float_to_byte (yocto_math.h).
+// ---------------------------------------------------------------------------
+YT_FN float rgb_to_srgb1(float rgb) {  // yocto_color.h:239-242
+  return (rgb <= 0.0031308f) ? 12.92f * rgb : (1 + 0.055f) * powf(rgb, 1 / 2.4f) - 0.055f;
+}
+YT_FN vec3f tonemap_filmic(vec3f hdr_) {  // yocto_color.h:322-329 (accurate_fit = false)
+  auto hdr = hdr_ * 0.6f;
+  auto ldr = (hdr * hdr * 2.51f + hdr * 0.03f) / (hdr * hdr * 2.43f + hdr * 0.59f + 0.14f);
+  return {max_(0.0f, ldr.x), max_(0.0f, ldr.y), max_(0.0f, ldr.z)};
+}
+YT_FN vec3f tonemap(vec3f hdr, float exposure, bool filmic, bool srgb) {  // yocto_color.h:355-361
+  auto rgb = hdr;
+  if (exposure != 0) rgb *= exp2f(exposure);
+  if (filmic) rgb = tonemap_filmic(rgb);
+  if (srgb) rgb = {rgb_to_srgb1(rgb.x), rgb_to_srgb1(rgb.y), rgb_to_srgb1(rgb.z)};
+  return rgb;
+}
+YT_FN unsigned char float_to_byte(float a) { return (unsigned char)clamp_((int)(a * 256), 0, 255); }
+__global__ void __launch_bounds__(YT_BLOCK) k_tonemap(const float4* image, int n, float exposure, int filmic,
+    int srgb, float4* outf, uchar4* outb) {
+  int i = blockIdx.x * YT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float4 h   = image[i];
+  auto   ldr = tonemap({h.x, h.y, h.z}, exposure, filmic != 0, srgb != 0);
+  if (outf) outf[i] = {ldr.x, ldr.y, ldr.z, h.w};
+  if (outb) outb[i] = {float_to_byte(ldr.x), float_to_byte(ldr.y), float_to_byte(ldr.z), float_to_byte(h.w)};
+}
+
 __global__ void __launch_bounds__(YT_BLOCK) k_camera_rays(DScene sc, DState st, KParams kp, ythip_ray* rays) {
   int slot = blockIdx.x * YT_BLOCK + threadIdx.x;
   if (slot >= st.npix) return;

@@ -1005,6 +1005,39 @@ int ythip_state_download(ythip_ctx* ctx, float* image, float* albedo, float* nor
   return YTHIP_OK;
 }
 
+int ythip_get_image(ythip_ctx* ctx, float* image) {
+  if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  if (!image) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipMemcpyAsync(image, ctx->st.image, (size_t)ctx->st.npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return YTHIP_OK;
+}
+
+int ythip_tonemap_image(ythip_ctx* ctx, float exposure, int filmic, int srgb, float* ldr, uint8_t* ldr_bytes) {
+  if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  if (!ldr && !ldr_bytes) return fail(ctx, YTHIP_ERR_INVALID, "no output buffer");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  const size_t       n = (size_t)ctx->st.npix;
+  std::vector<void*> tmp;
+  float4*            d_f = nullptr;
+  uchar4*            d_b = nullptr;
+  int                rc  = 0;
+  if (ldr && (rc = dalloc(ctx, tmp, &d_f, n))) return rc;
+  if (ldr_bytes && (rc = dalloc(ctx, tmp, &d_b, n))) {
+    free_all(tmp);
+    return rc;
+  }
+  hipLaunchKernelGGL(k_tonemap, dim3(grid_for((long long)n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->st.image, (int)n,
+      exposure, filmic, srgb, d_f, d_b);
+  auto e1 = ldr ? hipMemcpyAsync(ldr, d_f, n * 16, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+  auto e2 = ldr_bytes ? hipMemcpyAsync(ldr_bytes, d_b, n * 4, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+  auto e3 = hipStreamSynchronize(ctx->stream);
+  free_all(tmp);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "tonemap_image failed");
+  return YTHIP_OK;
+}
+
 int ythip_state_bind_device(ythip_ctx* ctx, void* image, void* albedo, void* normal, void* hits, void* rngs) {
   if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
   if (!image || !albedo || !normal || !hits || !rngs) return fail(ctx, YTHIP_ERR_INVALID, "null device pointer");

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -424,9 +425,104 @@ image_data trace_image(const scene_data& scene, const trace_params& params) {
   for (auto sample = 0; sample < params.samples; sample++)  // yocto_trace.cpp:1588-1590
     trace_samples_resident(state, scene, bvh, lights, params);
   download_state(state);
-  auto image = get_image(state);
+  auto image = yocto::get_image(state);
   release();  // bvh / lights / state die with this frame: their stamps must not outlive them
   return image;
+}
+
+// ---------------------------------------------------------------------------
+// the interactive loop
+// ---------------------------------------------------------------------------
+namespace {
+// true when the device slice is the up-to-date copy of `state`
+bool device_has(residency& r, const trace_state& state) {
+  return r.ctx && r.state == &state && r.width == state.width && r.height == state.height &&
+         r.dev_samples == state.samples;
+}
+}  // namespace
+
+void get_image(image_data& image, const trace_state& state) {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  if (!device_has(r, state) || !r.host_stale) return yocto::get_image(image, state);  // host copy is current
+  if (image.width != state.width || image.height != state.height)
+    throw std::invalid_argument{"image should have the same size"};  // check_image, yocto_trace.cpp:1679-1686
+  if (!image.linear) throw std::invalid_argument{"expected linear image"};
+  check(r.ctx, ythip_get_image(r.ctx, (float*)image.pixels.data()));
+}
+image_data get_image(const trace_state& state) {
+  auto image = make_image(state.width, state.height, true);
+  hip::get_image(image, state);
+  return image;
+}
+
+namespace {
+void tonemap_device(residency& r, const trace_state& state, float exposure, bool filmic, float* ldr, uint8_t* ldrb) {
+  if (!device_has(r, state)) {  // bring the host copy over (image only is enough for this)
+    ensure_context(r);
+    check(r.ctx, ythip_state_create(r.ctx, state.width, state.height, 0, state.height));
+    check(r.ctx, ythip_state_upload(r.ctx, (const float*)state.image.data(), (const float*)state.albedo.data(),
+                     (const float*)state.normal.data(), state.hits.data(), (const uint64_t*)state.rngs.data(),
+                     state.samples));
+    r.state = &state, r.width = state.width, r.height = state.height, r.dev_samples = state.samples;
+    r.host_stale = false;
+  }
+  check(r.ctx, ythip_tonemap_image(r.ctx, exposure, filmic ? 1 : 0, 1, ldr, ldrb));
+}
+}  // namespace
+
+image_data tonemap_image(const trace_state& state, float exposure, bool filmic) {
+  auto& r      = cache();
+  auto  lock   = std::lock_guard{r.mutex};
+  auto  result = make_image(state.width, state.height, false);  // yocto_image.cpp:185-192
+  tonemap_device(r, state, exposure, filmic, (float*)result.pixels.data(), nullptr);
+  return result;
+}
+vector<vec4b> tonemap_image_bytes(const trace_state& state, float exposure, bool filmic) {
+  auto& r      = cache();
+  auto  lock   = std::lock_guard{r.mutex};
+  auto  result = vector<vec4b>((size_t)state.width * state.height);
+  tonemap_device(r, state, exposure, filmic, nullptr, (uint8_t*)result.data());
+  return result;
+}
+
+// trace_start — yocto_trace.cpp:1627-1649
+void trace_start(trace_context& context, trace_state& state, const scene_data& scene, const trace_bvh& bvh,
+    const trace_lights& lights, const trace_params& params) {
+  if (state.samples >= params.samples) return;
+  context.stop   = false;
+  context.done   = false;
+  context.worker = std::async(std::launch::async, [&]() {
+    if (context.stop) return;
+    hip::trace_samples_resident(state, scene, bvh, lights, params);  // includes the denoise hand-off
+    if (context.stop) return;
+    context.done = true;
+  });
+}
+// trace_cancel — yocto_trace.cpp:1652-1655
+void trace_cancel(trace_context& context) {
+  context.stop = true;
+  if (context.worker.valid()) context.worker.get();
+}
+// trace_preview — yocto_trace.cpp:1660-1676
+void trace_preview(color_image& image, trace_context& context, trace_state& state, const scene_data& scene,
+    const trace_bvh& bvh, const trace_lights& lights, const trace_params& params) {
+  auto pparams = params;
+  pparams.resolution /= params.pratio;
+  pparams.samples = 1;
+  auto pstate     = yocto::make_trace_state(scene, pparams);
+  hip::trace_samples(pstate, scene, bvh, lights, pparams);
+  {  // the preview state dies here: forget its device mirror
+    auto& r    = cache();
+    auto  lock = std::lock_guard{r.mutex};
+    if (r.state == &pstate) r.state = nullptr, r.dev_samples = -1, r.host_stale = false;
+  }
+  auto preview = yocto::get_image(pstate);
+  for (auto idx = 0; idx < state.width * state.height; idx++) {
+    auto i = idx % image.width, j = idx / image.width;
+    auto pi = clamp(i / params.pratio, 0, preview.width - 1), pj = clamp(j / params.pratio, 0, preview.height - 1);
+    image.pixels[idx] = preview.pixels[pj * preview.width + pi];
+  }
 }
 
 void release() {

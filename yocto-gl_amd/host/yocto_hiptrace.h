@@ -61,6 +61,30 @@ void download_state(trace_state& state);
 // yocto_trace.h:116 — make_* + the progressive loop + get_image.
 image_data trace_image(const scene_data& scene, const trace_params& params);
 
+// ---- the interactive loop ---------------------------------
+// yocto_trace.h:179-180 for a state that trace_samples_resident left on the device:
+// moves only `image` (16 B/pixel, not the whole 60 B/pixel trace_state).
+image_data get_image(const trace_state& state);
+void       get_image(image_data& image, const trace_state& state);
+// tonemap_image (yocto_image.h:104-112) of the resident render, computed ON THE
+// DEVICE: exposure, optional filmic curve, sRGB encoding.  The float version is
+// what a viewer uploads to its display; the byte version what save_image writes
+// for 8-bit formats (4 B/pixel over PCIe).
+image_data    tonemap_image(const trace_state& state, float exposure, bool filmic = false);
+vector<vec4b> tonemap_image_bytes(const trace_state& state, float exposure, bool filmic = false);
+
+// yocto_trace.h:201-225 — same names, same trace_context, same protocol as
+// apps/ytrace.cpp:183-216 uses them: trace_start launches one batch on a worker
+// (hip::trace_samples_resident), context.done flips when it is complete,
+// trace_cancel joins the worker (a batch already on the GPU runs to its end — the
+// reference checks `stop` per sample, here per batch), trace_preview renders the
+// 1-sample low-resolution stand-in.
+void trace_start(trace_context& context, trace_state& state, const scene_data& scene, const trace_bvh& bvh,
+    const trace_lights& lights, const trace_params& params);
+void trace_cancel(trace_context& context);
+void trace_preview(color_image& image, trace_context& context, trace_state& state, const scene_data& scene,
+    const trace_bvh& bvh, const trace_lights& lights, const trace_params& params);
+
 // Drop every cached device mirror and the context (e.g. before the scene's
 // storage is reused for different content of the same sizes).
 void release();

@@ -431,6 +431,8 @@ _SIGNATURES = {
     "ythip_state_upload": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]),
     "ythip_state_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5
                              + [C.POINTER(C.c_int)]),
+    "ythip_get_image": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_tonemap_image": (C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ythip_state_bind_device": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     "ythip_state_set_samples": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_trace_samples": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_void_p]),
@@ -685,8 +687,19 @@ class Context:
 
     def get_image(self):
         """get_image (yocto_trace.cpp:1694-1708): width x rows x 4 linear floats."""
-        st = self.download_state()
-        return st["image"].reshape(st["height"], st["width"], 4)
+        h = self.row_end - self.row_begin
+        image = np.zeros((h, self.local_width, 4), "f4")
+        self._check(self.lib.ythip_get_image(self.h, image.ctypes.data), "get_image")
+        return image
+
+    def tonemap_image(self, exposure=0.0, filmic=False, srgb=True):
+        """tonemap_image on the device: (float [h, w, 4], bytes [h, w, 4])."""
+        h = self.row_end - self.row_begin
+        ldr = np.zeros((h, self.local_width, 4), "f4")
+        ldrb = np.zeros((h, self.local_width, 4), "u1")
+        self._check(self.lib.ythip_tonemap_image(self.h, exposure, int(filmic), int(srgb),
+                                                 ldr.ctypes.data, ldrb.ctypes.data), "tonemap_image")
+        return ldr, ldrb
 
     def bind_device_state(self, image, albedo, normal, hits, rngs):
         self._check(self.lib.ythip_state_bind_device(self.h, image, albedo, normal,
