@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <memory>
+#include <utility>
 #include <vector>
 
 #include "../../include/ythip.h"
@@ -245,10 +247,27 @@ inline bbox transform_bbox(const ythip_frame& a, const bbox& b) {
   return xformed;
 }
 
+// resize() without value-initialisation: the slices of device-built trees are only
+// written when somebody downloads the tree (20 MB for 1M triangles)
+template <typename T>
+struct noinit_allocator : std::allocator<T> {
+  template <typename U>
+  struct rebind {
+    using other = noinit_allocator<U>;
+  };
+  template <typename U>
+  void construct(U* p) noexcept {
+    ::new ((void*)p) U;
+  }
+  template <typename U, typename... Args>
+  void construct(U* p, Args&&... args) {
+    ::new ((void*)p) U(std::forward<Args>(args)...);
+  }
+};
 struct flat_bvh {
-  std::vector<int64_t>        node_offset, prim_offset;
-  std::vector<ythip_bvh_node> nodes;
-  std::vector<int32_t>        prims;
+  std::vector<int64_t>                                          node_offset, prim_offset;
+  std::vector<ythip_bvh_node, noinit_allocator<ythip_bvh_node>> nodes;
+  std::vector<int32_t, noinit_allocator<int32_t>>               prims;
 };
 
 // make_scene_bvh — yocto_bvh.cpp:364-396

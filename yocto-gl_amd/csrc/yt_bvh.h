@@ -170,12 +170,16 @@ YT_FN bool slab(vec3f o, vec3f dinv, float tmin, vec3f bmin, vec3f bmax, float& 
   auto it_min = (bmin - o) * dinv;
   auto it_max = (bmax - o) * dinv;
   if constexpr (TAME) {
-    float nx = __builtin_fminf(it_min.x, it_max.x), ny = __builtin_fminf(it_min.y, it_max.y),
-          nz = __builtin_fminf(it_min.z, it_max.z);
-    float fx = __builtin_fmaxf(it_min.x, it_max.x), fy = __builtin_fmaxf(it_min.y, it_max.y),
-          fz = __builtin_fmaxf(it_min.z, it_max.z);
-    t0       = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), tmin);
-    auto far = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    // the hardware min/max directly: no operand is a NaN here, so the canonicalising
+    // v_max x, x the compiler puts in front of fminf/fmaxf (6 per box) buys nothing
+    auto vmin = [](float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto vmax = [](float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto vmin3 = [](float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+    auto vmax3 = [](float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+    float nx = vmin(it_min.x, it_max.x), ny = vmin(it_min.y, it_max.y), nz = vmin(it_min.z, it_max.z);
+    float fx = vmax(it_min.x, it_max.x), fy = vmax(it_min.y, it_max.y), fz = vmax(it_min.z, it_max.z);
+    t0       = vmax(vmax3(nx, ny, nz), tmin);
+    auto far = vmin3(fx, fy, fz);
     return t0 <= far * BBOX_K;
   } else {
     auto tmn = min3_(it_min, it_max);
@@ -328,12 +332,14 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       cnt.steps++;
       float t0a, t0b;
       bool  fa, fb;
+      // record: {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axis} per child — the x/y
+      // and the z pairs sit in adjacent registers for the packed subtract / multiply
       if (tame) {
-        fa = slab<true>(o, dinv, tmin, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, t0a);
-        fb = slab<true>(o, dinv, tmin, {q2.x, q2.y, q2.z}, {q2.w, q3.x, q3.y}, t0b);
+        fa = slab<true>(o, dinv, tmin, {q0.x, q0.y, q1.x}, {q0.z, q0.w, q1.y}, t0a);
+        fb = slab<true>(o, dinv, tmin, {q2.x, q2.y, q3.x}, {q2.z, q2.w, q3.y}, t0b);
       } else {
-        fa = slab<false>(o, dinv, tmin, {q0.x, q0.y, q0.z}, {q0.w, q1.x, q1.y}, t0a);
-        fb = slab<false>(o, dinv, tmin, {q2.x, q2.y, q2.z}, {q2.w, q3.x, q3.y}, t0b);
+        fa = slab<false>(o, dinv, tmin, {q0.x, q0.y, q1.x}, {q0.z, q0.w, q1.y}, t0a);
+        fb = slab<false>(o, dinv, tmin, {q2.x, q2.y, q3.x}, {q2.z, q2.w, q3.y}, t0b);
       }
       int   axis = __float_as_int(q1.w);
       bool  swp  = ((sign >> axis) & 1) != 0;  // ray_dsign[axis]: child 1 is popped first

@@ -122,32 +122,53 @@ __global__ void k_init_root(BNode* nodes, Acc* acc, int n, int* counter, int* am
 }
 
 // Per-range reductions of the level: node box (merge of the primitives' boxes,
-// yocto_bvh.cpp:263-266) and centroid box (split_middle, :207-209).
+// yocto_bvh.cpp:263-266) and centroid box (split_middle, :207-209).  A lane folds
+// RED_ITEMS consecutive primitives (flushing with atomics where the range changes
+// inside its stretch), then the wavefront combines equal-range neighbours with a
+// segmented scan: one set of atomics per (wavefront, range) — at the top of the
+// tree, where every primitive belongs to the same few ranges, that is what keeps
+// the same-address atomics (~88 per microsecond on this part) off the critical path.
+constexpr int RED_ITEMS = 8;
 __global__ void k_reduce(int n, const int* prim, const float4* bbmin, const float4* bbmax, const int* node_of,
     Acc* acc) {
-  int  i    = blockIdx.x * BLK + threadIdx.x;
-  int  lane = threadIdx.x & 63;
-  int  node = (i < n) ? node_of[i] : -1;
-  bool act  = node >= 0;
-  unsigned v[12], fl = 0;
-  if (act) {
+  const int lane  = threadIdx.x & 63;
+  const int first = (blockIdx.x * BLK + threadIdx.x) * RED_ITEMS;
+  unsigned  v[12], fl = 0;
+  int       node = -1;
+#pragma unroll
+  for (int k = 0; k < 12; k++) v[k] = 0xffffffffu;
+  auto flush = [&](int nd) {
+    unsigned* a = acc[nd].v;
+#pragma unroll
+    for (int k = 0; k < 12; k++) atomicMin(&a[k], v[k]);
+    if (fl) atomicOr(&a[12], fl);
+  };
+  for (int it = 0; it < RED_ITEMS; it++) {
+    int i = first + it;
+    int nd = (i < n) ? node_of[i] : -1;
+    if (nd < 0) continue;
+    if (nd != node) {
+      if (node >= 0) flush(node);  // the range changed inside this lane's stretch
+      node = nd, fl = 0;
+#pragma unroll
+      for (int k = 0; k < 12; k++) v[k] = 0xffffffffu;
+    }
     int    p  = prim[i];
     float4 mn = bbmin[p], mx = bbmax[p];
-    float  cx = (mn.x + mx.x) / 2, cy = (mn.y + mx.y) / 2, cz = (mn.z + mx.z) / 2;  // center(bbox), yocto_geometry.h
-    v[0] = fkey(mn.x), v[1] = fkey(mn.y), v[2] = fkey(mn.z);
-    v[3] = ~fkey(mx.x), v[4] = ~fkey(mx.y), v[5] = ~fkey(mx.z);
-    v[6] = fkey(cx), v[7] = fkey(cy), v[8] = fkey(cz);
-    v[9] = ~fkey(cx), v[10] = ~fkey(cy), v[11] = ~fkey(cz);
+    float  cx = (mn.x + mx.x) / 2, cy = (mn.y + mx.y) / 2, cz = (mn.z + mx.z) / 2;  // center(bbox)
+    unsigned w[12] = {fkey(mn.x), fkey(mn.y), fkey(mn.z), ~fkey(mx.x), ~fkey(mx.y), ~fkey(mx.z),
+        fkey(cx), fkey(cy), fkey(cz), ~fkey(cx), ~fkey(cy), ~fkey(cz)};
+#pragma unroll
+    for (int k = 0; k < 12; k++) v[k] = w[k] < v[k] ? w[k] : v[k];
     float f[6] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};
 #pragma unroll
     for (int c = 0; c < 6; c++)
       if (f[c] == 0) fl |= (__float_as_uint(f[c]) >> 31 ? 2u : 1u) << (2 * c);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 12; k++) v[k] = 0xffffffffu;
   }
-  // segmented inclusive scan over the wavefront (ranges are contiguous runs)
-  int seg = act ? node : (-2 - lane);
+  // `node` / v / fl now describe the LAST range of the lane's stretch; combine lanes
+  // whose last range is the same (ranges are contiguous, so equal neighbours form runs)
+  const bool act = node >= 0;
+  int        seg = act ? node : (-2 - lane);
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     int      oseg = __shfl_up(seg, d);
@@ -162,12 +183,7 @@ __global__ void k_reduce(int n, const int* prim, const float4* bbmin, const floa
   }
   int  nseg = __shfl_down(seg, 1);
   bool last = lane == 63 || nseg != seg;
-  if (act && last) {
-    unsigned* a = acc[node].v;
-#pragma unroll
-    for (int k = 0; k < 12; k++) atomicMin(&a[k], v[k]);
-    if (fl) atomicOr(&a[12], fl);
-  }
+  if (act && last) flush(node);
 }
 
 // Leaf / internal decision and split plane of every node of the level
@@ -435,8 +451,8 @@ __global__ void k_bake_pairs(const ythip_bvh_node* nodes, int n, const int* pid,
   for (int c = 0; c < 2; c++) {
     int            cn = nd.start + c;
     ythip_bvh_node ch = nodes[cn];
-    P[2 * c]          = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_min[2], ch.bbox_max[0]};
-    P[2 * c + 1]      = {ch.bbox_max[1], ch.bbox_max[2], __int_as_float(ref_of(ch, cn, pid, pair_base, prim_base)),
+    P[2 * c]          = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_max[0], ch.bbox_max[1]};
+    P[2 * c + 1]      = {ch.bbox_min[2], ch.bbox_max[2], __int_as_float(ref_of(ch, cn, pid, pair_base, prim_base)),
              __int_as_float((int)nd.axis)};
   }
 }
@@ -560,7 +576,8 @@ int build_shape_tree(hipStream_t s, int kind, const int32_t* elems, const float*
       return BUILD_FALLBACK;
     }
     int lb = level_base[level];
-    hipLaunchKernelGGL(k_reduce, dim3(grid(n)), dim3(BLK), 0, s, n, prim, bbmin, bbmax, node_of, acc);
+    hipLaunchKernelGGL(k_reduce, dim3(grid((n + RED_ITEMS - 1) / RED_ITEMS)), dim3(BLK), 0, s, n, prim, bbmin, bbmax,
+        node_of, acc);
     hipLaunchKernelGGL(k_decide, dim3(grid(le - lb)), dim3(BLK), 0, s, nodes, acc, lb, le, ambig);
     hipLaunchKernelGGL(k_flags, dim3(grid(n)), dim3(BLK), 0, s, n, prim, bbmin, bbmax, node_of, nodes, flag);
     exclusive_scan(s, flag, G, tiles, n);

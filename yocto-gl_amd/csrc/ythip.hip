@@ -295,8 +295,8 @@ int bake_bvh(ythip_ctx* ctx) {
         for (int c = 0; c < 2; c++) {
           int64_t     lc = node.start + c;
           const auto& ch = nodes[b.node_offset[t] + lc];
-          P[2 * c]       = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_min[2], ch.bbox_max[0]};
-          P[2 * c + 1]   = {ch.bbox_max[1], ch.bbox_max[2], __builtin_bit_cast(float, ref_of(lc)),
+          P[2 * c]       = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_max[0], ch.bbox_max[1]};
+          P[2 * c + 1]   = {ch.bbox_min[2], ch.bbox_max[2], __builtin_bit_cast(float, ref_of(lc)),
                 __builtin_bit_cast(float, (int32_t)node.axis)};
         }
       }
