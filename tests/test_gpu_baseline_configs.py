@@ -1,4 +1,5 @@
-"""BASELINE.json's configs at FULL size (`-m gpu`): cfg2 (1M-triangle plane), cfg4
+"""BASELINE.json's configs at FULL size (`-m gpu`): cfg2 (1M-triangle plane), cfg2b
+(the Cornell box with 1M-triangle walls: deep paths, area-light pdf walks), cfg4
 (10,000 instances of a 1,024-triangle sphere) and cfg5 (800,000 hair segments,
 subsurface) — bit-exact hit records for whole frames of camera rays against the
 live compiled reference, renders within the float tolerances written below, and
@@ -38,7 +39,8 @@ def cfg(request):
 
     def get(name):
         if name not in cache:
-            flat = {"cfg2": ysc.plane_scene, "cfg4": ysc.instanced_scene, "cfg5": hair_scene}[name]()
+            flat = {"cfg2": ysc.plane_scene, "cfg2b": P.scene_cornell_1m, "cfg4": ysc.instanced_scene,
+                    "cfg5": hair_scene}[name]()
             cache[name] = (flat, P.gpu_context(flat), P.RefBundle(flat) if P.have_ref() else None)
         return cache[name]
 
@@ -56,7 +58,7 @@ def test_cfg2_is_the_baseline_scene(cfg):
 
 
 @needs_ref
-@pytest.mark.parametrize("name,res", [("cfg2", 1280), ("cfg4", 1920), ("cfg5", 1280)])
+@pytest.mark.parametrize("name,res", [("cfg2", 1280), ("cfg2b", 1024), ("cfg4", 1920), ("cfg5", 1280)])
 def test_full_frame_primary_hits_bit_exact(cfg, name, res):
     """Every primary ray of the BASELINE frame (0.9M / 2M rays): identical
     (instance, element, uv, distance) to intersect_scene_bvh of the reference."""
@@ -77,7 +79,8 @@ def test_full_frame_primary_hits_bit_exact(cfg, name, res):
 
 @needs_ref
 @pytest.mark.parametrize("name,res,spp,rng_frac,frac_1e4", [
-    ("cfg2", 1280, 2, 0.999, 0.999), ("cfg4", 640, 4, 0.999, 0.999), ("cfg5", 320, 2, 0.999, 0.999)])
+    ("cfg2", 1280, 2, 0.999, 0.999), ("cfg2b", 256, 2, 0.97, 0.97), ("cfg4", 640, 4, 0.999, 0.999),
+    ("cfg5", 320, 2, 0.999, 0.999)])
 def test_render_vs_live_reference(cfg, name, res, spp, rng_frac, frac_1e4):
     """`path`, 8 bounces, clamp 10, default seed.  Float tolerance: the stated
     fraction of pixels must have an identical rng state (= identical path

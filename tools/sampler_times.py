@@ -12,6 +12,16 @@ import ythip as yt, scenes as ysc
 SCENE = os.environ.get("SCENE", "plane")
 if SCENE == "plane":
     flat = ysc.plane_scene()
+elif SCENE == "cfg4":  # BASELINE configs[3]: 10,000 instances of a 1,024-triangle sphere
+    flat = ysc.instanced_scene()
+elif SCENE == "cfg5":  # BASELINE configs[4]: 800,000 hair segments (geometry from the compiled reference)
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import test_gpu_baseline_configs as T
+    flat = T.hair_scene()
+elif SCENE == "cornell1m":  # cfg2b: the Cornell box with 1M-triangle walls
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import parity as P
+    flat = P.scene_cornell_1m()
 else:
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import parity as P

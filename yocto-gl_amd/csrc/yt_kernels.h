@@ -15,9 +15,10 @@
 //               so that kernel carries no traversal, then the rest of the loop
 //               body (weight update, termination tests, russian roulette).
 //
-// Compaction is BLOCK-LOCAL and atomic-free: workgroup b owns the 256 pixel
-// slots [256 b, 256 b + 256) for the whole batch and, after every iteration,
-// partitions them (wave ballots + an LDS prefix over its 4 waves) into its own
+// Compaction is BLOCK-LOCAL and atomic-free: workgroup b (ONE wavefront, see
+// YT_BLOCK in yt_bvh.h) owns the YT_BLOCK pixel slots [YT_BLOCK b, YT_BLOCK (b + 1))
+// for the whole batch and, after every iteration,
+// partitions them (wave ballots + an LDS prefix over its waves) into its own
 // double-ended queue segment: regenerated (primary) rays from the front,
 // continuing (bounce) rays from the back, dead slots dropped.  Waves of the next
 // k_extend therefore stay homogeneous (primary rays of neighbouring pixels /
@@ -60,9 +61,10 @@ struct DState {
   // frame, side by side in a local image `lwidth` pixels wide (the whole frame:
   // col_first 0, col_stride 1, lwidth == width)
   int lwidth, col_first, col_stride;
-  // path slots: the slice is cut into 16x16-pixel tiles; workgroup (logical
-  // block) t owns the 256 slots of tile t for the whole batch.  Slots whose
-  // pixel falls outside the slice are never queued.
+  // path slots: the slice is cut into 16 x YT_TILE_H pixel tiles (16x4 with one
+  // wavefront per workgroup); workgroup (logical block) t owns the YT_BLOCK slots
+  // of tile t for the whole batch.  Slots whose pixel falls outside the slice are
+  // never queued.
   int tiles_x, tiles_y, nblocks, nslots;
   int sample_base;  // state.samples at the start of this batch
   int batch;        // samples to add per pixel in this batch
@@ -93,9 +95,10 @@ struct KParams {
   int   hold;     // scheduling policy of k_trace (0 off, 1 hold back partial primary wavefronts)
 };
 
-constexpr int YT_TILE = 16;  // 16 x 16 pixels = YT_BLOCK slots
+constexpr int YT_TILE   = 16;                  // a workgroup's tile: 16 pixels wide ...
+constexpr int YT_TILE_H = YT_BLOCK / YT_TILE;  // ... and YT_BLOCK / 16 tall (16 x 4 for one wavefront)
 constexpr int YT_PROBE_ITERS = 48;  // iterations over which a workgroup measures its per-class traversal work
-static_assert(YT_TILE * YT_TILE == YT_BLOCK, "one tile per workgroup");
+static_assert(YT_TILE * YT_TILE_H == YT_BLOCK, "one tile per workgroup");
 
 // Block → tile mapping.  Hardware block b runs on XCD b % 8 (each XCD has its own
 // 4 MB L2), so with the identity mapping each XCD serves every 8th tile of a
@@ -115,11 +118,11 @@ YT_FN int logical_block(const DState& st) { return blockIdx.x < st.nblocks ? (in
 // pixels: 256-B runs of the image rows (8 x 8 quadrants traced 1 % faster but
 // shaded 6 % slower: trace_state rows are touched in 128-B pieces).
 YT_FN int slot_pixel(const DState& st, int slot, int& i, int& j) {
-  int tile = slot >> 8, w = slot & 255;
+  int tile = slot / YT_BLOCK, w = slot & (YT_BLOCK - 1);
   int ty = tile / st.tiles_x, tx = tile - ty * st.tiles_x;
   int il = tx * YT_TILE + (w & 15);
   i      = (st.col_first + tx * st.col_stride) * YT_TILE + (w & 15);
-  int jl = ty * YT_TILE + (w >> 4);
+  int jl = ty * YT_TILE_H + (w >> 4);
   j      = st.row_begin + jl;
   return (i < st.width && jl < st.rows) ? jl * st.lwidth + il : -1;
 }
@@ -719,7 +722,7 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
 // Path slot I/O, accumulation, regeneration, compaction
 // ===========================================================================
 
-// Path state of the 256 slots of a tile, resident in LDS for the whole batch
+// Path state of the YT_BLOCK slots of a tile, resident in LDS for the whole batch
 // (SoA of 16-B records: ds_read/write_b128).  Slots change threads at every
 // compaction, so the state cannot stay in registers; keeping it in LDS instead
 // of HBM removes 160 B of global traffic per path per bounce.  The pixel's PCG
@@ -901,9 +904,12 @@ YT_FN int max_bounces_of(const KParams& kp) {
 }
 
 // ===========================================================================
-// k_trace — the whole of trace_samples for one 16x16 tile, one launch per batch.
+// k_trace — the whole of trace_samples for one tile, one launch per batch.
 //
-// A persistent workgroup owns its tile's 256 path slots and loops
+// A persistent workgroup — ONE wavefront, so that no wave ever waits for a sibling
+// at the two barriers of an iteration (with four waves per workgroup that wait was
+// 30-40 % of the wave time on interior scenes, yt_bvh.h) — owns its tile's
+// YT_BLOCK path slots and loops
 //     extend (BVH traversal)  →  shade (one bounce-loop body)  →
 //     [deferred light-pdf walks]  →  block-local compaction
 // until every pixel of the tile has taken its `batch` samples.  Workgroups

@@ -946,7 +946,7 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
   if (npix > 0x7fffffffll / 4) return fail(ctx, YTHIP_ERR_INVALID, "state too large");
   st.npix      = (int)npix;
   st.tiles_x   = (lwidth + YT_TILE - 1) / YT_TILE;
-  st.tiles_y   = (st.rows + YT_TILE - 1) / YT_TILE;
+  st.tiles_y   = (st.rows + YT_TILE_H - 1) / YT_TILE_H;
   st.nblocks   = st.tiles_x * st.tiles_y;
   st.nslots    = st.nblocks * YT_BLOCK;
   size_t n = (size_t)npix, ns = (size_t)st.nslots;
