@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sharding", choices=["columns", "rows"], default="columns")
+    ap.add_argument("--traversal", choices=["auto", "binary", "wide"], default="auto")
     ap.add_argument("--as-rank", default=None, metavar="R/N",
                     help="single-GPU experiment: render only the slice rank R of N would "
                          "(no gather); the JSON line then describes that slice")
@@ -121,6 +122,7 @@ def main():
     ctx.upload_scene(flat)
     ctx.make_trace_bvh(flat)
     ctx.make_trace_lights(flat)
+    ctx.set_traversal(args.traversal)
     setup_s = time.time() - t0
     build_info = ctx.bvh_build_info()
     w, h = yt.state_size(flat.cameras[0], params.resolution)

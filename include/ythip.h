@@ -267,10 +267,10 @@ typedef struct ythip_build_info {
   double  bake_ms;   /* wall time of baking pairs / leaf data / instance records   */
 } ythip_build_info;
 int ythip_bvh_build_info(ythip_ctx* ctx, ythip_build_info* info);
-/* The baked traversal arrays, for tests: pairs are 64-B records,
- * leaf data 16-B records. */
+/* The baked traversal arrays, for tests: pairs are 64-B records
+ * (num_pairs), quads 128-B records (num_pairs), leaf data 16-B records. */
 int ythip_bvh_baked_sizes(ythip_ctx* ctx, int64_t* num_pairs, int64_t* num_leaf4);
-int ythip_bvh_baked_download(ythip_ctx* ctx, float* pairs, float* leafdata);
+int ythip_bvh_baked_download(ythip_ctx* ctx, float* pairs, float* leafdata, float* quads);
 /* Upload a tree built elsewhere (e.g. by the reference's make_trace_bvh). */
 int ythip_upload_bvh(ythip_ctx* ctx, const ythip_bvh* bvh);
 /* Read back the resident tree (for tree-identity tests). */
@@ -371,6 +371,14 @@ int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params);
  * (DESIGN.md §4); 0: every queued ray runs in every iteration.  The environment
  * variable YTHIP_HOLD=0/1 sets the default of new contexts (A/B measurements). */
 int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait);
+
+/* Which BVH walk k_trace's extend stage and the test entries below use: 0 the
+ * binary walk (one sibling pair per dependent fetch), 1 the wide walk (the four
+ * grandchildren per fetch: half the fetch chain, yt_bvh.h), 2 (default) chosen by
+ * the resident BVH (wide unless every tree is tiny, < 64 primitives).  All give
+ * the reference's hit records bit for bit; find_any queries, irregular rays and
+ * the work-counting launches always walk binary. */
+int ythip_set_traversal(ythip_ctx* ctx, int mode);
 
 /* intersect_scene_bvh for a batch of rays (yocto_bvh.h:105-106,
  * yocto_bvh.cpp:554-617); parity/test entry using the same device function as

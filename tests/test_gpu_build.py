@@ -32,13 +32,14 @@ def build_both(flat, min_prims=8):
 
 
 def assert_same(dev, host, what=""):
-    (db, (dp, dl), di), (hb, (hp, hl), hi) = dev, host
+    (db, (dp, dl, dq), di), (hb, (hp, hl, hq), hi) = dev, host
     assert np.array_equal(db.node_offset, hb.node_offset), what
     assert np.array_equal(db.prim_offset, hb.prim_offset), what
     assert db.primitives.tobytes() == hb.primitives.tobytes(), what + " primitives"
     assert db.nodes.tobytes() == hb.nodes.tobytes(), what + " nodes"
     assert dp.tobytes() == hp.tobytes(), what + " baked pairs"
     assert dl.tobytes() == hl.tobytes(), what + " baked leaf data"
+    assert dq.tobytes() == hq.tobytes(), what + " baked quads"
 
 
 @pytest.mark.parametrize("name", list(P.SCENES))

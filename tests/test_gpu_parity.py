@@ -383,6 +383,26 @@ def test_results_do_not_depend_on_the_scheduling_policy(bundles, name, sampler):
         assert out[0][k].tobytes() == out[1][k].tobytes(), k
 
 
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_wide_and_binary_walks_agree(bundles, name):
+    """The wide walk (four grandchildren per fetch) and the binary walk give the same
+    hit records on 100k seeded rays incl. degenerate directions (which the wide walk
+    hands over to the binary one), single-instance walks, and the same images."""
+    flat, ctx, _ = bundles(name)
+    rays = P.random_rays(flat, 100000, seed=29)
+    inst = (np.arange(len(rays)) % len(flat.instances)).astype("i4")
+    p = yt.trace_params(sampler="path", resolution=96, samples=3, batch=3)
+    out = {}
+    for mode in ["binary", "wide"]:
+        ctx.set_traversal(mode)
+        out[mode] = (ctx.intersect_batch(rays), ctx.intersect_instance_batch(inst, rays), P.gpu_render(ctx, flat, p))
+    ctx.set_traversal("auto")
+    assert out["binary"][0].tobytes() == out["wide"][0].tobytes()
+    assert out["binary"][1].tobytes() == out["wide"][1].tobytes()
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert out["binary"][2][k].tobytes() == out["wide"][2][k].tobytes(), k
+
+
 def test_get_image_and_device_tonemap(bundles):
     """§8(f) rank 2, the display path: ythip_get_image returns exactly
     trace_state.image; ythip_tonemap_image (device) vs the reference's tonemap_image

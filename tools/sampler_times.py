@@ -28,6 +28,8 @@ else:
     flat = P.SCENES[SCENE]()
 ctx = yt.Context(0)
 ctx.upload_scene(flat); ctx.make_trace_bvh(flat); ctx.make_trace_lights(flat)
+if os.environ.get('TRAVERSAL'):
+    ctx.set_traversal(os.environ['TRAVERSAL'])
 spp = int(os.environ.get('SPP', '64'))
 RES = int(os.environ.get('RES', '1280'))
 for sampler in (os.environ.get("SAMPLERS") or "falsecolor,eyelight,naive,pathtest,path").split(","):

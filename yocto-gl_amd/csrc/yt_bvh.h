@@ -20,6 +20,21 @@
 //     `t0 <= min(far, tmax) * k` exactly (NaN cases spelled out at slab());
 //   * "while-while" control flow: a lane that reaches a leaf waits for the
 //     rest of its wavefront to reach one, so primitive tests run convergent.
+//   * WIDE mode (the production path; the binary walk stays for work counting,
+//     find_any and irregular rays): every internal node also has a 128-B "quad"
+//     record holding its (up to) four GRANDCHILDREN {bbox, ref} + the three split
+//     axes, so one dependent fetch advances two tree levels — the dependent-fetch
+//     chain of a ray, which is what bounds an iteration of k_trace, halves.  The
+//     grandchildren are visited in exactly the order the reference's binary walk
+//     reaches them (near child of the near child first, ...), each with the same
+//     pop-time test, and the two skipped box tests are implied: a box contains its
+//     children's boxes and float rounding is monotonic, so for a ray whose slab
+//     products are all ordinary numbers "grandchild passes" ⇒ "its parent passes"
+//     with the same tmax.  Same leaves in the same order with the same tmax
+//     ⇒ the same hit record, bit for bit (tests/test_gpu_parity.py).  A ray that
+//     is not "tame" at world level or at the level of an instance it enters makes
+//     the wide walk give up (HIT_ABORT) and is redone by the binary walk
+//     (traverse_any).
 #pragma once
 
 #include "yt_scene.h"
@@ -208,9 +223,12 @@ YT_FN bool ray_is_tame(vec3f o, vec3f dinv, float tmin) {
 
 // The traversal.  `only_instance` < 0: intersect_scene_bvh (yocto_bvh.cpp:554-617);
 // otherwise intersect_instance_bvh of that instance (yocto_bvh.cpp:619-628).
-template <bool COUNT>
+constexpr int HIT_ABORT = -2;  // Hit::instance of a wide walk that met an irregular ray: redo it binary
+
+template <bool COUNT, bool WIDE = false>
 YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt) {
+  static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   Hit best = {-1, -1, 0, 0, 0, false};
 
   // world-level ray + the ray of the level being walked
@@ -226,6 +244,10 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   const vec3f wdinv = {1 / wd.x, 1 / wd.y, 1 / wd.z};
   const int   wsign = ((wdinv.x < 0) ? 1 : 0) | ((wdinv.y < 0) ? 2 : 0) | ((wdinv.z < 0) ? 4 : 0);
   const bool  wtame = ray_is_tame(wo, wdinv, tmin);
+  bool abort = false;
+  if constexpr (WIDE) {
+    if (!wtame || weird || find_any) return Hit{HIT_ABORT, -1, 0, 0, 0, false};
+  }
   vec3f o = wo, d = wd, dinv = wdinv;
   int   sign     = wsign;
   bool  tame     = wtame;
@@ -271,6 +293,12 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     vec3f   io   = transform_point(inv, wo);
     vec3f   id   = transform_vector(inv, wd);
     vec3f   idin = {1 / id.x, 1 / id.y, 1 / id.z};
+    if constexpr (WIDE) {
+      if (!ray_is_tame(io, idin, tmin)) {  // irregular at this instance's level: the caller redoes the ray binary
+        abort = true;
+        return REF_NONE;
+      }
+    }
     if (COUNT) cnt.nodes++;
     float t0;
     bool  ok = slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
@@ -299,6 +327,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   if (only_instance >= 0) {
     cur_last = true;
     cur      = enter(only_instance);
+    if (WIDE && abort) return Hit{HIT_ABORT, -1, 0, 0, 0, false};
     if (cur_inst < 0) return best;
   } else {
     if (sc.tlas_ref == REF_NONE) return best;
@@ -332,6 +361,50 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         if (cur == REF_NONE) continue;
       }
       if ((unsigned)cur >= (unsigned)REF_INST) break;  // leaf, instance entry or exit → phase 2
+      if constexpr (WIDE) {
+        // internal node, two levels at once: its grandchildren in the order the
+        // reference's walk reaches them, each pushed with its own pop-time test
+        const float4* Qp = sc.wide + 8 * (int64_t)cur;
+        float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
+        cnt.steps++;
+        float ta, tb, tc, td;
+        bool  fa = slab<true>(o, dinv, tmin, {a0.x, a0.y, a0.z}, {a0.w, a1.x, a1.y}, ta);
+        bool  fb = slab<true>(o, dinv, tmin, {b0.x, b0.y, b0.z}, {b0.w, b1.x, b1.y}, tb);
+        bool  fc = slab<true>(o, dinv, tmin, {c0.x, c0.y, c0.z}, {c0.w, c1.x, c1.y}, tc);
+        bool  fd = slab<true>(o, dinv, tmin, {d0.x, d0.y, d0.z}, {d0.w, d1.x, d1.y}, td);
+        // slots: a, b = children of child 0 (or child 0 itself, then b is empty); c, d likewise for child 1
+        int ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
+        int rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;
+        int rc = (fc && tc <= tmaxk) ? __float_as_int(c1.z) : REF_NONE;
+        int rd = (fd && td <= tmaxk) ? __float_as_int(d1.z) : REF_NONE;
+        const int  axes = __float_as_int(a1.w);  // node axis | child 0's axis << 2 | child 1's axis << 4
+        const bool hs = ((sign >> (axes & 3)) & 1) != 0, ls = ((sign >> ((axes >> 2) & 3)) & 1) != 0,
+                   rs = ((sign >> ((axes >> 4) & 3)) & 1) != 0;
+        // within each half: ray_dsign[child.axis] → its child 1 first (yocto_bvh.cpp:498-504)
+        int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
+        float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
+        // the halves: ray_dsign[node.axis] → child 1's half first
+        int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
+        float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
+        // last to first: whatever passed is pushed, the nearest one becomes `cur`
+        int   pr = REF_NONE;
+        float pt = 0;
+        if (v3r != REF_NONE) pr = v3r, pt = v3t;
+        if (v2r != REF_NONE) {
+          if (pr != REF_NONE) push(pr, pt);
+          pr = v2r, pt = v2t;
+        }
+        if (v1r != REF_NONE) {
+          if (pr != REF_NONE) push(pr, pt);
+          pr = v1r, pt = v1t;
+        }
+        if (v0r != REF_NONE) {
+          if (pr != REF_NONE) push(pr, pt);
+          pr = v0r, pt = v0t;
+        }
+        cur = pr;
+        continue;
+      }
       // internal node: its two children in the reference's visit order
       // (near-first along the split axis — yocto_bvh.cpp:498-504, 592-598)
       const float4* P  = pairs + 4 * (int64_t)cur;
@@ -376,6 +449,10 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       cur_last = (code & 1) != 0;
       if (COUNT) cnt.instances++;  // TLAS leaf entry (yocto_bvh.cpp:600-604)
       cur = enter(sc.tlas_prims[code >> 1]);
+      if (WIDE && abort) {
+        best = Hit{HIT_ABORT, -1, 0, 0, 0, false};
+        done = true;
+      }
       if (cur_inst < 0 && find_any && cur_last && best.hit) done = true;
       continue;
     }
@@ -438,6 +515,18 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     }
   }
   return best;
+}
+
+// The production entry: the wide walk, and the binary walk for the rays it declines
+// (irregular at world or instance level, find_any) — the same hit record either way.
+template <bool COUNT, bool WIDE>
+YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
+    Counters& cnt) {
+  if constexpr (WIDE && !COUNT) {
+    Hit h = traverse<false, true>(sc, wray, only_instance, find_any, st, cnt);
+    if (h.instance != HIT_ABORT) return h;
+  }
+  return traverse<COUNT, false>(sc, wray, only_instance, find_any, st, cnt);
 }
 
 }  // namespace yt

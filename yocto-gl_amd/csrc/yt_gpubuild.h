@@ -45,11 +45,12 @@ void free_tree(DeviceTree* tree);
 // Device bake of one BLAS into the traversal layout of yt_bvh.h (what
 // bake_bvh() in ythip.hip does on the host for host-built trees):
 //   pairs    + 4 * pair_base    sibling-pair records of this tree's internal nodes
+//   quads    + 8 * pair_base    grandchildren records (same ids)
 //   leafdata + leaf_base        pre-gathered primitives in leaf order
 // prim_base = global index of the tree's first primitive (leaf refs are global).
 // Writes the root's {bbox, ref} to root_out (host pointer, 7 floats: bmin, bmax, ref bits).
 int bake_shape_tree(hipStream_t stream, const DeviceTree& tree, int kind, const int32_t* elems,
     const float* positions, const float* radius, int64_t pair_base, int64_t prim_base, int64_t leaf_base,
-    float4* pairs, float4* leafdata, float* root_out, std::string* err);
+    float4* pairs, float4* quads, float4* leafdata, float* root_out, std::string* err);
 
 }  // namespace ytgpu

@@ -456,6 +456,38 @@ __global__ void k_bake_pairs(const ythip_bvh_node* nodes, int n, const int* pid,
              __int_as_float((int)nd.axis)};
   }
 }
+// grandchildren ("quad") records, same ids as the pairs (yt_bvh.h WIDE walk)
+__global__ void k_bake_quads(const ythip_bvh_node* nodes, int n, const int* pid, long long pair_base,
+    long long prim_base, float4* quads) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  ythip_bvh_node nd = nodes[i];
+  if (!nd.internal) return;
+  float4* Q    = quads + 8 * (pair_base + pid[i]);
+  int     axes = nd.axis & 3;
+  for (int h = 0; h < 2; h++) {
+    int            cn = nd.start + h;
+    ythip_bvh_node ch = nodes[cn];
+    int            s0 = cn, s1 = -1;
+    if (ch.internal) {
+      s0 = ch.start, s1 = ch.start + 1;
+      axes |= (ch.axis & 3) << (2 + 2 * h);
+    }
+    for (int k = 0; k < 2; k++) {
+      int     sn = k == 0 ? s0 : s1;
+      float4* S  = Q + 2 * (2 * h + k);
+      if (sn < 0) {
+        S[0] = {0, 0, 0, 0};
+        S[1] = {0, 0, __int_as_float(0x7ffffffe), 0};  // REF_NONE
+        continue;
+      }
+      ythip_bvh_node g = nodes[sn];
+      S[0]             = {g.bbox_min[0], g.bbox_min[1], g.bbox_min[2], g.bbox_max[0]};
+      S[1]             = {g.bbox_max[1], g.bbox_max[2], __int_as_float(ref_of(g, sn, pid, pair_base, prim_base)), 0};
+    }
+  }
+  Q[1].w = __int_as_float(axes);
+}
 __global__ void k_bake_leaf(int kind, const int* elems, const float* P, const float* R, const int* prims, int n,
     float4* leaf) {
   int k = blockIdx.x * BLK + threadIdx.x;
@@ -618,8 +650,8 @@ int build_shape_tree(hipStream_t s, int kind, const int32_t* elems, const float*
 }
 
 int bake_shape_tree(hipStream_t s, const DeviceTree& tree, int kind, const int32_t* elems, const float* positions,
-    const float* radius, int64_t pair_base, int64_t prim_base, int64_t leaf_base, float4* pairs, float4* leafdata,
-    float* root_out, std::string* err) {
+    const float* radius, int64_t pair_base, int64_t prim_base, int64_t leaf_base, float4* pairs, float4* quads,
+    float4* leafdata, float* root_out, std::string* err) {
   const int n = (int)tree.num_nodes, np = (int)tree.num_prims;
   const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   int *     flag = nullptr, *pid = nullptr, *tiles = nullptr;
@@ -636,6 +668,8 @@ int bake_shape_tree(hipStream_t s, const DeviceTree& tree, int kind, const int32
   exclusive_scan(s, flag, pid, tiles, n);
   hipLaunchKernelGGL(k_bake_pairs, dim3(grid(n)), dim3(BLK), 0, s, tree.nodes, n, pid, (long long)pair_base,
       (long long)prim_base, pairs);
+  hipLaunchKernelGGL(k_bake_quads, dim3(grid(n)), dim3(BLK), 0, s, tree.nodes, n, pid, (long long)pair_base,
+      (long long)prim_base, quads);
   hipLaunchKernelGGL(k_bake_leaf, dim3(grid(np)), dim3(BLK), 0, s, kind, elems, positions, radius, tree.prims, np,
       leafdata + leaf_base);
   ythip_bvh_node root;

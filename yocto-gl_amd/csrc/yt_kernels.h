@@ -917,8 +917,9 @@ YT_FN int max_bounces_of(const KParams& kp) {
 // tile's path state (≈40 KB) stays in the XCD's L2 between iterations.  The
 // ray and the hit record never leave registers between extend and shade.
 // ===========================================================================
-template <int SAMPLER, int LP, bool COUNT>
+template <int SAMPLER, int LP, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KParams kp) {
+  static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   __shared__ WgQueues   Q;
@@ -996,7 +997,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
       } else {
         ray3f          ray = make_ray(P.o, P.d);
         const unsigned s0  = cnt.steps;
-        P.isec             = traverse<COUNT>(sc, ray, -1, false, stack, cnt);
+        P.isec             = traverse_any<COUNT, WIDE>(sc, ray, -1, false, stack, cnt);
         work               = cnt.steps - s0 + 1;
       }
 #ifdef YT_TIMING
@@ -1100,7 +1101,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
 }
 
 // Test/parity entries ---------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const ythip_ray* rays,
     const int* instances, long long n, int find_any, ythip_hit* hits, unsigned long long* counters) {
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
@@ -1111,7 +1112,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const y
     YT_STACK_INIT(stack, s_stack);
     auto  r   = rays[idx];
     ray3f ray = {{r.o[0], r.o[1], r.o[2]}, {r.d[0], r.d[1], r.d[2]}, r.tmin, r.tmax};
-    Hit   h   = traverse<COUNT>(sc, ray, instances ? instances[idx] : -1, find_any != 0, stack, cnt);
+    Hit   h   = traverse_any<COUNT, WIDE>(sc, ray, instances ? instances[idx] : -1, find_any != 0, stack, cnt);
     // scene_intersection{} defaults when missed: instance -1, element -1, uv 0, distance 0
     if (!h.hit) h = {-1, -1, 0, 0, 0, false};
     hits[idx] = {h.instance, h.element, h.u, h.v, h.distance, h.hit ? 1 : 0};

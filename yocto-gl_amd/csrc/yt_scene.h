@@ -65,6 +65,7 @@ struct DScene {
   const uint8_t* pixelsb;
   // bvh
   const float4*     pairs;      // sibling-pair records (4 float4 each), all trees
+  const float4*     wide;       // grandchildren ("quad") records (8 float4 each), same ids as `pairs`
   const float4*     leafdata;   // pre-gathered leaf primitives in leaf order
   const int*        tlas_prims; // instance ids in TLAS leaf order
   const DInstanceT* tinst;      // per instance

@@ -60,6 +60,11 @@ struct ythip_ctx {
   int64_t                        device_build_min_prims = 16384;
   int                            bvh_builder            = 1;  // 0 host only, 1 device for large shapes
   int                            hold_policy            = 1;
+  // which walk k_trace / the test entries use: 0 binary, 1 wide, 2 (default) by the
+  // work at hand — see use_wide()
+  int     traversal_mode = 2;
+  int64_t largest_tree   = 0;  // primitives of the largest tree of the resident BVH
+  bool    use_wide() const;
   ythip_build_info               build_info             = {};
   int64_t                        num_pairs = 0, num_leaf4 = 0;
   ythost::flat_lights h_lights;
@@ -80,6 +85,15 @@ struct ythip_ctx {
   float4*                                      nhit_a   = nullptr;
   int*                                         nhit_e   = nullptr;
 };
+
+// The wide walk halves a ray's chain of dependent fetches and costs a little more
+// arithmetic per level.  It pays when the waves have the machine to themselves
+// (small slices: one GPU of eight, previews) and on large trees; on scenes made of
+// tiny trees the 4-slot records are mostly empty.  Measured in DESIGN.md §6.
+bool ythip_ctx::use_wide() const {
+  if (traversal_mode != 2) return traversal_mode == 1;
+  return largest_tree >= 64;
+}
 
 namespace {
 
@@ -193,9 +207,10 @@ int bake_bvh(ythip_ctx* ctx) {
   if (npairs >= (int64_t)REF_INST) return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit device references");
 
   const int LEAF_PAD = 8;  // the triangle loop fetches two primitives per round trip
-  float4 *  d_pairs = nullptr, *d_leaf = nullptr;
+  float4 *  d_pairs = nullptr, *d_leaf = nullptr, *d_quads = nullptr;
   int       rc;
   if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_pairs, (size_t)npairs * 4 + 4))) return rc;
+  if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_quads, (size_t)npairs * 8 + 8))) return rc;
   if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_leaf, (size_t)nleaf4 + LEAF_PAD))) return rc;
   HIPCHECK(ctx, hipMemsetAsync(d_pairs + 4 * npairs, 0, 4 * sizeof(float4), ctx->stream));
   HIPCHECK(ctx, hipMemsetAsync(d_leaf + nleaf4, 0, LEAF_PAD * sizeof(float4), ctx->stream));
@@ -223,7 +238,7 @@ int bake_bvh(ythip_ctx* ctx) {
       std::string err;
       if (ytgpu::bake_shape_tree(ctx->stream, ctx->d_trees[t], kind, el, ctx->ds.positions + 3 * sh.positions_offset,
               sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, pair_base[t],
-              b.prim_offset[t], leaf_base[t], d_pairs, d_leaf, root7, &err) != ytgpu::BUILD_OK)
+              b.prim_offset[t], leaf_base[t], d_pairs, d_quads, d_leaf, root7, &err) != ytgpu::BUILD_OK)
         return fail(ctx, YTHIP_ERR_HIP, "device bvh bake failed: %s", err.c_str());
       for (int c = 0; c < 3; c++) roots[t].bmin[c] = root7[c], roots[t].bmax[c] = root7[3 + c];
       std::memcpy(&roots[t].ref, &root7[6], 4);
@@ -302,6 +317,40 @@ int bake_bvh(ythip_ctx* ctx) {
       }
       HIPCHECK(ctx, hipMemcpyAsync(d_pairs + 4 * pair_base[t], pairs.data(), pairs.size() * sizeof(float4),
                         hipMemcpyHostToDevice, ctx->stream));
+      // grandchildren ("quad") records of the wide walk, same ids: slots 0,1 = children
+      // of child 0 (or child 0 itself when it is a leaf, slot 1 empty), slots 2,3
+      // likewise for child 1
+      staging.emplace_back((size_t)np_t * 8, float4{0, 0, 0, 0});
+      auto& quads = staging.back();
+      for (int64_t n = 0; n < nn; n++) {
+        const auto& node = nodes[b.node_offset[t] + n];
+        if (!node.internal) continue;
+        float4* Qr   = quads.data() + 8 * (size_t)(pair_id[n] - pair_base[t]);
+        int     axes = node.axis & 3;
+        for (int h = 0; h < 2; h++) {
+          int64_t     lc = node.start + h;
+          const auto& ch = nodes[b.node_offset[t] + lc];
+          int64_t     slot_node[2] = {lc, -1};
+          if (ch.internal) {
+            slot_node[0] = ch.start, slot_node[1] = ch.start + 1;
+            axes |= (ch.axis & 3) << (2 + 2 * h);
+          }
+          for (int k = 0; k < 2; k++) {
+            float4* S = Qr + 2 * (2 * h + k);
+            if (slot_node[k] < 0) {
+              S[0] = {0, 0, 0, 0};
+              S[1] = {0, 0, __builtin_bit_cast(float, (int32_t)REF_NONE), 0};
+              continue;
+            }
+            const auto& g = nodes[b.node_offset[t] + slot_node[k]];
+            S[0]          = {g.bbox_min[0], g.bbox_min[1], g.bbox_min[2], g.bbox_max[0]};
+            S[1]          = {g.bbox_max[1], g.bbox_max[2], __builtin_bit_cast(float, ref_of(slot_node[k])), 0};
+          }
+        }
+        Qr[1].w = __builtin_bit_cast(float, (int32_t)axes);
+      }
+      HIPCHECK(ctx, hipMemcpyAsync(d_quads + 8 * pair_base[t], quads.data(), quads.size() * sizeof(float4),
+                        hipMemcpyHostToDevice, ctx->stream));
     }
     if (nn > 0) {
       const auto& root = nodes[b.node_offset[t]];
@@ -328,7 +377,11 @@ int bake_bvh(ythip_ctx* ctx) {
   ctx->ds.tlas_bmax = {roots[nshapes].bmax[0], roots[nshapes].bmax[1], roots[nshapes].bmax[2]};
   if (bad_leaf) return fail(ctx, YTHIP_ERR_INVALID, "bvh leaf with more than 7 primitives (reference builds <= 4)");
   ctx->ds.pairs    = d_pairs;
+  ctx->ds.wide     = d_quads;
   ctx->ds.leafdata = d_leaf;
+  ctx->largest_tree = 0;
+  for (int t = 0; t < ntrees; t++)
+    ctx->largest_tree = std::max<int64_t>(ctx->largest_tree, b.prim_offset[t + 1] - b.prim_offset[t]);
   ctx->num_pairs   = npairs;
   ctx->num_leaf4   = nleaf4;
   if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tlas_prims, b.prims.data() + b.prim_offset[nshapes],
@@ -462,11 +515,13 @@ int upload_lights_impl(ythip_ctx* ctx) {
 
 template <int S, int LP>
 void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
-  dim3 grid(ctx->st.nblocks), block(YT_BLOCK);  // one persistent workgroup per 16x16 tile
-  if (count)
-    hipLaunchKernelGGL((k_trace<S, LP, true>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
+  dim3 grid(ctx->st.nblocks), block(YT_BLOCK);  // one persistent one-wave workgroup per 16x4 tile
+  if (count)  // the counting launch walks binary: its counts are the reference's
+    hipLaunchKernelGGL((k_trace<S, LP, true, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
+  else if (ctx->use_wide())
+    hipLaunchKernelGGL((k_trace<S, LP, false, true>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
   else
-    hipLaunchKernelGGL((k_trace<S, LP, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
+    hipLaunchKernelGGL((k_trace<S, LP, false, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
 }
 
 // lp: LP_NONE / LP_DEFER for path & pathtest (area lights absent / present);
@@ -777,9 +832,11 @@ int ythip_bvh_baked_sizes(ythip_ctx* ctx, int64_t* num_pairs, int64_t* num_leaf4
   return YTHIP_OK;
 }
 
-int ythip_bvh_baked_download(ythip_ctx* ctx, float* pairs, float* leafdata) {
+int ythip_bvh_baked_download(ythip_ctx* ctx, float* pairs, float* leafdata, float* quads) {
   if (!ctx || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "no bvh resident");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  if (quads && ctx->num_pairs)
+    HIPCHECK(ctx, hipMemcpy(quads, ctx->ds.wide, (size_t)ctx->num_pairs * 128, hipMemcpyDeviceToHost));
   if (pairs && ctx->num_pairs)
     HIPCHECK(ctx, hipMemcpy(pairs, ctx->ds.pairs, (size_t)ctx->num_pairs * 64, hipMemcpyDeviceToHost));
   if (leafdata && ctx->num_leaf4)
@@ -1103,10 +1160,13 @@ static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_
     return cleanup(fail(ctx, YTHIP_ERR_HIP, "instance upload failed"));
   bool count = (ctx->prof_mode & 2) != 0;
   if (count)
-    hipLaunchKernelGGL((k_intersect_batch<true>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
+    hipLaunchKernelGGL((k_intersect_batch<true, false>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
         d_rays, d_inst, (long long)n, find_any, d_hits, ctx->d_counters);
+  else if (ctx->use_wide())
+    hipLaunchKernelGGL((k_intersect_batch<false, true>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
+        d_rays, d_inst, (long long)n, find_any, d_hits, (unsigned long long*)nullptr);
   else
-    hipLaunchKernelGGL((k_intersect_batch<false>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
+    hipLaunchKernelGGL((k_intersect_batch<false, false>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
         d_rays, d_inst, (long long)n, find_any, d_hits, (unsigned long long*)nullptr);
   if (hipMemcpyAsync(hits, d_hits, n * sizeof(ythip_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess)
@@ -1144,6 +1204,12 @@ int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params, ythip_ray* ray
 int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait) {
   if (!ctx) return YTHIP_ERR_INVALID;
   ctx->hold_policy = adaptive_wait ? 1 : 0;
+  return YTHIP_OK;
+}
+
+int ythip_set_traversal(ythip_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) return fail(ctx, YTHIP_ERR_INVALID, "traversal mode must be 0, 1 or 2");
+  ctx->traversal_mode = mode;
   return YTHIP_OK;
 }
 

@@ -406,7 +406,8 @@ _SIGNATURES = {
     "ythip_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "ythip_bvh_build_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_bvh_baked_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "ythip_bvh_baked_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ythip_bvh_baked_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ythip_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_bvh_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ythip_bvh_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
@@ -599,8 +600,10 @@ class Context:
         n, m = C.c_int64(), C.c_int64()
         self._check(self.lib.ythip_bvh_baked_sizes(self.h, C.byref(n), C.byref(m)), "bvh_baked_sizes")
         pairs, leaf = np.zeros((n.value, 16), "f4"), np.zeros((m.value, 4), "f4")
-        self._check(self.lib.ythip_bvh_baked_download(self.h, _ptr(pairs), _ptr(leaf)), "bvh_baked_download")
-        return pairs, leaf
+        quads = np.zeros((n.value, 32), "f4")
+        self._check(self.lib.ythip_bvh_baked_download(self.h, _ptr(pairs), _ptr(leaf), _ptr(quads)),
+                    "bvh_baked_download")
+        return pairs, leaf, quads
 
     def upload_bvh(self, bvh):
         cb = bvh.c_struct()
@@ -741,6 +744,11 @@ class Context:
     # measurement ------------------------------------------------------------------
     def set_scheduling(self, adaptive_wait):
         self._check(self.lib.ythip_set_scheduling(self.h, int(adaptive_wait)), "set_scheduling")
+
+    def set_traversal(self, mode):
+        """"binary" | "wide" | "auto" (default): which BVH walk the kernels use."""
+        self._check(self.lib.ythip_set_traversal(self.h, {"binary": 0, "wide": 1, "auto": 2}[mode]),
+                    "set_traversal")
 
     def set_profiling(self, mode):
         self._check(self.lib.ythip_set_profiling(self.h, mode), "set_profiling")
