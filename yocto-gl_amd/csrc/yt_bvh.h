@@ -368,10 +368,11 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
         cnt.steps++;
         float ta, tb, tc, td;
-        bool  fa = slab<true>(o, dinv, tmin, {a0.x, a0.y, a0.z}, {a0.w, a1.x, a1.y}, ta);
-        bool  fb = slab<true>(o, dinv, tmin, {b0.x, b0.y, b0.z}, {b0.w, b1.x, b1.y}, tb);
-        bool  fc = slab<true>(o, dinv, tmin, {c0.x, c0.y, c0.z}, {c0.w, c1.x, c1.y}, tc);
-        bool  fd = slab<true>(o, dinv, tmin, {d0.x, d0.y, d0.z}, {d0.w, d1.x, d1.y}, td);
+        // per slot {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axes}, like the pair records
+        bool  fa = slab<true>(o, dinv, tmin, {a0.x, a0.y, a1.x}, {a0.z, a0.w, a1.y}, ta);
+        bool  fb = slab<true>(o, dinv, tmin, {b0.x, b0.y, b1.x}, {b0.z, b0.w, b1.y}, tb);
+        bool  fc = slab<true>(o, dinv, tmin, {c0.x, c0.y, c1.x}, {c0.z, c0.w, c1.y}, tc);
+        bool  fd = slab<true>(o, dinv, tmin, {d0.x, d0.y, d1.x}, {d0.z, d0.w, d1.y}, td);
         // slots: a, b = children of child 0 (or child 0 itself, then b is empty); c, d likewise for child 1
         int ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
         int rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;

@@ -482,8 +482,8 @@ __global__ void k_bake_quads(const ythip_bvh_node* nodes, int n, const int* pid,
         continue;
       }
       ythip_bvh_node g = nodes[sn];
-      S[0]             = {g.bbox_min[0], g.bbox_min[1], g.bbox_min[2], g.bbox_max[0]};
-      S[1]             = {g.bbox_max[1], g.bbox_max[2], __int_as_float(ref_of(g, sn, pid, pair_base, prim_base)), 0};
+      S[0]             = {g.bbox_min[0], g.bbox_min[1], g.bbox_max[0], g.bbox_max[1]};
+      S[1]             = {g.bbox_min[2], g.bbox_max[2], __int_as_float(ref_of(g, sn, pid, pair_base, prim_base)), 0};
     }
   }
   Q[1].w = __int_as_float(axes);

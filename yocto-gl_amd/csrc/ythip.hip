@@ -343,8 +343,8 @@ int bake_bvh(ythip_ctx* ctx) {
               continue;
             }
             const auto& g = nodes[b.node_offset[t] + slot_node[k]];
-            S[0]          = {g.bbox_min[0], g.bbox_min[1], g.bbox_min[2], g.bbox_max[0]};
-            S[1]          = {g.bbox_max[1], g.bbox_max[2], __builtin_bit_cast(float, ref_of(slot_node[k])), 0};
+            S[0]          = {g.bbox_min[0], g.bbox_min[1], g.bbox_max[0], g.bbox_max[1]};
+            S[1]          = {g.bbox_min[2], g.bbox_max[2], __builtin_bit_cast(float, ref_of(slot_node[k])), 0};
           }
         }
         Qr[1].w = __builtin_bit_cast(float, (int32_t)axes);
