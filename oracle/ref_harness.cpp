@@ -14,6 +14,7 @@
 #include <yocto/yocto_math.h>
 #include <yocto/yocto_sampling.h>
 #include <yocto/yocto_scene.h>
+#include <yocto/yocto_sceneio.h>
 #include <yocto/yocto_shading.h>
 #include <yocto/yocto_shape.h>
 #include <yocto/yocto_trace.h>
@@ -284,6 +285,24 @@ ref_scene* ref_scene_from_flat(const ythip_scene* in) {
 
 // reference generators --------------------------------------------------------
 // make_cornellbox (yocto_scene.cpp:970-1075)
+// load_scene (yocto_sceneio.h:201) + what apps/ytrace.cpp:103-120 does before rendering
+// (tesselate_subdivs); returns null and keeps the message on failure
+static thread_local std::string g_load_error;
+const char* ref_load_error() { return g_load_error.c_str(); }
+ref_scene*  ref_scene_load(const char* filename) {
+  auto rs = new ref_scene{};
+  try {
+    rs->scene = load_scene(filename);
+    if (!rs->scene.subdivs.empty()) tesselate_subdivs(rs->scene);
+  } catch (const std::exception& e) {
+    g_load_error = e.what();
+    delete rs;
+    return nullptr;
+  }
+  flatten(*rs);
+  return rs;
+}
+
 ref_scene* ref_scene_cornellbox() {
   auto rs   = new ref_scene{};
   rs->scene = make_cornellbox();

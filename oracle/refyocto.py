@@ -67,6 +67,8 @@ def lib():
             "ref_camera_rays": (None, [vp, vp, C.POINTER(yt.CParams), vp]),
             "ref_eval_shading": (None, [vp, vp, vp, C.c_int64, vp]),
             "ref_eval_environment": (None, [vp, vp, C.c_int64, vp]),
+            "ref_scene_load": (vp, [C.c_char_p]),
+            "ref_load_error": (C.c_char_p, []),
             "ref_tonemap": (None, [vp, C.c_int64, C.c_float, C.c_int, C.c_int, vp, vp]),
             "ref_make_rng": (None, [C.c_uint64, C.c_uint64, vp]),
             "ref_rand1f": (None, [vp, C.c_int, vp]),
@@ -92,6 +94,14 @@ class RefScene:
     @staticmethod
     def new():
         return RefScene(lib().ref_scene_new())
+
+    @staticmethod
+    def load(filename):
+        """The reference's own load_scene (+ tesselate_subdivs, as ytrace does)."""
+        h = lib().ref_scene_load(str(filename).encode())
+        if not h:
+            raise RuntimeError(lib().ref_load_error().decode())
+        return RefScene(h)
 
     @staticmethod
     def from_flat(flat):

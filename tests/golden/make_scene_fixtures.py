@@ -1,0 +1,105 @@
+"""Fixtures from the REFERENCE'S OWN test corpus, generated here
+(where /root/reference exists) so that they can travel to the GPU box:
+
+  scenes/<name>.json + scenes/blobs/<sha1>.npz
+      the scenes of /root/reference/tests/_version43 read by the reference's own
+      load_scene (+ tesselate_subdivs, as apps/ytrace.cpp does) through
+      oracle/_ref, flattened to the POD layout of include/ythip.h.  Arrays are
+      stored once by content hash (the test scenes share their sky, textures and
+      most geometry), compressed.
+  scenes/golden_<name>.npz
+      8x8-block means (+ the global mean) of the reference's golden renders
+      tests/_renderings/<name>-mst.hdr — the only pinned outputs the reference's own
+      tests hold for this path (they are converged renders: statistical match only).
+
+Run:  python tests/golden/make_scene_fixtures.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import parity as P  # noqa: E402
+from parity import ry  # noqa: E402
+
+REF_TESTS = "/root/reference/tests"
+OUT = os.path.join(HERE, "scenes")
+SCENES = ["features1", "materials1", "materials2", "materials3", "materials4", "shapes1", "instances1",
+          "arealights1", "environments1", "furnace2"]
+GOLDEN = {"features1": "features1-mst", "materials1": "materials1-mst", "materials2": "materials2-mst",
+          "materials3": "materials3-mst", "materials4": "materials4-mst"}
+
+
+def read_rgbe(path):
+    """Radiance .hdr (RLE or flat) -> float32 [h, w, 3]; decoding as stb_image does:
+    value = mantissa * 2^(exponent - 136)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = data.index(b"\n\n") + 2
+    line_end = data.index(b"\n", pos)
+    toks = data[pos:line_end].split()
+    h, w = int(toks[1]), int(toks[3])
+    pos = line_end + 1
+    img = np.zeros((h, w, 4), np.uint8)
+    buf = np.frombuffer(data, np.uint8)
+    for y in range(h):
+        if w < 8 or w > 32767 or buf[pos] != 2 or buf[pos + 1] != 2 or (buf[pos + 2] & 0x80):
+            img[y] = buf[pos:pos + 4 * w].reshape(w, 4)  # flat scanline
+            pos += 4 * w
+            continue
+        pos += 4
+        for c in range(4):
+            x = 0
+            while x < w:
+                n = int(buf[pos]); pos += 1
+                if n > 128:
+                    n -= 128
+                    img[y, x:x + n, c] = buf[pos]; pos += 1
+                else:
+                    img[y, x:x + n, c] = buf[pos:pos + n]; pos += n
+                x += n
+    e = img[..., 3].astype(np.int32)
+    scale = np.where(e > 0, np.ldexp(np.float32(1), e - 136), 0).astype(np.float32)
+    return img[..., :3].astype(np.float32) * scale[..., None]
+
+
+def block_means(img, b=8):
+    h, w = img.shape[0] // b * b, img.shape[1] // b * b
+    return img[:h, :w].reshape(h // b, b, w // b, b, 3).mean((1, 3)).astype(np.float32)
+
+
+def save_scene(name, flat):
+    os.makedirs(os.path.join(OUT, "blobs"), exist_ok=True)
+    manifest = {}
+    for field in P._FIELDS:
+        a = np.ascontiguousarray(getattr(flat, field))
+        key = hashlib.sha1(a.tobytes() + str(a.dtype).encode() + str(a.shape).encode()).hexdigest()[:16]
+        path = os.path.join(OUT, "blobs", key + ".npz")
+        if not os.path.exists(path):
+            np.savez_compressed(path, a=a)
+        manifest[field] = key
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+def main():
+    assert ry.available(), "build oracle/_ref first (make -C oracle ref)"
+    for name in SCENES:
+        flat = ry.RefScene.load(f"{REF_TESTS}/_version43/{name}/{name}.json").flat()
+        save_scene(name, flat)
+        print(name, "saved", flush=True)
+    for name, hdr in GOLDEN.items():
+        img = read_rgbe(f"{REF_TESTS}/_renderings/{hdr}.hdr")
+        np.savez_compressed(os.path.join(OUT, f"golden_{name}.npz"), blocks=block_means(img),
+                            mean=img.mean(dtype=np.float64), shape=np.array(img.shape[:2]))
+        print("golden", name, img.shape, float(img.mean()), flush=True)
+    total = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(OUT) for f in fs)
+    print("total bytes", total)
+
+
+if __name__ == "__main__":
+    main()

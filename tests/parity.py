@@ -212,6 +212,28 @@ def scene_cornell_1m(n=316):
     return sc
 
 
+REF_SCENE_DIR = os.path.join(GOLDEN, "scenes")
+
+
+def ref_scene_names():
+    """Scenes of the reference's own test corpus (tests/_version43) available as
+    fixtures — see tests/golden/make_scene_fixtures.py."""
+    return sorted(f[:-5] for f in os.listdir(REF_SCENE_DIR) if f.endswith(".json")) \
+        if os.path.isdir(REF_SCENE_DIR) else []
+
+
+def load_ref_scene(name):
+    """A scene of the reference's test corpus as the reference's own loader read it
+    (flat POD layout; arrays stored by content hash)."""
+    import json
+    with open(os.path.join(REF_SCENE_DIR, name + ".json")) as f:
+        manifest = json.load(f)
+    sc = yt.FlatScene()
+    for field, key in manifest.items():
+        setattr(sc, field, np.load(os.path.join(REF_SCENE_DIR, "blobs", key + ".npz"))["a"])
+    return sc
+
+
 SCENES = {
     "cornellbox": scene_cornellbox,
     "plane": scene_plane,
