@@ -1057,6 +1057,13 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
     n = block_partition(Q, slot, cls, {0, 0}, LP == LP_DEFER);
 #ifdef YT_TIMING
     {  // extend | shade | probe + partition (incl. waiting for the workgroup's slower waves)
+      unsigned tm_sum = work, tm_max = work;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        tm_sum += __shfl_xor(tm_sum, off);
+        unsigned o = __shfl_xor(tm_max, off);
+        tm_max     = o > tm_max ? o : tm_max;
+      }
       const long long tm3     = __builtin_readcyclecounter();
       const bool      any_run = __ballot(run) != 0;
       if ((tid & 63) == 0 && st.counters) {
@@ -1066,6 +1073,9 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
         atomicAdd(&c[11], (unsigned long long)(tm3 - tm2));
         atomicAdd(&c[12], (unsigned long long)(any_run ? 0 : tm2 - tm0));
         atomicAdd(&c[13], 1ull);
+        // lane utilisation of the traversal: sum of lane steps vs 64 x the longest lane
+        atomicAdd(&c[6], (unsigned long long)tm_sum);
+        atomicAdd(&c[7], (unsigned long long)tm_max * 64ull);
         // shade split (waves whose lane 0 shaded a hit): shading point | bsdf + sampling | finish + regenerate
         if (any_run && tmG) {
           atomicAdd(&c[14], (unsigned long long)(tmG - tm1));

@@ -1242,7 +1242,7 @@ int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
   {
     unsigned long long t[16] = {};
     for (int b = 0; b < CNT_BANKS; b++)
-      for (int k = 8; k < 16; k++) t[k] += banks[b * CNT_STRIDE + k];
+      for (int k = 6; k < 16; k++) t[k] += banks[b * CNT_STRIDE + k];
     double tot = (double)(t[9] + t[10] + t[11] + t[12]);
     std::fprintf(stderr, "[timing] wave-iterations %llu | extend %.1f%% shade %.1f%% partition+wait %.1f%% "
                          "idle-wave %.1f%% | cycles/wave-iteration %.0f\n",
@@ -1250,6 +1250,8 @@ int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
     std::fprintf(stderr, "[timing] of all wave time: hit shading point %.1f%% | bsdf+sampling after it %.1f%% | "
                          "finish+regenerate (resolve_step) %.1f%%\n",
         100 * t[14] / tot, 100 * t[15] / tot, 100 * t[8] / tot);
+    std::fprintf(stderr, "[timing] traversal lane utilisation (sum of lane steps / 64 x longest lane): %.1f%%\n",
+        t[7] ? 100.0 * t[6] / t[7] : 0.0);
   }
 #endif
   *stats           = ctx->stats;
