@@ -372,6 +372,12 @@ int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params);
  * variable YTHIP_HOLD=0/1 sets the default of new contexts (A/B measurements). */
 int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait);
 
+/* Kernel specialisation by scene content (results do not depend on it).  1 (default):
+ * when every material of the resident scene is matte, the `path` sampler runs a
+ * k_trace variant compiled without the other seven lobes and the volume code
+ * (5 % faster on BASELINE configs[1]); 0: always the general kernel. */
+int ythip_set_specialization(ythip_ctx* ctx, int enable);
+
 /* Which BVH walk k_trace's extend stage and the test entries below use: 0 the
  * binary walk (one sibling pair per dependent fetch), 1 the wide walk (the four
  * grandchildren per fetch: half the fetch chain, yt_bvh.h), 2 (default) chosen by

@@ -403,6 +403,23 @@ def test_wide_and_binary_walks_agree(bundles, name):
         assert out["binary"][2][k].tobytes() == out["wide"][2][k].tobytes(), k
 
 
+@pytest.mark.parametrize("name", ["cornellbox", "plane"])
+def test_matte_specialised_kernel_gives_identical_results(bundles, name):
+    """All-matte scenes run a k_trace variant compiled without the other lobes: every
+    state array is bit-identical to the general kernel's (area lights: the deferred
+    light-pdf variant on the Cornell box; environment light on the plane)."""
+    flat, ctx, _ = bundles(name)
+    assert (flat.materials["type"] == 0).all()
+    p = yt.trace_params(sampler="path", resolution=128, samples=6, batch=3)
+    out = []
+    for spec in [1, 0]:
+        ctx.set_specialization(spec)
+        out.append(P.gpu_render(ctx, flat, p))
+    ctx.set_specialization(1)
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert out[0][k].tobytes() == out[1][k].tobytes(), k
+
+
 def test_get_image_and_device_tonemap(bundles):
     """§8(f) rank 2, the display path: ythip_get_image returns exactly
     trace_state.image; ythip_tonemap_image (device) vs the reference's tonemap_image

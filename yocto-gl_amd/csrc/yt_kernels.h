@@ -345,14 +345,14 @@ YT_FN int step_tail(Path& P) {
 // trace_path / trace_pathdirect / trace_pathmis / trace_pathtest — one iteration
 // of the bounce loop after the intersection (yocto_trace.cpp:453-1029)
 // ---------------------------------------------------------------------------
-template <int SAMPLER, int LP>
+template <int SAMPLER, int LP, bool MATTE = false>
 YT_FN int step_path(ShadeEnv& E, Path& P) {
   const auto& sc = E.sc;
   const auto& kp = E.kp;
   constexpr bool DIRECT  = SAMPLER == YTHIP_SAMPLER_PATHDIRECT;
   constexpr bool MIS     = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   constexpr bool TEST    = SAMPLER == YTHIP_SAMPLER_PATHTEST;
-  constexpr bool VOLUMES = !TEST;
+  constexpr bool VOLUMES = !TEST && !MATTE;
   static_assert(!(DIRECT || MIS) || LP == LP_INLINE, "NEE samplers trace inline");
   const bool next_emission = !(P.flags & PF_NOEMIT);
 
@@ -390,6 +390,10 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     E.t_geo = __builtin_readcyclecounter();
 #endif
     if (TEST) material.type = YTHIP_MATTE;
+    // MATTE: every material of the resident scene is matte (checked at upload), so this
+    // assignment changes nothing — it tells the compiler, which then drops the other
+    // seven lobes, the volume code and the registers they pin
+    if (MATTE) material.type = YTHIP_MATTE;
 
     // correct roughness
     if (!TEST && kp.nocaustics) {
@@ -917,7 +921,7 @@ YT_FN int max_bounces_of(const KParams& kp) {
 // tile's path state (≈40 KB) stays in the XCD's L2 between iterations.  The
 // ray and the hit record never leave registers between extend and shade.
 // ===========================================================================
-template <int SAMPLER, int LP, bool COUNT, bool WIDE>
+template <int SAMPLER, int LP, bool COUNT, bool WIDE, bool MATTE = false>
 __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KParams kp) {
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
@@ -1013,7 +1017,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
       } else {
         ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
         if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
-          step = step_path<SAMPLER, LP>(E, P);
+          step = step_path<SAMPLER, LP, MATTE>(E, P);
 #ifdef YT_TIMING
           tmG = E.t_geo;
 #endif

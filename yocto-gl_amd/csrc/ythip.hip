@@ -50,6 +50,8 @@ struct ythip_ctx {
   std::vector<float>          h_positions, h_radius;
   bool                        may_retry = false;  // opacity < 1 possible → bounce loop may exceed `bounces`
   bool                        has_volumes = false;
+  bool                        all_matte   = false;  // every material is matte: k_trace's specialised variant applies
+  int                         specialize  = 1;
   int                         num_cameras = 0;
 
   ythost::flat_bvh    h_bvh;     // as uploaded/built (reference layout) for download
@@ -529,7 +531,17 @@ void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
 int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
   switch (kp.sampler) {
     case YTHIP_SAMPLER_PATH:
-      if (lp == LP_DEFER)
+      if (!count && ctx->all_matte && ctx->specialize && ctx->use_wide()) {
+        // the default sampler on an all-matte scene: the variant compiled without the
+        // other material lobes and the volume code (same results, fewer registers)
+        dim3 grid(ctx->st.nblocks), block(YT_BLOCK);
+        if (lp == LP_DEFER)
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, true>), grid, block, 0, ctx->stream,
+              ctx->ds, ctx->st, kp);
+        else
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, true>), grid, block, 0, ctx->stream,
+              ctx->ds, ctx->st, kp);
+      } else if (lp == LP_DEFER)
         launch_trace<YTHIP_SAMPLER_PATH, LP_DEFER>(ctx, kp, count);
       else
         launch_trace<YTHIP_SAMPLER_PATH, LP_NONE>(ctx, kp, count);
@@ -784,6 +796,9 @@ int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* sc) {
   ctx->h_quads.assign(sc->quads, sc->quads + sc->num_quads * 4);
   ctx->h_positions.assign(sc->positions, sc->positions + sc->num_positions * 3);
   ctx->h_radius.assign(sc->radius, sc->radius + sc->num_radius);
+  ctx->all_matte = sc->num_materials > 0;
+  for (int k = 0; k < sc->num_materials; k++)
+    if (sc->materials[k].type != YTHIP_MATTE) ctx->all_matte = false;
   ctx->may_retry = false;
   for (int k = 0; k < sc->num_materials; k++)
     if (sc->materials[k].opacity < 1 || sc->materials[k].color_tex != YTHIP_INVALIDID) ctx->may_retry = true;
@@ -1204,6 +1219,12 @@ int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params, ythip_ray* ray
 int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait) {
   if (!ctx) return YTHIP_ERR_INVALID;
   ctx->hold_policy = adaptive_wait ? 1 : 0;
+  return YTHIP_OK;
+}
+
+int ythip_set_specialization(ythip_ctx* ctx, int enable) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  ctx->specialize = enable ? 1 : 0;
   return YTHIP_OK;
 }
 

@@ -445,6 +445,7 @@ _SIGNATURES = {
                                                  C.c_void_p]),
     "ythip_camera_rays": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_void_p]),
     "ythip_set_scheduling": (C.c_int, [C.c_void_p, C.c_int]),
+    "ythip_set_specialization": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_reset_stats": (C.c_int, [C.c_void_p]),
     "ythip_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CStats)]),
@@ -742,6 +743,9 @@ class Context:
         return rays
 
     # measurement ------------------------------------------------------------------
+    def set_specialization(self, enable):
+        self._check(self.lib.ythip_set_specialization(self.h, int(enable)), "set_specialization")
+
     def set_scheduling(self, adaptive_wait):
         self._check(self.lib.ythip_set_scheduling(self.h, int(adaptive_wait)), "set_scheduling")
 
