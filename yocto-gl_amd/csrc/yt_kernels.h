@@ -382,17 +382,17 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     auto outgoing = -P.d;
     auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
     auto position = eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
-    auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
-    auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
+    auto normal   = eval_shading_normal<MATTE>(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
+    auto material = eval_material<MATTE>(sc, *s.sh, *s.mat, s.e, s.uv);
     count_shade(E.st);
 #ifdef YT_TIMING
     asm volatile("" ::"v"(position.x), "v"(normal.x), "v"(material.color.x), "v"(material.roughness));
     E.t_geo = __builtin_readcyclecounter();
 #endif
     if (TEST) material.type = YTHIP_MATTE;
-    // MATTE: every material of the resident scene is matte (checked at upload), so this
-    // assignment changes nothing — it tells the compiler, which then drops the other
-    // seven lobes, the volume code and the registers they pin
+    // MATTE: every material of the resident scene is matte and untextured (checked at
+    // upload), so this assignment changes nothing — it tells the compiler, which then
+    // drops the other seven lobes, the volume and texture code and the registers they pin
     if (MATTE) material.type = YTHIP_MATTE;
 
     // correct roughness

@@ -377,11 +377,12 @@ YT_FN vec3f eval_shading_position(const DScene& sc, const frame3f& frame, const 
   return {0, 0, 0};
 }
 // eval_shading_normal — yocto_scene.cpp:485-505
+template <bool NOTEX = false>
 YT_FN vec3f eval_shading_normal(const DScene& sc, const frame3f& frame, const DShape& sh,
     const ythip_material& material, elem4 e, vec2f uv, vec3f outgoing) {
   if (sh.kind_eval == KIND_TRIANGLES || sh.kind_eval == KIND_QUADS) {
     auto normal = eval_normal(sc, frame, sh, e, uv);
-    if (material.normal_tex != YTHIP_INVALIDID) normal = eval_normalmap(sc, frame, sh, material, e, uv);
+    if (!NOTEX && material.normal_tex != YTHIP_INVALIDID) normal = eval_normalmap(sc, frame, sh, material, e, uv);
     if (material.type == YTHIP_REFRACTIVE) return normal;
     return dot(normal, outgoing) >= 0 ? normal : -normal;
   } else if (sh.kind_eval == KIND_LINES) {
@@ -405,8 +406,12 @@ struct material_point {
 };
 constexpr float min_roughness = 0.03f * 0.03f;
 
-YT_FN material_point eval_material(const DScene& sc, const DShape& sh, const ythip_material& material,
+// NOTEX: the caller knows that no material of the scene references a texture
+template <bool NOTEX = false>
+YT_FN material_point eval_material(const DScene& sc, const DShape& sh, const ythip_material& material_,
     elem4 e, vec2f uv) {
+  ythip_material material = material_;
+  if (NOTEX) material.emission_tex = material.color_tex = material.roughness_tex = material.scattering_tex = -1;
   // texcoords are only read by texture lookups: skip the three gathers for untextured materials
   const bool textured = (material.emission_tex & material.color_tex & material.roughness_tex &
                             material.scattering_tex) != YTHIP_INVALIDID;
