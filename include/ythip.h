@@ -373,10 +373,10 @@ int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params);
 int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait);
 
 /* Kernel specialisation by scene content (results do not depend on it).  1 (default):
- * when every material of the resident scene is matte and untextured, the `path`
- * sampler runs a k_trace variant compiled without the other seven lobes, the volume
- * and the texture code (7 % faster on BASELINE configs[1]); 0: always the general
- * kernel. */
+ * when every material of the resident scene is matte and untextured and every shape
+ * a triangle mesh, the `path` sampler runs a k_trace variant compiled without the
+ * other seven lobes, the volume and texture code and the quad / line / point paths
+ * (10 % faster on BASELINE configs[1]); 0: always the general kernel. */
 int ythip_set_specialization(ythip_ctx* ctx, int enable);
 
 /* Which BVH walk k_trace's extend stage and the test entries below use: 0 the

@@ -225,7 +225,7 @@ YT_FN bool ray_is_tame(vec3f o, vec3f dinv, float tmin) {
 // otherwise intersect_instance_bvh of that instance (yocto_bvh.cpp:619-628).
 constexpr int HIT_ABORT = -2;  // Hit::instance of a wide walk that met an irregular ray: redo it binary
 
-template <bool COUNT, bool WIDE = false>
+template <bool COUNT, bool WIDE = false, bool TRI = false>
 YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt) {
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
@@ -307,7 +307,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     tame = ray_is_tame(o, dinv, tmin);
     sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
     cur_inst = inst;
-    kind     = __float_as_int(m4.w);
+    kind     = TRI ? KIND_TRIANGLES : __float_as_int(m4.w);  // TRI: every shape of the scene is a triangle mesh
     leafbias = m5.x;
     blas_hit = false;
     push(REF_EXIT, 0);
@@ -520,14 +520,14 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
 
 // The production entry: the wide walk, and the binary walk for the rays it declines
 // (irregular at world or instance level, find_any) — the same hit record either way.
-template <bool COUNT, bool WIDE>
+template <bool COUNT, bool WIDE, bool TRI = false>
 YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt) {
   if constexpr (WIDE && !COUNT) {
-    Hit h = traverse<false, true>(sc, wray, only_instance, find_any, st, cnt);
+    Hit h = traverse<false, true, TRI>(sc, wray, only_instance, find_any, st, cnt);
     if (h.instance != HIT_ABORT) return h;
   }
-  return traverse<COUNT, false>(sc, wray, only_instance, find_any, st, cnt);
+  return traverse<COUNT, false, TRI>(sc, wray, only_instance, find_any, st, cnt);
 }
 
 }  // namespace yt

@@ -166,18 +166,21 @@ __device__ __noinline__ Hit trace_ray(const DScene& sc, vec3f o, vec3f d, int on
 // ---------------------------------------------------------------------------
 struct Surface {
   frame3f               frame;
-  const DShape*         sh;
+  DShape                shc;
   const ythip_material* mat;
   elem4                 e;
   vec2f                 uv;
 };
+// TRI: the caller knows that every shape of the scene is a triangle mesh
+template <bool TRI = false>
 YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv) {
   const auto& inst = sc.instances[instance];
   Surface     s;
   s.frame = ldframe(inst.frame);
-  s.sh    = &sc.shapes[inst.shape];
+  s.shc   = sc.shapes[inst.shape];
+  if (TRI) s.shc.kind_eval = KIND_TRIANGLES;
   s.mat   = &sc.materials[inst.material];
-  s.e     = load_element(sc, *s.sh, element);
+  s.e     = load_element(sc, s.shc, element);
   s.uv    = uv;
   return s;
 }
@@ -324,8 +327,8 @@ YT_FN void count_shade(const DState& s) { count_lanes(s.counters, CNT_SHADES); }
 YT_FN vec3f nee_emission(const DScene& sc, const Hit& isec, vec3f incoming) {
   if (!isec.hit) return eval_environment(sc, incoming);
   auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
-  auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, -incoming);
+  auto material = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
+  auto normal   = eval_shading_normal(sc, s.frame, s.shc, *s.mat, s.e, s.uv, -incoming);
   return eval_emission(material, normal, -incoming);
 }
 
@@ -380,18 +383,19 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
   if (!in_volume) {
     // prepare shading point
     auto outgoing = -P.d;
-    auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
-    auto position = eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
-    auto normal   = eval_shading_normal<MATTE>(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
-    auto material = eval_material<MATTE>(sc, *s.sh, *s.mat, s.e, s.uv);
+    auto s        = load_surface<MATTE>(sc, isec.instance, isec.element, {isec.u, isec.v});
+    auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
+    auto normal   = eval_shading_normal<MATTE>(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
+    auto material = eval_material<MATTE>(sc, s.shc, *s.mat, s.e, s.uv);
     count_shade(E.st);
 #ifdef YT_TIMING
     asm volatile("" ::"v"(position.x), "v"(normal.x), "v"(material.color.x), "v"(material.roughness));
     E.t_geo = __builtin_readcyclecounter();
 #endif
     if (TEST) material.type = YTHIP_MATTE;
-    // MATTE: every material of the resident scene is matte and untextured (checked at
-    // upload), so this assignment changes nothing — it tells the compiler, which then
+    // MATTE (the "simple scene" variant): every material of the resident scene is matte
+    // and untextured and every shape a triangle mesh (checked at upload), so this
+    // assignment changes nothing — it tells the compiler, which then
     // drops the other seven lobes, the volume and texture code and the registers they pin
     if (MATTE) material.type = YTHIP_MATTE;
 
@@ -512,7 +516,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     // update volume stack
     if (VOLUMES && is_volumetric(*s.mat) && dot(normal, outgoing) * dot(normal, incoming) < 0) {
       if (!(P.flags & PF_VOLUME)) {
-        auto vmat = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
+        auto vmat = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
         store_volume(E.st, E.slot, vmat);
         P.flags |= PF_VOLUME;
       } else {
@@ -573,10 +577,10 @@ YT_FN int step_naive(ShadeEnv& E, Path& P) {
   auto outgoing = -P.d;
   auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
   // furnace uses eval_position (instance transform always); naive eval_shading_position
-  auto position = FURNACE ? eval_position(sc, s.frame, *s.sh, s.e, s.uv)
-                          : eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
-  auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
+  auto position = FURNACE ? eval_position(sc, s.frame, s.shc, s.e, s.uv)
+                          : eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
+  auto normal   = eval_shading_normal(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
+  auto material = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
   count_shade(E.st);
 
   if (material.opacity < 1 && rand1f(P.rng) >= material.opacity) {
@@ -636,9 +640,9 @@ YT_FN int step_eyelight(ShadeEnv& E, Path& P) {
   }
   auto outgoing = -P.d;
   auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
-  auto position = eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
-  auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
+  auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
+  auto normal   = eval_shading_normal(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
+  auto material = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
   count_shade(E.st);
 
   if (material.opacity < 1 && rand1f(P.rng) >= material.opacity) {
@@ -682,11 +686,11 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
   if (!isec.hit) return STEP_END;  // trace_result{}: radiance 0, hit false
   auto outgoing = -P.d;
   auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
-  auto position = eval_shading_position(sc, s.frame, *s.sh, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, *s.sh, *s.mat, s.e, s.uv, outgoing);
-  auto gnormal  = eval_element_normal(sc, s.frame, *s.sh, s.e);
-  auto texcoord = eval_texcoord(sc, *s.sh, s.e, s.uv);
-  auto material = eval_material(sc, *s.sh, *s.mat, s.e, s.uv);
+  auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
+  auto normal   = eval_shading_normal(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
+  auto gnormal  = eval_element_normal(sc, s.frame, s.shc, s.e);
+  auto texcoord = eval_texcoord(sc, s.shc, s.e, s.uv);
+  auto material = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
   auto delta    = is_delta(material) ? 1.0f : 0.0f;
   count_shade(E.st);
   const auto& inst = sc.instances[isec.instance];
@@ -1001,7 +1005,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
       } else {
         ray3f          ray = make_ray(P.o, P.d);
         const unsigned s0  = cnt.steps;
-        P.isec             = traverse_any<COUNT, WIDE>(sc, ray, -1, false, stack, cnt);
+        P.isec             = traverse_any<COUNT, WIDE, MATTE>(sc, ray, -1, false, stack, cnt);
         work               = cnt.steps - s0 + 1;
       }
 #ifdef YT_TIMING

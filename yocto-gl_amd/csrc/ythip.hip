@@ -50,7 +50,7 @@ struct ythip_ctx {
   std::vector<float>          h_positions, h_radius;
   bool                        may_retry = false;  // opacity < 1 possible → bounce loop may exceed `bounces`
   bool                        has_volumes = false;
-  bool                        all_matte   = false;  // every material is matte and untextured: k_trace's specialised variant applies
+  bool                        all_matte   = false;  // "simple scene": matte untextured materials, triangle meshes only
   int                         specialize  = 1;
   int                         num_cameras = 0;
 
@@ -802,6 +802,8 @@ int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* sc) {
     if (m.type != YTHIP_MATTE || (m.emission_tex & m.color_tex & m.roughness_tex & m.scattering_tex & m.normal_tex) != YTHIP_INVALIDID)
       ctx->all_matte = false;
   }
+  for (int k = 0; k < sc->num_shapes; k++)  // ... and every shape a triangle mesh
+    if (sc->shapes[k].num_points || sc->shapes[k].num_lines || sc->shapes[k].num_quads) ctx->all_matte = false;
   ctx->may_retry = false;
   for (int k = 0; k < sc->num_materials; k++)
     if (sc->materials[k].opacity < 1 || sc->materials[k].color_tex != YTHIP_INVALIDID) ctx->may_retry = true;
