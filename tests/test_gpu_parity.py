@@ -420,6 +420,22 @@ def test_matte_specialised_kernel_gives_identical_results(bundles, name):
         assert out[0][k].tobytes() == out[1][k].tobytes(), k
 
 
+@needs_ref
+@pytest.mark.parametrize("resolution,aspect", [(1, 1.0), (3, 1.0), (17, 0.5), (37, 1.7), (63, 1.0), (65, 2.9)])
+def test_odd_frame_sizes_bit_exact(resolution, aspect):
+    """Frames that do not fill the 16x4 tiles (1 pixel, 17x34, 37x22, 65x22 ...):
+    eyelight trace_state bit for bit vs the reference, in two batches."""
+    flat = P.SCENES["cornellbox"]()
+    flat.cameras["aspect"] = aspect
+    ctx, rb = P.gpu_context(flat), P.RefBundle(flat)
+    p = yt.trace_params(sampler="eyelight", resolution=resolution, samples=4, batch=2)
+    gpu, ref = P.gpu_render(ctx, flat, p), rb.render(p)
+    ctx.close()
+    assert (gpu["width"], gpu["height"]) == (ref["width"], ref["height"])
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert gpu[k].tobytes() == ref[k].tobytes(), (k, gpu["width"], gpu["height"])
+
+
 def test_get_image_and_device_tonemap(bundles):
     """§8(f) rank 2, the display path: ythip_get_image returns exactly
     trace_state.image; ythip_tonemap_image (device) vs the reference's tonemap_image

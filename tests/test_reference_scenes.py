@@ -114,6 +114,24 @@ def test_render_vs_live_reference(gpu_bundles, name):
 
 @pytest.mark.gpu
 @needs_ref
+@pytest.mark.parametrize("sampler", ["pathdirect", "pathmis", "naive", "eyelight", "falsecolor"])
+def test_other_samplers_on_features1(gpu_bundles, sampler):
+    """The other integrators on the reference's feature scene (textures, environment
+    map, area lights, every material): same tolerance as `path` above; eyelight has
+    no libm on most of its path and must keep every rng stream."""
+    flat, ctx, rb = gpu_bundles("features1")
+    p = yt.trace_params(sampler=sampler, resolution=256, samples=2, batch=2, falsecolor="normal")
+    gpu = P.gpu_render(ctx, flat, p)
+    ref = rb.render(p)
+    same = (gpu["rngs"] == ref["rngs"]).all(1)
+    assert same.mean() >= (0.999 if sampler in ("eyelight", "falsecolor") else 0.96), same.mean()
+    a, b = gpu["image"][same, :3], ref["image"][same, :3]
+    rel = np.abs(a - b).max(1) / np.maximum(np.abs(b).max(1), 1e-3)
+    assert (rel <= 1e-4).mean() >= 0.99, (rel <= 1e-4).mean()
+
+
+@pytest.mark.gpu
+@needs_ref
 @pytest.mark.parametrize("name", ["features1", "materials2"])
 def test_converged_render_vs_reference(gpu_bundles, name):
     """Converged images, independent rng streams (GPU seed 7, reference default seed):
