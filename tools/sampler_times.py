@@ -41,4 +41,12 @@ for sampler in (os.environ.get("SAMPLERS") or "falsecolor,eyelight,naive,pathtes
         ctx.trace_samples(p)
     s = ctx.get_stats(); ctx.set_profiling(0)
     ms = s["trace_ms"] / s["trace_launches"]
-    print(f"{SCENE} {sampler:10s} {ms:8.3f} ms/step  {ctx.npixels*spp/ms/1e3:8.1f} Msamples/s", flush=True)
+    digest = ""
+    if os.environ.get("DIGEST"):  # A/B builds must agree bit for bit: hash of the whole trace_state
+        import hashlib
+        d = ctx.download_state()
+        h = hashlib.sha1()
+        for k in sorted(d):
+            if hasattr(d[k], "tobytes"): h.update(d[k].tobytes())
+        digest = " state " + h.hexdigest()[:12]
+    print(f"{SCENE} {sampler:10s} {ms:8.3f} ms/step  {ctx.npixels*spp/ms/1e3:8.1f} Msamples/s{digest}", flush=True)
