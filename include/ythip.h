@@ -271,6 +271,30 @@ int ythip_bvh_build_info(ythip_ctx* ctx, ythip_build_info* info);
  * (num_pairs), quads 128-B records (num_pairs), leaf data 16-B records. */
 int ythip_bvh_baked_sizes(ythip_ctx* ctx, int64_t* num_pairs, int64_t* num_leaf4);
 int ythip_bvh_baked_download(ythip_ctx* ctx, float* pairs, float* leafdata, float* quads);
+/* update_scene_bvh / update_shape_bvh — libs/yocto/yocto_bvh.h:87-90,
+ * yocto_bvh.cpp:304-319 (refit_bvh), 398-451: after an edit that moves vertices
+ * or instances but keeps every element list, the resident trees keep their
+ * topology and only the boxes are recomputed, bottom-up, bit for bit the
+ * reference's.  Protocol (the scene edits of an interactive session):
+ *   ythip_update_shape_vertices(...)    per moved shape: new positions / normals / radii
+ *                                       (any of the three may be NULL = unchanged)
+ *   ythip_update_instance_frames(...)   moved instances
+ *   ythip_update_bvh(...)               refit the listed shapes' trees (on the
+ *                                       device when the tree was built there), then the
+ *                                       instance tree, then re-bake the traversal arrays
+ * `updated_instances` is accepted for signature parity and — like the reference
+ * (yocto_bvh.cpp:441-447 recomputes every instance box) — not used to skip work.
+ * Counts must equal the resident shape's (YTHIP_ERR_INVALID otherwise).  Lights
+ * are the caller's business, as in the reference (make_trace_lights again when
+ * emissive geometry moved).  ythip_bvh_build_info afterwards: device_trees /
+ * host_trees = trees refitted on either side, device_ms / build_ms / bake_ms of
+ * the update. */
+int ythip_update_shape_vertices(ythip_ctx* ctx, int32_t shape, const float* positions, int64_t num_positions,
+    const float* normals, int64_t num_normals, const float* radius, int64_t num_radius);
+int ythip_update_instance_frames(ythip_ctx* ctx, const int32_t* instances, int32_t num, const ythip_frame* frames);
+int ythip_update_bvh(ythip_ctx* ctx, const int32_t* updated_instances, int32_t num_instances,
+    const int32_t* updated_shapes, int32_t num_shapes);
+
 /* Upload a tree built elsewhere (e.g. by the reference's make_trace_bvh). */
 int ythip_upload_bvh(ythip_ctx* ctx, const ythip_bvh* bvh);
 /* Read back the resident tree (for tree-identity tests). */
@@ -284,6 +308,11 @@ int ythip_bvh_download(ythip_ctx* ctx, int64_t* node_offset,
 typedef struct ythip_hostbvh ythip_hostbvh;
 int  ythip_host_bvh_build(const ythip_scene* scene, int highquality,
      ythip_hostbvh** out);
+/* update_scene_bvh (yocto_bvh.cpp:434-451) on a host tree: `scene` is the edited
+ * scene (same element lists), the listed shapes' trees and the instance tree are
+ * refitted in place. */
+int  ythip_host_bvh_refit(ythip_hostbvh* bvh, const ythip_scene* scene,
+     const int32_t* updated_shapes, int32_t num_shapes);
 int  ythip_host_bvh_view(const ythip_hostbvh* bvh, ythip_bvh* view);
 void ythip_host_bvh_free(ythip_hostbvh* bvh);
 

@@ -437,11 +437,8 @@ void ref_scene_flat(const ref_scene* rs, ythip_scene* out) {
 // ---------------------------------------------------------------------------
 // make_trace_bvh / make_trace_lights / make_trace_state
 // ---------------------------------------------------------------------------
-ref_bvh* ref_bvh_build(const ref_scene* rs, int highquality) {
-  auto rb    = new ref_bvh{};
-  auto params = trace_params{};
-  params.highqualitybvh = highquality != 0;
-  rb->bvh    = make_trace_bvh(rs->scene, params);
+static void reflatten(ref_bvh* rb) {
+  rb->node_offset.clear(), rb->prim_offset.clear(), rb->nodes.clear(), rb->prims.clear();
   auto& sb   = rb->bvh.bvh;
   auto  push = [&](const bvh_tree& tree) {
     rb->node_offset.push_back((int64_t)rb->nodes.size());
@@ -459,7 +456,49 @@ ref_bvh* ref_bvh_build(const ref_scene* rs, int highquality) {
   push(sb.bvh);
   rb->node_offset.push_back((int64_t)rb->nodes.size());
   rb->prim_offset.push_back((int64_t)rb->prims.size());
+}
+ref_bvh* ref_bvh_build(const ref_scene* rs, int highquality) {
+  auto rb    = new ref_bvh{};
+  auto params = trace_params{};
+  params.highqualitybvh = highquality != 0;
+  rb->bvh    = make_trace_bvh(rs->scene, params);
+  reflatten(rb);
   return rb;
+}
+// scene edits that keep the element lists + update_scene_bvh (yocto_bvh.cpp:434-451)
+int ref_scene_set_vertices(ref_scene* rs, int shape, const float* positions,
+    int64_t num_positions, const float* normals, int64_t num_normals,
+    const float* radius, int64_t num_radius) {
+  if (shape < 0 || shape >= (int)rs->scene.shapes.size()) return -1;
+  auto& sh = rs->scene.shapes[shape];
+  if (positions) {
+    if (num_positions != (int64_t)sh.positions.size()) return -1;
+    std::memcpy((void*)sh.positions.data(), positions, sizeof(vec3f) * sh.positions.size());
+  }
+  if (normals) {
+    if (num_normals != (int64_t)sh.normals.size()) return -1;
+    std::memcpy((void*)sh.normals.data(), normals, sizeof(vec3f) * sh.normals.size());
+  }
+  if (radius) {
+    if (num_radius != (int64_t)sh.radius.size()) return -1;
+    std::memcpy(sh.radius.data(), radius, sizeof(float) * sh.radius.size());
+  }
+  return 0;
+}
+int ref_scene_set_instance_frame(ref_scene* rs, int instance, const ythip_frame* frame) {
+  if (instance < 0 || instance >= (int)rs->scene.instances.size()) return -1;
+  rs->scene.instances[instance].frame = to_frame(*frame);
+  return 0;
+}
+double ref_bvh_update(ref_bvh* rb, const ref_scene* rs, const int* instances,
+    int num_instances, const int* shapes, int num_shapes) {
+  auto vi = std::vector<int>(instances, instances + num_instances);
+  auto vs = std::vector<int>(shapes, shapes + num_shapes);
+  auto t0 = std::chrono::steady_clock::now();
+  update_scene_bvh(rb->bvh.bvh, rs->scene, vi, vs);
+  auto dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  reflatten(rb);
+  return dt;
 }
 void ref_bvh_free(ref_bvh* b) { delete b; }
 void ref_bvh_flat(const ref_bvh* rb, ythip_bvh* out) {

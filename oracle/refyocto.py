@@ -52,6 +52,9 @@ def lib():
             "ref_scene_flat": (None, [vp, C.POINTER(yt.CScene)]),
             "ref_bvh_build": (vp, [vp, C.c_int]),
             "ref_bvh_free": (None, [vp]),
+            "ref_scene_set_vertices": (C.c_int, [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64]),
+            "ref_scene_set_instance_frame": (C.c_int, [vp, C.c_int, vp]),
+            "ref_bvh_update": (C.c_double, [vp, vp, vp, C.c_int, vp, C.c_int]),
             "ref_bvh_flat": (None, [vp, C.POINTER(yt.CBvh)]),
             "ref_lights_build": (vp, [vp]),
             "ref_lights_free": (None, [vp]),
@@ -169,6 +172,22 @@ class RefScene:
     def add_sunsky_texture(self, width, height, sun_angle):
         return lib().ref_add_sunsky_texture(self.h, width, height, sun_angle)
 
+    def set_vertices(self, shape, positions=None, normals=None, radius=None):
+        """Edit a shape's vertices in place (element lists untouched)."""
+        p = None if positions is None else np.ascontiguousarray(positions, "f4").reshape(-1, 3)
+        n = None if normals is None else np.ascontiguousarray(normals, "f4").reshape(-1, 3)
+        r = None if radius is None else np.ascontiguousarray(radius, "f4").reshape(-1)
+        ptr = lambda a: None if a is None or a.size == 0 else a.ctypes.data  # noqa: E731
+        cnt = lambda a: 0 if a is None else len(a)  # noqa: E731
+        rc = lib().ref_scene_set_vertices(self.h, int(shape), ptr(p), cnt(p), ptr(n), cnt(n), ptr(r), cnt(r))
+        if rc != 0:
+            raise ValueError("set_vertices: shape / count mismatch")
+
+    def set_instance_frame(self, instance, frame):
+        f = np.ascontiguousarray(frame, "f4").reshape(12)
+        if lib().ref_scene_set_instance_frame(self.h, int(instance), f.ctypes.data) != 0:
+            raise ValueError("set_instance_frame: instance out of range")
+
     def flat(self):
         """Deep copy of the scene as a FlatScene (numpy-owned)."""
         lib().ref_scene_commit(self.h)
@@ -185,6 +204,12 @@ class RefBvh:
         if getattr(self, "h", None):
             lib().ref_bvh_free(self.h)
             self.h = None
+
+    def update(self, scene, updated_instances=(), updated_shapes=()):
+        """update_scene_bvh (yocto_bvh.cpp:434-451); returns the seconds it took."""
+        vi = np.ascontiguousarray(list(updated_instances), "i4")
+        vs = np.ascontiguousarray(list(updated_shapes), "i4")
+        return lib().ref_bvh_update(self.h, scene.h, vi.ctypes.data, len(vi), vs.ctypes.data, len(vs))
 
     def flat(self):
         cb = yt.CBvh()

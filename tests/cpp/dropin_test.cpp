@@ -4,8 +4,10 @@
 // one yocto::trace_samples (the CPU reference, linked from oracle/_ref) produces.
 // TEST INFRASTRUCTURE: built by oracle/Makefile (`make dropin`) when the
 // reference sources are present; run by tests/test_gpu_parity.py on the GPU box.
+#include <yocto/yocto_bvh.h>
 #include <yocto/yocto_image.h>
 #include <yocto/yocto_scene.h>
+#include <yocto/yocto_shape.h>
 #include <yocto/yocto_trace.h>
 
 #include <cmath>
@@ -138,6 +140,29 @@ int main() {
     trace_samples(cpu, big, dev, lights, params);       // the CPU tracer on the device-built tree
     hip::trace_samples(gpu, big, dev, lights, params);  // no re-upload: the tree is already resident
     EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.rngs, gpu.rngs), "eyelight on the device-built tree differs");
+
+    // 2b'. an edit that keeps the element lists: update_scene_bvh (yocto_bvh.h:88) on the CPU tree,
+    //      hip::update_trace_bvh on the resident one — same boxes, same pictures afterwards
+    for (auto k = (size_t)0; k < big.shapes[0].positions.size(); k++) {
+      auto& p = big.shapes[0].positions[k];
+      p.y += 0.3f * std::sin(0.7f * p.x) * std::cos(0.9f * p.z);  // a wave over the plane
+      if (k % 97 == 0) p.x = (k % 2) ? 0.0f : -0.0f;              // zero faces of both signs
+    }
+    big.shapes[0].normals = triangles_normals(big.shapes[0].triangles, big.shapes[0].positions);
+    big.instances[0].frame = rotation_frame(vec3f{0, 1, 0}, 0.3f) * translation_frame(vec3f{0.5f, 0.1f, -0.25f});
+    update_scene_bvh(ref.bvh, big, {0}, {0});
+    hip::update_trace_bvh(dev, big, {0}, {0});
+    EXPECT(std::memcmp(dev.bvh.shapes[0].bvh.nodes.data(), ref.bvh.shapes[0].bvh.nodes.data(),
+               ref.bvh.shapes[0].bvh.nodes.size() * sizeof(bvh_node)) == 0, "refitted BLAS nodes differ");
+    EXPECT(std::memcmp(dev.bvh.bvh.nodes.data(), ref.bvh.bvh.nodes.data(),
+               ref.bvh.bvh.nodes.size() * sizeof(bvh_node)) == 0, "refitted TLAS nodes differ");
+    auto cpu2 = make_trace_state(big, params);
+    auto gpu2 = make_trace_state(big, params);
+    trace_samples(cpu2, big, ref, lights, params);
+    hip::trace_samples(gpu2, big, dev, lights, params);  // resident tree, refitted in place
+    EXPECT(same_bytes(cpu2.image, gpu2.image) && same_bytes(cpu2.normal, gpu2.normal) && same_bytes(cpu2.rngs, gpu2.rngs),
+        "eyelight after update_trace_bvh differs");
+    EXPECT(!same_bytes(cpu.image, cpu2.image), "the edit did not change the picture");
     hip::release();
   }
 

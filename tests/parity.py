@@ -292,6 +292,63 @@ def render_pair(name, sampler="path", resolution=64, samples=4, batch=None, **kw
 
 
 # ----------------------------------------------------------------------------
+# scene edits that keep the element lists (update_scene_bvh, yocto_bvh.cpp:434-451)
+# ----------------------------------------------------------------------------
+def edit_scene(flat, seed=11, shapes=None, amount=0.05):
+    """Deep copy of `flat` with the vertices of `shapes` (default: every other
+    shape, at least one) displaced, their normals perturbed, their radii rescaled, a few coordinates snapped
+    to +0 / -0 (the merge order decides the sign of such a box face), and every
+    third instance re-posed.  Returns (edited, moved_shapes, moved_instances)."""
+    import copy
+    rng = np.random.default_rng(seed)
+    ed = copy.deepcopy(flat)
+    if shapes is None:
+        shapes = list(range(0, len(flat.shapes), 2))
+    for s in shapes:
+        off, n = int(ed.shapes[s]["positions_offset"]), int(ed.shapes[s]["num_positions"])
+        if n == 0:
+            continue
+        pos = ed.positions[off:off + n]
+        ext = max(float(np.abs(pos).max()), 1e-3)
+        pos += (rng.normal(size=pos.shape) * amount * ext).astype(f32)
+        k = max(n // 16, 1)
+        pos[rng.integers(0, n, k), rng.integers(0, 3, k)] = f32(0.0)
+        pos[rng.integers(0, n, k), rng.integers(0, 3, k)] = f32(-0.0)
+        noff, nn = int(ed.shapes[s]["normals_offset"]), int(ed.shapes[s]["num_normals"])
+        if nn > 0:  # shading normals move with the surface
+            nrm = ed.normals[noff:noff + nn] + (rng.normal(size=(nn, 3)) * 0.1).astype(f32)
+            ed.normals[noff:noff + nn] = (nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-6)).astype(f32)
+        roff, rn = int(ed.shapes[s]["radius_offset"]), int(ed.shapes[s]["num_radius"])
+        if rn > 0:
+            ed.radius[roff:roff + rn] *= (0.5 + rng.random((rn, 1))).astype(f32)
+    moved = list(range(0, len(flat.instances), 3))
+    for i in moved:
+        fr = ed.instances[i]["frame"].reshape(4, 3).copy()
+        a = rng.random() * 0.5
+        rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], f32)
+        fr[:3] = (fr[:3] @ rot).astype(f32)
+        fr[3] += (rng.normal(size=3) * amount).astype(f32)
+        ed.instances[i]["frame"] = fr.reshape(12)
+    return ed, list(shapes), moved
+
+
+def apply_edit_to_ref(ref_scene, edited, shapes, instances):
+    for s in shapes:
+        a = edited.shape_arrays(s)
+        ref_scene.set_vertices(s, a["positions"], a["normals"], a["radius"])
+    for i in instances:
+        ref_scene.set_instance_frame(i, edited.instances[i]["frame"])
+
+
+def apply_edit_to_gpu(ctx, edited, shapes, instances):
+    for s in shapes:
+        a = edited.shape_arrays(s)
+        ctx.update_shape_vertices(s, a["positions"], a["normals"], a["radius"])
+    if instances:
+        ctx.update_instance_frames(instances, np.stack([edited.instances[i]["frame"] for i in instances]))
+
+
+# ----------------------------------------------------------------------------
 # comparison
 # ----------------------------------------------------------------------------
 def image_stats(a, b):

@@ -190,8 +190,9 @@ inline int kind_eval(const ythip_shape& s) {
   return 0;
 }
 
-// make_shape_bvh — yocto_bvh.cpp:321-362 (primitive bounds: yocto_geometry.h:475-498)
-inline tree make_shape_bvh(const ythip_scene& sc, const ythip_shape& s, bool highquality) {
+// the primitive bounds of make_shape_bvh / update_shape_bvh — yocto_bvh.cpp:321-357, 398-428
+// (yocto_geometry.h:475-498)
+inline std::vector<bbox> shape_prim_bboxes(const ythip_scene& sc, const ythip_shape& s) {
   auto        bboxes = std::vector<bbox>{};
   const auto* P      = sc.positions + 3 * s.positions_offset;
   const auto* R      = sc.radius ? sc.radius + s.radius_offset : nullptr;
@@ -227,8 +228,33 @@ inline tree make_shape_bvh(const ythip_scene& sc, const ythip_shape& s, bool hig
       bboxes[i] = {vmin(p0, vmin(p1, vmin(p2, p3))), vmax(p0, vmax(p1, vmax(p2, p3)))};
     }
   }
+  return bboxes;
+}
+
+// make_shape_bvh — yocto_bvh.cpp:321-362
+inline tree make_shape_bvh(const ythip_scene& sc, const ythip_shape& s, bool highquality) {
   // NB: an element-less shape still gets a one-node tree (empty leaf, invalid bbox), as in the reference
-  return make_bvh(bboxes, highquality);
+  return make_bvh(shape_prim_bboxes(sc, s), highquality);
+}
+
+// refit_bvh — yocto_bvh.cpp:305-319: boxes bottom-up (children sit behind their parent
+// in the node array), topology and `primitives` untouched; the merge order is the
+// reference's (it decides the sign of a zero face).
+inline void refit_bvh(ythip_bvh_node* nodes, int64_t num_nodes, const int32_t* prims, const std::vector<bbox>& bboxes) {
+  auto box_of = [](const ythip_bvh_node& n) {
+    return bbox{{n.bbox_min[0], n.bbox_min[1], n.bbox_min[2]}, {n.bbox_max[0], n.bbox_max[1], n.bbox_max[2]}};
+  };
+  for (auto nodeid = num_nodes - 1; nodeid >= 0; nodeid--) {
+    auto& node = nodes[nodeid];
+    auto  box  = bbox{};
+    if (node.internal) {
+      for (auto idx = 0; idx < 2; idx++) box = merge(box, box_of(nodes[node.start + idx]));
+    } else {
+      for (auto idx = 0; idx < node.num; idx++) box = merge(box, bboxes[prims[node.start + idx]]);
+    }
+    node.bbox_min[0] = box.min.x, node.bbox_min[1] = box.min.y, node.bbox_min[2] = box.min.z;
+    node.bbox_max[0] = box.max.x, node.bbox_max[1] = box.max.y, node.bbox_max[2] = box.max.z;
+  }
 }
 
 // transform_point(frame, p) — yocto_math.h:2263
@@ -302,6 +328,29 @@ inline flat_bvh make_scene_bvh(const ythip_scene& sc, bool highquality) {
   out.node_offset.push_back((int64_t)out.nodes.size());
   out.prim_offset.push_back((int64_t)out.prims.size());
   return out;
+}
+
+// update_scene_bvh — yocto_bvh.cpp:434-451 on the flat layout: refit the listed
+// shapes' trees from the scene's current vertices, then the instance tree from every
+// instance's current frame.
+inline void update_scene_bvh(flat_bvh& b, const ythip_scene& sc, const int32_t* updated_shapes, int num_shapes) {
+  for (auto k = 0; k < num_shapes; k++) {
+    auto s = updated_shapes[k];
+    refit_bvh(b.nodes.data() + b.node_offset[s], b.node_offset[s + 1] - b.node_offset[s],
+        b.prims.data() + b.prim_offset[s], shape_prim_bboxes(sc, sc.shapes[s]));
+  }
+  auto bboxes = std::vector<bbox>(sc.num_instances);
+  for (auto k = 0; k < sc.num_instances; k++) {
+    auto& inst = sc.instances[k];
+    auto  s    = inst.shape;
+    if (b.node_offset[s + 1] == b.node_offset[s]) continue;
+    auto& n   = b.nodes[b.node_offset[s]];
+    bboxes[k] = transform_bbox(inst.frame, bbox{{n.bbox_min[0], n.bbox_min[1], n.bbox_min[2]},
+                                               {n.bbox_max[0], n.bbox_max[1], n.bbox_max[2]}});
+  }
+  auto t = sc.num_shapes;
+  refit_bvh(b.nodes.data() + b.node_offset[t], b.node_offset[t + 1] - b.node_offset[t],
+      b.prims.data() + b.prim_offset[t], bboxes);
 }
 
 // inverse(frame, non_rigid = true) — yocto_math.h:2114-2118, 1967-1974

@@ -53,4 +53,11 @@ int bake_shape_tree(hipStream_t stream, const DeviceTree& tree, int kind, const 
     const float* positions, const float* radius, int64_t pair_base, int64_t prim_base, int64_t leaf_base,
     float4* pairs, float4* quads, float4* leafdata, float* root_out, std::string* err);
 
+// refit_bvh (yocto_bvh.cpp:305-319) of a resident tree after the shape's vertices moved
+// (update_shape_bvh, yocto_bvh.cpp:398-431): every box recomputed bottom-up, topology
+// and `prims` untouched, the same boxes bit for bit as the host sweep.  tree.build_ms
+// = device time of the refit.
+int refit_shape_tree(hipStream_t stream, DeviceTree& tree, int kind, const int32_t* elems, const float* positions,
+    const float* radius, std::string* err);
+
 }  // namespace ytgpu

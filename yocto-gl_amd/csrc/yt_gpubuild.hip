@@ -78,16 +78,13 @@ struct float3x {
 };
 
 // primitive bounds — yocto_bvh.cpp:327-355 with yocto_geometry.h:475-498
-__global__ void k_init(int kind, const int* elems, const float* P, const float* R, int n, float4* bbmin,
-    float4* bbmax, int* prim, int* node_of) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void prim_bounds(int kind, const int* elems, const float* P, const float* R, int i,
+    float3x& lo, float3x& hi) {
   auto ld  = [&](int v) { return float3x{P[3 * v], P[3 * v + 1], P[3 * v + 2]}; };
   auto mn2 = [](float3x a, float3x b) { return float3x{fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)}; };
   auto mx2 = [](float3x a, float3x b) { return float3x{fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)}; };
   auto add = [](float3x a, float r) { return float3x{a.x + r, a.y + r, a.z + r}; };
   auto sub = [](float3x a, float r) { return float3x{a.x - r, a.y - r, a.z - r}; };
-  float3x lo, hi;
   if (kind == 1) {  // point_bounds(p, r) = {min(p - r, p + r), max(p - r, p + r)}
     int  v = elems[i];
     auto p = ld(v);
@@ -105,6 +102,14 @@ __global__ void k_init(int kind, const int* elems, const float* P, const float* 
     auto p0 = ld(elems[4 * i]), p1 = ld(elems[4 * i + 1]), p2 = ld(elems[4 * i + 2]), p3 = ld(elems[4 * i + 3]);
     lo = mn2(p0, mn2(p1, mn2(p2, p3))), hi = mx2(p0, mx2(p1, mx2(p2, p3)));
   }
+}
+
+__global__ void k_init(int kind, const int* elems, const float* P, const float* R, int n, float4* bbmin,
+    float4* bbmax, int* prim, int* node_of) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  float3x lo, hi;
+  prim_bounds(kind, elems, P, R, i, lo, hi);
   bbmin[i]   = {lo.x, lo.y, lo.z, 0};
   bbmax[i]   = {hi.x, hi.y, hi.z, 0};
   prim[i]    = i;
@@ -524,6 +529,71 @@ __global__ void k_bake_leaf(int kind, const int* elems, const float* P, const fl
   }
 }
 
+// ---- refit_bvh (yocto_bvh.cpp:305-319) on a resident tree ---------------------------------
+// The reference sweeps the node array backwards (children sit behind their parent).
+// Here every leaf recomputes its box from the moved vertices and climbs: the second of
+// two siblings to arrive at the parent (an atomic counter per node decides) merges the
+// children — always child 0 then child 1 into the invalid box, the reference's order,
+// which fixes the sign of a zero face — and goes on.  One launch, no level lists.
+__global__ void k_refit_parents(const ythip_bvh_node* nodes, int n, int* parent, int* arrived) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  arrived[i] = 0;
+  if (i == 0) parent[0] = -1;
+  if (nodes[i].internal) parent[nodes[i].start] = i, parent[nodes[i].start + 1] = i;
+}
+
+__device__ __forceinline__ void store_box(ythip_bvh_node* node, float3x lo, float3x hi) {
+  // agent-scope stores / loads: the sibling that merges may sit on another XCD (own L2)
+  __hip_atomic_store(&node->bbox_min[0], lo.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&node->bbox_min[1], lo.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&node->bbox_min[2], lo.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&node->bbox_max[0], hi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&node->bbox_max[1], hi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&node->bbox_max[2], hi.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void load_box(const ythip_bvh_node* node, float3x& lo, float3x& hi) {
+  lo.x = __hip_atomic_load(&node->bbox_min[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  lo.y = __hip_atomic_load(&node->bbox_min[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  lo.z = __hip_atomic_load(&node->bbox_min[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  hi.x = __hip_atomic_load(&node->bbox_max[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  hi.y = __hip_atomic_load(&node->bbox_max[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  hi.z = __hip_atomic_load(&node->bbox_max[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_refit(ythip_bvh_node* nodes, int n, const int* prims, int kind, const int* elems, const float* P,
+    const float* R, const int* parent, int* arrived) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  ythip_bvh_node node = nodes[i];
+  if (node.internal) return;
+  constexpr float FMAX = 3.402823466e+38f;
+  float3x lo = {FMAX, FMAX, FMAX}, hi = {-FMAX, -FMAX, -FMAX};  // invalidb3f
+  for (int k = 0; k < node.num; k++) {  // merge(node.bbox, bboxes[primitives[start + k]])
+    float3x a, b;
+    prim_bounds(kind, elems, P, R, prims[node.start + k], a, b);
+    lo = {fmin_(lo.x, a.x), fmin_(lo.y, a.y), fmin_(lo.z, a.z)};
+    hi = {fmax_(hi.x, b.x), fmax_(hi.y, b.y), fmax_(hi.z, b.z)};
+  }
+  store_box(&nodes[i], lo, hi);
+  int cur = i;
+  while (true) {
+    int p = parent[cur];
+    if (p < 0) break;
+    // acq_rel at agent scope: my box is visible before my arrival, the sibling's box after its arrival
+    if (__hip_atomic_fetch_add(&arrived[p], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0)
+      break;  // the sibling is still on its way: it will do the parent
+    int     c0 = nodes[p].start;
+    float3x l0, h0, l1, h1;
+    load_box(&nodes[c0], l0, h0);
+    load_box(&nodes[c0 + 1], l1, h1);
+    lo = {fmin_(fmin_(FMAX, l0.x), l1.x), fmin_(fmin_(FMAX, l0.y), l1.y), fmin_(fmin_(FMAX, l0.z), l1.z)};
+    hi = {fmax_(fmax_(-FMAX, h0.x), h1.x), fmax_(fmax_(-FMAX, h0.y), h1.y), fmax_(fmax_(-FMAX, h0.z), h1.z)};
+    store_box(&nodes[p], lo, hi);
+    cur = p;
+  }
+}
+
 int grid(long long n) { return (int)((n + BLK - 1) / BLK); }
 
 #define GCHECK(call)                                                                                   \
@@ -680,6 +750,37 @@ int bake_shape_tree(hipStream_t s, const DeviceTree& tree, int kind, const int32
   int ref = root.internal ? (int)pair_base
                           : (int)(0x80000000u | ((unsigned)(root.num & 7) << 28) | (unsigned)(prim_base + root.start));
   std::memcpy(&root_out[6], &ref, 4);
+  cleanup();
+  return BUILD_OK;
+}
+
+int refit_shape_tree(hipStream_t s, DeviceTree& tree, int kind, const int32_t* elems, const float* positions,
+    const float* radius, std::string* err) {
+  const int n = (int)tree.num_nodes;
+  if (n <= 0) return BUILD_OK;
+  if ((kind == 1 || kind == 2) && !radius) return BUILD_FALLBACK;
+  int* scratch = nullptr;
+  auto cleanup = [&]() {
+    if (scratch) (void)hipFree(scratch);
+    scratch = nullptr;
+  };
+  GCHECK(hipMalloc((void**)&scratch, 2 * (size_t)n * sizeof(int)));
+  int *parent = scratch, *arrived = scratch + n;
+  hipEvent_t e0, e1;
+  GCHECK(hipEventCreate(&e0));
+  GCHECK(hipEventCreate(&e1));
+  GCHECK(hipEventRecord(e0, s));
+  hipLaunchKernelGGL(k_refit_parents, dim3(grid(n)), dim3(BLK), 0, s, tree.nodes, n, parent, arrived);
+  hipLaunchKernelGGL(k_refit, dim3(grid(n)), dim3(BLK), 0, s, tree.nodes, n, tree.prims, kind, elems, positions,
+      radius, parent, arrived);
+  GCHECK(hipEventRecord(e1, s));
+  GCHECK(hipStreamSynchronize(s));
+  GCHECK(hipGetLastError());
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  tree.build_ms = ms;
   cleanup();
   return BUILD_OK;
 }

@@ -833,6 +833,133 @@ int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* sc, int highquality) {
   return build_bvh_mixed(ctx, *sc, highquality != 0, ctx->bvh_builder != 0);
 }
 
+// ---- update_scene_bvh (yocto_bvh.cpp:434-451) -------------------------------------------
+int ythip_update_shape_vertices(ythip_ctx* ctx, int32_t shape, const float* positions, int64_t num_positions,
+    const float* normals, int64_t num_normals, const float* radius, int64_t num_radius) {
+  if (!ctx) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  if (shape < 0 || shape >= (int)ctx->h_shapes.size())
+    return fail(ctx, YTHIP_ERR_INVALID, "shape %d out of range [0,%d)", shape, (int)ctx->h_shapes.size());
+  const auto& sh = ctx->h_shapes[shape];
+  if (positions && num_positions != sh.num_positions)
+    return fail(ctx, YTHIP_ERR_INVALID, "shape %d has %lld positions resident, %lld given", shape,
+        (long long)sh.num_positions, (long long)num_positions);
+  if (normals && num_normals != sh.num_normals)
+    return fail(ctx, YTHIP_ERR_INVALID, "shape %d has %lld normals resident, %lld given", shape,
+        (long long)sh.num_normals, (long long)num_normals);
+  if (radius && num_radius != sh.num_radius)
+    return fail(ctx, YTHIP_ERR_INVALID, "shape %d has %lld radii resident, %lld given", shape, (long long)sh.num_radius,
+        (long long)num_radius);
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  if (normals && num_normals > 0)  // shading data only: no host copy is kept
+    HIPCHECK(ctx, hipMemcpyAsync((void*)(ctx->ds.normals + 3 * sh.normals_offset), normals, (size_t)num_normals * 12,
+                      hipMemcpyHostToDevice, ctx->stream));
+  if (positions && num_positions > 0) {
+    std::memcpy(ctx->h_positions.data() + 3 * sh.positions_offset, positions, (size_t)num_positions * 12);
+    HIPCHECK(ctx, hipMemcpyAsync((void*)(ctx->ds.positions + 3 * sh.positions_offset), positions,
+                      (size_t)num_positions * 12, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (radius && num_radius > 0) {
+    std::memcpy(ctx->h_radius.data() + sh.radius_offset, radius, (size_t)num_radius * 4);
+    HIPCHECK(ctx, hipMemcpyAsync((void*)(ctx->ds.radius + sh.radius_offset), radius, (size_t)num_radius * 4,
+                      hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffers are free again
+  return YTHIP_OK;
+}
+
+int ythip_update_instance_frames(ythip_ctx* ctx, const int32_t* instances, int32_t num, const ythip_frame* frames) {
+  if (!ctx || (num > 0 && (!instances || !frames))) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  for (int k = 0; k < num; k++)
+    if (instances[k] < 0 || instances[k] >= (int)ctx->h_instances.size())
+      return fail(ctx, YTHIP_ERR_INVALID, "instance %d out of range [0,%d)", instances[k], (int)ctx->h_instances.size());
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  for (int k = 0; k < num; k++) {
+    ctx->h_instances[instances[k]].frame = frames[k];
+    HIPCHECK(ctx, hipMemcpyAsync((void*)&ctx->ds.instances[instances[k]].frame, &frames[k], sizeof(ythip_frame),
+                      hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return YTHIP_OK;
+}
+
+int ythip_update_bvh(ythip_ctx* ctx, const int32_t* updated_instances, int32_t num_instances,
+    const int32_t* updated_shapes, int32_t num_shapes) {
+  (void)updated_instances, (void)num_instances;  // every instance box is recomputed — yocto_bvh.cpp:441-447
+  if (!ctx || (num_shapes > 0 && !updated_shapes)) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "update_bvh needs scene and bvh resident");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  auto  t_start = std::chrono::steady_clock::now();
+  auto& b       = ctx->h_bvh;
+  int   nshapes = (int)ctx->h_shapes.size();
+  for (int k = 0; k < num_shapes; k++)
+    if (updated_shapes[k] < 0 || updated_shapes[k] >= nshapes)
+      return fail(ctx, YTHIP_ERR_INVALID, "shape %d out of range [0,%d)", updated_shapes[k], nshapes);
+  ctx->build_info = {};
+  auto on_device  = [&](int t) { return t < (int)ctx->d_trees.size() && ctx->d_trees[t].nodes != nullptr; };
+  // host-side view of the element pools (what make_shape_bvh read at build time)
+  ythip_scene view = {};
+  view.positions = ctx->h_positions.data(), view.radius = ctx->h_radius.empty() ? nullptr : ctx->h_radius.data();
+  view.points = ctx->h_points.data(), view.lines = ctx->h_lines.data();
+  view.triangles = ctx->h_triangles.data(), view.quads = ctx->h_quads.data();
+  // update_shape_bvh — yocto_bvh.cpp:398-431
+  for (int k = 0; k < num_shapes; k++) {
+    int         s  = updated_shapes[k];
+    const auto& sh = ctx->h_shapes[s];
+    if (on_device(s)) {
+      int        kind = ythost::kind_bvh(sh);
+      const int* el   = kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
+                        : kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
+                        : kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
+                                               : ctx->ds.points + sh.points_offset;
+      std::string err;
+      if (ytgpu::refit_shape_tree(ctx->stream, ctx->d_trees[s], kind, el, ctx->ds.positions + 3 * sh.positions_offset,
+              sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, &err) !=
+          ytgpu::BUILD_OK)
+        return fail(ctx, YTHIP_ERR_HIP, "device bvh refit failed: %s", err.c_str());
+      ctx->d_tree_on_host[s] = 0;  // the host copy of this tree is stale now
+      ctx->build_info.device_trees += 1;
+      ctx->build_info.device_prims += ctx->d_trees[s].num_prims;
+      ctx->build_info.device_ms += ctx->d_trees[s].build_ms;
+    } else {
+      auto bboxes = ythost::shape_prim_bboxes(view, sh);
+      ythost::refit_bvh(b.nodes.data() + b.node_offset[s], b.node_offset[s + 1] - b.node_offset[s],
+          b.prims.data() + b.prim_offset[s], bboxes);
+      ctx->build_info.host_trees += 1;
+    }
+  }
+  // the instance tree — yocto_bvh.cpp:441-450
+  std::vector<ythost::bbox> roots(nshapes);
+  std::vector<char>         empty(nshapes, 1);
+  for (int s = 0; s < nshapes; s++) {
+    ythip_bvh_node root;
+    if (on_device(s) && !ctx->d_tree_on_host[s]) {
+      HIPCHECK(ctx, hipMemcpy(&root, ctx->d_trees[s].nodes, sizeof(root), hipMemcpyDeviceToHost));
+    } else {
+      if (b.node_offset[s + 1] == b.node_offset[s]) continue;
+      root = b.nodes[b.node_offset[s]];
+    }
+    empty[s]     = 0;
+    roots[s].min = {root.bbox_min[0], root.bbox_min[1], root.bbox_min[2]};
+    roots[s].max = {root.bbox_max[0], root.bbox_max[1], root.bbox_max[2]};
+  }
+  std::vector<ythost::bbox> bboxes(ctx->h_instances.size());
+  for (size_t k = 0; k < bboxes.size(); k++) {
+    const auto& inst = ctx->h_instances[k];
+    bboxes[k]        = empty[inst.shape] ? ythost::bbox{} : ythost::transform_bbox(inst.frame, roots[inst.shape]);
+  }
+  ythost::refit_bvh(b.nodes.data() + b.node_offset[nshapes], b.node_offset[nshapes + 1] - b.node_offset[nshapes],
+      b.prims.data() + b.prim_offset[nshapes], bboxes);
+  ctx->build_info.build_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  auto t_bake = std::chrono::steady_clock::now();
+  int  rc     = bake_bvh(ctx);
+  ctx->build_info.bake_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bake).count();
+  return rc;
+}
+
 int ythip_set_bvh_builder(ythip_ctx* ctx, int mode, int64_t min_prims) {
   if (!ctx || mode < 0 || mode > 1) return fail(ctx, YTHIP_ERR_INVALID, "bvh builder mode must be 0 (host) or 1 (device)");
   ctx->bvh_builder = mode;
@@ -914,6 +1041,18 @@ int ythip_host_bvh_view(const ythip_hostbvh* bvh, ythip_bvh* view) {
   view->prim_offset = b->prim_offset.data();
   view->nodes       = b->nodes.data();
   view->primitives  = b->prims.data();
+  return YTHIP_OK;
+}
+int ythip_host_bvh_refit(ythip_hostbvh* bvh, const ythip_scene* sc, const int32_t* updated_shapes, int32_t num_shapes) {
+  if (!bvh || !sc || (num_shapes > 0 && !updated_shapes)) return fail(nullptr, YTHIP_ERR_INVALID, "null argument");
+  auto& b = *reinterpret_cast<ythost::flat_bvh*>(bvh);
+  if ((int)b.node_offset.size() != sc->num_shapes + 2)
+    return fail(nullptr, YTHIP_ERR_INVALID, "bvh was built for %d shapes, scene has %d", (int)b.node_offset.size() - 2,
+        sc->num_shapes);
+  for (int k = 0; k < num_shapes; k++)
+    if (updated_shapes[k] < 0 || updated_shapes[k] >= sc->num_shapes)
+      return fail(nullptr, YTHIP_ERR_INVALID, "shape %d out of range [0,%d)", updated_shapes[k], sc->num_shapes);
+  ythost::update_scene_bvh(b, *sc, updated_shapes, num_shapes);
   return YTHIP_OK;
 }
 void ythip_host_bvh_free(ythip_hostbvh* bvh) { delete reinterpret_cast<ythost::flat_bvh*>(bvh); }

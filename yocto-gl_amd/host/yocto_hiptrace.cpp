@@ -404,6 +404,56 @@ trace_bvh make_trace_bvh(const scene_data& scene, const trace_params& params) {
   return out;
 }
 
+void update_trace_bvh(trace_bvh& bvh, const scene_data& scene, const vector<int>& updated_instances,
+    const vector<int>& updated_shapes) {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  for (auto s : updated_shapes)
+    if (s < 0 || s >= (int)scene.shapes.size()) throw std::out_of_range("update_trace_bvh: shape index");
+  for (auto i : updated_instances)
+    if (i < 0 || i >= (int)scene.instances.size()) throw std::out_of_range("update_trace_bvh: instance index");
+  auto fresh_scene = stamp_of(scene) != r.scene;
+  ensure_scene(r, scene);  // a scene that was not resident goes up whole, already edited
+  if (auto bs = stamp_of(bvh); bs != r.bvh) {
+    flat_bvh f;
+    flatten(bvh.bvh, f);
+    check(r.ctx, ythip_upload_bvh(r.ctx, &f.view));
+    r.bvh = bs;
+  }
+  if (!fresh_scene) {
+    for (auto s : updated_shapes) {
+      auto& sh = scene.shapes[s];
+      check(r.ctx, ythip_update_shape_vertices(r.ctx, s, sh.positions.empty() ? nullptr : &sh.positions[0].x,
+                       (int64_t)sh.positions.size(), sh.normals.empty() ? nullptr : &sh.normals[0].x,
+                       (int64_t)sh.normals.size(), sh.radius.empty() ? nullptr : sh.radius.data(),
+                       (int64_t)sh.radius.size()));
+    }
+    auto frames = std::vector<ythip_frame>{};
+    for (auto i : updated_instances) frames.push_back(flat(scene.instances[i].frame));
+    check(r.ctx, ythip_update_instance_frames(r.ctx, updated_instances.data(), (int)updated_instances.size(),
+                     frames.data()));
+  }
+  check(r.ctx, ythip_update_bvh(r.ctx, updated_instances.data(), (int)updated_instances.size(),
+                   updated_shapes.data(), (int)updated_shapes.size()));
+  // the refitted boxes back into the caller's trace_bvh (listed shapes + the instance tree)
+  int32_t ntrees = 0;
+  int64_t nnodes = 0, nprims = 0;
+  check(r.ctx, ythip_bvh_sizes(r.ctx, &ntrees, &nnodes, &nprims));
+  if (ntrees != (int)bvh.bvh.shapes.size() + 1) throw std::invalid_argument("update_trace_bvh: bvh / scene mismatch");
+  auto node_offset = std::vector<int64_t>(ntrees + 1), prim_offset = std::vector<int64_t>(ntrees + 1);
+  auto nodes       = std::vector<ythip_bvh_node>((size_t)nnodes);
+  auto prims       = std::vector<int32_t>((size_t)nprims);
+  check(r.ctx, ythip_bvh_download(r.ctx, node_offset.data(), prim_offset.data(), nodes.data(), prims.data()));
+  auto fill = [&](bvh_tree& t, int k) {
+    auto n = (size_t)(node_offset[k + 1] - node_offset[k]);
+    if (n != t.nodes.size()) throw std::invalid_argument("update_trace_bvh: tree sizes changed");
+    if (n) std::memcpy((void*)t.nodes.data(), nodes.data() + node_offset[k], n * sizeof(bvh_node));
+  };
+  for (auto s : updated_shapes) fill(bvh.bvh.shapes[s].bvh, s);
+  fill(bvh.bvh.bvh, ntrees - 1);
+  r.bvh = stamp_of(bvh);
+}
+
 void trace_samples(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,
     const trace_params& params) {
   trace_impl(state, scene, bvh, lights, params, true);

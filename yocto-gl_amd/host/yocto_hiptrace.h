@@ -43,6 +43,15 @@ trace_state  make_trace_state(const scene_data& scene, const trace_params& param
 trace_lights make_trace_lights(const scene_data& scene, const trace_params& params);
 trace_bvh    make_trace_bvh(const scene_data& scene, const trace_params& params);
 
+// update_scene_bvh (yocto_bvh.h:88-90, yocto_bvh.cpp:434-451) for a trace_bvh: after the
+// caller moved vertices of `updated_shapes` (positions / normals / radius, same counts)
+// and / or instance frames in `scene`, refit instead of rebuilding.  The new vertices
+// and frames go to the device, trees built there are refitted there (yt_gpubuild.hip),
+// and `bvh` receives the refitted boxes — the reference's, bit for bit — so it stays
+// usable by either back-end.  Lights are the caller's business, as in the reference.
+void update_trace_bvh(trace_bvh& bvh, const scene_data& scene, const vector<int>& updated_instances,
+    const vector<int>& updated_shapes);
+
 // yocto_trace.h:171-173 — the accelerated call.  Synchronous; on return the host
 // vectors of `state` hold the new running means and `state.samples` has grown
 // by params.batch (no-op when state.samples >= params.samples,

@@ -405,6 +405,10 @@ _SIGNATURES = {
     "ythip_upload_bvh": (C.c_int, [C.c_void_p, C.POINTER(CBvh)]),
     "ythip_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "ythip_bvh_build_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_update_shape_vertices": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_int64]),
+    "ythip_update_instance_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "ythip_update_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "ythip_bvh_baked_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ythip_bvh_baked_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ythip_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
@@ -415,6 +419,7 @@ _SIGNATURES = {
                                        C.POINTER(C.c_void_p)]),
     "ythip_host_bvh_view": (C.c_int, [C.c_void_p, C.POINTER(CBvh)]),
     "ythip_host_bvh_free": (None, [C.c_void_p]),
+    "ythip_host_bvh_refit": (C.c_int, [C.c_void_p, C.POINTER(CScene), C.c_void_p, C.c_int32]),
     "ythip_host_lights_build": (C.c_int, [C.POINTER(CScene), C.POINTER(C.c_void_p)]),
     "ythip_host_lights_view": (C.c_int, [C.c_void_p, C.POINTER(CLights)]),
     "ythip_host_lights_free": (None, [C.c_void_p]),
@@ -519,6 +524,26 @@ def host_make_bvh(scene, highquality=False):
     return out
 
 
+def host_update_bvh(scene, edited_scene, updated_shapes, highquality=False):
+    """make_scene_bvh of `scene`, then update_scene_bvh (yocto_bvh.cpp:434-451) with
+    `edited_scene` (same element lists, moved vertices / instances); host only."""
+    lib = load_library()
+    cs, ce = scene.c_struct(), edited_scene.c_struct()
+    h = C.c_void_p()
+    if lib.ythip_host_bvh_build(C.byref(cs), int(highquality), C.byref(h)):
+        raise YthipError("ythip_host_bvh_build failed")
+    vs = np.ascontiguousarray(list(updated_shapes), "i4")
+    rc = lib.ythip_host_bvh_refit(h, C.byref(ce), _ptr(vs), len(vs))
+    if rc:
+        lib.ythip_host_bvh_free(h)
+        raise YthipError("ythip_host_bvh_refit failed")
+    cb = CBvh()
+    lib.ythip_host_bvh_view(h, C.byref(cb))
+    out = FlatBvh.from_c(cb)
+    lib.ythip_host_bvh_free(h)
+    return out
+
+
 def host_make_lights(scene):
     """make_trace_lights (yocto_trace.cpp:1528-1581) on the host, no GPU needed."""
     lib = load_library()
@@ -590,6 +615,27 @@ class Context:
         """mode "device" (default: shapes >= min_prims are built on the GPU) or "host"."""
         self._check(self.lib.ythip_set_bvh_builder(self.h, {"host": 0, "device": 1}[mode], min_prims),
                     "set_bvh_builder")
+
+    def update_shape_vertices(self, shape, positions=None, normals=None, radius=None):
+        """New positions / normals / radii of a resident shape (same counts; element lists stay)."""
+        p = None if positions is None else np.ascontiguousarray(positions, "f4").reshape(-1, 3)
+        nrm = None if normals is None else np.ascontiguousarray(normals, "f4").reshape(-1, 3)
+        r = None if radius is None else np.ascontiguousarray(radius, "f4").reshape(-1)
+        cnt = lambda a: 0 if a is None else len(a)  # noqa: E731
+        self._check(self.lib.ythip_update_shape_vertices(
+            self.h, int(shape), _ptr(p), cnt(p), _ptr(nrm), cnt(nrm), _ptr(r), cnt(r)), "update_shape_vertices")
+
+    def update_instance_frames(self, instances, frames):
+        ids = np.ascontiguousarray(instances, "i4").reshape(-1)
+        fr = np.ascontiguousarray(frames, "f4").reshape(len(ids), 12)
+        self._check(self.lib.ythip_update_instance_frames(self.h, _ptr(ids), len(ids), _ptr(fr)),
+                    "update_instance_frames")
+
+    def update_bvh(self, updated_instances=(), updated_shapes=()):
+        """update_scene_bvh (yocto_bvh.cpp:434-451): refit, topology kept."""
+        vi = np.ascontiguousarray(list(updated_instances), "i4")
+        vs = np.ascontiguousarray(list(updated_shapes), "i4")
+        self._check(self.lib.ythip_update_bvh(self.h, _ptr(vi), len(vi), _ptr(vs), len(vs)), "update_bvh")
 
     def bvh_build_info(self):
         info = CBuildInfo()
