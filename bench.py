@@ -7,11 +7,19 @@
   step     one trace_samples call rendering `--spp` (64) more samples for every
            pixel = 1280*720*64 = 58,982,400 camera paths
   N > 1    the frame's 16-pixel tile columns dealt round-robin across ranks
-           (configs[2]; sharding.py — balanced, unlike contiguous row blocks whose
-           top ranks would only see sky); every rank holds a full replica of
-           scene+BVH and its slice of trace_state; one RCCL all-gather of the
-           framebuffer + un-permute per step (inside the timed region).  Total
-           work is fixed → "strong" scaling.
+           (sharding.py — balanced, unlike contiguous row blocks whose top ranks
+           would only see sky); every rank holds a full replica of scene+BVH and
+           its slice of trace_state; no data-path collective; one RCCL all-gather
+           of the framebuffer + un-permute per step (inside the timed region, on
+           the kernel's stream: overlapping it with the next step's kernel on a
+           side stream was measured slower — the persistent kernel holds every CU —
+           see DESIGN.md §7).
+           Primary line, "scaling": "weak" — the frame grows with N at the same
+           camera (N x the pixels of configs[1]: 1280x720 per GPU, see
+           weak_resolution()), so per-GPU work is fixed.
+           The same line carries "configs2_strong": BASELINE configs[2] exactly
+           (the 1280x720 frame split N ways, total work fixed), timed right after
+           the primary region with the same K steps and fences.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -72,6 +80,22 @@ def cpu_baseline(flat, params_kw, budget_s=15.0):
                       f"reference trace_samples via oracle/_ref (g++ -O3, std::async x{cores})"}
 
 
+def weak_resolution(base, world, tile=16):
+    """Width of the weak-scaling frame: the same camera at `world` x the pixels of
+    the `base`-wide frame, i.e. base * sqrt(world), rounded to a multiple of
+    tile * world so every rank owns the same number of 16-pixel tile columns —
+    preferring 8 (then 4, 2) tile columns per rank and row-of-tiles, which keeps a
+    tile column on one XCD under the identity block->tile mapping (measured: a
+    57-column slice runs 8 % slower per pixel than a 56-column one) — as long as
+    the pixel count stays within 5 % of world x base.
+    1280 -> 1792 / 2560 / 3584 for 2 / 4 / 8 ranks: 1.96x / 4x / 7.84x the pixels."""
+    for m in (8, 4, 2, 1):
+        q = tile * world * m
+        w = max(q, int(round(base * world ** 0.5 / q)) * q)
+        if abs(w * w / (base * base * world) - 1) <= 0.05 or m == 1:
+            return w
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,7 +106,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sharding", choices=["columns", "rows"], default="columns")
+    ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
+                    help="N > 1: weak = frame grown to N x the pixels of configs[1] (primary "
+                         "line); strong = configs[2], the 1280x720 frame split N ways; both = "
+                         "weak as the primary line + configs2_strong inside it")
+    ap.add_argument("--overlap-gather", action="store_true",
+                    help="experiment: gather a snapshot of the frame on a side stream while the "
+                         "next step's kernel runs (measured slower than the default)")
     ap.add_argument("--traversal", choices=["auto", "binary", "wide"], default="auto")
+    ap.add_argument("--rehearse-gather", action="store_true",
+                    help="N=1 only: create a world_size-1 RCCL group and run the framebuffer "
+                         "gather path anyway (checks the stream handling on a 1-GPU box)")
     ap.add_argument("--as-rank", default=None, metavar="R/N",
                     help="single-GPU experiment: render only the slice rank R of N would "
                          "(no gather); the JSON line then describes that slice")
@@ -105,9 +139,14 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    gathering = world > 1 or args.rehearse_gather
+    if gathering:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29633")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -125,87 +164,123 @@ def main():
     ctx.set_traversal(args.traversal)
     setup_s = time.time() - t0
     build_info = ctx.bvh_build_info()
-    w, h = yt.state_size(flat.cameras[0], params.resolution)
-    if args.as_rank:
-        vr, vn = (int(x) for x in args.as_rank.split("/"))
-        shard = shard_frame(w, h, vn, vr, args.sharding)
-    else:
-        shard = shard_frame(w, h, world, rank, args.sharding)
-    rngs = yt.make_rngs(params.seed, w * h)
-    ctx.make_trace_state(flat, params, rows=shard.rows, cols=shard.cols, rngs=rngs)
-    npix = shard.npixels
-    assert npix == ctx.npixels
-
-    # state arrays live in torch tensors so the RCCL gather runs on them directly
     dev = torch.device("cuda", local)
-    image = torch.zeros(npix, 4, device=dev)
-    albedo = torch.zeros(npix, 3, device=dev)
-    normal = torch.zeros(npix, 3, device=dev)
-    hits = torch.zeros(npix, dtype=torch.int32, device=dev)
-    trng = torch.from_numpy(shard.take(rngs).view(np.int64).copy()).to(dev)
-    ctx.bind_device_state(image.data_ptr(), albedo.data_ptr(), normal.data_ptr(),
-                          hits.data_ptr(), trng.data_ptr())
-    stream = torch.cuda.Stream(device=dev)  # non-null: kernels and the RCCL gather share it
+    stream = torch.cuda.Stream(device=dev)  # non-null: the kernels run here
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
-    gather = FrameGather(dist, w, h, 4, dev, mode=args.sharding) if world > 1 else None
-
-    def step():
-        ctx.trace_samples_async(params)
-        if world > 1:  # framebuffer gather over RCCL/xGMI (§8e), once per batch
-            gather.frame(image)
+    comm = torch.cuda.Stream(device=dev) if gathering and args.overlap_gather else None
 
     def fence():
-        if world > 1:
+        if gathering:
             dist.barrier()
+        torch.cuda.synchronize()  # device-wide: kernel stream, gather stream, RCCL's own
+
+    def run(resolution, want_roofline):
+        """Render `--steps` timed steps of the frame of the given resolution, sharded
+        over the ranks; returns (seconds [max over ranks], frame size, pixels of this
+        rank, counting-pass stats, timing stats)."""
+        p = yt.trace_params(samples=1 << 30, batch=args.spp, **dict(params_kw, resolution=resolution))
+        w, h = yt.state_size(flat.cameras[0], p.resolution)
+        if args.as_rank:
+            vr, vn = (int(x) for x in args.as_rank.split("/"))
+            shard = shard_frame(w, h, vn, vr, args.sharding)
+        else:
+            shard = shard_frame(w, h, world, rank, args.sharding)
+        rngs = yt.make_rngs(p.seed, w * h)
+        ctx.make_trace_state(flat, p, rows=shard.rows, cols=shard.cols, rngs=rngs)
+        npix = shard.npixels
+        assert npix == ctx.npixels
+        # state arrays live in torch tensors so the RCCL gather runs on them directly
+        image = torch.zeros(npix, 4, device=dev)
+        albedo = torch.zeros(npix, 3, device=dev)
+        normal = torch.zeros(npix, 3, device=dev)
+        hits = torch.zeros(npix, dtype=torch.int32, device=dev)
+        trng = torch.from_numpy(shard.take(rngs).view(np.int64).copy()).to(dev)
         torch.cuda.synchronize()
+        ctx.bind_device_state(image.data_ptr(), albedo.data_ptr(), normal.data_ptr(),
+                              hits.data_ptr(), trng.data_ptr())
+        gather = FrameGather(dist, w, h, 4, dev, mode=args.sharding,
+                             always=args.rehearse_gather) if gathering else None
+        snapshot = torch.empty_like(image) if comm is not None else None
 
-    # ---- algorithmic work of one step (counting pass, untimed) --------------
-    stats_count = None
-    if not args.no_roofline:
-        ctx.set_profiling(2)
-        ctx.reset_stats()
-        step()
+        def step():
+            ctx.trace_samples_async(p)
+            if not gathering:
+                return
+            # framebuffer gather over RCCL/xGMI (§8e), once per batch
+            if comm is None:
+                gather.frame(image)
+                return
+            # the next step's kernel updates `image` in place: gather a snapshot (a
+            # 16 B/pixel device copy) on the side stream while that kernel runs
+            stream.wait_stream(comm)   # the previous gather has read the snapshot
+            snapshot.copy_(image)
+            comm.wait_stream(stream)
+            with torch.cuda.stream(comm):
+                gather.frame(snapshot)
+
+        # algorithmic work of one step (counting pass, untimed)
+        stats_count = None
+        if want_roofline:
+            ctx.set_profiling(2)
+            ctx.reset_stats()
+            step()
+            fence()
+            stats_count = ctx.get_stats()
+            ctx.set_profiling(0)
+        for _ in range(args.warmup):
+            step()
         fence()
-        stats_count = ctx.get_stats()
+        # timed region: exactly K steps
+        ctx.set_profiling(1 if want_roofline else 0)  # hipEvents around the k_trace launches
+        ctx.reset_stats()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        stats_time = ctx.get_stats()
         ctx.set_profiling(0)
-    for _ in range(args.warmup):
-        step()
-    fence()
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if gathering:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # the state's buffers stay referenced until the context is re-bound
+        keep.append((image, albedo, normal, hits, trng, snapshot, gather))
+        return float(tmax.item()), (w, h), npix, stats_count, stats_time
 
-    # ---- timed region: exactly K steps --------------------------------------
-    ctx.set_profiling(0 if args.no_roofline else 1)  # hipEvents around the k_trace launches
-    ctx.reset_stats()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    stats_time = ctx.get_stats()
-    ctx.set_profiling(0)
-
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    keep = []
+    weak = world > 1 and args.scaling in ("weak", "both") and not args.as_rank
+    resolution = weak_resolution(args.resolution, world) if weak else args.resolution
+    dt, (w, h), npix, stats_count, stats_time = run(resolution, not args.no_roofline)
 
     total_samples = (npix if args.as_rank else w * h) * args.spp * args.steps
     value = total_samples / dt / 1e6
+    if world == 1:
+        what = "BASELINE configs[1]"
+    elif weak:
+        what = (f"configs[1] per GPU: the configs[1] camera at {world}x the pixels of "
+                f"{args.resolution}x{args.resolution * 9 // 16}")
+    else:
+        what = "BASELINE configs[2]: the configs[1] frame split across the ranks"
 
     out = {
         "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak" if (weak or world == 1) else "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"1M-triangle plane + constant env, {w}x{h}x{args.spp}spp, "
-                               "sampler=path bounces=8 clamp=10 (BASELINE configs[1]"
-                               + ("/[2] sharded" if world > 1 else "") + ")"
+                               f"sampler=path bounces=8 clamp=10 ({what})"
                                + (f" — ONLY the slice of rank {args.as_rank}" if args.as_rank else ""),
                    "triangles": int(flat.shapes[0]["num_triangles"]),
                    "resolution": [w, h], "spp": args.spp, "pixels_per_rank": npix,
                    "sharding": (f"{args.sharding}/{world}" if world > 1 else "none")
                                if not args.as_rank else f"{args.sharding} {args.as_rank}",
+                   "framebuffer_gather": ("none" if not gathering else
+                                          "rccl all_gather + un-permute per step, "
+                                          + ("on the kernel stream" if comm is None else
+                                             "on a side stream (overlaps the next step)")),
                    "setup_s": round(setup_s, 3),
                    # make_trace_bvh: the 1M-triangle tree is built ON THE DEVICE (identical to
                    # the reference's tree); wall ms of tree construction / baking the traversal layout
@@ -227,7 +302,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic(),
+            "traffic": measured_traffic() if world == 1 and not args.as_rank else None,
             "launch_ms_avg": round(k_ms, 4), "launches_per_step": launches_per_step,
             "bytes_per_launch": int(bytes_per_launch),
             "traversal_bytes_per_launch": int(yt.traversal_bytes(stats_count) / launches_per_step),
@@ -238,6 +313,19 @@ def main():
                            "shades": round(stats_count["shades"] / nsamp, 3),
                            "bytes_all_stages": round(bytes_step / nsamp, 1)},
         }
+        if world > 1:
+            out["roofline"]["note"] = "rank 0's launches (its slice of the frame)"
+    if weak and args.scaling == "both":
+        # BASELINE configs[2] exactly: the 1280x720 frame split N ways (total work
+        # fixed), same K steps between the same fences
+        dt2, (w2, h2), npix2, _, _ = run(args.resolution, False)
+        out["configs2_strong"] = {
+            "value": round(w2 * h2 * args.spp * args.steps / dt2 / 1e6, 3), "unit": "Msamples/s",
+            "ms_per_step": round(dt2 / args.steps * 1e3, 3), "scaling": "strong",
+            "resolution": [w2, h2], "spp": args.spp, "pixels_per_rank": npix2,
+            "note": "a pixel's samples are sequential by contract (its PCG stream and running "
+                    "mean), so one pixel's 64-sample chain (~1.5 ms) bounds the step however "
+                    "few pixels a GPU holds (DESIGN.md §7)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(flat, params_kw)
@@ -245,7 +333,7 @@ def main():
             out["cpu_baseline"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if gathering:
         dist.destroy_process_group()
 
 

@@ -44,6 +44,22 @@ def test_column_shards_balance_the_baseline_frame():
     assert s.xs[:17].tolist() == list(range(48, 64)) + [48 + 128]
 
 
+def test_weak_scaling_frame_keeps_per_rank_work_fixed():
+    # bench.py's primary N > 1 line ("scaling": "weak"): the configs[1] camera at N x the
+    # pixels; every rank owns the same number of tile columns and (to 2 %) the
+    # pixel count of the 1280x720 single-GPU frame
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import bench
+    assert [bench.weak_resolution(1280, n) for n in (1, 2, 4, 8)] == [1280, 1792, 2560, 3584]
+    for world in [1, 2, 3, 4, 8]:
+        w = bench.weak_resolution(1280, world)
+        h = int(round(w * 9 / 16))  # image-size rule for the 16:9 camera
+        assert w % (16 * world) == 0
+        n = [sharding.shard_frame(w, h, world, r).npixels for r in range(world)]
+        assert len(set(n)) == 1 and sum(n) == w * h
+        assert abs(n[0] / (1280 * 720) - 1) < 0.03
+
+
 def test_local_width_matches_library():
     sys.path.insert(0, os.path.join(HERE, "..", "yocto-gl_amd"))
     import ythip as yt

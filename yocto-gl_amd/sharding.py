@@ -92,7 +92,7 @@ class FrameGather:
     (a 14.7 MB copy at 720p)."""
 
     def __init__(self, dist, width, height, channels, device, dtype=None, mode="columns",
-                 shards=None):
+                 shards=None, always=False):
         import torch
         self.dist, self.torch = dist, torch
         self.world = dist.get_world_size() if dist is not None else 1
@@ -101,6 +101,7 @@ class FrameGather:
         self.shards = shards or [shard_frame(width, height, self.world, r, mode)
                                  for r in range(self.world)]
         self.shard = self.shards[self.rank]
+        self.always = always  # run the collective + un-permute even for one rank (rehearsal)
         self.max_n = max(s.npixels for s in self.shards)
         dtype = dtype or torch.float32
         self.even = all(s.npixels == self.max_n for s in self.shards)
@@ -119,7 +120,7 @@ class FrameGather:
     def gather(self, local):
         """local: [npixels of this rank, channels] tensor.  Returns the padded
         gather buffer (rank-major)."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return local
         src = local
         if not self.even:
@@ -130,10 +131,10 @@ class FrameGather:
 
     def frame(self, local):
         """Gather + un-permute into a [height * width, channels] tensor."""
-        if self.world == 1 and self.identity:
+        if self.world == 1 and self.identity and not self.always:
             return local
         packed = self.gather(local)
-        if self.identity:  # row blocks: only the tail padding to drop
+        if self.identity and not self.always:  # row blocks: only the tail padding to drop
             return packed[:self.width * self.height]
         self.torch.index_select(packed, 0, self.perm, out=self.out)
         return self.out
