@@ -84,10 +84,9 @@ def weak_resolution(base, world, tile=16):
     """Width of the weak-scaling frame: the same camera at `world` x the pixels of
     the `base`-wide frame, i.e. base * sqrt(world), rounded to a multiple of
     tile * world so every rank owns the same number of 16-pixel tile columns —
-    preferring 8 (then 4, 2) tile columns per rank and row-of-tiles, which keeps a
-    tile column on one XCD under the identity block->tile mapping (measured: a
-    57-column slice runs 8 % slower per pixel than a 56-column one) — as long as
-    the pixel count stays within 5 % of world x base.
+    preferring a multiple of 8 (then 4, 2) tile columns per rank (measured: 57- and
+    58-column slices run 3-6 % slower per pixel than 56- and 80-column ones) — as
+    long as the pixel count stays within 5 % of world x base.
     1280 -> 1792 / 2560 / 3584 for 2 / 4 / 8 ranks: 1.96x / 4x / 7.84x the pixels."""
     for m in (8, 4, 2, 1):
         q = tile * world * m

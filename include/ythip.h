@@ -366,6 +366,14 @@ int ythip_state_download(ythip_ctx* ctx, float* image, float* albedo,
  * linear.  The download point of a viewer (16 B/pixel instead of the 60 B/pixel
  * of ythip_state_download). */
 int ythip_get_image(ythip_ctx* ctx, float* image);
+/* get_albedo_image / get_normal_image (yocto_trace.h:187-190,
+ * yocto_trace.cpp:1769-1791): the denoiser's guide buffers as images — width*rows
+ * vec4f {albedo.xyz | normal.xyz, 1}, expanded on the device from the vec3f running
+ * means trace_sample keeps (the hand-off to a denoiser).
+ * get_rendered_image (:1711-1721) is ythip_get_image; get_denoised_image
+ * (:1724-1766) without OIDN is get_rendered_image. */
+int ythip_get_albedo_image(ythip_ctx* ctx, float* image);
+int ythip_get_normal_image(ythip_ctx* ctx, float* image);
 /* tonemap_image (yocto_image.cpp:911-922; tonemap yocto_color.h:355-364) of the
  * resident image ON THE DEVICE: exposure in stops, optional filmic curve, optional
  * sRGB encoding.  `ldr` (vec4f per pixel) and/or `ldr_bytes` (vec4b per pixel,
@@ -392,6 +400,14 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params,
     const volatile int32_t* stop);
 /* Same, but only enqueues the work on the stream (pair with ythip_sync). */
 int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params);
+/* trace_sample (yocto_trace.h:174-176, yocto_trace.cpp:1461-1492): ONE sample of the
+ * pixel (i, j) of the frame — the pixel's next four rng draws, one path, the
+ * running-mean update with weight 1 / (sample + 1), hits += 1.  Leaves
+ * state.samples alone, as the reference does.  YTHIP_ERR_INVALID when the pixel is
+ * not part of the resident slice.  Synchronous; a one-workgroup launch of the same
+ * kernel trace_samples uses. */
+int ythip_trace_sample(ythip_ctx* ctx, const ythip_params* params, int i, int j,
+    int sample);
 
 /* Scheduling inside the persistent kernel (no reference equivalent; results do
  * not depend on it).  adaptive_wait = 1 (default): a workgroup that has measured
@@ -400,6 +416,13 @@ int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params);
  * (DESIGN.md §4); 0: every queued ray runs in every iteration.  The environment
  * variable YTHIP_HOLD=0/1 sets the default of new contexts (A/B measurements). */
 int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait);
+/* Early miss (no reference equivalent; results do not depend on it).  1 (default):
+ * trace_path / trace_pathtest decide at the end of a bounce whether the next ray can
+ * enter the scene's root box at all (the test intersect_scene_bvh opens with,
+ * yocto_bvh.cpp:554-590) and, if not, take the next iteration's miss branch
+ * (yocto_trace.cpp:473-477) in place; 0: every continuing ray goes through the queue.
+ * YTHIP_PEEK=0/1 sets the default of new contexts (A/B measurements). */
+int ythip_set_early_miss(ythip_ctx* ctx, int enable);
 
 /* Kernel specialisation by scene content (results do not depend on it).  1 (default):
  * when every material of the resident scene is matte and untextured and every shape

@@ -576,6 +576,17 @@ double ref_trace_samples(ref_state* st, const ref_scene* rs, const ref_bvh* rb,
   return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// trace_sample (yocto_trace.cpp:1461-1492): one sample of one pixel
+void ref_trace_sample(ref_state* st, const ref_scene* rs, const ref_bvh* rb,
+    const ref_lights* rl, const ythip_params* p, int i, int j, int sample) {
+  trace_sample(st->state, rs->scene, rb->bvh, rl->lights, i, j, sample, to_params(*p));
+}
+// get_albedo_image / get_normal_image (yocto_trace.cpp:1769-1791): which = 0 / 1
+void ref_guide_image(const ref_state* st, int which, float* out) {
+  auto img = which == 0 ? get_albedo_image(st->state) : get_normal_image(st->state);
+  std::memcpy(out, img.pixels.data(), img.pixels.size() * sizeof(vec4f));
+}
+
 // intersect_scene_bvh (yocto_bvh.cpp:554-617) over a ray batch
 void ref_intersect_batch(const ref_bvh* rb, const ref_scene* rs,
     const ythip_ray* rays, int64_t n, int find_any, ythip_hit* hits) {

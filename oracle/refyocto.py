@@ -68,6 +68,8 @@ def lib():
             "ref_intersect_batch": (None, [vp, vp, vp, C.c_int64, C.c_int, vp]),
             "ref_intersect_instance_batch": (None, [vp, vp, vp, vp, C.c_int64, C.c_int, vp]),
             "ref_camera_rays": (None, [vp, vp, C.POINTER(yt.CParams), vp]),
+            "ref_trace_sample": (None, [vp, vp, vp, vp, C.POINTER(yt.CParams), C.c_int, C.c_int, C.c_int]),
+            "ref_guide_image": (None, [vp, C.c_int, vp]),
             "ref_eval_shading": (None, [vp, vp, vp, C.c_int64, vp]),
             "ref_eval_environment": (None, [vp, vp, C.c_int64, vp]),
             "ref_scene_load": (vp, [C.c_char_p]),
@@ -274,6 +276,18 @@ class RefState:
 def trace_samples(state, scene, bvh, lights, params):
     """The reference's trace_samples; returns wall seconds."""
     return lib().ref_trace_samples(state.h, scene.h, bvh.h, lights.h, C.byref(params))
+
+
+def trace_sample(state, scene, bvh, lights, params, i, j, sample):
+    """The reference's trace_sample: one sample of pixel (i, j)."""
+    lib().ref_trace_sample(state.h, scene.h, bvh.h, lights.h, C.byref(params), i, j, sample)
+
+
+def guide_image(state, which):
+    """The reference's get_albedo_image (which=0) / get_normal_image (which=1)."""
+    out = np.zeros((state.height, state.width, 4), "f4")
+    lib().ref_guide_image(state.h, which, out.ctypes.data)
+    return out
 
 
 def intersect_batch(bvh, scene, rays, find_any=False):

@@ -211,8 +211,71 @@ int main() {
       EXPECT(ldr_g.linear == false && worst <= 1e-6f, "device tonemap differs by %g", worst);
       EXPECT(bdiff <= (int)(ldr_c.pixels.size() / 1000), "device tonemap bytes differ in %d pixels", bdiff);
     }
+    // the denoiser hand-off (yocto_trace.h:183-190) straight from the resident state
+    {
+      auto rc = get_rendered_image(cpu), rg = hip::get_rendered_image(gpu);
+      auto ac = get_albedo_image(cpu), ag = hip::get_albedo_image(gpu);
+      auto nc = get_normal_image(cpu), ng = hip::get_normal_image(gpu);
+      auto dc = get_denoised_image(cpu), dg = hip::get_denoised_image(gpu);
+      EXPECT(rg.linear && same_bytes(rc.pixels, rg.pixels), "get_rendered_image differs");
+      EXPECT(ag.linear && same_bytes(ac.pixels, ag.pixels), "get_albedo_image differs");
+      EXPECT(ng.linear && same_bytes(nc.pixels, ng.pixels), "get_normal_image differs");
+      EXPECT(same_bytes(dc.pixels, dg.pixels), "get_denoised_image differs");
+      auto wrong = make_image(gpu.width + 1, gpu.height, true);
+      auto threw = false;
+      try {
+        hip::get_albedo_image(wrong, gpu);
+      } catch (const std::invalid_argument&) {
+        threw = true;
+      }
+      EXPECT(threw, "get_albedo_image must reject an image of another size");
+    }
     hip::download_state(gpu);
     EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.rngs, gpu.rngs), "state after the async loop differs");
+    hip::release();
+  }
+
+  // 2d. trace_sample (yocto_trace.h:174-176): single pixels, arbitrary order, on top of a
+  //     rendered state — every array of the state bit for bit, state.samples untouched
+  {
+    auto params       = trace_params{};
+    params.sampler    = trace_sampler_type::eyelight;
+    params.resolution = 70;  // 70 x 70: ragged last tile column / row
+    params.samples    = 2;
+    params.batch      = 2;
+    auto bvh          = make_trace_bvh(scene, params);
+    auto lights       = make_trace_lights(scene, params);
+    auto cpu          = make_trace_state(scene, params);
+    auto gpu          = make_trace_state(scene, params);
+    trace_samples(cpu, scene, bvh, lights, params);
+    hip::trace_samples(gpu, scene, bvh, lights, params);
+    const int pix[][2] = {{0, 0}, {69, 69}, {17, 3}, {64, 68}, {35, 35}, {35, 35}, {16, 4}};
+    auto      sample   = 2;
+    for (auto& ij : pix) {
+      trace_sample(cpu, scene, bvh, lights, ij[0], ij[1], sample, params);
+      hip::trace_sample(gpu, scene, bvh, lights, ij[0], ij[1], sample, params);
+      sample++;
+    }
+    EXPECT(cpu.samples == 2 && gpu.samples == 2, "trace_sample must leave state.samples alone (%d / %d)", cpu.samples,
+        gpu.samples);
+    EXPECT(same_bytes(cpu.image, gpu.image), "trace_sample image differs");
+    EXPECT(same_bytes(cpu.albedo, gpu.albedo), "trace_sample albedo differs");
+    EXPECT(same_bytes(cpu.normal, gpu.normal), "trace_sample normal differs");
+    EXPECT(same_bytes(cpu.hits, gpu.hits), "trace_sample hits differ");
+    EXPECT(same_bytes(cpu.rngs, gpu.rngs), "trace_sample rngs differ");
+    // and the batch API continues from there on both sides
+    params.samples = 4;
+    trace_samples(cpu, scene, bvh, lights, params);
+    hip::trace_samples(gpu, scene, bvh, lights, params);
+    EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.rngs, gpu.rngs), "trace_samples after trace_sample differs");
+    auto threw = false;
+    try {
+      hip::trace_sample(gpu, scene, bvh, lights, 70, 0, 0, params);
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    EXPECT(threw, "trace_sample outside the frame must throw std::invalid_argument");
+    EXPECT(hip::is_sampler_lit(params) == is_sampler_lit(params), "is_sampler_lit");
     hip::release();
   }
 

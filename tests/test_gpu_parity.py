@@ -383,6 +383,47 @@ def test_results_do_not_depend_on_the_scheduling_policy(bundles, name, sampler):
         assert out[0][k].tobytes() == out[1][k].tobytes(), k
 
 
+@pytest.mark.parametrize("name,sampler,kw", [
+    ("plane", "path", {}), ("plane", "pathtest", {}), ("plane", "path", {"envhidden": 1}),
+    ("plane", "path", {"bounces": 1}), ("plane", "path", {"bounces": 2, "tentfilter": 1}),
+    ("cornellbox", "path", {}), ("materials", "path", {}), ("instances", "path", {}),
+    ("lines_points", "path", {})])
+def test_results_do_not_depend_on_the_early_miss(bundles, name, sampler, kw):
+    """resolve_step's early miss (a continuing path whose next ray cannot enter the
+    scene's root box takes its miss branch in place) performs the same
+    operations per path in the same order: every state array is bit-identical with it
+    on and off — open scenes where it fires for most bounce rays (the plane), with
+    envhidden / the bounce limit deciding whether the environment is added, opacity
+    retries and volumes (materials), closed scenes where it never fires."""
+    flat, ctx, _ = bundles(name)
+    p = yt.trace_params(sampler=sampler, resolution=160, samples=6, batch=3, **kw)
+    out = []
+    for on in [1, 0]:
+        ctx.set_early_miss(on)
+        out.append(P.gpu_render(ctx, flat, p))
+    ctx.set_early_miss(1)
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert out[0][k].tobytes() == out[1][k].tobytes(), k
+
+
+def test_early_miss_does_not_change_the_work_counts(bundles):
+    """The counting launch keeps the plain flow: rays / nodes per sample are the
+    reference's whether the early miss is on or off."""
+    flat, ctx, _ = bundles("plane")
+    p = yt.trace_params(sampler="path", resolution=96, samples=2, batch=2)
+    stats = []
+    for on in [1, 0]:
+        ctx.set_early_miss(on)
+        ctx.set_profiling(2)
+        ctx.reset_stats()
+        P.gpu_render(ctx, flat, p)
+        stats.append(ctx.get_stats())
+        ctx.set_profiling(0)
+    ctx.set_early_miss(1)
+    for k in ["samples", "rays", "nodes", "triangles", "instances", "shades"]:
+        assert stats[0][k] == stats[1][k], k
+
+
 @pytest.mark.parametrize("name", ALL_SCENES)
 def test_wide_and_binary_walks_agree(bundles, name):
     """The wide walk (four grandchildren per fetch) and the binary walk give the same
@@ -457,6 +498,92 @@ def test_get_image_and_device_tonemap(bundles):
         ref, refb = ry.tonemap(img, exposure, filmic, True)
         assert np.abs(ldr.reshape(-1, 4) - ref).max() <= 1e-6, (exposure, filmic)
         assert (ldrb.reshape(-1, 4) == refb).all(1).mean() >= 0.999, (exposure, filmic)
+
+
+def test_guide_images_for_the_denoiser(bundles):
+    """§8(f) rank 3, the denoiser hand-off: get_albedo_image / get_normal_image
+    (yocto_trace.cpp:1769-1791) expanded on the device = {guide.xyz, 1} of the state,
+    and equal to the reference's functions on the reference's own state (eyelight:
+    the whole state is bit-exact)."""
+    flat, ctx, rb = bundles("cornellbox")
+    p = yt.trace_params(sampler="eyelight", resolution=96, samples=3, batch=3)
+    st = P.gpu_render(ctx, flat, p)
+    for get, key in [(ctx.get_albedo_image, "albedo"), (ctx.get_normal_image, "normal")]:
+        img = get().reshape(-1, 4)
+        assert img[:, :3].tobytes() == st[key].reshape(-1, 3).tobytes()
+        assert (img[:, 3] == 1.0).all()
+    if rb is None:
+        pytest.skip("oracle/_ref did not travel")
+    rst = ry.RefState(rb.scene, p)
+    ry.trace_samples(rst, rb.scene, rb.bvh, rb.lights, p)
+    assert ctx.get_albedo_image().tobytes() == ry.guide_image(rst, 0).tobytes()
+    assert ctx.get_normal_image().tobytes() == ry.guide_image(rst, 1).tobytes()
+
+
+@pytest.mark.parametrize("sampler", ["eyelight", "path", "falsecolor"])
+def test_trace_sample_single_pixels(bundles, sampler):
+    """trace_sample (yocto_trace.cpp:1461-1492) through ythip_trace_sample: single
+    pixels in arbitrary order (corners, ragged last tile, the same pixel twice) on top
+    of a rendered state.  Untouched pixels keep their bytes; touched pixels equal the
+    reference's trace_sample (bit for bit for eyelight / falsecolor and for the rng
+    streams; path radiance within 1e-4 relative — device libm)."""
+    flat, ctx, rb = bundles("cornellbox")
+    p = yt.trace_params(sampler=sampler, resolution=70, samples=2, batch=2)
+    before = P.gpu_render(ctx, flat, p)
+    w, h = before["width"], before["height"]
+    pixels = [(0, 0), (w - 1, h - 1), (17, 3), (64, h - 2), (35, 35), (35, 35), (16, 4)]
+    for k, (i, j) in enumerate(pixels):
+        ctx.trace_sample(p, i, j, 2 + k)
+    after = ctx.download_state()
+    assert after["samples"] == 2  # trace_sample leaves state.samples alone
+    touched = np.zeros(w * h, bool)
+    touched[[j * w + i for i, j in pixels]] = True
+    for key in ["image", "albedo", "normal", "hits", "rngs"]:
+        a, b = after[key].reshape(w * h, -1), before[key].reshape(w * h, -1)
+        assert a[~touched].tobytes() == b[~touched].tobytes(), key
+    assert (after["rngs"].reshape(w * h, -1)[touched] != before["rngs"].reshape(w * h, -1)[touched]).any(1).all()
+    with pytest.raises(yt.YthipError):
+        ctx.trace_sample(p, w, 0, 0)
+    with pytest.raises(yt.YthipError):
+        ctx.trace_sample(p, 0, 0, -1)
+    if rb is None:
+        pytest.skip("oracle/_ref did not travel")
+    rst = ry.RefState(rb.scene, p)
+    rst.set(**{k: before[k] for k in ["image", "albedo", "normal", "hits", "rngs"]}, samples=2)
+    for k, (i, j) in enumerate(pixels):
+        ry.trace_sample(rst, rb.scene, rb.bvh, rb.lights, p, i, j, 2 + k)
+    ref = rst.get()
+    assert after["rngs"].tobytes() == ref["rngs"].tobytes()
+    assert after["hits"].tobytes() == ref["hits"].tobytes()
+    for key in ["image", "albedo", "normal"]:
+        if sampler == "path":
+            assert np.allclose(after[key], ref[key], rtol=1e-4, atol=1e-6), key
+        else:
+            assert after[key].tobytes() == ref[key].tobytes(), key
+
+
+def test_trace_sample_on_a_column_striped_slice(bundles):
+    """The same through a slice of the frame (rank 1 of 3, tile columns 1, 4, ...): a pixel
+    of the slice equals the full-frame result, a pixel of another rank is refused."""
+    flat, ctx, _ = bundles("cornellbox")
+    p = yt.trace_params(sampler="eyelight", resolution=100, samples=1, batch=1)
+    full = P.gpu_render(ctx, flat, p)
+    w, h = full["width"], full["height"]
+    i, j = 4 * 16 + 5, 41  # tile column 4 = local tile column 1 of rank 1/3
+    ctx.trace_sample(p, i, j, 1)
+    want = ctx.download_state()
+    rngs = yt.make_rngs(p.seed, w * h)
+    sl = P.gpu_render(ctx, flat, p, rngs=rngs, cols=(1, 3))
+    lw = sl["width"]
+    ctx.trace_sample(p, i, j, 1)
+    got = ctx.download_state()
+    il = 1 * 16 + 5
+    for key in ["image", "albedo", "normal", "hits", "rngs"]:
+        a = got[key].reshape(h * lw, -1)[j * lw + il]
+        b = want[key].reshape(h * w, -1)[j * w + i]
+        assert a.tobytes() == b.tobytes(), key
+    with pytest.raises(yt.YthipError):
+        ctx.trace_sample(p, 5, j, 1)  # tile column 0 belongs to rank 0
 
 
 def test_work_counters_and_cancel(bundles):

@@ -68,6 +68,7 @@ struct DState {
   int tiles_x, tiles_y, nblocks, nslots;
   int sample_base;  // state.samples at the start of this batch
   int batch;        // samples to add per pixel in this batch
+  int only_pix;     // >= 0: trace_sample() — only this local pixel takes the sample (one workgroup)
   // trace_state
   float4*     image;   // vec4f
   float*      albedo;  // vec3f
@@ -93,6 +94,7 @@ struct KParams {
   int   nocaustics, envhidden, tentfilter;
   int   has_env;  // !scene.environments.empty()
   int   hold;     // scheduling policy of k_trace (0 off, 1 hold back partial primary wavefronts)
+  int   peek;     // resolve a continuing path's root-box miss in place (resolve_step), 0 off
 };
 
 constexpr int YT_TILE   = 16;                  // a workgroup's tile: 16 pixels wide ...
@@ -111,7 +113,18 @@ static_assert(YT_TILE * YT_TILE_H == YT_BLOCK, "one tile per workgroup");
 // with the adaptive-wait scheduler: vertical bands of tile columns per XCD, plain
 // and interleaved in groups of 2 / 4 columns, gain 2-7 % on the plane and the
 // instanced scene and LOSE 15-45 % on the Cornell box, whose column costs differ.)
-YT_FN int logical_block(const DState& st) { return blockIdx.x < st.nblocks ? (int)blockIdx.x : -1; }
+// (Also measured: keeping "tile column mod 8 = XCD" — what the identity mapping gives
+// for 1280 / 1920 / 2560 px — for widths whose tile-column count is not a multiple of
+// 8: within the 1-2 % run-to-run noise, not adopted.)
+YT_FN int logical_block(const DState& st) {
+  int b = (int)blockIdx.x;
+  if (b >= st.nblocks) return -1;
+  if (st.only_pix >= 0) {  // trace_sample(): a one-workgroup launch on the pixel's tile
+    int jl = st.only_pix / st.lwidth, il = st.only_pix - jl * st.lwidth;
+    return b == 0 ? (jl / YT_TILE_H) * st.tiles_x + il / YT_TILE : -1;
+  }
+  return b;
+}
 
 // Pixel of a path slot: index into the slice's trace_state arrays (row-major,
 // as the reference lays them out), -1 when outside.  A wave covers 16 x 4
@@ -838,8 +851,30 @@ YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Pa
 // Path outcome classes for the compaction
 enum { OUT_DEAD = 0, OUT_PRIMARY = 1, OUT_BOUNCE = 2, OUT_DEFER = 3 };
 
+// The head of intersect_scene_bvh for the path's NEXT ray: true when the walk would end
+// at the root (empty scene, or the ray misses the root box — yocto_bvh.cpp:554-590 with
+// the ray of make_ray: tmin 1e-4, tmax flt_max).  Exactly the test `traverse` opens
+// with, on the same operands, so deciding it here or there gives the same answer.
+YT_FN bool misses_scene_root(const DScene& sc, vec3f o, vec3f d) {
+  if (sc.tlas_ref == REF_NONE) return true;
+  const vec3f dinv = {1 / d.x, 1 / d.y, 1 / d.z};
+  float       t0;
+  return !(slab<false>(o, dinv, ray_eps, sc.tlas_bmin, sc.tlas_bmax, t0) && t0 <= flt_max * BBOX_K);
+}
+
 // Applies a step decision: bounce bookkeeping, end-of-sample accumulation and
 // regeneration.  Returns the queue class of the slot.
+//
+// PEEK (trace_path / trace_pathtest, not the counting launch): a continuing path whose
+// next ray cannot enter the scene's root box takes the miss branch of its next loop
+// iteration (yocto_trace.cpp:473-477) right here instead of going through the queue,
+// the traversal prologue and the shade stage again.  On open scenes (configs[1]: every
+// bounce ray leaves the plane's box) that is most bounce rays: a sample then costs one
+// iteration instead of two, and the end-of-sample code (running means, the next
+// camera ray) runs once per iteration with every lane active instead of twice with
+// 16 % + 84 % of them.  Same operations on the same operands in the same per-path
+// order: results are bit-identical (tested against the counting launch's flow).
+template <bool PEEK = false>
 YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, int slot, Path& P, int step,
     int max_bounces) {
   if (step == STEP_DEFER) return OUT_DEFER;
@@ -849,6 +884,12 @@ YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, in
     alive = P.bounce < max_bounces;
   } else if (step == STEP_RETRY) {
     alive = true;
+  }
+  if constexpr (PEEK) {
+    if (alive && kp.peek && misses_scene_root(sc, P.o, P.d)) {
+      if (P.bounce > 0 || !kp.envhidden) P.radiance += P.weight * eval_environment(sc, P.d);
+      alive = false;
+    }
   }
   if (alive) return OUT_BOUNCE;
   finish_sample(st, kp, slot, P);
@@ -929,6 +970,9 @@ template <int SAMPLER, int LP, bool COUNT, bool WIDE, bool MATTE = false>
 __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KParams kp) {
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
+  // root-box misses of continuing paths resolved in place (resolve_step); the counting
+  // launch keeps the plain flow, whose ray / node counts are the reference's
+  constexpr bool PEEK = !COUNT && (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST);
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   __shared__ WgQueues   Q;
   __shared__ WgState    W;
@@ -946,6 +990,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
   {
     int slot = lb * YT_BLOCK + tid, i, j;
     int pix  = slot_pixel(st, slot, i, j);
+    if (st.only_pix >= 0 && pix != st.only_pix) pix = -1;
     if (pix >= 0) {
       Path P;
       auto r = st.rngs[pix];
@@ -1045,7 +1090,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
 #ifdef YT_TIMING
       tmS = __builtin_readcyclecounter();
 #endif
-      cls = resolve_step(sc, st, kp, slot, P, step, max_bounces);
+      cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces);
       store_path(W, slot, P);
     }
 #ifdef YT_TIMING
@@ -1107,7 +1152,7 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
           auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
           P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
           int step = step_tail(P);
-          cls      = resolve_step(sc, st, kp, slot, P, step, max_bounces);
+          cls      = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces);
           store_path(W, slot, P);
         }
         // append behind what the shade stage queued
@@ -1167,6 +1212,14 @@ __global__ void __launch_bounds__(YT_BLOCK) k_tonemap(const float4* image, int n
   auto   ldr = tonemap({h.x, h.y, h.z}, exposure, filmic != 0, srgb != 0);
   if (outf) outf[i] = {ldr.x, ldr.y, ldr.z, h.w};
   if (outb) outb[i] = {float_to_byte(ldr.x), float_to_byte(ldr.y), float_to_byte(ldr.z), float_to_byte(h.w)};
+}
+
+// get_albedo_image / get_normal_image (yocto_trace.cpp:1769-1791): the vec3f guide
+// buffer as the vec4f image a denoiser / viewer takes, alpha 1.
+__global__ void __launch_bounds__(YT_BLOCK) k_guide_image(const float* rgb, int n, float4* out) {
+  int i = blockIdx.x * YT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  out[i] = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1.0f};
 }
 
 __global__ void __launch_bounds__(YT_BLOCK) k_camera_rays(DScene sc, DState st, KParams kp, ythip_ray* rays) {

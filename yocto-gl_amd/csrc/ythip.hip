@@ -62,6 +62,7 @@ struct ythip_ctx {
   int64_t                        device_build_min_prims = 16384;
   int                            bvh_builder            = 1;  // 0 host only, 1 device for large shapes
   int                            hold_policy            = 1;
+  int                            peek_policy            = 1;
   // which walk k_trace / the test entries use: 0 binary, 1 wide, 2 (default) by the
   // work at hand — see use_wide()
   int     traversal_mode = 2;
@@ -158,6 +159,7 @@ KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
   k.tentfilter = p->tentfilter;
   k.has_env    = ctx->ds.num_environments > 0;
   k.hold       = ctx->hold_policy;
+  k.peek       = ctx->peek_policy;
   return k;
 }
 
@@ -600,7 +602,9 @@ void harvest_events(ythip_ctx* ctx) {
   ctx->ev_next = 0;
 }
 
-int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop) {
+// only_pix >= 0: trace_sample() — one sample, numbered `sample`, of that local pixel
+int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop, int only_pix = -1,
+    int sample = 0) {
   if (!ctx->have_scene || !ctx->have_bvh || !ctx->have_lights || !ctx->have_state)
     return fail(ctx, YTHIP_ERR_STATE, "trace_samples needs scene, bvh, lights and state resident");
   if (params->sampler < 0 || params->sampler > YTHIP_SAMPLER_FALSECOLOR)
@@ -608,7 +612,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   if (params->camera < 0 || params->camera >= ctx->num_cameras)
     return fail(ctx, YTHIP_ERR_INVALID, "camera index %d out of range [0,%d)", params->camera, ctx->num_cameras);
   if (params->batch < 1) return fail(ctx, YTHIP_ERR_INVALID, "batch must be >= 1");
-  if (ctx->samples >= params->samples) return YTHIP_OK;  // yocto_trace.cpp:1598
+  if (only_pix < 0 && ctx->samples >= params->samples) return YTHIP_OK;  // yocto_trace.cpp:1598
   if (stop && *stop) return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
 
   auto kp          = to_kparams(ctx, params);
@@ -626,8 +630,18 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   }
   ctx->st.nhit_a      = mis ? ctx->nhit_a : nullptr;
   ctx->st.nhit_e      = mis ? ctx->nhit_e : nullptr;
-  ctx->st.sample_base = ctx->samples;
-  ctx->st.batch       = params->batch;
+  ctx->st.sample_base = only_pix < 0 ? ctx->samples : sample;
+  ctx->st.batch       = only_pix < 0 ? params->batch : 1;
+  ctx->st.only_pix    = only_pix;
+  // trace_sample(): one workgroup, on the pixel's tile (logical_block)
+  struct GridScope {
+    DState& st;
+    int     saved;
+    GridScope(DState& s, bool one) : st(s), saved(s.nblocks) {
+      if (one) st.nblocks = 1;
+    }
+    ~GridScope() { st.nblocks = saved, st.only_pix = -1; }
+  } grid_scope(ctx->st, only_pix >= 0);
 
   // how sample_lights_pdf's instance walks run
   int lp = LP_NONE;
@@ -644,7 +658,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
     if (rc) return rc;
   }
   HIPCHECK(ctx, hipGetLastError());
-  ctx->samples += params->batch;  // yocto_trace.cpp:1614
+  if (only_pix < 0) ctx->samples += params->batch;  // yocto_trace.cpp:1614
   return YTHIP_OK;
 }
 
@@ -672,6 +686,7 @@ int ythip_create(int device, ythip_ctx** out) {
   }
   ctx->stream = ctx->own_stream;
   if (const char* e = std::getenv("YTHIP_HOLD")) ctx->hold_policy = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_PEEK")) ctx->peek_policy = std::atoi(e);
   if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       false) {
@@ -1230,6 +1245,32 @@ int ythip_get_image(ythip_ctx* ctx, float* image) {
   return YTHIP_OK;
 }
 
+namespace {
+int guide_image(ythip_ctx* ctx, const float* rgb, float* image) {
+  if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  if (!image) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  const size_t       n = (size_t)ctx->st.npix;
+  std::vector<void*> tmp;
+  float4*            d = nullptr;
+  int                rc;
+  if ((rc = dalloc(ctx, tmp, &d, n))) return rc;
+  hipLaunchKernelGGL(k_guide_image, dim3(grid_for((long long)n)), dim3(YT_BLOCK), 0, ctx->stream, rgb, (int)n, d);
+  auto e1 = hipMemcpyAsync(image, d, n * 16, hipMemcpyDeviceToHost, ctx->stream);
+  auto e2 = hipStreamSynchronize(ctx->stream);
+  free_all(tmp);
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "guide image download failed");
+  return YTHIP_OK;
+}
+}  // namespace
+
+int ythip_get_albedo_image(ythip_ctx* ctx, float* image) {
+  return guide_image(ctx, ctx && ctx->have_state ? ctx->st.albedo : nullptr, image);
+}
+int ythip_get_normal_image(ythip_ctx* ctx, float* image) {
+  return guide_image(ctx, ctx && ctx->have_state ? ctx->st.normal : nullptr, image);
+}
+
 int ythip_tonemap_image(ythip_ctx* ctx, float exposure, int filmic, int srgb, float* ldr, uint8_t* ldr_bytes) {
   if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
   if (!ldr && !ldr_bytes) return fail(ctx, YTHIP_ERR_INVALID, "no output buffer");
@@ -1276,6 +1317,24 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volati
   if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   int rc = enqueue_samples(ctx, params, stop);
+  if (rc) return rc;
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  harvest_events(ctx);
+  return YTHIP_OK;
+}
+
+int ythip_trace_sample(ythip_ctx* ctx, const ythip_params* params, int i, int j, int sample) {
+  if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  auto& st = ctx->st;
+  if (sample < 0) return fail(ctx, YTHIP_ERR_INVALID, "sample must be >= 0");
+  int tc = i / YT_TILE, dc = tc - st.col_first;
+  if (i < 0 || i >= st.width || j < st.row_begin || j >= st.row_begin + st.rows || dc < 0 || dc % st.col_stride)
+    return fail(ctx, YTHIP_ERR_INVALID, "pixel (%d,%d) is not in this slice of the %dx%d frame", i, j, st.width,
+        st.height);
+  int pix = (j - st.row_begin) * st.lwidth + (dc / st.col_stride) * YT_TILE + i % YT_TILE;
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  int rc = enqueue_samples(ctx, params, nullptr, pix, sample);
   if (rc) return rc;
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   harvest_events(ctx);
@@ -1363,6 +1422,12 @@ int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params, ythip_ray* ray
 int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait) {
   if (!ctx) return YTHIP_ERR_INVALID;
   ctx->hold_policy = adaptive_wait ? 1 : 0;
+  return YTHIP_OK;
+}
+
+int ythip_set_early_miss(ythip_ctx* ctx, int enable) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  ctx->peek_policy = enable ? 1 : 0;
   return YTHIP_OK;
 }
 

@@ -317,13 +317,10 @@ void pull_state(residency& r, trace_state& state) {
   r.host_stale  = false;
 }
 
-void trace_impl(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,
-    const trace_params& params, bool download) {
-  if (state.samples >= params.samples) return;  // yocto_trace.cpp:1598
-  if (params.embreebvh) throw std::invalid_argument("yocto::hip::trace_samples: embreebvh has no device mirror");
+// scene / bvh / lights / state resident and current on the device (caller holds the lock)
+void ensure_state(residency& r, trace_state& state, const scene_data& scene, const trace_bvh& bvh,
+    const trace_lights& lights) {
   static_assert(sizeof(rng_state) == 16 && sizeof(vec4f) == 16 && sizeof(vec3f) == 12, "trace_state layout");
-  auto& r = cache();
-  auto  lock = std::lock_guard{r.mutex};
   ensure_resident(r, scene, bvh, lights);
   auto npix = (size_t)state.width * (size_t)state.height;
   if (state.image.size() != npix || state.albedo.size() != npix || state.normal.size() != npix ||
@@ -339,7 +336,17 @@ void trace_impl(trace_state& state, const scene_data& scene, const trace_bvh& bv
                      (const float*)state.normal.data(), state.hits.data(), (const uint64_t*)state.rngs.data(),
                      state.samples));
     r.state = &state, r.width = state.width, r.height = state.height;
+    r.dev_samples = state.samples;
   }
+}
+
+void trace_impl(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,
+    const trace_params& params, bool download) {
+  if (state.samples >= params.samples) return;  // yocto_trace.cpp:1598
+  if (params.embreebvh) throw std::invalid_argument("yocto::hip::trace_samples: embreebvh has no device mirror");
+  auto& r = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  ensure_state(r, state, scene, bvh, lights);
   auto p = flat(params);
   check(r.ctx, ythip_trace_samples(r.ctx, &p, nullptr));
   state.samples += params.batch;  // yocto_trace.cpp:1614
@@ -462,6 +469,21 @@ void trace_samples_resident(trace_state& state, const scene_data& scene, const t
     const trace_lights& lights, const trace_params& params) {
   trace_impl(state, scene, bvh, lights, params, false);
 }
+void trace_sample(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,
+    int i, int j, int sample, const trace_params& params) {
+  if (params.embreebvh) throw std::invalid_argument("yocto::hip::trace_sample: embreebvh has no device mirror");
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  // a per-pixel caller may have edited the host arrays without touching state.samples:
+  // unless the device copy is known to be ahead, the host copy goes up again
+  if (!r.host_stale) r.state = nullptr;
+  ensure_state(r, state, scene, bvh, lights);
+  auto p = flat(params);
+  check(r.ctx, ythip_trace_sample(r.ctx, &p, i, j, sample));
+  auto samples = state.samples;
+  pull_state(r, state);  // the pixel's five entries changed; state.samples did not
+  state.samples = samples;
+}
 void download_state(trace_state& state) {
   auto& r    = cache();
   auto  lock = std::lock_guard{r.mutex};
@@ -503,6 +525,59 @@ void get_image(image_data& image, const trace_state& state) {
 image_data get_image(const trace_state& state) {
   auto image = make_image(state.width, state.height, true);
   hip::get_image(image, state);
+  return image;
+}
+
+// the render and the denoiser's guide buffers (yocto_trace.h:183-190)
+namespace {
+void check_linear_image(const image_data& image, const trace_state& state) {  // check_image, yocto_trace.cpp:1679-1686
+  if (image.width != state.width || image.height != state.height)
+    throw std::invalid_argument{"image should have the same size"};
+  if (!image.linear) throw std::invalid_argument{"expected linear image"};
+}
+}  // namespace
+void get_rendered_image(image_data& image, const trace_state& state) {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  if (!device_has(r, state) || !r.host_stale) return yocto::get_rendered_image(image, state);
+  check_linear_image(image, state);
+  check(r.ctx, ythip_get_image(r.ctx, (float*)image.pixels.data()));
+}
+void get_albedo_image(image_data& image, const trace_state& state) {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  if (!device_has(r, state) || !r.host_stale) return yocto::get_albedo_image(image, state);
+  check_linear_image(image, state);
+  check(r.ctx, ythip_get_albedo_image(r.ctx, (float*)image.pixels.data()));
+}
+void get_normal_image(image_data& image, const trace_state& state) {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  if (!device_has(r, state) || !r.host_stale) return yocto::get_normal_image(image, state);
+  check_linear_image(image, state);
+  check(r.ctx, ythip_get_normal_image(r.ctx, (float*)image.pixels.data()));
+}
+void get_denoised_image(image_data& image, const trace_state& state) {
+  hip::get_rendered_image(image, state);  // yocto_trace.cpp:1763-1765 (no OIDN in this build)
+}
+image_data get_rendered_image(const trace_state& state) {
+  auto image = make_image(state.width, state.height, true);
+  hip::get_rendered_image(image, state);
+  return image;
+}
+image_data get_albedo_image(const trace_state& state) {
+  auto image = make_image(state.width, state.height, true);
+  hip::get_albedo_image(image, state);
+  return image;
+}
+image_data get_normal_image(const trace_state& state) {
+  auto image = make_image(state.width, state.height, true);
+  hip::get_normal_image(image, state);
+  return image;
+}
+image_data get_denoised_image(const trace_state& state) {
+  auto image = make_image(state.width, state.height, true);
+  hip::get_denoised_image(image, state);
   return image;
 }
 

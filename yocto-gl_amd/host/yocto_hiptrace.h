@@ -67,6 +67,16 @@ void trace_samples_resident(trace_state& state, const scene_data& scene,
     const trace_bvh& bvh, const trace_lights& lights, const trace_params& params);
 void download_state(trace_state& state);
 
+// yocto_trace.h:174-176 — one sample of pixel (i, j), numbered `sample` (the weight of
+// the running mean is 1 / (sample + 1)); state.samples is left alone, as in the
+// reference.  Synchronous, host vectors of `state` refreshed.  A one-workgroup launch
+// of the kernel trace_samples uses: for debugging / pixel inspection, not for speed.
+void trace_sample(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,
+    int i, int j, int sample, const trace_params& params);
+
+// yocto_trace.h:144
+using yocto::is_sampler_lit;
+
 // yocto_trace.h:116 — make_* + the progressive loop + get_image.
 image_data trace_image(const scene_data& scene, const trace_params& params);
 
@@ -75,6 +85,19 @@ image_data trace_image(const scene_data& scene, const trace_params& params);
 // moves only `image` (16 B/pixel, not the whole 60 B/pixel trace_state).
 image_data get_image(const trace_state& state);
 void       get_image(image_data& image, const trace_state& state);
+// yocto_trace.h:183-190 for a resident state — the denoiser hand-off (SURVEY.md §8(f)
+// rank 3): the render and its two guide buffers as linear vec4f images (alpha 1 for the
+// guides, expanded on the device).  get_denoised_image: the reference's is OIDN when
+// built with YOCTO_DENOISE and get_rendered_image otherwise (yocto_trace.cpp:1724-1766);
+// OIDN is not part of this build, so it is the latter.
+image_data get_rendered_image(const trace_state& state);
+void       get_rendered_image(image_data& image, const trace_state& state);
+image_data get_albedo_image(const trace_state& state);
+void       get_albedo_image(image_data& image, const trace_state& state);
+image_data get_normal_image(const trace_state& state);
+void       get_normal_image(image_data& image, const trace_state& state);
+image_data get_denoised_image(const trace_state& state);
+void       get_denoised_image(image_data& image, const trace_state& state);
 // tonemap_image (yocto_image.h:104-112) of the resident render, computed ON THE
 // DEVICE: exposure, optional filmic curve, sRGB encoding.  The float version is
 // what a viewer uploads to its display; the byte version what save_image writes

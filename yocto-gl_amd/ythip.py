@@ -438,6 +438,9 @@ _SIGNATURES = {
     "ythip_state_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5
                              + [C.POINTER(C.c_int)]),
     "ythip_get_image": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_get_albedo_image": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_get_normal_image": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_trace_sample": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_int, C.c_int, C.c_int]),
     "ythip_tonemap_image": (C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ythip_state_bind_device": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     "ythip_state_set_samples": (C.c_int, [C.c_void_p, C.c_int]),
@@ -450,6 +453,7 @@ _SIGNATURES = {
                                                  C.c_void_p]),
     "ythip_camera_rays": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_void_p]),
     "ythip_set_scheduling": (C.c_int, [C.c_void_p, C.c_int]),
+    "ythip_set_early_miss": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_set_specialization": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_reset_stats": (C.c_int, [C.c_void_p]),
@@ -742,6 +746,18 @@ class Context:
         self._check(self.lib.ythip_get_image(self.h, image.ctypes.data), "get_image")
         return image
 
+    def get_albedo_image(self):
+        """get_albedo_image (yocto_trace.cpp:1769-1780): {albedo.xyz, 1} per pixel."""
+        image = np.zeros((self.row_end - self.row_begin, self.local_width, 4), "f4")
+        self._check(self.lib.ythip_get_albedo_image(self.h, image.ctypes.data), "get_albedo_image")
+        return image
+
+    def get_normal_image(self):
+        """get_normal_image (yocto_trace.cpp:1781-1791): {normal.xyz, 1} per pixel."""
+        image = np.zeros((self.row_end - self.row_begin, self.local_width, 4), "f4")
+        self._check(self.lib.ythip_get_normal_image(self.h, image.ctypes.data), "get_normal_image")
+        return image
+
     def tonemap_image(self, exposure=0.0, filmic=False, srgb=True):
         """tonemap_image on the device: (float [h, w, 4], bytes [h, w, 4])."""
         h = self.row_end - self.row_begin
@@ -760,6 +776,10 @@ class Context:
         self._check(self.lib.ythip_trace_samples(
             self.h, C.byref(params), None if stop is None else stop.ctypes.data),
             "trace_samples")
+
+    def trace_sample(self, params, i, j, sample):
+        """trace_sample (yocto_trace.cpp:1461-1492): one sample of frame pixel (i, j)."""
+        self._check(self.lib.ythip_trace_sample(self.h, C.byref(params), i, j, sample), "trace_sample")
 
     def trace_samples_async(self, params):
         self._check(self.lib.ythip_trace_samples_async(self.h, C.byref(params)),
@@ -794,6 +814,9 @@ class Context:
 
     def set_scheduling(self, adaptive_wait):
         self._check(self.lib.ythip_set_scheduling(self.h, int(adaptive_wait)), "set_scheduling")
+
+    def set_early_miss(self, enable):
+        self._check(self.lib.ythip_set_early_miss(self.h, int(enable)), "set_early_miss")
 
     def set_traversal(self, mode):
         """"binary" | "wide" | "auto" (default): which BVH walk the kernels use."""
