@@ -80,6 +80,60 @@ def cpu_baseline(flat, params_kw, budget_s=15.0):
                       f"reference trace_samples via oracle/_ref (g++ -O3, std::async x{cores})"}
 
 
+def other_configs(device, args):
+    """The other single-GPU BASELINE configs through the same path, short runs (their
+    parity lives in tests/test_gpu_baseline_configs.py): cfg2b — the north star's
+    "1M-triangle Cornell-box-style scene" (every ray hits, area-light
+    pdf walks) at 1024x1024x64spp — and configs[3], 10,000 instances of a
+    1,024-triangle mesh at 1920x1080x256spp.  One counting launch + 1 warm-up + 2 timed
+    steps each; algorithmic bytes by the same formula as the headline."""
+    import ythip as yt
+    import scenes as ysc
+    res = []
+    cornell = os.path.join(ROOT, "tests", "golden", "cornellbox.npz")  # make_cornellbox() as exported
+    for name, make, resolution, spp in [
+            ("cfg2b: Cornell box with 998,586 wall triangles, 1 area light",
+             lambda: ysc.cornell_1m_scene(ysc.load_scene(cornell)), 1024, 64),
+            ("configs[3]: 10,000 instances x 1,024-triangle sphere + constant env",
+             ysc.instanced_scene, 1920, 256)]:
+        flat = make()
+        ctx = yt.Context(device)
+        ctx.upload_scene(flat)
+        ctx.make_trace_bvh(flat)
+        ctx.make_trace_lights(flat)
+        p = yt.trace_params(sampler="path", resolution=resolution, bounces=8, clamp=10.0,
+                            samples=1 << 30, batch=spp)
+        w, h = ctx.make_trace_state(flat, p)
+        ctx.set_profiling(2)
+        ctx.reset_stats()
+        ctx.trace_samples(p)
+        cnt = ctx.get_stats()
+        ctx.set_profiling(0)
+        ctx.trace_samples(p)
+        ctx.set_profiling(1)
+        ctx.reset_stats()
+        steps = 2
+        for _ in range(steps):
+            ctx.trace_samples(p)
+        st = ctx.get_stats()
+        ctx.set_profiling(0)
+        ctx.close()
+        ms = st["trace_ms"] / steps
+        nsamp = max(cnt["samples"], 1)
+        bps = yt.algorithmic_bytes(cnt) / nsamp
+        res.append({"workload": f"{name}, {w}x{h}x{spp}spp, sampler=path bounces=8 clamp=10",
+                    "value": round(w * h * spp / ms / 1e3, 3), "unit": "Msamples/s",
+                    "ms_per_step": round(ms, 3), "steps": steps,
+                    "bytes_per_sample": round(bps, 1),
+                    "achieved_GBps": round(bps * w * h * spp / (ms * 1e-3) / 1e9, 1),
+                    "per_sample": {"rays": round(cnt["rays"] / nsamp, 3),
+                                   "nodes": round(cnt["nodes"] / nsamp, 3),
+                                   "triangles": round(cnt["triangles"] / nsamp, 3),
+                                   "instances": round(cnt["instances"] / nsamp, 3),
+                                   "shades": round(cnt["shades"] / nsamp, 3)}})
+    return res
+
+
 def weak_resolution(base, world, tile=16):
     """Width of the weak-scaling frame: the same camera at `world` x the pixels of
     the `base`-wide frame, i.e. base * sqrt(world), rounded to a multiple of
@@ -104,6 +158,8 @@ def main():
     ap.add_argument("--resolution", type=int, default=1280)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N=1: skip the short runs of the other BASELINE configs (other_configs)")
     ap.add_argument("--sharding", choices=["columns", "rows"], default="columns")
     ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
                     help="N > 1: weak = frame grown to N x the pixels of configs[1] (primary "
@@ -325,6 +381,12 @@ def main():
             "note": "a pixel's samples are sequential by contract (its PCG stream and running "
                     "mean), so one pixel's 64-sample chain (~1.5 ms) bounds the step however "
                     "few pixels a GPU holds (DESIGN.md §7)"}
+    if rank == 0 and world == 1 and not args.as_rank and not args.no_other_configs:
+        ctx.close()
+        try:
+            out["other_configs"] = other_configs(local, args)
+        except Exception as e:  # reported, never required
+            out["other_configs"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(flat, params_kw)

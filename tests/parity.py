@@ -25,20 +25,7 @@ def have_ref():
 # ----------------------------------------------------------------------------
 # flat scene <-> npz
 # ----------------------------------------------------------------------------
-_FIELDS = ["cameras", "instances", "environments", "shapes", "textures", "materials"] + \
-    [p[0] for p in yt.FlatScene.POOLS]
-
-
-def save_scene(path, sc):
-    np.savez_compressed(path, **{k: getattr(sc, k) for k in _FIELDS})
-
-
-def load_scene(path):
-    z = np.load(path)
-    sc = yt.FlatScene()
-    for k in _FIELDS:
-        setattr(sc, k, z[k])
-    return sc
+save_scene, load_scene, _FIELDS = ysc.save_scene, ysc.load_scene, ysc.SCENE_FIELDS
 
 
 # ----------------------------------------------------------------------------
@@ -183,33 +170,8 @@ def scene_lines_points():
 
 
 def scene_cornell_1m(n=316):
-    """cfg2b (the north star's "1M-triangle Cornell-box-style scene"):
-    the reference's Cornell box with each of the five walls replaced by an n x n grid
-    of quads over the same corners, triangulated — 5 * 2 * 316^2 + 26 = 998,586
-    triangles; boxes, area light, materials and camera unchanged.  Deep paths (every
-    ray hits) and area-light pdf walks."""
-    base = scene_cornellbox()
-    sc = yt.FlatScene()
-    sc.cameras = base.cameras.copy()
-    sc.materials = base.materials.copy()
-    i = np.arange(n + 1, dtype=f32) / f32(n)
-    uu, vv = np.meshgrid(i, i)  # index j * (n + 1) + i
-    ii, jj = np.meshgrid(np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32))
-    a = jj * (n + 1) + ii
-    quads = np.stack([a, a + 1, a + (n + 1) + 1, a + (n + 1)], -1).reshape(-1, 4)
-    tris = ysc.quads_to_triangles(quads)
-    for k in range(len(base.shapes)):
-        arr = base.shape_arrays(k)
-        if k < 5:  # a wall: bilinear grid over its corners p0 p1 p2 p3
-            p0, p1, p2, p3 = (arr["positions"][c] for c in range(4))
-            u, v = uu[..., None], vv[..., None]
-            pos = ((p0 * (f32(1) - u) + p1 * u) * (f32(1) - v) + (p3 * (f32(1) - u) + p2 * u) * v)
-            sc.add_shape(pos.reshape(-1, 3).astype(f32), triangles=tris)
-        else:
-            sc.add_shape(arr["positions"], triangles=arr["triangles"])
-    for inst in base.instances:
-        sc.add_instance(int(inst["shape"]), int(inst["material"]), inst["frame"])
-    return sc
+    """cfg2b: the Cornell box with 1M-triangle walls (scenes.cornell_1m_scene)."""
+    return ysc.cornell_1m_scene(scene_cornellbox(), n)
 
 
 REF_SCENE_DIR = os.path.join(GOLDEN, "scenes")
