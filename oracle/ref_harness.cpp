@@ -303,6 +303,34 @@ ref_scene*  ref_scene_load(const char* filename) {
   return rs;
 }
 
+// save_scene (yocto_sceneio.h:204) + make_scene_directories: writes the scene as the
+// reference's own JSON + shapes/*.ply + textures, so that the reference's own apps can
+// load it (tests: apps/ytrace.cpp on both back-ends).  0 on success.
+int ref_scene_save(const ref_scene* rs, const char* filename) {
+  try {
+    make_scene_directories(filename, rs->scene);
+    save_scene(filename, rs->scene);
+  } catch (const std::exception& e) {
+    g_load_error = e.what();
+    return 1;
+  }
+  return 0;
+}
+
+// load_image (yocto_sceneio.h): reads back what the reference's apps saved.  Call with
+// rgba == nullptr for the size, then with a width*height*4 float buffer.  0 on success.
+int ref_image_load(const char* filename, int* width, int* height, float* rgba) {
+  try {
+    auto img = load_image(filename);
+    *width = img.width, *height = img.height;
+    if (rgba) std::memcpy(rgba, img.pixels.data(), img.pixels.size() * sizeof(vec4f));
+  } catch (const std::exception& e) {
+    g_load_error = e.what();
+    return 1;
+  }
+  return 0;
+}
+
 ref_scene* ref_scene_cornellbox() {
   auto rs   = new ref_scene{};
   rs->scene = make_cornellbox();

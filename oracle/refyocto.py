@@ -73,6 +73,8 @@ def lib():
             "ref_eval_shading": (None, [vp, vp, vp, C.c_int64, vp]),
             "ref_eval_environment": (None, [vp, vp, C.c_int64, vp]),
             "ref_scene_load": (vp, [C.c_char_p]),
+            "ref_scene_save": (C.c_int, [vp, C.c_char_p]),
+            "ref_image_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
             "ref_load_error": (C.c_char_p, []),
             "ref_tonemap": (None, [vp, C.c_int64, C.c_float, C.c_int, C.c_int, vp, vp]),
             "ref_make_rng": (None, [C.c_uint64, C.c_uint64, vp]),
@@ -107,6 +109,11 @@ class RefScene:
         if not h:
             raise RuntimeError(lib().ref_load_error().decode())
         return RefScene(h)
+
+    def save(self, filename):
+        """The reference's own save_scene: JSON + shapes/*.ply (+ textures)."""
+        if lib().ref_scene_save(self.h, str(filename).encode()):
+            raise RuntimeError(lib().ref_load_error().decode())
 
     @staticmethod
     def from_flat(flat):
@@ -276,6 +283,18 @@ class RefState:
 def trace_samples(state, scene, bvh, lights, params):
     """The reference's trace_samples; returns wall seconds."""
     return lib().ref_trace_samples(state.h, scene.h, bvh.h, lights.h, C.byref(params))
+
+
+def load_image(filename):
+    """The reference's load_image: [h, w, 4] float32 (what its apps wrote)."""
+    w, h = C.c_int(), C.c_int()
+    fn = str(filename).encode()
+    if lib().ref_image_load(fn, C.byref(w), C.byref(h), None):
+        raise RuntimeError(lib().ref_load_error().decode())
+    out = np.zeros((h.value, w.value, 4), "f4")
+    if lib().ref_image_load(fn, C.byref(w), C.byref(h), out.ctypes.data):
+        raise RuntimeError(lib().ref_load_error().decode())
+    return out
 
 
 def trace_sample(state, scene, bvh, lights, params, i, j, sample):
