@@ -462,6 +462,23 @@ def test_matte_specialised_kernel_gives_identical_results(bundles, name):
 
 
 @needs_ref
+def test_8k_frame_bit_exact():
+    """A large frame: 7680 x 4320 (33 M pixels, 2 GB of trace_state, 518,400 one-wave
+    workgroups, int32 pixel indexing x 3 for the vec3f arrays) — eyelight, 1 spp, every
+    state array bit for bit vs the reference."""
+    flat = P.SCENES["plane"]()
+    ctx, rb = P.gpu_context(flat), P.RefBundle(flat)
+    p = yt.trace_params(sampler="eyelight", resolution=7680, samples=1, batch=1)
+    gpu = P.gpu_render(ctx, flat, p)
+    ctx.close()
+    ref = rb.render(p)
+    assert (gpu["width"], gpu["height"]) == (ref["width"], ref["height"]) == (7680, 4320)
+    for k in ["image", "albedo", "normal", "hits", "rngs"]:
+        assert gpu[k].tobytes() == ref[k].tobytes(), k
+    assert int(gpu["hits"].sum()) == 7680 * 4320  # plane or environment: every sample counts
+
+
+@needs_ref
 @pytest.mark.parametrize("resolution,aspect", [(1, 1.0), (3, 1.0), (17, 0.5), (37, 1.7), (63, 1.0), (65, 2.9)])
 def test_odd_frame_sizes_bit_exact(resolution, aspect):
     """Frames that do not fill the 16x4 tiles (1 pixel, 17x34, 37x22, 65x22 ...):
