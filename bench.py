@@ -53,6 +53,22 @@ def measured_traffic():
         return None
 
 
+def measured_valu_busy():
+    """Fraction of the VALU issue slots k_trace keeps busy, from the PMC pass of the
+    same command committed under profiles/ (SQ_ACTIVE_INST_VALU x 4 cycles per wave64
+    instruction / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)); None when no profile is
+    present.  What actually bounds the kernel: the working set is
+    cache-resident, so the algorithmic byte rate exceeds the HBM peak."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            d = json.load(f)
+        k = [v for n, v in d.items() if "k_trace<0, 0, false, true, true>" in n][0]
+        cycles = k["GRBM_GUI_ACTIVE"]["per_dispatch"] / 8.0  # summed over the 8 XCDs
+        return round(k["SQ_ACTIVE_INST_VALU"]["per_dispatch"] * 4.0 / (cycles * 1024.0), 4)
+    except Exception:
+        return None
+
+
 def cpu_baseline(flat, params_kw, budget_s=15.0):
     """The reference itself (oracle/_ref, g++ -O3, all host cores) timed on a
     bounded sample of the same workload."""
@@ -358,6 +374,7 @@ def main():
             "bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": measured_traffic() if world == 1 and not args.as_rank else None,
+            "valu_busy": measured_valu_busy() if world == 1 and not args.as_rank else None,
             "launch_ms_avg": round(k_ms, 4), "launches_per_step": launches_per_step,
             "bytes_per_launch": int(bytes_per_launch),
             "traversal_bytes_per_launch": int(yt.traversal_bytes(stats_count) / launches_per_step),
