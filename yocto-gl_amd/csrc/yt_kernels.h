@@ -966,8 +966,11 @@ YT_FN int max_bounces_of(const KParams& kp) {
 // tile's path state (≈40 KB) stays in the XCD's L2 between iterations.  The
 // ray and the hit record never leave registers between extend and shade.
 // ===========================================================================
+#ifndef YT_WAVES_PER_EU  // development builds: occupancy experiments
+#define YT_WAVES_PER_EU 4
+#endif
 template <int SAMPLER, int LP, bool COUNT, bool WIDE, bool MATTE = false>
-__global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KParams kp) {
+__global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, DState st, KParams kp) {
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   // root-box misses of continuing paths resolved in place (resolve_step); the counting
@@ -976,6 +979,10 @@ __global__ void __launch_bounds__(YT_BLOCK, 4) k_trace(DScene sc, DState st, KPa
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   __shared__ WgQueues   Q;
   __shared__ WgState    W;
+#ifdef YT_LDS_PAD  // development builds: occupancy sensitivity (extra LDS per workgroup)
+  __shared__ int s_pad[YT_LDS_PAD / 4];
+  if (st.npix < 0) s_pad[threadIdx.x] = st.npix, st.image[0].x = (float)s_pad[(threadIdx.x + 1) & 63];
+#endif
   const int lb = logical_block(st);
   if (lb < 0) return;
   const int tid = threadIdx.x;
