@@ -1,0 +1,55 @@
+"""bench.py's output contract (one JSON line, the keys the driver reads, the roofline
+and cpu_baseline objects) checked on a short run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "rank 0 prints exactly ONE line on stdout"
+    return json.loads(lines[0])
+
+
+def test_default_line_carries_the_contract():
+    j = run_bench("--steps", "2", "--warmup", "1")
+    for k in ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]:
+        assert k in j, k
+    assert j["metric"] == "Msamples/s" and j["unit"] == "Msamples/s" and j["higher_is_better"] is True
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["vs_baseline"] is None and j["data"] == "synthetic" and j["dtype"] == "f32"
+    c = j["config"]
+    assert "workload" in c and "model" not in c
+    assert c["resolution"] == [1280, 720] and c["spp"] == 64 and c["triangles"] == 1000000
+    # value = units / time
+    assert abs(j["value"] - 1280 * 720 * 64 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_ms_avg"] * 1e-3) / 1e9) <= 1e-3 * r["achieved"]
+    assert 0 < r["launch_ms_avg"] <= j["ms_per_step"] * 1.05  # the kernel is the step
+    # the counted work is the reference's (32.59 node pops, 3.35 triangle tests per sample)
+    assert abs(r["per_sample"]["nodes"] - 32.592) < 0.01 and abs(r["per_sample"]["triangles"] - 3.348) < 0.01
+    b = j["cpu_baseline"]
+    if "error" not in b:
+        assert b["kind"] == "reference" and b["unit"] == "Msamples/s" and b["cores"] >= 1 and b["value"] > 0
+        assert j["value"] > b["value"]
+    assert isinstance(j.get("other_configs"), list) and len(j["other_configs"]) == 2
+    for o in j["other_configs"]:
+        assert o["value"] > 0 and o["unit"] == "Msamples/s"
+
+
+def test_slice_run_and_flags():
+    j = run_bench("--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--as-rank", "3/8")
+    assert j["config"]["pixels_per_rank"] == 1280 * 720 // 8 and "roofline" not in j and "cpu_baseline" not in j
+    assert abs(j["value"] - j["config"]["pixels_per_rank"] * 64 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
