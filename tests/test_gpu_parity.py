@@ -688,3 +688,31 @@ def test_unmodified_ytrace_app_on_both_backends(tmp_path, scene, args, exact):
         close = np.isclose(a, b, rtol=1e-3, atol=1e-5).all(-1)
         assert close.mean() >= 0.95, close.mean()
         assert abs(a[..., :3].mean() - b[..., :3].mean()) <= 0.01 * a[..., :3].mean()
+
+
+def test_no_device_memory_leak_over_context_and_state_cycles():
+    """Contexts, scenes, trees, lights and states come and go (an interactive session
+    rebuilds the state on every camera edit, apps/ytrace.cpp:189-204): device memory
+    returns to where it was."""
+    import torch
+    flat = P.SCENES["plane"]()
+    p = yt.trace_params(sampler="path", resolution=256, samples=2, batch=2)
+
+    def cycle(n_states):
+        ctx = P.gpu_context(flat)
+        for k in range(n_states):
+            q = yt.trace_params(sampler="pathmis" if k % 2 else "path", resolution=128 + 16 * (k % 5),
+                                samples=2, batch=2)
+            P.gpu_render(ctx, flat, q)
+        ctx.tonemap_image()
+        ctx.get_albedo_image()
+        ctx.close()
+
+    cycle(2)  # warm-up: runtime pools, code objects
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(10):
+        cycle(12)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB"
