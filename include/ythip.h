@@ -417,7 +417,7 @@ int ythip_trace_sample(ythip_ctx* ctx, const ythip_params* params, int i, int j,
  * variable YTHIP_HOLD=0/1 sets the default of new contexts (A/B measurements). */
 int ythip_set_scheduling(ythip_ctx* ctx, int adaptive_wait);
 /* Early miss (no reference equivalent; results do not depend on it).  1 (default):
- * trace_path / trace_pathtest decide at the end of a bounce whether the next ray can
+ * trace_path / trace_pathtest / trace_naive / trace_eyelight decide at the end of a bounce whether the next ray can
  * enter the scene's root box at all (the test intersect_scene_bvh opens with,
  * yocto_bvh.cpp:554-590) and, if not, take the next iteration's miss branch
  * (yocto_trace.cpp:473-477) in place; 0: every continuing ray goes through the queue.

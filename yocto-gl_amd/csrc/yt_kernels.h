@@ -865,7 +865,7 @@ YT_FN bool misses_scene_root(const DScene& sc, vec3f o, vec3f d) {
 // Applies a step decision: bounce bookkeeping, end-of-sample accumulation and
 // regeneration.  Returns the queue class of the slot.
 //
-// PEEK (trace_path / trace_pathtest, not the counting launch): a continuing path whose
+// PEEK (trace_path / trace_pathtest / trace_naive / trace_eyelight, not the counting launch): a continuing path whose
 // next ray cannot enter the scene's root box takes the miss branch of its next loop
 // iteration (yocto_trace.cpp:473-477) right here instead of going through the queue,
 // the traversal prologue and the shade stage again.  On open scenes (configs[1]: every
@@ -975,7 +975,9 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   // root-box misses of continuing paths resolved in place (resolve_step); the counting
   // launch keeps the plain flow, whose ray / node counts are the reference's
-  constexpr bool PEEK = !COUNT && (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST);
+  // (trace_naive and trace_eyelight have the same miss branch: yocto_trace.cpp:1048-1052, 1127-1131)
+  constexpr bool PEEK = !COUNT && (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST ||
+                                      SAMPLER == YTHIP_SAMPLER_NAIVE || SAMPLER == YTHIP_SAMPLER_EYELIGHT);
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   __shared__ WgQueues   Q;
   __shared__ WgState    W;
