@@ -28,6 +28,43 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(yt.exported_symbols()), declared ^ set(yt.exported_symbols())
 
 
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/ythip.h compiles as C99 on its own (plain pointers
+    and sizes, no C++ or torch types), and a C translation unit can call through it."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                    os.path.join(inc, "ythip.h")], check=True)
+    src = """#include <stdio.h>
+#include "ythip.h"
+int main(void) {
+  ythip_ctx* ctx = 0;
+  int rc = ythip_create(0, &ctx);           /* no GPU here: must fail loudly, not fall back */
+  printf("%d %s\\n", rc, ythip_last_error(ctx));
+  if (ctx) ythip_destroy(ctx);
+  return 0;
+}
+"""
+    libdir = os.path.join(ROOT, "yocto-gl_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "abi.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "abi")
+        subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", inc, c, "-o", exe, "-L", libdir, "-lythip",
+                        "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        rc, _, msg = r.stdout.strip().partition(" ")
+        import torch
+        if not torch.cuda.is_available():
+            assert int(rc) != 0 and "no CPU fallback" in msg, r.stdout
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():
