@@ -53,3 +53,29 @@ def test_slice_run_and_flags():
     j = run_bench("--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--as-rank", "3/8")
     assert j["config"]["pixels_per_rank"] == 1280 * 720 // 8 and "roofline" not in j and "cpu_baseline" not in j
     assert abs(j["value"] - j["config"]["pixels_per_rank"] * 64 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
+
+
+def test_two_rank_launch_rehearsed_with_gloo():
+    """The N > 1 path of bench.py launched exactly as the driver launches it
+    (torch.distributed.run, one process per rank) — rehearsed on this one GPU with the
+    gloo backend (YTHIP_DIST_BACKEND; both ranks share the device, so the timings mean
+    nothing): weak-scaling frame, column sharding, framebuffer gather, MAX over ranks,
+    the configs2_strong leg, one JSON line from rank 0."""
+    env = dict(os.environ, YTHIP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29700 + os.getpid() % 200
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--resolution", "320", "--spp", "4"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 2
+    w, h = j["config"]["resolution"]
+    assert (w, h) == (448, 252) and j["config"]["pixels_per_rank"] == w * h // 2  # weak_resolution(320, 2)
+    assert j["config"]["sharding"] == "columns/2"
+    assert abs(j["value"] - w * h * 4 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
+    s = j["configs2_strong"]
+    assert s["resolution"] == [320, 180] and s["pixels_per_rank"] == 320 * 180 // 2 and s["value"] > 0
+    assert "cpu_baseline" not in j and "other_configs" not in j  # rank 0 at N=1 only

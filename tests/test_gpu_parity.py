@@ -539,7 +539,7 @@ def test_guide_images_for_the_denoiser(bundles):
     assert ctx.get_normal_image().tobytes() == ry.guide_image(rst, 1).tobytes()
 
 
-@pytest.mark.parametrize("sampler", ["eyelight", "path", "falsecolor"])
+@pytest.mark.parametrize("sampler", ["eyelight", "path", "falsecolor", "naive", "pathdirect", "pathmis"])
 def test_trace_sample_single_pixels(bundles, sampler):
     """trace_sample (yocto_trace.cpp:1461-1492) through ythip_trace_sample: single
     pixels in arbitrary order (corners, ragged last tile, the same pixel twice) on top
@@ -575,7 +575,7 @@ def test_trace_sample_single_pixels(bundles, sampler):
     assert after["rngs"].tobytes() == ref["rngs"].tobytes()
     assert after["hits"].tobytes() == ref["hits"].tobytes()
     for key in ["image", "albedo", "normal"]:
-        if sampler == "path":
+        if sampler in ("path", "naive", "pathdirect", "pathmis"):
             assert np.allclose(after[key], ref[key], rtol=1e-4, atol=1e-6), key
         else:
             assert after[key].tobytes() == ref[key].tobytes(), key
