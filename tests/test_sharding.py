@@ -91,6 +91,10 @@ def _worker(rank, world, port, height, width, mode, out):
         fg = sharding.FrameGather(dist, width, height, 4, "cpu", mode=mode)
         frame = fg.frame(local)
         ok = torch.equal(frame, torch.from_numpy(full))
+        if mode == "columns" and width % (16 * world) == 0:
+            ok = ok and fg.blocked is not None  # even stripes take the strided-copy un-permute
+            fg.blocked = None                   # ... which must agree with the index_select one
+            ok = ok and torch.equal(fg.frame(local), torch.from_numpy(full))
         # the timing contract of bench.py: barrier, then MAX over ranks
         dist.barrier()
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
@@ -108,6 +112,7 @@ def _worker(rank, world, port, height, width, mode, out):
 @pytest.mark.parametrize("world,height,width,mode", [
     (2, 32, 32, "rows"), (2, 9, 16, "rows"), (3, 10, 8, "rows"),
     (2, 12, 64, "columns"), (2, 9, 40, "columns"), (3, 10, 100, "columns"),
+    (2, 8, 96, "columns"), (4, 6, 128, "columns"), (3, 7, 144, "columns"),  # even stripes: the blocked un-permute
     (3, 10, 8, "columns")])  # fewer tile columns than ranks: falls back to rows
 def test_sharded_gather_gloo(tmp_path, world, height, width, mode):
     import torch.multiprocessing as mp

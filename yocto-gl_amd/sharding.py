@@ -116,6 +116,14 @@ class FrameGather:
         self.identity = bool((perm == np.arange(width * height)).all())
         self.perm = torch.from_numpy(perm).to(device)
         self.out = torch.empty(width * height, channels, device=device, dtype=dtype)
+        # Column stripes of equal width over the full height (what bench.py uses): the
+        # un-permute is a transposition of whole 16-pixel runs — packed [rank, row, col, 16]
+        # → frame [row, col, rank, 16] — i.e. one strided copy, no index array to read.
+        s0 = self.shards[0]
+        self.blocked = None
+        if ((self.world > 1 or always) and self.even and width % (TILE * self.world) == 0 and
+                all(s.rows == (0, height) and s.cols == (r, self.world) for r, s in enumerate(self.shards))):
+            self.blocked = (height, s0.local_width // TILE)
 
     def gather(self, local):
         """local: [npixels of this rank, channels] tensor.  Returns the padded
@@ -136,5 +144,10 @@ class FrameGather:
         packed = self.gather(local)
         if self.identity and not self.always:  # row blocks: only the tail padding to drop
             return packed[:self.width * self.height]
+        if self.blocked is not None:
+            h, c = self.blocked
+            self.out.view(h, c, self.world, TILE, self.channels).copy_(
+                packed.view(self.world, h, c, TILE, self.channels).permute(1, 2, 0, 3, 4))
+            return self.out
         self.torch.index_select(packed, 0, self.perm, out=self.out)
         return self.out
