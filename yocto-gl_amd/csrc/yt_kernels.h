@@ -97,7 +97,10 @@ struct KParams {
   int   peek;     // resolve a continuing path's root-box miss in place (resolve_step), 0 off
 };
 
-constexpr int YT_TILE   = 16;                  // a workgroup's tile: 16 pixels wide ...
+#ifndef YT_TILE_W  // development builds: tile shape experiments (8 -> 8 x 8 tiles; single-GPU full frames only)
+#define YT_TILE_W 16
+#endif
+constexpr int YT_TILE   = YT_TILE_W;                  // a workgroup's tile: 16 pixels wide ...
 constexpr int YT_TILE_H = YT_BLOCK / YT_TILE;  // ... and YT_BLOCK / 16 tall (16 x 4 for one wavefront)
 constexpr int YT_PROBE_ITERS = 48;  // iterations over which a workgroup measures its per-class traversal work
 static_assert(YT_TILE * YT_TILE_H == YT_BLOCK, "one tile per workgroup");
@@ -133,9 +136,9 @@ YT_FN int logical_block(const DState& st) {
 YT_FN int slot_pixel(const DState& st, int slot, int& i, int& j) {
   int tile = slot / YT_BLOCK, w = slot & (YT_BLOCK - 1);
   int ty = tile / st.tiles_x, tx = tile - ty * st.tiles_x;
-  int il = tx * YT_TILE + (w & 15);
-  i      = (st.col_first + tx * st.col_stride) * YT_TILE + (w & 15);
-  int jl = ty * YT_TILE_H + (w >> 4);
+  int il = tx * YT_TILE + (w % YT_TILE);
+  i      = (st.col_first + tx * st.col_stride) * YT_TILE + (w % YT_TILE);
+  int jl = ty * YT_TILE_H + (w / YT_TILE);
   j      = st.row_begin + jl;
   return (i < st.width && jl < st.rows) ? jl * st.lwidth + il : -1;
 }
