@@ -230,9 +230,14 @@ YT_FN bool ray_is_tame(vec3f o, vec3f dinv, float tmin) {
 // otherwise intersect_instance_bvh of that instance (yocto_bvh.cpp:619-628).
 constexpr int HIT_ABORT = -2;  // Hit::instance of a wide walk that met an irregular ray: redo it binary
 
-template <bool COUNT, bool WIDE = false, bool TRI = false>
+// LDSD: stack entries per lane kept in the LDS column of `st` (the rest, up to the
+// reference's 128, in scratch).  0 = a walk that leaves the LDS stack alone — k_pool
+// runs sample_lights_pdf's walks that way while other lanes' scene walks are suspended
+// with their stack columns live.
+template <bool COUNT, bool WIDE = false, bool TRI = false, int LDSD = YT_LDS_DEPTH>
 YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt) {
+  constexpr int LDS_LEVELS = LDSD, SPILL_LEVELS = 128 - LDSD;
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   Hit best = {-1, -1, 0, 0, 0, false};
 
@@ -264,23 +269,23 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   if (COUNT && only_instance < 0) cnt.rays++;  // intersect_scene_bvh call (yocto_bvh.cpp:554)
   lds_entry* const lds = st.lds;
   int             sp  = 0;
-  StackEntry      spill[YT_SPILL];
+  StackEntry      spill[SPILL_LEVELS];
   auto push = [&](int ref, float t0) {
     StackEntry v = {ref, __float_as_int(t0)};
-    if (sp < YT_LDS_DEPTH)
+    if (sp < LDS_LEVELS)
       lds[sp * YT_BLOCK].ref = v.ref, lds[sp * YT_BLOCK].t0 = v.t0;
-    else if (sp < YT_LDS_DEPTH + YT_SPILL)
-      spill[sp - YT_LDS_DEPTH] = v;
+    else if (sp < LDS_LEVELS + SPILL_LEVELS)
+      spill[sp - LDS_LEVELS] = v;
     sp++;  // entries beyond 128 are dropped (the reference's array<int,128> would overflow)
   };
   auto pop = [&]() -> StackEntry {
     sp--;
-    if (sp < YT_LDS_DEPTH) {
+    if (sp < LDS_LEVELS) {
       StackEntry v;
       v.ref = lds[sp * YT_BLOCK].ref, v.t0 = lds[sp * YT_BLOCK].t0;
       return v;
     }
-    return (sp < YT_LDS_DEPTH + YT_SPILL) ? spill[sp - YT_LDS_DEPTH] : StackEntry{REF_EXIT, 0};
+    return (sp < LDS_LEVELS + SPILL_LEVELS) ? spill[sp - LDS_LEVELS] : StackEntry{REF_EXIT, 0};
   };
 
   // intersect_shape_bvh prologue for instance `inst`: transform_ray(inverse(frame,

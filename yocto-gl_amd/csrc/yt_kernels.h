@@ -230,7 +230,9 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
 }
 
 // sample_lights_pdf — yocto_trace.cpp:391-443.  WALK: 0 = no instance lights in
-// the scene, 1 = walks through the out-of-line trace_ray, 2 = walks inline.
+// the scene, 1 = walks through the out-of-line trace_ray, 2 = walks inline, 3 = walks
+// inline with their stack in scratch only (k_pool: the LDS stack columns belong to
+// suspended scene walks).
 template <int WALK>
 YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt) {
   auto pdf = 0.0f;
@@ -248,6 +250,9 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
           Hit isec;
           if constexpr (WALK == 1) {
             isec = trace_ray(sc, next_position, direction, light.instance, *st, *cnt);
+          } else if constexpr (WALK == 3) {
+            ray3f ray = make_ray(next_position, direction);
+            isec      = traverse<true, false, false, 0>(sc, ray, light.instance, false, *st, *cnt);
           } else {
             ray3f ray = make_ray(next_position, direction);
             isec      = traverse<true>(sc, ray, light.instance, false, *st, *cnt);

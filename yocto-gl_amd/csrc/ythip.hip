@@ -21,6 +21,7 @@
 #include "yt_build.h"
 #include "yt_gpubuild.h"
 #include "yt_kernels.h"
+#include "yt_pool.h"
 
 using namespace yt;
 
@@ -87,6 +88,15 @@ struct ythip_ctx {
   ythip_stats                                  stats   = {};
   float4*                                      nhit_a   = nullptr;
   int*                                         nhit_e   = nullptr;
+
+  // k_pool (yt_pool.h): 0 never, 1 always (where it applies), 2 by the scene (see pool_applies)
+  int                pool_mode = 0;
+  DPool              pool      = {};
+  std::vector<void*> pool_allocs;
+  int                pool_waves = 0, pool_target = 0, pool_refill = 16, pool_shade_min = 64, pool_max_iters = 1 << 28;
+  unsigned           pool_tile_mul = 1;
+  int                pool_rounds   = 0, pool_phase_min = 1, pool_heavy_min = 64;
+  int*               d_stop        = nullptr;  // device-visible cancel flag polled by the kernels
 };
 
 // The wide walk halves a ray's chain of dependent fetches and costs a little more
@@ -570,6 +580,91 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
   return YTHIP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// k_pool (yt_pool.h): the persistent pool kernel.  Applies to whole-slice batches of
+// the path samplers; everything else (trace_sample, counting launches, the NEE
+// samplers) stays on k_trace.  Same trace_state either way.
+// ---------------------------------------------------------------------------
+int ensure_pool(ythip_ctx* ctx, int nwaves) {
+  if (ctx->pool.wgt && ctx->pool.nwaves >= nwaves) return YTHIP_OK;
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  free_all(ctx->pool_allocs);
+  ctx->pool = DPool{};
+  size_t n  = (size_t)nwaves * POOL_T;
+  int    rc;
+#define PAL(field, count) \
+  if ((rc = dalloc(ctx, ctx->pool_allocs, &ctx->pool.field, (size_t)(count)))) return rc;
+  PAL(wgt, n);
+  PAL(rad, n);
+  PAL(rng, n);
+  PAL(misc, n);
+  PAL(hit, n);
+  PAL(park, n);
+  PAL(vol_a, n);
+  PAL(vol_b, n);
+  PAL(pend, n);
+  PAL(tile_counter, 16);
+  PAL(dbg, (size_t)nwaves * POOL_DBG_STRIDE);
+#undef PAL
+  ctx->pool.nwaves = nwaves;
+  return YTHIP_OK;
+}
+
+template <int S, int LP, bool MATTE>
+int launch_pool(ythip_ctx* ctx, const KParams& kp) {
+  int per_cu = 0, cus = 0;
+  HIPCHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<S, LP, MATTE>, 64, 0));
+  HIPCHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+  const int ntiles = ctx->st.nblocks;
+  int       nwaves = ctx->pool_waves > 0 ? ctx->pool_waves : std::max(1, per_cu) * std::max(1, cus);
+  nwaves           = std::max(1, std::min(nwaves, ntiles));  // no more wavefronts than tiles
+  // rays a wavefront keeps in flight (queued or being walked) before it takes another tile
+  int target = ctx->pool_target > 0 ? ctx->pool_target : 128;
+  target     = std::max(1, std::min(POOL_T, target));
+  int rc     = ensure_pool(ctx, nwaves);
+  if (rc) return rc;
+  DPool pl      = ctx->pool;
+  pl.nwaves     = nwaves;
+  pl.ntiles     = ntiles;
+  pl.target     = target;
+  pl.refill_min = std::max(1, std::min(64, ctx->pool_refill));
+  pl.shade_min  = std::max(1, std::min(64, ctx->pool_shade_min));
+  pl.max_iters  = ctx->pool_max_iters;
+  pl.tile_mul   = ctx->pool_tile_mul ? ctx->pool_tile_mul : 1u;
+  pl.stop       = ctx->d_stop;
+  pl.rounds     = ctx->pool_rounds;
+  pl.phase_min  = std::max(1, std::min(64, ctx->pool_phase_min));
+  pl.heavy_min  = std::max(64, std::min(POOL_T, ctx->pool_heavy_min));
+  // a multiplier that is not coprime to the tile count would skip tiles
+  auto gcd = [](unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; };
+  while (gcd(pl.tile_mul, (unsigned)ntiles) != 1) pl.tile_mul++;
+  HIPCHECK(ctx, hipMemsetAsync(pl.tile_counter, 0, 16 * sizeof(unsigned), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(pl.dbg, 0, (size_t)nwaves * POOL_DBG_STRIDE * sizeof(unsigned long long), ctx->stream));
+  PoolLaunch launch = {ctx->ds, ctx->st, kp, pl};
+  launch.st.vol_a = pl.vol_a, launch.st.vol_b = pl.vol_b, launch.st.pend = pl.pend;  // per-slot arrays: the pool's
+  hipLaunchKernelGGL((k_pool<S, LP, MATTE>), dim3(nwaves), dim3(64), 0, ctx->stream, launch);
+  return YTHIP_OK;
+}
+
+bool pool_applies(const ythip_ctx* ctx, const ythip_params* params, bool count, int only_pix) {
+  if (ctx->pool_mode == 0 || count || only_pix >= 0 || !ctx->use_wide()) return false;
+  if (params->sampler != YTHIP_SAMPLER_PATH && params->sampler != YTHIP_SAMPLER_PATHTEST) return false;
+  if (params->bounces >= 65536 || ctx->st.width >= 65536 || ctx->st.height >= 65536) return false;  // packed slot words
+  return true;
+}
+
+int launch_pool_any(ythip_ctx* ctx, const KParams& kp, int lp) {
+  if (kp.sampler == YTHIP_SAMPLER_PATH) {
+    if (ctx->all_matte && ctx->specialize)
+      return lp == LP_DEFER ? launch_pool<YTHIP_SAMPLER_PATH, LP_DEFER, true>(ctx, kp)
+                            : launch_pool<YTHIP_SAMPLER_PATH, LP_NONE, true>(ctx, kp);
+    return lp == LP_DEFER ? launch_pool<YTHIP_SAMPLER_PATH, LP_DEFER, false>(ctx, kp)
+                          : launch_pool<YTHIP_SAMPLER_PATH, LP_NONE, false>(ctx, kp);
+  }
+  return lp == LP_DEFER ? launch_pool<YTHIP_SAMPLER_PATHTEST, LP_DEFER, false>(ctx, kp)
+                        : launch_pool<YTHIP_SAMPLER_PATHTEST, LP_NONE, false>(ctx, kp);
+}
+
 // hipEvent bracketing of one launch (profiling mode bit 0)
 struct EvScope {
   ythip_ctx* ctx;
@@ -654,7 +749,8 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   // until its pixels have taken `batch` samples (k_trace)
   {
     EvScope ev(ctx, 0);
-    int     rc = launch_trace_any(ctx, kp, lp, count);
+    int     rc = pool_applies(ctx, params, count, only_pix) ? launch_pool_any(ctx, kp, lp)
+                                                            : launch_trace_any(ctx, kp, lp, count);
     if (rc) return rc;
   }
   HIPCHECK(ctx, hipGetLastError());
@@ -687,9 +783,19 @@ int ythip_create(int device, ythip_ctx** out) {
   ctx->stream = ctx->own_stream;
   if (const char* e = std::getenv("YTHIP_HOLD")) ctx->hold_policy = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_PEEK")) ctx->peek_policy = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL")) ctx->pool_mode = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_WAVES")) ctx->pool_waves = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_TARGET")) ctx->pool_target = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_REFILL")) ctx->pool_refill = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_SHADEMIN")) ctx->pool_shade_min = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_TILEMUL")) ctx->pool_tile_mul = (unsigned)std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_MAXITERS")) ctx->pool_max_iters = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_ROUNDS")) ctx->pool_rounds = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_PHASEMIN")) ctx->pool_phase_min = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_POOL_HEAVYMIN")) ctx->pool_heavy_min = std::atoi(e);
   if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
-      false) {
+      hipMalloc((void**)&ctx->d_stop, 64) != hipSuccess || hipMemset(ctx->d_stop, 0, 64) != hipSuccess) {
     delete ctx;
     return fail(nullptr, YTHIP_ERR_HIP, "context allocation failed");
   }
@@ -711,6 +817,8 @@ void ythip_destroy(ythip_ctx* ctx) {
     (void)hipEventDestroy(ev.second);
   }
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->d_stop) (void)hipFree(ctx->d_stop);
+  free_all(ctx->pool_allocs);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -1434,6 +1542,34 @@ int ythip_set_early_miss(ythip_ctx* ctx, int enable) {
 int ythip_set_specialization(ythip_ctx* ctx, int enable) {
   if (!ctx) return YTHIP_ERR_INVALID;
   ctx->specialize = enable ? 1 : 0;
+  return YTHIP_OK;
+}
+
+int ythip_set_pool(ythip_ctx* ctx, int mode, int waves, int target, int refill_min, int shade_min, int tile_mul) {
+  if (!ctx || mode < 0 || mode > 2) return fail(ctx, YTHIP_ERR_INVALID, "pool mode must be 0, 1 or 2");
+  ctx->pool_mode = mode;
+  if (waves > 0) ctx->pool_waves = waves;
+  if (target > 0) ctx->pool_target = target;
+  if (refill_min > 0) ctx->pool_refill = refill_min;
+  if (shade_min > 0) ctx->pool_shade_min = shade_min;
+  if (tile_mul > 0) ctx->pool_tile_mul = (unsigned)tile_mul;
+  return YTHIP_OK;
+}
+
+int ythip_pool_stats(ythip_ctx* ctx, uint64_t* sums, uint64_t* maxs) {
+  if (!ctx || !sums || !maxs) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  for (int k = 0; k < POOL_DBG_STRIDE; k++) sums[k] = maxs[k] = 0;
+  if (!ctx->pool.dbg) return YTHIP_OK;
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<unsigned long long> h((size_t)ctx->pool.nwaves * POOL_DBG_STRIDE);
+  HIPCHECK(ctx, hipMemcpy(h.data(), ctx->pool.dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (int w = 0; w < ctx->pool.nwaves; w++)
+    for (int k = 0; k < POOL_DBG_STRIDE; k++) {
+      auto v = h[(size_t)w * POOL_DBG_STRIDE + k];
+      sums[k] += v;
+      maxs[k] = std::max<uint64_t>(maxs[k], v);
+    }
   return YTHIP_OK;
 }
 
