@@ -245,6 +245,13 @@ int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* scene);
  * trace_samples calls (apps/ytrace.cpp:189-204, 248-254) without touching the
  * geometry; everything else stays resident. */
 int ythip_update_cameras(ythip_ctx* ctx, const ythip_camera* cameras, int num);
+/* In-place edits of the other small pools between batches (the reference reads
+ * scene.materials / scene.environments fresh on every trace_samples call,
+ * yocto_trace.cpp:1595-1612; its GUI edits them in place): same counts as the
+ * resident scene, texture references validated.  ythip_update_materials also
+ * re-derives the kernel specialisation from the new material types. */
+int ythip_update_materials(ythip_ctx* ctx, const ythip_material* materials, int num);
+int ythip_update_environments(ythip_ctx* ctx, const ythip_environment* environments, int num);
 
 /* make_trace_bvh → make_scene_bvh (yocto_trace.cpp:88-96,
  * yocto_bvh.cpp:238-302,321-396): host-side build that reproduces the
@@ -386,6 +393,13 @@ int ythip_tonemap_image(ythip_ctx* ctx, float exposure, int filmic, int srgb,
 int ythip_state_bind_device(ythip_ctx* ctx, void* image, void* albedo,
     void* normal, void* hits, void* rngs);
 int ythip_state_set_samples(ythip_ctx* ctx, int samples);
+int ythip_state_get_samples(ythip_ctx* ctx, int* samples);
+/* The device address of the resident `image` array (vec4f per pixel of the slice), after
+ * draining the context's stream: what a framebuffer gather (RCCL) reads. */
+int ythip_state_device_image(ythip_ctx* ctx, void** image);
+/* 1 when everything enqueued on the context's stream has completed, 0 when not yet,
+ * < 0 on error (pairs with ythip_trace_samples_async / ythip_cancel). */
+int ythip_poll(ythip_ctx* ctx);
 
 /* ------------------------------------------------------------------------- */
 /* The hot path                                                                */
@@ -394,12 +408,21 @@ int ythip_state_set_samples(ythip_ctx* ctx, int samples);
 /* trace_samples (yocto_trace.h:171-173, yocto_trace.cpp:1595-1619): renders
  * `params->batch` more samples for every pixel of the resident state slice and
  * bumps state.samples.  Returns immediately (no-op) when
- * state.samples >= params->samples.  `stop` (may be NULL) is polled between
- * samples like trace_start does (yocto_trace.cpp:1637).  Synchronous. */
+ * state.samples >= params->samples.  `stop` (may be NULL) cancels the batch the way
+ * trace_start's worker does (yocto_trace.cpp:1636-1637 checks context.stop before
+ * every sample): the host watches `*stop` while the batch runs and relays it to a
+ * device flag the kernel polls at every sample boundary, so the call returns within
+ * about one sample's time with YTHIP_ERR_CANCELLED; as in the reference the pixels
+ * have then taken different numbers of the batch's samples and state.samples is not
+ * advanced.  Synchronous. */
 int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params,
     const volatile int32_t* stop);
 /* Same, but only enqueues the work on the stream (pair with ythip_sync). */
 int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params);
+/* trace_cancel (yocto_trace.h:219) for an enqueued batch: raises the device flag from
+ * another host thread / after ythip_trace_samples_async; the batch winds down at its
+ * pixels' sample boundaries.  The next batch lowers the flag again. */
+int ythip_cancel(ythip_ctx* ctx);
 /* trace_sample (yocto_trace.h:174-176, yocto_trace.cpp:1461-1492): ONE sample of the
  * pixel (i, j) of the frame — the pixel's next four rng draws, one path, the
  * running-mean update with weight 1 / (sample + 1), hits += 1.  Leaves
@@ -467,6 +490,40 @@ int ythip_intersect_instance_batch(ythip_ctx* ctx, const int32_t* instances,
  * writes width*(rows) rays.  Test entry. */
 int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params,
     ythip_ray* rays);
+
+/* ------------------------------------------------------------------------- */
+/* One process, several GPUs (SURVEY.md §8(b) `ythip_create(device_ids[], n)`, §8(e)) */
+/* ------------------------------------------------------------------------- */
+/* A ythip_multi owns one context per device id (ids may repeat: several ranks on one GPU,
+ * a rehearsal of the sharding).  Scene, BVH and lights are full replicas: upload / build them
+ * on every rank's context (ythip_multi_ctx).  trace_state is sharded by 16-pixel tile
+ * columns dealt round-robin (rank r of n: ythip_state_create_striped(.., r, n)); a pixel's
+ * samples stay on one device (its PCG stream and running means are order-dependent), pixels
+ * are independent (yocto_trace.cpp:1600-1612), so there is NO data-path collective — only the
+ * framebuffer gather of ythip_multi_get_image: RCCL send/recv to device 0 over xGMI between
+ * distinct devices, device copies when ranks share a device. */
+typedef struct ythip_multi ythip_multi;
+int         ythip_create_multi(const int* device_ids, int n, ythip_multi** out);
+void        ythip_destroy_multi(ythip_multi* multi);
+int         ythip_multi_size(const ythip_multi* multi);
+ythip_ctx*  ythip_multi_ctx(ythip_multi* multi, int rank);
+const char* ythip_multi_last_error(const ythip_multi* multi);
+/* make_trace_state's storage for a width x height frame, one column-striped slice per rank */
+int ythip_multi_state_create(ythip_multi* multi, int width, int height);
+/* full-frame host arrays (reference layout, any may be NULL) <-> the ranks' slices */
+int ythip_multi_state_upload(ythip_multi* multi, const float* image, const float* albedo,
+    const float* normal, const int32_t* hits, const uint64_t* rngs, int samples);
+int ythip_multi_state_download(ythip_multi* multi, float* image, float* albedo, float* normal,
+    int32_t* hits, uint64_t* rngs, int* samples);
+/* trace_samples on every device concurrently (one host thread, asynchronous launches);
+ * `stop` as in ythip_trace_samples, relayed to every rank. */
+int ythip_multi_trace_samples(ythip_multi* multi, const ythip_params* params,
+    const volatile int32_t* stop);
+/* get_image (yocto_trace.cpp:1694-1709) of the whole frame: the framebuffer gather. */
+int ythip_multi_get_image(ythip_multi* multi, float* image);
+/* How the last gather moved the slices ("rccl send/recv", "device copies", ...) and the
+ * rank count RCCL's communicator reports (0 when RCCL was not used). */
+int ythip_multi_gather_info(const ythip_multi* multi, char* mode, int mode_len, int* rccl_ranks);
 
 /* ------------------------------------------------------------------------- */
 /* Measurement                                                                 */

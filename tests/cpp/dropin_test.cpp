@@ -10,6 +10,7 @@
 #include <yocto/yocto_shape.h>
 #include <yocto/yocto_trace.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -310,6 +311,110 @@ int main() {
     }
     EXPECT(threw, "embreebvh must be rejected");
   }
+  // 4. make_trace_state / make_trace_lights through libythip's builders: the reference's bytes
+  {
+    auto params       = trace_params{};
+    params.resolution = 200;
+    auto a = make_trace_state(scene, params), b = hip::make_trace_state(scene, params);
+    EXPECT(a.width == b.width && a.height == b.height && a.samples == b.samples, "make_trace_state geometry");
+    EXPECT(same_bytes(a.rngs, b.rngs) && same_bytes(a.image, b.image) && same_bytes(a.hits, b.hits),
+        "hip::make_trace_state differs from the reference's");
+    auto la = make_trace_lights(scene, params), lb = hip::make_trace_lights(scene, params);
+    EXPECT(la.lights.size() == lb.lights.size(), "make_trace_lights count");
+    for (size_t k = 0; k < la.lights.size() && k < lb.lights.size(); k++)
+      EXPECT(la.lights[k].instance == lb.lights[k].instance && la.lights[k].environment == lb.lights[k].environment &&
+                 same_bytes(la.lights[k].elements_cdf, lb.lights[k].elements_cdf),
+          "hip::make_trace_lights: light %zu differs", k);
+  }
+
+  // 5. in-place edits between batches (the reference reads the scene fresh on every call):
+  //    a material colour, an environment-free scene's instance material index
+  {
+    auto params       = trace_params{};
+    params.sampler    = trace_sampler_type::eyelight;
+    params.resolution = 64;
+    params.samples    = 4;
+    params.batch      = 1;
+    auto bvh          = make_trace_bvh(scene, params);
+    auto lights       = make_trace_lights(scene, params);
+    auto cpu = make_trace_state(scene, params), gpu = make_trace_state(scene, params);
+    trace_samples(cpu, scene, bvh, lights, params);
+    hip::trace_samples(gpu, scene, bvh, lights, params);
+    auto saved                = scene.materials[1].color;
+    scene.materials[1].color  = {0.1f, 0.9f, 0.2f};  // edited in place: same object, same sizes
+    trace_samples(cpu, scene, bvh, lights, params);
+    hip::trace_samples(gpu, scene, bvh, lights, params);
+    EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.albedo, gpu.albedo), "in-place material edit not seen");
+    auto saved_m                 = scene.instances[2].material;
+    scene.instances[2].material  = 1;  // an instance switched to another material
+    trace_samples(cpu, scene, bvh, lights, params);
+    hip::trace_samples(gpu, scene, bvh, lights, params);
+    EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.albedo, gpu.albedo), "in-place instance edit not seen");
+    scene.materials[1].color    = saved;
+    scene.instances[2].material = saved_m;
+    hip::invalidate();  // (and the explicit form)
+    trace_samples(cpu, scene, bvh, lights, params);
+    hip::trace_samples(gpu, scene, bvh, lights, params);
+    EXPECT(same_bytes(cpu.image, gpu.image), "render after invalidate() differs");
+  }
+
+  // 6. two states interleaved with trace_samples_resident: the device copy of the first must
+  //    survive the second taking the device (it is stashed, not lost)
+  {
+    auto params       = trace_params{};
+    params.sampler    = trace_sampler_type::eyelight;
+    params.resolution = 64;
+    params.samples    = 8;
+    params.batch      = 2;
+    auto bvh          = make_trace_bvh(scene, params);
+    auto lights       = make_trace_lights(scene, params);
+    auto pb           = params;
+    pb.resolution     = 48;
+    auto ca = make_trace_state(scene, params), ga = make_trace_state(scene, params);
+    auto cb = make_trace_state(scene, pb), gb = make_trace_state(scene, pb);
+    for (auto k = 0; k < 3; k++) {
+      trace_samples(ca, scene, bvh, lights, params);
+      trace_samples(cb, scene, bvh, lights, pb);
+      hip::trace_samples_resident(ga, scene, bvh, lights, params);
+      hip::trace_samples_resident(gb, scene, bvh, lights, pb);
+    }
+    auto img = hip::get_image(ga);  // served from the stash (gb holds the device)
+    EXPECT(same_bytes(img.pixels, ca.image), "get_image of a stashed state differs");
+    hip::download_state(ga);
+    hip::download_state(gb);
+    EXPECT(ga.samples == ca.samples && gb.samples == cb.samples, "interleaved states: samples");
+    EXPECT(same_bytes(ca.image, ga.image) && same_bytes(ca.rngs, ga.rngs) && same_bytes(ca.hits, ga.hits),
+        "interleaved states: first state lost samples");
+    EXPECT(same_bytes(cb.image, gb.image) && same_bytes(cb.rngs, gb.rngs), "interleaved states: second state differs");
+  }
+
+  // 7. cancellation (yocto_trace.cpp:1636-1637): trace_cancel stops a long batch at its pixels'
+  //    sample boundaries; state.samples is not advanced
+  {
+    auto params       = trace_params{};
+    params.resolution = 1280;
+    params.samples    = 1 << 20;
+    params.batch      = 4096;  // seconds of work if it ran to its end
+    auto bvh          = make_trace_bvh(scene, params);
+    auto lights       = make_trace_lights(scene, params);
+    auto state        = make_trace_state(scene, params);
+    auto context      = make_trace_context(params);
+    hip::trace_start(context, state, scene, bvh, lights, params);
+    std::this_thread::sleep_for(std::chrono::milliseconds(200));  // (uploads + launch)
+    auto t0 = std::chrono::steady_clock::now();
+    hip::trace_cancel(context);
+    auto ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    EXPECT(ms < 250.0, "trace_cancel took %.1f ms", ms);
+    EXPECT(!context.done && state.samples == 0, "cancelled batch: done %d samples %d", (int)context.done.load(), state.samples);
+    std::printf("trace_cancel of a 1280x1280x4096spp batch returned in %.1f ms\n", ms);
+    // the back-end keeps working after a cancel
+    params.sampler = trace_sampler_type::eyelight, params.resolution = 64, params.samples = 2, params.batch = 2;
+    auto cpu = make_trace_state(scene, params), gpu = make_trace_state(scene, params);
+    trace_samples(cpu, scene, bvh, lights, params);
+    hip::trace_samples(gpu, scene, bvh, lights, params);
+    EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.rngs, gpu.rngs), "render after a cancel differs");
+  }
+  std::printf("devices: %d\n", hip::hip_device_count());
   hip::release();
   std::printf(failures ? "dropin_test: %d FAILURES\n" : "dropin_test: OK\n", failures);
   return failures ? 1 : 0;

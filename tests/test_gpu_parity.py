@@ -642,7 +642,21 @@ def test_cpp_dropin_matches_reference_api():
     import subprocess
     r = subprocess.run([DROPIN], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "dropin_test: OK" in r.stdout
+    assert "dropin_test: OK" in r.stdout and "devices: 1" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_test did not travel")
+def test_cpp_dropin_sharded_over_two_ranks():
+    """The same C++ program with YOCTO_HIP_DEVICES=0,0: the shim drives TWO ranks through
+    libythip's ythip_multi (tile columns dealt round-robin, per-rank contexts and streams,
+    concurrent launches, the framebuffer gather + un-permute) — here on one physical GPU,
+    where the gather uses device copies (RCCL refuses a communicator with a duplicate
+    device).  Every comparison with the CPU reference must hold exactly as with one rank."""
+    import subprocess
+    env = dict(os.environ, YOCTO_HIP_DEVICES="0,0")
+    r = subprocess.run([DROPIN], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "dropin_test: OK" in r.stdout and "devices: 2" in r.stdout
 
 
 YTRACE_CPU = os.path.join(os.path.dirname(DROPIN), "ytrace_cpu")

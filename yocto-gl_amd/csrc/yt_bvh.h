@@ -368,6 +368,14 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         StackEntry e = pop();
         cur          = e.ref;
         if (e.ref < REF_INST && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;  // culled at pop time
+#ifdef YT_TIGHT_POP
+        // a culled entry costs this lane a pop, not a whole lock-step iteration of the loop
+        while (cur == REF_NONE && sp > 0) {
+          e   = pop();
+          cur = e.ref;
+          if (e.ref < REF_INST && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;
+        }
+#endif
         if (cur == REF_NONE) continue;
       }
       if ((unsigned)cur >= (unsigned)REF_INST) break;  // leaf, instance entry or exit → phase 2
@@ -528,14 +536,232 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   return best;
 }
 
+// The wide walk with MAJORITY-PHASE scheduling instead of while-while.  A lane's walk
+// alternates node steps (W), leaf steps (L) and instance entries (E); with incoherent rays
+// the lanes of a wavefront want different things at any moment and "descend until
+// everybody holds a leaf" leaves most of them waiting.  Here every iteration first lets each
+// lane do its cheap bookkeeping (pops, pop-time culling, instance exits, TLAS-leaf
+// expansion) in a short private loop and then runs the ONE step kind most lanes are waiting
+// for.  Same nodes, same order, same tests per ray as traverse<false, true, TRI> — only the
+// interleaving between lanes differs — so the hit records are identical (tested).
+template <bool TRI>
+YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance, Stack& st, Counters& cnt) {
+  Hit best = {-1, -1, 0, 0, 0, false};
+  const vec3f wo = wray.o, wd = wray.d;
+  const float tmin  = wray.tmin;
+  float       tmax  = wray.tmax;
+  float       tmaxk = tmax * BBOX_K;
+  const vec3f wdinv = {1 / wd.x, 1 / wd.y, 1 / wd.z};
+  const int   wsign = ((wdinv.x < 0) ? 1 : 0) | ((wdinv.y < 0) ? 2 : 0) | ((wdinv.z < 0) ? 4 : 0);
+  if (!ray_is_tame(wo, wdinv, tmin) || tmax != tmax) return Hit{HIT_ABORT, -1, 0, 0, 0, false};
+  vec3f o = wo, d = wd, dinv = wdinv;
+  int   sign = wsign, cur_inst = -1, kind = KIND_NONE, leafbias = 0;
+  bool  done = false;
+  lds_entry* const lds = st.lds;
+  int             sp  = 0;
+  StackEntry      spill[YT_SPILL];
+  auto push = [&](int ref, float t0) {
+    StackEntry v = {ref, __float_as_int(t0)};
+    if (sp < YT_LDS_DEPTH)
+      lds[sp * YT_BLOCK].ref = v.ref, lds[sp * YT_BLOCK].t0 = v.t0;
+    else if (sp < YT_LDS_DEPTH + YT_SPILL)
+      spill[sp - YT_LDS_DEPTH] = v;
+    sp++;
+  };
+  auto pop = [&]() -> StackEntry {
+    sp--;
+    if (sp < YT_LDS_DEPTH) {
+      StackEntry v;
+      v.ref = lds[sp * YT_BLOCK].ref, v.t0 = lds[sp * YT_BLOCK].t0;
+      return v;
+    }
+    return (sp < YT_LDS_DEPTH + YT_SPILL) ? spill[sp - YT_LDS_DEPTH] : StackEntry{REF_EXIT, 0};
+  };
+  auto enter = [&](int inst) -> int {
+    const float4* ti = reinterpret_cast<const float4*>(sc.tinst + inst);
+    float4        m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
+    int4          m5 = reinterpret_cast<const int4*>(ti)[5];
+    int           root = __float_as_int(m4.z);
+    if (root == REF_NONE) return REF_NONE;
+    frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
+    vec3f   io   = transform_point(inv, wo);
+    vec3f   id   = transform_vector(inv, wd);
+    vec3f   idin = {1 / id.x, 1 / id.y, 1 / id.z};
+    if (!ray_is_tame(io, idin, tmin)) {  // irregular at this instance's level: the caller redoes the ray binary
+      best = Hit{HIT_ABORT, -1, 0, 0, 0, false};
+      done = true;
+      return REF_NONE;
+    }
+    float t0;
+    bool  ok = slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
+    if (!ok) return REF_NONE;
+    o = io, d = id, dinv = idin;
+    sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
+    cur_inst = inst;
+    kind     = TRI ? KIND_TRIANGLES : __float_as_int(m4.w);
+    leafbias = m5.x;
+    push(REF_EXIT, 0);
+    return root;
+  };
+  auto accept = [&](int element, const PrimHit& h) {
+    best  = {cur_inst, element, h.u, h.v, h.t, true};
+    tmax  = h.t;
+    tmaxk = h.t * BBOX_K;
+  };
+  int cur = REF_NONE;
+  if (only_instance >= 0) {
+    cur = enter(only_instance);
+    if (best.instance == HIT_ABORT) return best;
+    if (cur_inst < 0) return best;
+  } else {
+    if (sc.tlas_ref == REF_NONE) return best;
+    float t0;
+    if (!(slab<false>(o, dinv, tmin, sc.tlas_bmin, sc.tlas_bmax, t0) && t0 <= tmaxk)) return best;
+    cur = sc.tlas_ref;
+  }
+  while (true) {
+    if (!done) {
+      while (true) {
+        if (cur == REF_NONE) {
+          if (sp == 0) {
+            done = true;
+            break;
+          }
+          StackEntry e = pop();
+          cur          = e.ref;
+          if (e.ref < REF_INST && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;  // culled at pop time
+          continue;
+        }
+        if (cur == REF_EXIT) {  // back to the TLAS level: the world ray again
+          cur = REF_NONE;
+          o = wo, d = wd, dinv = wdinv, sign = wsign, cur_inst = -1;
+          if (only_instance >= 0) {  // intersect_instance_bvh: the one instance has been walked
+            done = true;
+            break;
+          }
+          continue;
+        }
+        if (cur < 0 && cur_inst < 0) {
+          // TLAS leaf: its instances in order, each to completion (yocto_bvh.cpp:600-609)
+          const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+          for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
+          cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
+          continue;
+        }
+        break;
+      }
+    }
+    const bool wantW = !done && (unsigned)cur < (unsigned)REF_INST;
+    const bool wantL = !done && cur < 0;
+    const bool wantE = !done && cur >= REF_INST;
+    const int  nW = __popcll(__ballot(wantW)), nL = __popcll(__ballot(wantL)), nE = __popcll(__ballot(wantE));
+    if (nW + nL + nE == 0) break;
+#ifndef YT_PHASE_W  // node steps run while at least 1 / YT_PHASE_W of the waiting lanes want one
+#define YT_PHASE_W 2
+#endif
+#ifndef YT_PHASE_L
+#define YT_PHASE_L 2
+#endif
+    if (nW > 0 && nW * YT_PHASE_W >= nW + nL + nE) {
+      if (wantW) {
+        const float4* Qp = sc.wide + 8 * (int64_t)cur;
+        float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
+        cnt.steps++;
+        float ta, tb, tc, td;
+        bool  fa = slab<true>(o, dinv, tmin, {a0.x, a0.y, a1.x}, {a0.z, a0.w, a1.y}, ta);
+        bool  fb = slab<true>(o, dinv, tmin, {b0.x, b0.y, b1.x}, {b0.z, b0.w, b1.y}, tb);
+        bool  fc = slab<true>(o, dinv, tmin, {c0.x, c0.y, c1.x}, {c0.z, c0.w, c1.y}, tc);
+        bool  fd = slab<true>(o, dinv, tmin, {d0.x, d0.y, d1.x}, {d0.z, d0.w, d1.y}, td);
+        int   ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
+        int   rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;
+        int   rc = (fc && tc <= tmaxk) ? __float_as_int(c1.z) : REF_NONE;
+        int   rd = (fd && td <= tmaxk) ? __float_as_int(d1.z) : REF_NONE;
+        const int  axes = __float_as_int(a1.w);
+        const bool hs = ((sign >> (axes & 3)) & 1) != 0, ls = ((sign >> ((axes >> 2) & 3)) & 1) != 0,
+                   rs = ((sign >> ((axes >> 4) & 3)) & 1) != 0;
+        int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
+        float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
+        int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
+        float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
+        int   pr = REF_NONE;
+        float pt = 0;
+        if (v3r != REF_NONE) pr = v3r, pt = v3t;
+        if (v2r != REF_NONE) {
+          if (pr != REF_NONE) push(pr, pt);
+          pr = v2r, pt = v2t;
+        }
+        if (v1r != REF_NONE) {
+          if (pr != REF_NONE) push(pr, pt);
+          pr = v1r, pt = v1t;
+        }
+        if (v0r != REF_NONE) {
+          if (pr != REF_NONE) push(pr, pt);
+          pr = v0r, pt = v0t;
+        }
+        cur = pr;
+      }
+    } else if (nL > 0 && nL * YT_PHASE_L >= nL + nE) {
+      if (wantL) {
+        const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+        cur = REF_NONE;
+        cnt.steps++;
+        if (TRI || kind == KIND_TRIANGLES) {
+          const float4* L = sc.leafdata + (leafbias + first * 3);
+          for (int k0 = 0; k0 < num; k0 += 2) {
+            float4 a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
+            float4 a1 = L[3 * k0 + 3], b1 = L[3 * k0 + 4], c1 = L[3 * k0 + 5];
+            auto h = intersect_triangle(o, d, tmin, tmax, {a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x});
+            if (h.hit) accept(__float_as_int(c0.y), h);
+            if (k0 + 1 < num) {
+              h = intersect_triangle(o, d, tmin, tmax, {a1.x, a1.y, a1.z}, {a1.w, b1.x, b1.y}, {b1.z, b1.w, c1.x});
+              if (h.hit) accept(__float_as_int(c1.y), h);
+            }
+          }
+        } else if (kind == KIND_QUADS) {
+          const float4* L = sc.leafdata + (leafbias + first * 4);
+          for (int k = 0; k < num; k++) {
+            float4 a = L[4 * k], b = L[4 * k + 1], c = L[4 * k + 2], e4 = L[4 * k + 3];
+            auto h = intersect_quad(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, {c.y, c.z, c.w});
+            if (h.hit) accept(__float_as_int(e4.x), h);
+          }
+        } else if (kind == KIND_LINES) {
+          const float4* L = sc.leafdata + (leafbias + first * 3);
+          for (int k = 0; k < num; k++) {
+            float4 a = L[3 * k], b = L[3 * k + 1], c = L[3 * k + 2];
+            auto h = intersect_line(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
+            if (h.hit) accept(__float_as_int(c.x), h);
+          }
+        } else if (kind == KIND_POINTS) {
+          const float4* L = sc.leafdata + (leafbias + first * 2);
+          for (int k = 0; k < num; k++) {
+            float4 a = L[2 * k], b = L[2 * k + 1];
+            auto h = intersect_point(o, d, tmin, tmax, {a.x, a.y, a.z}, a.w);
+            if (h.hit) accept(__float_as_int(b.x), h);
+          }
+        }
+      }
+    } else {
+      if (wantE) cur = enter(sc.tlas_prims[(cur - REF_INST) >> 1]);
+    }
+  }
+  return best;
+}
+
 // The production entry: the wide walk, and the binary walk for the rays it declines
 // (irregular at world or instance level, find_any) — the same hit record either way.
 template <bool COUNT, bool WIDE, bool TRI = false>
 YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt) {
   if constexpr (WIDE && !COUNT) {
+#ifdef YT_PHASED
+    if (!find_any) {
+      Hit h = traverse_phased<TRI>(sc, wray, only_instance, st, cnt);
+      if (h.instance != HIT_ABORT) return h;
+    }
+#else
     Hit h = traverse<false, true, TRI>(sc, wray, only_instance, find_any, st, cnt);
     if (h.instance != HIT_ABORT) return h;
+#endif
   }
   return traverse<COUNT, false, TRI>(sc, wray, only_instance, find_any, st, cnt);
 }

@@ -84,7 +84,13 @@ struct DState {
   float4* pend;     // deferred light pdf: bsdfcos.xyz (or scattering), bsdf pdf
   // work counters (ythip_stats), may be null
   unsigned long long* counters;
+  // cancellation: a device-visible flag the host raises when the caller's `stop` goes up
+  // (yocto_trace.cpp:1636-1637 polls context.stop per sample); may be null
+  const int* stop;
 };
+YT_FN bool stop_requested(const int* stop) {
+  return stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_QUADS, CNT_LINES, CNT_POINTS, CNT_INST, CNT_SHADES, CNT_SAMPLES, CNT_NUM };
 
@@ -884,7 +890,7 @@ YT_FN bool misses_scene_root(const DScene& sc, vec3f o, vec3f d) {
 // order: results are bit-identical (tested against the counting launch's flow).
 template <bool PEEK = false>
 YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, int slot, Path& P, int step,
-    int max_bounces) {
+    int max_bounces, bool stopped = false) {
   if (step == STEP_DEFER) return OUT_DEFER;
   bool alive = false;
   if (step == STEP_NEXT) {
@@ -902,7 +908,7 @@ YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, in
   if (alive) return OUT_BOUNCE;
   finish_sample(st, kp, slot, P);
   P.sidx += 1;
-  if (P.sidx < st.batch) {
+  if (P.sidx < st.batch && !stopped) {  // (cancelled: the pixel stops at this sample boundary)
     start_sample(sc, st, kp, slot, P);
     return OUT_PRIMARY;
   }
@@ -995,6 +1001,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
 #endif
   const int lb = logical_block(st);
   if (lb < 0) return;
+  if (stop_requested(st.stop)) return;  // cancelled before this tile started
   const int tid = threadIdx.x;
   Stack     stack;
   YT_STACK_INIT(stack, s_stack);
@@ -1015,7 +1022,20 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
       P.sidx = 0;
       P.pix  = pix;
       start_sample(sc, st, kp, slot, P);
-      store_path(W, slot, P);
+      if (max_bounces <= 0 && SAMPLER != YTHIP_SAMPLER_FALSECOLOR) {
+        // the reference's bounce loop never runs (yocto_trace.cpp:466, 1045, 1260): every
+        // sample is its camera-ray draws + the tail of trace_sample with radiance 0, no hit
+        while (true) {
+          finish_sample(st, kp, slot, P);
+          P.sidx += 1;
+          if (P.sidx >= st.batch) break;
+          start_sample(sc, st, kp, slot, P);
+        }
+        st.rngs[pix] = {P.rng.state, P.rng.inc};
+        pix          = -1;
+      } else {
+        store_path(W, slot, P);
+      }
     }
     n = block_partition(Q, slot, pix >= 0 ? OUT_PRIMARY : OUT_DEAD, {0, 0}, false);
   }
@@ -1032,6 +1052,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
     // as much (interiors) everything runs at once, which keeps the lanes full.  The
     // workgroup decides from the traversal work it has measured itself; results do
     // not depend on the decision (pixels are independent).
+    const bool stopped = stop_requested(st.stop);  // once per iteration = at most one sample late
     bool wait = false;
     if (kp.hold && n.y > 0 && n.x > 0) {
       float wp = (float)Q.work[0], rp = (float)Q.rays[0], wb = (float)Q.work[1], rb_ = (float)Q.rays[1];
@@ -1107,7 +1128,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
 #ifdef YT_TIMING
       tmS = __builtin_readcyclecounter();
 #endif
-      cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces);
+      cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
       store_path(W, slot, P);
     }
 #ifdef YT_TIMING
@@ -1169,7 +1190,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
           auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
           P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
           int step = step_tail(P);
-          cls      = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces);
+          cls      = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
           store_path(W, slot, P);
         }
         // append behind what the shade stage queued

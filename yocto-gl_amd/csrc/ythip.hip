@@ -10,11 +10,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ythip.h"
@@ -97,6 +99,9 @@ struct ythip_ctx {
   unsigned           pool_tile_mul = 1;
   int                pool_rounds   = 0, pool_phase_min = 1, pool_heavy_min = 64;
   int*               d_stop        = nullptr;  // device-visible cancel flag polled by the kernels
+  hipStream_t        side_stream   = nullptr;  // raises the flag while the kernel runs on `stream`
+  hipEvent_t         done_event    = nullptr;
+  std::atomic<bool>  stop_raised{false};
 };
 
 // The wide walk halves a ray's chain of dependent fetches and costs a little more
@@ -371,6 +376,35 @@ int bake_bvh(ythip_ctx* ctx) {
       roots[t].ref     = ref_of(0);
       for (int c = 0; c < 3; c++) roots[t].bmin[c] = root.bbox_min[c], roots[t].bmax[c] = root.bbox_max[c];
     }
+  }
+  // One 128-entry stack serves the TLAS walk, the TLAS-leaf continuation entries, the exit
+  // marker and the BLAS walk (yt_bvh.h), where the reference has 128 entries PER LEVEL
+  // (yocto_bvh.cpp:470, 560): refuse trees so deep that the shared stack could overflow
+  // where the reference's would not (a DFS holds at most one pending sibling per level;
+  // + 3 continuation entries of a 4-instance TLAS leaf + the exit marker).
+  {
+    auto depth_of = [&](int t) -> int {
+      if (on_device(t)) return ctx->d_trees[t].depth;
+      const int64_t nn = b.node_offset[t + 1] - b.node_offset[t];
+      if (nn <= 0) return 0;
+      int                                  best = 0;
+      std::vector<std::pair<int64_t, int>> todo = {{0, 1}};
+      while (!todo.empty()) {
+        auto [n, dpt] = todo.back();
+        todo.pop_back();
+        best = std::max(best, dpt);
+        const auto& node = nodes[b.node_offset[t] + n];
+        if (node.internal) todo.push_back({node.start, dpt + 1}), todo.push_back({node.start + 1, dpt + 1});
+      }
+      return best;
+    };
+    int deepest_blas = 0;
+    for (int t = 0; t < nshapes; t++) deepest_blas = std::max(deepest_blas, depth_of(t));
+    const int tlas_depth = depth_of(nshapes);
+    if (tlas_depth + deepest_blas + 5 > 128)
+      return fail(ctx, YTHIP_ERR_INVALID,
+          "bvh too deep for the shared traversal stack: instance tree %d levels + deepest shape tree %d levels + 5 > 128",
+          tlas_depth, deepest_blas);
   }
   // per-instance traversal records
   std::vector<DInstanceT> tinst(ctx->h_instances.size());
@@ -649,7 +683,7 @@ int launch_pool(ythip_ctx* ctx, const KParams& kp) {
 bool pool_applies(const ythip_ctx* ctx, const ythip_params* params, bool count, int only_pix) {
   if (ctx->pool_mode == 0 || count || only_pix >= 0 || !ctx->use_wide()) return false;
   if (params->sampler != YTHIP_SAMPLER_PATH && params->sampler != YTHIP_SAMPLER_PATHTEST) return false;
-  if (params->bounces >= 65536 || ctx->st.width >= 65536 || ctx->st.height >= 65536) return false;  // packed slot words
+  if (params->bounces <= 0 || params->bounces >= 65536 || ctx->st.width >= 65536 || ctx->st.height >= 65536) return false;  // packed slot words
   return true;
 }
 
@@ -725,6 +759,11 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   }
   ctx->st.nhit_a      = mis ? ctx->nhit_a : nullptr;
   ctx->st.nhit_e      = mis ? ctx->nhit_e : nullptr;
+  ctx->st.stop        = ctx->d_stop;
+  if (ctx->stop_raised) {  // a previous batch was cancelled: lower the flag (stream-ordered)
+    HIPCHECK(ctx, hipMemsetAsync(ctx->d_stop, 0, sizeof(int), ctx->stream));
+    ctx->stop_raised = false;
+  }
   ctx->st.sample_base = only_pix < 0 ? ctx->samples : sample;
   ctx->st.batch       = only_pix < 0 ? params->batch : 1;
   ctx->st.only_pix    = only_pix;
@@ -758,6 +797,26 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   return YTHIP_OK;
 }
 
+}  // namespace
+
+namespace {
+// what the kernel specialisation and the bounce-loop bound depend on (from the resident
+// shapes + the given materials)
+void classify_scene(ythip_ctx* ctx, const ythip_material* materials, int num_materials) {
+  ctx->all_matte = num_materials > 0;
+  for (int k = 0; k < num_materials; k++) {
+    const auto& m = materials[k];
+    if (m.type != YTHIP_MATTE || (m.emission_tex & m.color_tex & m.roughness_tex & m.scattering_tex & m.normal_tex) != YTHIP_INVALIDID)
+      ctx->all_matte = false;
+  }
+  for (auto& sh : ctx->h_shapes)  // ... and every shape a triangle mesh
+    if (sh.num_points || sh.num_lines || sh.num_quads) ctx->all_matte = false;
+  ctx->may_retry = false;
+  for (int k = 0; k < num_materials; k++)
+    if (materials[k].opacity < 1 || materials[k].color_tex != YTHIP_INVALIDID) ctx->may_retry = true;
+  for (auto& sh : ctx->h_shapes)
+    if (sh.num_colors) ctx->may_retry = true;
+}
 }  // namespace
 
 // ===========================================================================
@@ -795,7 +854,8 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_POOL_HEAVYMIN")) ctx->pool_heavy_min = std::atoi(e);
   if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void**)&ctx->d_stop, 64) != hipSuccess || hipMemset(ctx->d_stop, 0, 64) != hipSuccess) {
+      hipMalloc((void**)&ctx->d_stop, 64) != hipSuccess || hipMemset(ctx->d_stop, 0, 64) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return fail(nullptr, YTHIP_ERR_HIP, "context allocation failed");
   }
@@ -818,6 +878,8 @@ void ythip_destroy(ythip_ctx* ctx) {
   }
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_stop) (void)hipFree(ctx->d_stop);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
   free_all(ctx->pool_allocs);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -919,21 +981,51 @@ int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* sc) {
   ctx->h_quads.assign(sc->quads, sc->quads + sc->num_quads * 4);
   ctx->h_positions.assign(sc->positions, sc->positions + sc->num_positions * 3);
   ctx->h_radius.assign(sc->radius, sc->radius + sc->num_radius);
-  ctx->all_matte = sc->num_materials > 0;
-  for (int k = 0; k < sc->num_materials; k++) {
-    const auto& m = sc->materials[k];
-    if (m.type != YTHIP_MATTE || (m.emission_tex & m.color_tex & m.roughness_tex & m.scattering_tex & m.normal_tex) != YTHIP_INVALIDID)
-      ctx->all_matte = false;
-  }
-  for (int k = 0; k < sc->num_shapes; k++)  // ... and every shape a triangle mesh
-    if (sc->shapes[k].num_points || sc->shapes[k].num_lines || sc->shapes[k].num_quads) ctx->all_matte = false;
-  ctx->may_retry = false;
-  for (int k = 0; k < sc->num_materials; k++)
-    if (sc->materials[k].opacity < 1 || sc->materials[k].color_tex != YTHIP_INVALIDID) ctx->may_retry = true;
-  for (int k = 0; k < sc->num_shapes; k++)
-    if (sc->shapes[k].num_colors) ctx->may_retry = true;
+  classify_scene(ctx, sc->materials, sc->num_materials);
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_scene = true;
+  return YTHIP_OK;
+}
+
+// In-place edits of the small pools (what the reference's GUI does between batches: it
+// reads the scene fresh on every trace_samples call).  Counts must match the resident scene.
+int ythip_update_materials(ythip_ctx* ctx, const ythip_material* materials, int num) {
+  if (!ctx || (!materials && num > 0)) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  if (num != ctx->ds.num_materials)
+    return fail(ctx, YTHIP_ERR_INVALID, "scene has %d materials resident, %d given", ctx->ds.num_materials, num);
+  for (int k = 0; k < num; k++) {
+    const auto& m   = materials[k];
+    const int   t[] = {m.emission_tex, m.color_tex, m.roughness_tex, m.scattering_tex, m.normal_tex};
+    for (int x : t)
+      if (x != YTHIP_INVALIDID && (x < 0 || x >= ctx->ds.num_textures))
+        return fail(ctx, YTHIP_ERR_INVALID, "material %d references texture %d out of range", k, x);
+  }
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipMemcpyAsync((void*)ctx->ds.materials, materials, (size_t)num * sizeof(ythip_material),
+                    hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  classify_scene(ctx, materials, num);  // the kernel specialisation follows the materials
+  return YTHIP_OK;
+}
+
+int ythip_update_environments(ythip_ctx* ctx, const ythip_environment* environments, int num) {
+  if (!ctx || (!environments && num > 0)) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  if (num != ctx->ds.num_environments)
+    return fail(ctx, YTHIP_ERR_INVALID, "scene has %d environments resident, %d given", ctx->ds.num_environments, num);
+  for (int k = 0; k < num; k++)
+    if (environments[k].emission_tex != YTHIP_INVALIDID &&
+        (environments[k].emission_tex < 0 || environments[k].emission_tex >= ctx->ds.num_textures))
+      return fail(ctx, YTHIP_ERR_INVALID, "environment %d references texture %d out of range", k, environments[k].emission_tex);
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<float> env_inv((size_t)num * 12);
+  for (int k = 0; k < num; k++) ythost::inverse_frame_rigid(environments[k].frame, env_inv.data() + 12 * k);
+  HIPCHECK(ctx, hipMemcpyAsync((void*)ctx->ds.environments, environments, (size_t)num * sizeof(ythip_environment),
+                    hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, hipMemcpyAsync((void*)ctx->ds.env_inv, env_inv.data(), env_inv.size() * sizeof(float),
+                    hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   return YTHIP_OK;
 }
 
@@ -1415,20 +1507,90 @@ int ythip_state_bind_device(ythip_ctx* ctx, void* image, void* albedo, void* nor
   return YTHIP_OK;
 }
 
+int ythip_state_get_samples(ythip_ctx* ctx, int* samples) {
+  if (!ctx || !samples || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  *samples = ctx->samples;
+  return YTHIP_OK;
+}
+
+int ythip_state_device_image(ythip_ctx* ctx, void** image) {
+  if (!ctx || !image || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *image = ctx->st.image;
+  return YTHIP_OK;
+}
+
+int ythip_poll(ythip_ctx* ctx) {
+  if (!ctx) return -YTHIP_ERR_INVALID;
+  if (hipSetDevice(ctx->device) != hipSuccess) return -YTHIP_ERR_HIP;
+  auto e = hipStreamQuery(ctx->stream);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  fail(ctx, YTHIP_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+  return -YTHIP_ERR_HIP;
+}
+
 int ythip_state_set_samples(ythip_ctx* ctx, int samples) {
   if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
   ctx->samples = samples;
   return YTHIP_OK;
 }
 
+namespace {
+// Raise the device-visible cancel flag from the side stream (the batch's kernel polls it
+// once per sample boundary; yocto_trace.cpp:1636-1637).
+int raise_stop(ythip_ctx* ctx) {
+  ctx->stop_raised = true;
+  // A write by the command processor: it needs neither a compute unit nor a DMA engine, so
+  // it lands while the batch's persistent workgroups hold every CU (a copy that is executed
+  // as a blit kernel would wait for one of them to retire — seconds for a long batch).
+  if (hipStreamWriteValue32(ctx->side_stream, ctx->d_stop, 1, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    static const int one = 1;
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_stop, &one, sizeof(int), hipMemcpyHostToDevice, ctx->side_stream));
+  }
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->side_stream));
+  return YTHIP_OK;
+}
+}  // namespace
+
 int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop) {
   if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
-  int rc = enqueue_samples(ctx, params, stop);
+  const int samples_before = ctx->samples;
+  int       rc             = enqueue_samples(ctx, params, stop);
   if (rc) return rc;
+  bool cancelled = false;
+  if (stop) {
+    // the reference checks context.stop before every sample of every pixel; here the host
+    // watches the caller's flag while the batch runs and relays it to the device
+    if (!ctx->done_event) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->done_event, hipEventDisableTiming));
+    HIPCHECK(ctx, hipEventRecord(ctx->done_event, ctx->stream));
+    while (hipEventQuery(ctx->done_event) == hipErrorNotReady) {
+      if (*stop) {
+        if ((rc = raise_stop(ctx))) return rc;
+        cancelled = true;
+        break;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   harvest_events(ctx);
+  if (cancelled) {
+    // as in the reference, some pixels have taken more samples of the batch than others and
+    // state.samples does not advance (yocto_trace.cpp:1636-1641)
+    ctx->samples = samples_before;
+    return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
+  }
   return YTHIP_OK;
+}
+
+int ythip_cancel(ythip_ctx* ctx) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  return raise_stop(ctx);
 }
 
 int ythip_trace_sample(ythip_ctx* ctx, const ythip_params* params, int i, int j, int sample) {

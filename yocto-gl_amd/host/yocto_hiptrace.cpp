@@ -10,6 +10,7 @@
 //
 #include "yocto_hiptrace.h"
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -206,149 +207,314 @@ ythip_params flat(const trace_params& p) {
 // ---------------------------------------------------------------------------
 // residency cache
 // ---------------------------------------------------------------------------
-// A stamp identifies "the same content" cheaply: the object's address plus the
-// sizes of everything that would force a re-flatten.  Cameras are excluded on
-// purpose: they are re-sent on every call (72 B each).
-struct stamp {
-  const void*         who = nullptr;
-  std::vector<size_t> sizes;
-  bool operator==(const stamp& o) const { return who == o.who && sizes == o.sizes; }
-  bool operator!=(const stamp& o) const { return !(*this == o); }
-};
-stamp stamp_of(const scene_data& s) {
-  stamp st{&s, {s.cameras.size(), s.instances.size(), s.environments.size(), s.shapes.size(), s.textures.size(),
-                   s.materials.size()}};
-  for (auto& sh : s.shapes)
-    st.sizes.insert(st.sizes.end(), {sh.points.size(), sh.lines.size(), sh.triangles.size(), sh.quads.size(),
-                                        sh.positions.size(), (size_t)(uintptr_t)sh.positions.data()});
-  return st;
+// The reference reads scene / bvh / lights fresh on every trace_samples call; the device
+// mirrors must notice edits.  A stamp = the object's identity + a CONTENT hash:
+//   * small pools (cameras, materials, environments, instances): hashed in full on every
+//     call — a material edited in place by the GUI is seen, and only that pool is re-sent;
+//   * large arrays (vertices, elements, texture pixels, bvh nodes, light cdfs): their size,
+//     their storage address and a strided sample of 256 elements each (what a refit, a
+//     re-tesselation or a texture reload changes); an edit that keeps all of these can be
+//     announced with hip::invalidate().
+using hash_t = uint64_t;
+hash_t fnv(const void* data, size_t bytes, hash_t h = 1469598103934665603ull) {
+  auto p = (const unsigned char*)data;
+  for (size_t k = 0; k < bytes; k++) h = (h ^ p[k]) * 1099511628211ull;
+  return h;
 }
-// (identified by its node storage, not by the object's address: a trace_bvh is
-// returned by value from make_trace_bvh and moved into the caller's variable)
-stamp stamp_of(const trace_bvh& b) {
-  stamp st{b.bvh.bvh.nodes.data(), {b.bvh.bvh.nodes.size(), b.bvh.shapes.size()}};
-  for (auto& s : b.bvh.shapes) st.sizes.insert(st.sizes.end(), {s.bvh.nodes.size(), (size_t)(uintptr_t)s.bvh.nodes.data()});
-  return st;
+template <typename T>
+hash_t fnv_all(const std::vector<T>& v, hash_t h) {
+  auto n = v.size();
+  h      = fnv(&n, sizeof(n), h);
+  return v.empty() ? h : fnv(v.data(), v.size() * sizeof(T), h);
 }
-stamp stamp_of(const trace_lights& l) {
-  stamp st{&l, {l.lights.size()}};
-  for (auto& x : l.lights) st.sizes.push_back(x.elements_cdf.size());
-  return st;
+template <typename T>
+hash_t fnv_sampled(const std::vector<T>& v, hash_t h) {
+  auto n = v.size();
+  auto a = (uintptr_t)v.data();
+  h      = fnv(&n, sizeof(n), h);
+  h      = fnv(&a, sizeof(a), h);
+  if (n == 0) return h;
+  if (n <= 256) return fnv(v.data(), n * sizeof(T), h);
+  for (size_t k = 0; k < 256; k++) h = fnv(&v[(size_t)((unsigned __int128)k * (n - 1) / 255)], sizeof(T), h);
+  return h;
 }
 
+struct scene_stamp {
+  const void* who = nullptr;
+  hash_t      layout = 0;     // counts + large arrays (sampled): a change re-uploads the scene
+  hash_t      cameras = 0, materials = 0, environments = 0;  // small pools: re-sent on their own
+  bool        valid   = false;
+};
+scene_stamp stamp_of(const scene_data& s) {
+  scene_stamp st;
+  st.who   = &s;
+  st.valid = true;
+  hash_t h = 1469598103934665603ull;
+  size_t counts[] = {s.cameras.size(), s.instances.size(), s.environments.size(), s.shapes.size(), s.textures.size(),
+      s.materials.size()};
+  h = fnv(counts, sizeof(counts), h);
+  // instances: frames feed the instance tree and the traversal records, so they belong to the layout
+  static_assert(sizeof(instance_data) == 56, "instance_data layout");
+  h = fnv_all(s.instances, h);
+  for (auto& sh : s.shapes) {
+    h = fnv_sampled(sh.points, h), h = fnv_sampled(sh.lines, h), h = fnv_sampled(sh.triangles, h);
+    h = fnv_sampled(sh.quads, h), h = fnv_sampled(sh.positions, h), h = fnv_sampled(sh.normals, h);
+    h = fnv_sampled(sh.texcoords, h), h = fnv_sampled(sh.colors, h), h = fnv_sampled(sh.radius, h);
+  }
+  for (auto& t : s.textures) {
+    int f[] = {t.width, t.height, t.linear, t.nearest, t.clamp};
+    h       = fnv(f, sizeof(f), h);
+    h = fnv_sampled(t.pixelsf, h), h = fnv_sampled(t.pixelsb, h);
+  }
+  st.layout = h;
+  hash_t c  = 1469598103934665603ull;
+  for (auto& cam : s.cameras) {
+    auto f = flat(cam);
+    c      = fnv(&f, sizeof(f), c);
+  }
+  st.cameras   = c;
+  st.materials = fnv_all(s.materials, 1469598103934665603ull);
+  hash_t e     = 1469598103934665603ull;
+  for (auto& env : s.environments) {
+    ythip_environment f = {flat(env.frame), {env.emission.x, env.emission.y, env.emission.z}, env.emission_tex};
+    e                   = fnv(&f, sizeof(f), e);
+  }
+  st.environments = e;
+  return st;
+}
+// (a trace_bvh is identified by its node storage, not by the object's address: it is
+// returned by value from make_trace_bvh and moved into the caller's variable)
+hash_t stamp_of(const trace_bvh& b) {
+  hash_t h = fnv_sampled(b.bvh.bvh.nodes, 1469598103934665603ull);
+  h        = fnv_sampled(b.bvh.bvh.primitives, h);
+  for (auto& s : b.bvh.shapes) h = fnv_sampled(s.bvh.nodes, h), h = fnv_sampled(s.bvh.primitives, h);
+  return h ? h : 1;
+}
+hash_t stamp_of(const trace_lights& l) {
+  auto   a = (uintptr_t)&l;
+  hash_t h = fnv(&a, sizeof(a));
+  for (auto& x : l.lights) {
+    int ids[] = {x.instance, x.environment};
+    h         = fnv(ids, sizeof(ids), h);
+    h         = fnv_sampled(x.elements_cdf, h);
+  }
+  return h ? h : 1;
+}
+
+// A device state that ran ahead of its host vectors (trace_samples_resident) and then had to
+// make room for another trace_state: kept here, NOT written through the old object's
+// address (which may be gone), until that state comes back or asks for its data.
+struct shadow_state {
+  const void*           who = nullptr;
+  int                   width = 0, height = 0, samples = 0;
+  std::vector<float>    image, albedo, normal;
+  std::vector<int>      hits;
+  std::vector<uint64_t> rngs;
+};
+
 struct residency {
-  std::mutex  mutex;
-  ythip_ctx*  ctx = nullptr;
-  stamp       scene, bvh, lights;
-  const void* state       = nullptr;  // which trace_state the device slice mirrors
-  int         width = 0, height = 0;
-  int         dev_samples = -1;       // state.samples the device arrays correspond to
-  bool        host_stale  = false;    // device ahead of the host vectors (trace_samples_resident)
+  std::mutex   mutex;
+  ythip_multi* multi = nullptr;
+  int          ranks = 0;
+  scene_stamp  scene;
+  hash_t       bvh = 0, lights = 0;
+  const void*  state       = nullptr;  // which trace_state the device slices mirror
+  int          width = 0, height = 0;
+  int          dev_samples = -1;       // state.samples the device arrays correspond to
+  bool         host_stale  = false;    // device ahead of the host vectors (trace_samples_resident)
+  std::vector<shadow_state> shadows;
+  ythip_ctx*   ctx(int r = 0) { return ythip_multi_ctx(multi, r); }
 };
 residency& cache() {
   static residency r;
   return r;
 }
 
-[[noreturn]] void raise(ythip_ctx* ctx, int code) {
-  std::string msg = ythip_last_error(ctx);
+[[noreturn]] void raise(const std::string& msg, int code) {
   if (code == YTHIP_ERR_SAMPLER) throw std::runtime_error("sampler unknown");  // yocto_trace.cpp:1437
   if (code == YTHIP_ERR_INVALID) throw std::invalid_argument(msg);
   throw std::runtime_error("ythip: " + msg);
 }
 void check(ythip_ctx* ctx, int code) {
-  if (code != YTHIP_OK) raise(ctx, code);
+  if (code != YTHIP_OK) raise(ythip_last_error(ctx), code);
+}
+void mcheck(residency& r, int code) {
+  if (code != YTHIP_OK) raise(ythip_multi_last_error(r.multi), code);
+}
+// a replicated call: the same on every rank's context
+template <typename F>
+void on_all(residency& r, F f) {
+  for (int k = 0; k < r.ranks; k++) check(r.ctx(k), f(r.ctx(k)));
 }
 
+// YOCTO_HIP_DEVICES=0,1,...,7 (one process drives them all: pixels sharded by tile columns,
+// one RCCL framebuffer gather) or YOCTO_HIP_DEVICE=k; default device 0.
 void ensure_context(residency& r) {
-  if (r.ctx) return;
-  auto device = 0;
-  if (auto env = std::getenv("YOCTO_HIP_DEVICE")) device = std::atoi(env);
-  check(nullptr, ythip_create(device, &r.ctx));
+  if (r.multi) return;
+  std::vector<int> devices;
+  if (auto env = std::getenv("YOCTO_HIP_DEVICES")) {
+    for (auto p = env; *p;) {
+      char* end = nullptr;
+      auto  v   = std::strtol(p, &end, 10);
+      if (end == p) break;
+      devices.push_back((int)v);
+      p = *end ? end + 1 : end;
+    }
+  } else if (auto env1 = std::getenv("YOCTO_HIP_DEVICE")) {
+    devices.push_back(std::atoi(env1));
+  }
+  if (devices.empty()) devices.push_back(0);
+  auto rc = ythip_create_multi(devices.data(), (int)devices.size(), &r.multi);
+  if (rc != YTHIP_OK) raise(ythip_multi_last_error(nullptr), rc);
+  r.ranks = ythip_multi_size(r.multi);
 }
 
-// the scene's device mirror (uploads when the stamp changed)
+// the scene's device mirrors (uploads what the stamp says changed)
 void ensure_scene(residency& r, const scene_data& scene, flat_scene* keep = nullptr) {
   ensure_context(r);
-  auto ss = stamp_of(scene);
-  if (ss != r.scene || keep) {
+  auto ss    = stamp_of(scene);
+  bool whole = !r.scene.valid || ss.who != r.scene.who || ss.layout != r.scene.layout;
+  if (whole || keep) {
     flat_scene  local;
     flat_scene& f = keep ? *keep : local;
     flatten(scene, f);
-    if (ss != r.scene) {
-      check(r.ctx, ythip_upload_scene(r.ctx, &f.view));
+    if (whole) {
+      on_all(r, [&](ythip_ctx* c) { return ythip_upload_scene(c, &f.view); });
       r.scene = ss;
-      r.bvh = r.lights = {};
+      r.bvh = r.lights = 0;
+      return;
     }
   }
+  if (ss.cameras != r.scene.cameras) {
+    std::vector<ythip_camera> cams;
+    for (auto& c : scene.cameras) cams.push_back(flat(c));
+    on_all(r, [&](ythip_ctx* c) { return ythip_update_cameras(c, cams.data(), (int)cams.size()); });
+  }
+  if (ss.materials != r.scene.materials) {
+    static_assert(sizeof(ythip_material) == sizeof(material_data), "material layout drifted");
+    on_all(r, [&](ythip_ctx* c) {
+      return ythip_update_materials(c, (const ythip_material*)scene.materials.data(), (int)scene.materials.size());
+    });
+  }
+  if (ss.environments != r.scene.environments) {
+    std::vector<ythip_environment> envs;
+    for (auto& e : scene.environments)
+      envs.push_back({flat(e.frame), {e.emission.x, e.emission.y, e.emission.z}, e.emission_tex});
+    on_all(r, [&](ythip_ctx* c) { return ythip_update_environments(c, envs.data(), (int)envs.size()); });
+  }
+  r.scene = ss;
 }
 
 void ensure_resident(residency& r, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights) {
-  ensure_context(r);
-  auto ss = stamp_of(scene);
-  if (ss != r.scene) {
-    ensure_scene(r, scene);
-  } else {
-    std::vector<ythip_camera> cams;
-    for (auto& c : scene.cameras) cams.push_back(flat(c));
-    check(r.ctx, ythip_update_cameras(r.ctx, cams.data(), (int)cams.size()));
-  }
+  ensure_scene(r, scene);
   auto bs = stamp_of(bvh);
   if (bs != r.bvh) {
     flat_bvh f;
     flatten(bvh.bvh, f);
-    check(r.ctx, ythip_upload_bvh(r.ctx, &f.view));
+    on_all(r, [&](ythip_ctx* c) { return ythip_upload_bvh(c, &f.view); });
     r.bvh = bs;
   }
   auto ls = stamp_of(lights);
   if (ls != r.lights) {
     flat_lights f;
     flatten(lights, f);
-    check(r.ctx, ythip_upload_lights(r.ctx, &f.view));
+    on_all(r, [&](ythip_ctx* c) { return ythip_upload_lights(c, &f.view); });
     r.lights = ls;
   }
 }
 
 void pull_state(residency& r, trace_state& state) {
   int samples = 0;
-  check(r.ctx, ythip_state_download(r.ctx, (float*)state.image.data(), (float*)state.albedo.data(),
-                   (float*)state.normal.data(), state.hits.data(), (uint64_t*)state.rngs.data(), &samples));
+  mcheck(r, ythip_multi_state_download(r.multi, (float*)state.image.data(), (float*)state.albedo.data(),
+                (float*)state.normal.data(), state.hits.data(), (uint64_t*)state.rngs.data(), &samples));
   state.samples = samples;
   r.host_stale  = false;
 }
 
+shadow_state* find_shadow(residency& r, const trace_state& state) {
+  for (auto& s : r.shadows)
+    if (s.who == &state && s.width == state.width && s.height == state.height && s.samples == state.samples) return &s;
+  return nullptr;
+}
+void drop_shadows(residency& r, const void* who) {
+  for (size_t k = 0; k < r.shadows.size();)
+    if (r.shadows[k].who == who)
+      r.shadows.erase(r.shadows.begin() + (long)k);
+    else
+      k++;
+}
+// the device is about to hold another trace_state: if it is the only up-to-date copy of
+// the one it mirrors now, keep that copy
+void stash_device_state(residency& r) {
+  if (!r.multi || !r.state || !r.host_stale) return;
+  drop_shadows(r, r.state);
+  shadow_state s;
+  s.who = r.state, s.width = r.width, s.height = r.height;
+  auto n = (size_t)r.width * (size_t)r.height;
+  s.image.resize(n * 4), s.albedo.resize(n * 3), s.normal.resize(n * 3), s.hits.resize(n), s.rngs.resize(n * 2);
+  mcheck(r, ythip_multi_state_download(r.multi, s.image.data(), s.albedo.data(), s.normal.data(), s.hits.data(),
+                s.rngs.data(), &s.samples));
+  if (r.shadows.size() >= 4) r.shadows.erase(r.shadows.begin());
+  r.shadows.push_back(std::move(s));
+  r.host_stale = false;
+}
+
+// true when the device slices are the up-to-date copy of `state`
+bool device_has(residency& r, const trace_state& state) {
+  return r.multi && r.state == &state && r.width == state.width && r.height == state.height &&
+         r.dev_samples == state.samples;
+}
+
 // scene / bvh / lights / state resident and current on the device (caller holds the lock)
-void ensure_state(residency& r, trace_state& state, const scene_data& scene, const trace_bvh& bvh,
-    const trace_lights& lights) {
+void ensure_state_only(residency& r, const trace_state& state) {
   static_assert(sizeof(rng_state) == 16 && sizeof(vec4f) == 16 && sizeof(vec3f) == 12, "trace_state layout");
-  ensure_resident(r, scene, bvh, lights);
   auto npix = (size_t)state.width * (size_t)state.height;
   if (state.image.size() != npix || state.albedo.size() != npix || state.normal.size() != npix ||
       state.hits.size() != npix || state.rngs.size() != npix)
     throw std::invalid_argument("yocto::hip::trace_samples: trace_state arrays do not match width x height");
-  // the device slice mirrors `state` iff it is the same object, same size, and
-  // nobody advanced it on the host since (samples match)
-  bool current = r.state == &state && r.width == state.width && r.height == state.height &&
-                 r.dev_samples == state.samples;
-  if (!current) {
-    check(r.ctx, ythip_state_create(r.ctx, state.width, state.height, 0, state.height));
-    check(r.ctx, ythip_state_upload(r.ctx, (const float*)state.image.data(), (const float*)state.albedo.data(),
-                     (const float*)state.normal.data(), state.hits.data(), (const uint64_t*)state.rngs.data(),
-                     state.samples));
-    r.state = &state, r.width = state.width, r.height = state.height;
-    r.dev_samples = state.samples;
+  // the device slices mirror `state` iff it is the same object, same size, and nobody
+  // advanced it on the host since (samples match)
+  if (device_has(r, state)) return;
+  stash_device_state(r);
+  mcheck(r, ythip_multi_state_create(r.multi, state.width, state.height));
+  if (auto sh = find_shadow(r, state)) {  // its newest copy is the one that was stashed
+    mcheck(r, ythip_multi_state_upload(r.multi, sh->image.data(), sh->albedo.data(), sh->normal.data(),
+                  sh->hits.data(), sh->rngs.data(), state.samples));
+    drop_shadows(r, &state);
+    r.host_stale = true;
+  } else {
+    drop_shadows(r, &state);  // (a stale shadow of another incarnation at this address)
+    mcheck(r, ythip_multi_state_upload(r.multi, (const float*)state.image.data(), (const float*)state.albedo.data(),
+                  (const float*)state.normal.data(), state.hits.data(), (const uint64_t*)state.rngs.data(),
+                  state.samples));
+    r.host_stale = false;
   }
+  r.state = &state, r.width = state.width, r.height = state.height;
+  r.dev_samples = state.samples;
+}
+void ensure_state(residency& r, trace_state& state, const scene_data& scene, const trace_bvh& bvh,
+    const trace_lights& lights) {
+  ensure_resident(r, scene, bvh, lights);
+  ensure_state_only(r, state);
 }
 
 void trace_impl(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,
-    const trace_params& params, bool download) {
+    const trace_params& params, bool download, const std::atomic<bool>* stop = nullptr) {
   if (state.samples >= params.samples) return;  // yocto_trace.cpp:1598
   if (params.embreebvh) throw std::invalid_argument("yocto::hip::trace_samples: embreebvh has no device mirror");
   auto& r = cache();
   auto  lock = std::lock_guard{r.mutex};
   ensure_state(r, state, scene, bvh, lights);
   auto p = flat(params);
-  check(r.ctx, ythip_trace_samples(r.ctx, &p, nullptr));
+  mcheck(r, ythip_multi_trace_samples(r.multi, &p, nullptr));
+  if (stop && stop->load()) {
+    // cancelled while the batch ran (trace_cancel raised the device flags): as in the
+    // reference (yocto_trace.cpp:1636-1641) the pixels have taken different numbers of the
+    // batch's samples and state.samples does not advance
+    for (int k = 0; k < r.ranks; k++) check(r.ctx(k), ythip_state_set_samples(r.ctx(k), state.samples));
+    r.host_stale = true;
+    return;
+  }
   state.samples += params.batch;  // yocto_trace.cpp:1614
   r.dev_samples = state.samples;
   r.host_stale  = true;
@@ -372,11 +538,65 @@ bool hip_supported() {
   }
 }
 
-trace_state make_trace_state(const scene_data& scene, const trace_params& params) {
-  return yocto::make_trace_state(scene, params);
+int hip_device_count() {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  ensure_context(r);
+  return r.ranks;
 }
+
+void invalidate() {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  r.scene    = {};
+  r.bvh = r.lights = 0;
+}
+
+// make_trace_state — yocto_trace.cpp:1495-1520, through libythip's own builders (the image-size
+// rule ythip_state_size, the serial master stream ythip_make_rngs): the same code the
+// multi-GPU launcher and the tests use.
+trace_state make_trace_state(const scene_data& scene, const trace_params& params) {
+  if (params.camera < 0 || params.camera >= (int)scene.cameras.size()) return yocto::make_trace_state(scene, params);
+  auto cam = flat(scene.cameras[params.camera]);
+  auto state = trace_state{};
+  if (auto rc = ythip_state_size(&cam, params.resolution, &state.width, &state.height); rc != YTHIP_OK)
+    raise(ythip_last_error(nullptr), rc);
+  state.samples = 0;
+  auto n = (size_t)state.width * (size_t)state.height;
+  state.image.assign(n, {0, 0, 0, 0});
+  state.albedo.assign(n, {0, 0, 0});
+  state.normal.assign(n, {0, 0, 0});
+  state.hits.assign(n, 0);
+  state.rngs.assign(n, {});
+  if (auto rc = ythip_make_rngs(params.seed, (int64_t)n, (uint64_t*)state.rngs.data()); rc != YTHIP_OK)
+    raise(ythip_last_error(nullptr), rc);
+  if (params.denoise) state.denoised.assign(n, {0, 0, 0, 0});
+  return state;
+}
+// make_trace_lights — yocto_trace.cpp:1528-1581, through libythip's host builder
+// (ythip_host_lights_build: area CDFs and environment texel CDFs, tested equal to the
+// reference's bytes).
 trace_lights make_trace_lights(const scene_data& scene, const trace_params& params) {
-  return yocto::make_trace_lights(scene, params);
+  (void)params;
+  flat_scene f;
+  flatten(scene, f);
+  ythip_hostlights* hl = nullptr;
+  if (auto rc = ythip_host_lights_build(&f.view, &hl); rc != YTHIP_OK) raise(ythip_last_error(nullptr), rc);
+  ythip_lights view = {};
+  if (auto rc = ythip_host_lights_view(hl, &view); rc != YTHIP_OK) {
+    ythip_host_lights_free(hl);
+    raise(ythip_last_error(nullptr), rc);
+  }
+  auto lights = trace_lights{};
+  for (int k = 0; k < view.num_lights; k++) {
+    auto& l     = view.lights[k];
+    auto& light = lights.lights.emplace_back();
+    light.instance    = l.instance;
+    light.environment = l.environment;
+    light.elements_cdf.assign(view.cdf + l.cdf_offset, view.cdf + l.cdf_offset + l.cdf_count);
+  }
+  ythip_host_lights_free(hl);
+  return lights;
 }
 // make_trace_bvh — yocto_trace.cpp:88-96.  Large shapes are built on the device
 // (ythip_build_bvh, yt_gpubuild.hip: the reference's tree node for node), the
@@ -389,14 +609,14 @@ trace_bvh make_trace_bvh(const scene_data& scene, const trace_params& params) {
   auto       lock = std::lock_guard{r.mutex};
   flat_scene f;
   ensure_scene(r, scene, &f);
-  check(r.ctx, ythip_build_bvh(r.ctx, &f.view, 0));
+  on_all(r, [&](ythip_ctx* c) { return ythip_build_bvh(c, &f.view, 0); });  // deterministic: the same tree on every rank
   int32_t ntrees = 0;
   int64_t nnodes = 0, nprims = 0;
-  check(r.ctx, ythip_bvh_sizes(r.ctx, &ntrees, &nnodes, &nprims));
+  check(r.ctx(), ythip_bvh_sizes(r.ctx(), &ntrees, &nnodes, &nprims));
   auto node_offset = std::vector<int64_t>(ntrees + 1), prim_offset = std::vector<int64_t>(ntrees + 1);
   auto nodes       = std::vector<ythip_bvh_node>((size_t)nnodes);
   auto prims       = std::vector<int32_t>((size_t)nprims);
-  check(r.ctx, ythip_bvh_download(r.ctx, node_offset.data(), prim_offset.data(), nodes.data(), prims.data()));
+  check(r.ctx(), ythip_bvh_download(r.ctx(), node_offset.data(), prim_offset.data(), nodes.data(), prims.data()));
   static_assert(sizeof(ythip_bvh_node) == sizeof(bvh_node), "bvh_node layout drifted");
   auto out  = trace_bvh{};
   auto fill = [&](bvh_tree& t, int k) {
@@ -419,38 +639,45 @@ void update_trace_bvh(trace_bvh& bvh, const scene_data& scene, const vector<int>
     if (s < 0 || s >= (int)scene.shapes.size()) throw std::out_of_range("update_trace_bvh: shape index");
   for (auto i : updated_instances)
     if (i < 0 || i >= (int)scene.instances.size()) throw std::out_of_range("update_trace_bvh: instance index");
-  auto fresh_scene = stamp_of(scene) != r.scene;
-  ensure_scene(r, scene);  // a scene that was not resident goes up whole, already edited
+  ensure_context(r);
+  // the scene as the device has it differs from `scene` exactly by the announced edits when
+  // the same object with the same element lists is resident: then they go up on their own
+  auto fresh_scene = !r.scene.valid || r.scene.who != &scene;
+  if (fresh_scene) ensure_scene(r, scene);  // a scene that was not resident goes up whole, already edited
   if (auto bs = stamp_of(bvh); bs != r.bvh) {
     flat_bvh f;
     flatten(bvh.bvh, f);
-    check(r.ctx, ythip_upload_bvh(r.ctx, &f.view));
+    on_all(r, [&](ythip_ctx* c) { return ythip_upload_bvh(c, &f.view); });
     r.bvh = bs;
   }
   if (!fresh_scene) {
     for (auto s : updated_shapes) {
       auto& sh = scene.shapes[s];
-      check(r.ctx, ythip_update_shape_vertices(r.ctx, s, sh.positions.empty() ? nullptr : &sh.positions[0].x,
-                       (int64_t)sh.positions.size(), sh.normals.empty() ? nullptr : &sh.normals[0].x,
-                       (int64_t)sh.normals.size(), sh.radius.empty() ? nullptr : sh.radius.data(),
-                       (int64_t)sh.radius.size()));
+      on_all(r, [&](ythip_ctx* c) {
+        return ythip_update_shape_vertices(c, s, sh.positions.empty() ? nullptr : &sh.positions[0].x,
+            (int64_t)sh.positions.size(), sh.normals.empty() ? nullptr : &sh.normals[0].x, (int64_t)sh.normals.size(),
+            sh.radius.empty() ? nullptr : sh.radius.data(), (int64_t)sh.radius.size());
+      });
     }
     auto frames = std::vector<ythip_frame>{};
     for (auto i : updated_instances) frames.push_back(flat(scene.instances[i].frame));
-    check(r.ctx, ythip_update_instance_frames(r.ctx, updated_instances.data(), (int)updated_instances.size(),
-                     frames.data()));
+    on_all(r, [&](ythip_ctx* c) {
+      return ythip_update_instance_frames(c, updated_instances.data(), (int)updated_instances.size(), frames.data());
+    });
   }
-  check(r.ctx, ythip_update_bvh(r.ctx, updated_instances.data(), (int)updated_instances.size(),
-                   updated_shapes.data(), (int)updated_shapes.size()));
+  on_all(r, [&](ythip_ctx* c) {
+    return ythip_update_bvh(c, updated_instances.data(), (int)updated_instances.size(), updated_shapes.data(),
+        (int)updated_shapes.size());
+  });
   // the refitted boxes back into the caller's trace_bvh (listed shapes + the instance tree)
   int32_t ntrees = 0;
   int64_t nnodes = 0, nprims = 0;
-  check(r.ctx, ythip_bvh_sizes(r.ctx, &ntrees, &nnodes, &nprims));
+  check(r.ctx(), ythip_bvh_sizes(r.ctx(), &ntrees, &nnodes, &nprims));
   if (ntrees != (int)bvh.bvh.shapes.size() + 1) throw std::invalid_argument("update_trace_bvh: bvh / scene mismatch");
   auto node_offset = std::vector<int64_t>(ntrees + 1), prim_offset = std::vector<int64_t>(ntrees + 1);
   auto nodes       = std::vector<ythip_bvh_node>((size_t)nnodes);
   auto prims       = std::vector<int32_t>((size_t)nprims);
-  check(r.ctx, ythip_bvh_download(r.ctx, node_offset.data(), prim_offset.data(), nodes.data(), prims.data()));
+  check(r.ctx(), ythip_bvh_download(r.ctx(), node_offset.data(), prim_offset.data(), nodes.data(), prims.data()));
   auto fill = [&](bvh_tree& t, int k) {
     auto n = (size_t)(node_offset[k + 1] - node_offset[k]);
     if (n != t.nodes.size()) throw std::invalid_argument("update_trace_bvh: tree sizes changed");
@@ -458,7 +685,8 @@ void update_trace_bvh(trace_bvh& bvh, const scene_data& scene, const vector<int>
   };
   for (auto s : updated_shapes) fill(bvh.bvh.shapes[s].bvh, s);
   fill(bvh.bvh.bvh, ntrees - 1);
-  r.bvh = stamp_of(bvh);
+  r.bvh   = stamp_of(bvh);
+  r.scene = stamp_of(scene);  // the edited vertices / frames are what is resident now
 }
 
 void trace_samples(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,
@@ -478,8 +706,9 @@ void trace_sample(trace_state& state, const scene_data& scene, const trace_bvh& 
   // unless the device copy is known to be ahead, the host copy goes up again
   if (!r.host_stale) r.state = nullptr;
   ensure_state(r, state, scene, bvh, lights);
-  auto p = flat(params);
-  check(r.ctx, ythip_trace_sample(r.ctx, &p, i, j, sample));
+  auto p    = flat(params);
+  auto rank = i >= 0 ? (i / 16) % r.ranks : 0;  // the rank that owns the pixel's tile column
+  check(r.ctx(rank), ythip_trace_sample(r.ctx(rank), &p, i, j, sample));
   auto samples = state.samples;
   pull_state(r, state);  // the pixel's five entries changed; state.samples did not
   state.samples = samples;
@@ -487,7 +716,15 @@ void trace_sample(trace_state& state, const scene_data& scene, const trace_bvh& 
 void download_state(trace_state& state) {
   auto& r    = cache();
   auto  lock = std::lock_guard{r.mutex};
-  if (r.ctx && r.state == &state && r.host_stale) pull_state(r, state);
+  if (device_has(r, state) && r.host_stale) return pull_state(r, state);
+  if (auto sh = find_shadow(r, state)) {  // its newest copy was stashed when another state took the device
+    std::memcpy((void*)state.image.data(), sh->image.data(), sh->image.size() * sizeof(float));
+    std::memcpy((void*)state.albedo.data(), sh->albedo.data(), sh->albedo.size() * sizeof(float));
+    std::memcpy((void*)state.normal.data(), sh->normal.data(), sh->normal.size() * sizeof(float));
+    std::memcpy((void*)state.hits.data(), sh->hits.data(), sh->hits.size() * sizeof(int));
+    std::memcpy((void*)state.rngs.data(), sh->rngs.data(), sh->rngs.size() * sizeof(uint64_t));
+    drop_shadows(r, &state);
+  }
 }
 
 image_data trace_image(const scene_data& scene, const trace_params& params) {
@@ -506,21 +743,49 @@ image_data trace_image(const scene_data& scene, const trace_params& params) {
 // the interactive loop
 // ---------------------------------------------------------------------------
 namespace {
-// true when the device slice is the up-to-date copy of `state`
-bool device_has(residency& r, const trace_state& state) {
-  return r.ctx && r.state == &state && r.width == state.width && r.height == state.height &&
-         r.dev_samples == state.samples;
+void check_linear_image(const image_data& image, const trace_state& state) {  // check_image, yocto_trace.cpp:1679-1686
+  if (image.width != state.width || image.height != state.height)
+    throw std::invalid_argument{"image should have the same size"};
+  if (!image.linear) throw std::invalid_argument{"expected linear image"};
+}
+// where the newest copy of `state` is: 0 the host vectors, 1 the device, 2 a stashed shadow
+int newest_copy(residency& r, const trace_state& state) {
+  if (device_has(r, state) && r.host_stale) return 1;
+  if (find_shadow(r, state)) return 2;
+  return 0;
+}
+// a guide buffer (vec3f per pixel) of the resident / stashed state as the {xyz, 1} image
+// get_albedo_image / get_normal_image return (yocto_trace.cpp:1769-1791)
+void guide_image(residency& r, const trace_state& state, image_data& image, bool albedo) {
+  auto n = (size_t)state.width * (size_t)state.height;
+  if (r.ranks == 1 && device_has(r, state) && r.host_stale) {  // expanded on the device
+    check(r.ctx(), albedo ? ythip_get_albedo_image(r.ctx(), (float*)image.pixels.data())
+                          : ythip_get_normal_image(r.ctx(), (float*)image.pixels.data()));
+    return;
+  }
+  std::vector<float> g(n * 3);
+  if (auto sh = find_shadow(r, state); sh && !(device_has(r, state) && r.host_stale)) {
+    g = albedo ? sh->albedo : sh->normal;
+  } else {
+    mcheck(r, ythip_multi_state_download(r.multi, nullptr, albedo ? g.data() : nullptr, albedo ? nullptr : g.data(),
+                  nullptr, nullptr, nullptr));
+  }
+  for (size_t k = 0; k < n; k++) image.pixels[k] = {g[3 * k], g[3 * k + 1], g[3 * k + 2], 1};
 }
 }  // namespace
 
 void get_image(image_data& image, const trace_state& state) {
-  auto& r    = cache();
-  auto  lock = std::lock_guard{r.mutex};
-  if (!device_has(r, state) || !r.host_stale) return yocto::get_image(image, state);  // host copy is current
-  if (image.width != state.width || image.height != state.height)
-    throw std::invalid_argument{"image should have the same size"};  // check_image, yocto_trace.cpp:1679-1686
-  if (!image.linear) throw std::invalid_argument{"expected linear image"};
-  check(r.ctx, ythip_get_image(r.ctx, (float*)image.pixels.data()));
+  auto& r     = cache();
+  auto  lock  = std::lock_guard{r.mutex};
+  auto  where = newest_copy(r, state);
+  if (where == 0) return yocto::get_image(image, state);  // host copy is current
+  check_linear_image(image, state);
+  if (where == 1) {  // the framebuffer gather: 16 B/pixel, not the whole 60 B/pixel trace_state
+    mcheck(r, ythip_multi_get_image(r.multi, (float*)image.pixels.data()));
+  } else {
+    auto sh = find_shadow(r, state);
+    std::memcpy((void*)image.pixels.data(), sh->image.data(), sh->image.size() * sizeof(float));
+  }
 }
 image_data get_image(const trace_state& state) {
   auto image = make_image(state.width, state.height, true);
@@ -529,33 +794,27 @@ image_data get_image(const trace_state& state) {
 }
 
 // the render and the denoiser's guide buffers (yocto_trace.h:183-190)
-namespace {
-void check_linear_image(const image_data& image, const trace_state& state) {  // check_image, yocto_trace.cpp:1679-1686
-  if (image.width != state.width || image.height != state.height)
-    throw std::invalid_argument{"image should have the same size"};
-  if (!image.linear) throw std::invalid_argument{"expected linear image"};
-}
-}  // namespace
 void get_rendered_image(image_data& image, const trace_state& state) {
-  auto& r    = cache();
-  auto  lock = std::lock_guard{r.mutex};
-  if (!device_has(r, state) || !r.host_stale) return yocto::get_rendered_image(image, state);
-  check_linear_image(image, state);
-  check(r.ctx, ythip_get_image(r.ctx, (float*)image.pixels.data()));
+  {
+    auto& r    = cache();
+    auto  lock = std::lock_guard{r.mutex};
+    if (newest_copy(r, state) == 0) return yocto::get_rendered_image(image, state);
+  }
+  hip::get_image(image, state);
 }
 void get_albedo_image(image_data& image, const trace_state& state) {
   auto& r    = cache();
   auto  lock = std::lock_guard{r.mutex};
-  if (!device_has(r, state) || !r.host_stale) return yocto::get_albedo_image(image, state);
+  if (newest_copy(r, state) == 0) return yocto::get_albedo_image(image, state);
   check_linear_image(image, state);
-  check(r.ctx, ythip_get_albedo_image(r.ctx, (float*)image.pixels.data()));
+  guide_image(r, state, image, true);
 }
 void get_normal_image(image_data& image, const trace_state& state) {
   auto& r    = cache();
   auto  lock = std::lock_guard{r.mutex};
-  if (!device_has(r, state) || !r.host_stale) return yocto::get_normal_image(image, state);
+  if (newest_copy(r, state) == 0) return yocto::get_normal_image(image, state);
   check_linear_image(image, state);
-  check(r.ctx, ythip_get_normal_image(r.ctx, (float*)image.pixels.data()));
+  guide_image(r, state, image, false);
 }
 void get_denoised_image(image_data& image, const trace_state& state) {
   hip::get_rendered_image(image, state);  // yocto_trace.cpp:1763-1765 (no OIDN in this build)
@@ -583,16 +842,28 @@ image_data get_denoised_image(const trace_state& state) {
 
 namespace {
 void tonemap_device(residency& r, const trace_state& state, float exposure, bool filmic, float* ldr, uint8_t* ldrb) {
-  if (!device_has(r, state)) {  // bring the host copy over (image only is enough for this)
-    ensure_context(r);
-    check(r.ctx, ythip_state_create(r.ctx, state.width, state.height, 0, state.height));
-    check(r.ctx, ythip_state_upload(r.ctx, (const float*)state.image.data(), (const float*)state.albedo.data(),
-                     (const float*)state.normal.data(), state.hits.data(), (const uint64_t*)state.rngs.data(),
-                     state.samples));
-    r.state = &state, r.width = state.width, r.height = state.height, r.dev_samples = state.samples;
-    r.host_stale = false;
+  ensure_context(r);
+  if (r.ranks > 1) {
+    // several devices: gather the frame (RCCL), tonemap with the reference's own function
+    auto hdr = make_image(state.width, state.height, true);
+    if (newest_copy(r, state) == 1)
+      mcheck(r, ythip_multi_get_image(r.multi, (float*)hdr.pixels.data()));
+    else if (auto sh = find_shadow(r, state))
+      std::memcpy((void*)hdr.pixels.data(), sh->image.data(), sh->image.size() * sizeof(float));
+    else
+      yocto::get_image(hdr, state);
+    auto out = yocto::tonemap_image(hdr, exposure, filmic);
+    auto n   = (size_t)state.width * (size_t)state.height;
+    if (ldr) std::memcpy(ldr, out.pixels.data(), n * sizeof(vec4f));
+    if (ldrb)
+      for (size_t k = 0; k < n; k++) {
+        auto b = float_to_byte(out.pixels[k]);
+        std::memcpy(ldrb + 4 * k, &b, 4);
+      }
+    return;
   }
-  check(r.ctx, ythip_tonemap_image(r.ctx, exposure, filmic ? 1 : 0, 1, ldr, ldrb));
+  if (!device_has(r, state)) ensure_state_only(r, state);  // bring the newest copy over (host vectors or its shadow)
+  check(r.ctx(), ythip_tonemap_image(r.ctx(), exposure, filmic ? 1 : 0, 1, ldr, ldrb));
 }
 }  // namespace
 
@@ -619,14 +890,22 @@ void trace_start(trace_context& context, trace_state& state, const scene_data& s
   context.done   = false;
   context.worker = std::async(std::launch::async, [&]() {
     if (context.stop) return;
-    hip::trace_samples_resident(state, scene, bvh, lights, params);  // includes the denoise hand-off
+    trace_impl(state, scene, bvh, lights, params, false, &context.stop);  // includes the denoise hand-off
     if (context.stop) return;
     context.done = true;
   });
 }
-// trace_cancel — yocto_trace.cpp:1652-1655
+// trace_cancel — yocto_trace.cpp:1652-1655.  The reference's workers test context.stop
+// before every sample; here the flag is relayed to the devices (ythip_cancel), whose
+// kernels test it at every sample boundary, so the batch in flight winds down within
+// about one sample's time instead of running to its end.
 void trace_cancel(trace_context& context) {
   context.stop = true;
+  {
+    auto& r = cache();  // (no lock: the worker holds it while its batch runs; ythip_cancel is made for this)
+    if (r.multi)
+      for (int k = 0; k < r.ranks; k++) (void)ythip_cancel(r.ctx(k));
+  }
   if (context.worker.valid()) context.worker.get();
 }
 // trace_preview — yocto_trace.cpp:1660-1676
@@ -635,12 +914,13 @@ void trace_preview(color_image& image, trace_context& context, trace_state& stat
   auto pparams = params;
   pparams.resolution /= params.pratio;
   pparams.samples = 1;
-  auto pstate     = yocto::make_trace_state(scene, pparams);
+  auto pstate     = hip::make_trace_state(scene, pparams);
   hip::trace_samples(pstate, scene, bvh, lights, pparams);
   {  // the preview state dies here: forget its device mirror
     auto& r    = cache();
     auto  lock = std::lock_guard{r.mutex};
     if (r.state == &pstate) r.state = nullptr, r.dev_samples = -1, r.host_stale = false;
+    drop_shadows(r, &pstate);
   }
   auto preview = yocto::get_image(pstate);
   for (auto idx = 0; idx < state.width * state.height; idx++) {
@@ -653,12 +933,15 @@ void trace_preview(color_image& image, trace_context& context, trace_state& stat
 void release() {
   auto& r    = cache();
   auto  lock = std::lock_guard{r.mutex};
-  if (r.ctx) ythip_destroy(r.ctx);
-  r.ctx   = nullptr;
-  r.scene = r.bvh = r.lights = {};
-  r.state                    = nullptr;
-  r.dev_samples              = -1;
-  r.host_stale               = false;
+  if (r.multi) ythip_destroy_multi(r.multi);
+  r.multi = nullptr;
+  r.ranks = 0;
+  r.scene = {};
+  r.bvh = r.lights = 0;
+  r.state          = nullptr;
+  r.dev_samples    = -1;
+  r.host_stale     = false;
+  r.shadows.clear();
 }
 
 }  // namespace yocto::hip

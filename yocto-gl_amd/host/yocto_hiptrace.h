@@ -14,11 +14,12 @@
 // trace_samples runs on the GPU, and so does make_trace_bvh for large shapes (the
 // tree it returns is the reference's own tree, node for node — DESIGN.md §7b —
 // as the reference's own value type, so a `trace_bvh` built by either side works
-// with either trace_samples).  make_trace_lights / make_trace_state stay the
-// reference's host functions.
+// with either trace_samples).  make_trace_lights / make_trace_state are built by
+// libythip's own host builders (the ones its multi-GPU launcher and tests use), byte for
+// byte the reference's results.
 //
 // The device mirrors of (scene, bvh, lights, state) are cached between calls by
-// identity + a cheap content stamp, so the progressive loop
+// identity + a content stamp (see invalidate() below), so the progressive loop
 //     for (...) trace_samples(state, scene, bvh, lights, params);
 // of apps/ytrace.cpp:141-158 uploads once.
 //
@@ -34,9 +35,22 @@ namespace yocto::hip {
 // True when a HIP device and libythip are usable (mirrors embree_supported(),
 // yocto_bvh.h).  Never throws.
 bool hip_supported();
+// Devices this back-end drives: 1, or the length of YOCTO_HIP_DEVICES=0,1,...,7 — one
+// process, the frame's pixels sharded over the devices by 16-pixel tile columns, one RCCL
+// framebuffer gather (libythip's ythip_multi).
+int hip_device_count();
 
-// yocto_trace.h:160-168.  State and lights: forwarded to the reference's host
-// implementations.  make_trace_bvh: built by libythip (device for shapes >= 16384
+// The device mirrors follow in-place edits of the scene the way the reference does (it
+// reads everything fresh on every call): cameras, materials, environments and instances
+// are compared by content on every call, large arrays (vertices, elements, texture
+// pixels, bvh nodes, light cdfs) by size, storage address and a 256-element content
+// sample.  An edit that escapes the sample (a few vertices moved without
+// update_trace_bvh, a few texels repainted) is announced with invalidate(): the next
+// call uploads scene, bvh and lights again.
+void invalidate();
+
+// yocto_trace.h:160-168.  State and lights: libythip's host builders (the image-size
+// rule + the serial master rng stream; the light CDFs).  make_trace_bvh: built by libythip (device for shapes >= 16384
 // primitives, host otherwise; params.highqualitybvh → the reference's SAH build),
 // left resident, and returned in the reference's layout.
 trace_state  make_trace_state(const scene_data& scene, const trace_params& params);
@@ -108,9 +122,10 @@ vector<vec4b> tonemap_image_bytes(const trace_state& state, float exposure, bool
 // yocto_trace.h:201-225 — same names, same trace_context, same protocol as
 // apps/ytrace.cpp:183-216 uses them: trace_start launches one batch on a worker
 // (hip::trace_samples_resident), context.done flips when it is complete,
-// trace_cancel joins the worker (a batch already on the GPU runs to its end — the
-// reference checks `stop` per sample, here per batch), trace_preview renders the
-// 1-sample low-resolution stand-in.
+// trace_cancel raises the stop flag on the devices too — the kernels test it at every
+// sample boundary, as the reference's workers do (yocto_trace.cpp:1636-1637) — and joins
+// the worker; state.samples is then not advanced.  trace_preview renders the 1-sample
+// low-resolution stand-in.
 void trace_start(trace_context& context, trace_state& state, const scene_data& scene, const trace_bvh& bvh,
     const trace_lights& lights, const trace_params& params);
 void trace_cancel(trace_context& context);

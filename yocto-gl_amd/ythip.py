@@ -401,6 +401,8 @@ _SIGNATURES = {
     "ythip_sync": (C.c_int, [C.c_void_p]),
     "ythip_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(CScene)]),
     "ythip_update_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "ythip_update_materials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "ythip_update_environments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ythip_build_bvh": (C.c_int, [C.c_void_p, C.POINTER(CScene), C.c_int]),
     "ythip_upload_bvh": (C.c_int, [C.c_void_p, C.POINTER(CBvh)]),
     "ythip_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
@@ -446,6 +448,21 @@ _SIGNATURES = {
     "ythip_state_set_samples": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_trace_samples": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_void_p]),
     "ythip_trace_samples_async": (C.c_int, [C.c_void_p, C.POINTER(CParams)]),
+    "ythip_cancel": (C.c_int, [C.c_void_p]),
+    "ythip_poll": (C.c_int, [C.c_void_p]),
+    "ythip_state_get_samples": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "ythip_state_device_image": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ythip_create_multi": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "ythip_destroy_multi": (None, [C.c_void_p]),
+    "ythip_multi_size": (C.c_int, [C.c_void_p]),
+    "ythip_multi_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "ythip_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "ythip_multi_state_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ythip_multi_state_upload": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]),
+    "ythip_multi_state_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)]),
+    "ythip_multi_trace_samples": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_void_p]),
+    "ythip_multi_get_image": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_multi_gather_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "ythip_intersect_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_int, C.c_void_p]),
     "ythip_intersect_instance_batch": (C.c_int, [C.c_void_p, C.c_void_p,
@@ -611,6 +628,15 @@ class Context:
         cams = np.ascontiguousarray(cameras, camera_dt)
         self._check(self.lib.ythip_update_cameras(self.h, cams.ctypes.data, len(cams)),
                     "update_cameras")
+
+    def update_materials(self, materials):
+        """In-place material edits (same count as the resident scene)."""
+        m = np.ascontiguousarray(materials, material_dt)
+        self._check(self.lib.ythip_update_materials(self.h, m.ctypes.data, len(m)), "update_materials")
+
+    def update_environments(self, environments):
+        e = np.ascontiguousarray(environments, environment_dt)
+        self._check(self.lib.ythip_update_environments(self.h, e.ctypes.data, len(e)), "update_environments")
 
     def make_trace_bvh(self, scene, highquality=False):
         cs = scene.c_struct()
@@ -782,6 +808,9 @@ class Context:
     def trace_sample(self, params, i, j, sample):
         """trace_sample (yocto_trace.cpp:1461-1492): one sample of frame pixel (i, j)."""
         self._check(self.lib.ythip_trace_sample(self.h, C.byref(params), i, j, sample), "trace_sample")
+
+    def cancel(self):
+        self._check(self.lib.ythip_cancel(self.h), "cancel")
 
     def trace_samples_async(self, params):
         self._check(self.lib.ythip_trace_samples_async(self.h, C.byref(params)),
