@@ -6,20 +6,29 @@
            default seed  (configs[1]; SURVEY.md §8d recipe cfg2)
   step     one trace_samples call rendering `--spp` (64) more samples for every
            pixel = 1280*720*64 = 58,982,400 camera paths
-  N > 1    the frame's 16-pixel tile columns dealt round-robin across ranks
-           (sharding.py — balanced, unlike contiguous row blocks whose top ranks
-           would only see sky); every rank holds a full replica of scene+BVH and
-           its slice of trace_state; no data-path collective; one RCCL all-gather
-           of the framebuffer + un-permute per step (inside the timed region, on
-           the kernel's stream: overlapping it with the next step's kernel on a
-           side stream was measured slower — the persistent kernel holds every CU —
-           see DESIGN.md §7).
-           Primary line, "scaling": "weak" — the frame grows with N at the same
-           camera (N x the pixels of configs[1]: 1280x720 per GPU, see
-           weak_resolution()), so per-GPU work is fixed.
-           The same line carries "configs2_strong": BASELINE configs[2] exactly
-           (the 1280x720 frame split N ways, total work fixed), timed right after
-           the primary region with the same K steps and fences.
+  N > 1    BASELINE configs[2]: the SAME 1280x720 frame, its 16-pixel tile columns dealt
+           round-robin across the ranks (sharding.py — balanced, unlike contiguous row
+           blocks whose top ranks would only see sky); every rank holds a full replica
+           of scene + BVH and its slice of trace_state; no data-path collective; one
+           RCCL all-gather of the framebuffer + un-permute per step inside the timed
+           region.  "scaling": "strong" (total work fixed).  The same line carries
+           "weak_scaling": the configs[1] camera at N x the pixels (one configs[1]
+           frame of work per GPU), timed right after with the same K steps and fences.
+
+Roofline (N = 1).  The working sets of the BASELINE scenes are cache-resident (SURVEY.md
+§7/§8d), so no single roof is assumed: for every workload the line reports the
+fraction of each roof that CAN bind, from counters of THAT workload collected live —
+this script re-runs itself as `--worker` under `rocprofv3 --pmc` (two counter passes
+per workload, counters only, outside the timed region) —
+  hbm   (2 x FETCH_SIZE + WRITE_SIZE) per launch / launch time / 8 TB/s
+  l2    TCC_REQ_sum x 128 B per launch / launch time / 34.5 TB/s
+  valu  SQ_INSTS_VALU x c per launch / (1024 SIMDs x shader cycles of the launch), c = the
+        cycles a wave64 VALU instruction of this kernel's mix occupies a SIMD at 4 waves per
+        SIMD, calibrated by tools/microbench/valu_calib.hip (profiles/r02_valu_calib.json)
+and names the largest as `bound`; `frac` is that fraction (<= 1).  The ALGORITHMIC byte
+rate of SURVEY.md §8(d) (reference data layouts x counted work) is reported next to it
+as `algorithmic_GBps` — how fast the kernel consumes the reference's data structures,
+not a roofline (it exceeds the HBM peak on cache-resident scenes).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -27,9 +36,14 @@ Launch:  python bench.py [--gpus N --steps K --warmup W]
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -37,36 +51,196 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "yocto-gl_amd"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+L2_PEAK_GBS = 34500.0    # MI355X_MICROARCH.md §L2: ~34.5 TB/s aggregate
+L2_REQ_BYTES = 128       # one TCC request = one 128-B line
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+CORNELL = os.path.join(ROOT, "tests", "golden", "cornellbox.npz")  # make_cornellbox() as exported (a scene file)
 
 
-def measured_traffic():
-    """HBM bytes per k_trace launch from the PMC passes of the same command
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled
-    as MI355X_MICROARCH.md §HBM prescribes for gfx950), as committed by
-    tools/prof.sh in profiles/traffic.json; None when no profile is present.
-    Counters cannot be read from inside the timed run, so this is not live."""
+# ----------------------------------------------------------------------------
+# workloads: BASELINE.json's single-GPU configs + one cache-exceeding scene
+# ----------------------------------------------------------------------------
+def _workloads():
+    import scenes as ysc
+    return {
+        "configs1": dict(label="BASELINE configs[1]: 1M-triangle plane + constant env",
+                         make=ysc.plane_scene, resolution=1280, spp=64),
+        "cfg2b": dict(label="cfg2b (north star's 1M-triangle Cornell-box-style scene): Cornell box with "
+                            "998,586 wall triangles, 1 area light",
+                      make=lambda: ysc.cornell_1m_scene(ysc.load_scene(CORNELL)), resolution=1024, spp=64),
+        "configs3": dict(label="BASELINE configs[3]: 10,000 instances x 1,024-triangle sphere + constant env",
+                         make=ysc.instanced_scene, resolution=1920, spp=256),
+        "configs4": dict(label="BASELINE configs[4]: 100,000 hair strands (800,000 line segments) + subsurface "
+                               "material on a sphere + constant env",
+                         make=ysc.hair_scene_synthetic, resolution=1280, spp=64),
+        "cornell9m": dict(label="cache-exceeding scene: Cornell box with 8,987,066 triangles "
+                                "(1.3 GB of baked BVH + leaf data, > the 256 MB Infinity Cache)",
+                          make=lambda: ysc.cornell_1m_scene(ysc.load_scene(CORNELL), n=948), resolution=1024,
+                          spp=16),
+    }
+
+
+def open_context(device, flat):
+    import ythip as yt
+    ctx = yt.Context(device)
+    ctx.upload_scene(flat)
+    ctx.make_trace_bvh(flat)
+    ctx.make_trace_lights(flat)
+    return ctx
+
+
+def run_workload(name, device, steps, warmup, count=True):
+    """One workload through the C ABI: optional counting launch, warm-up, `steps` timed
+    launches (hipEvents on the launch stream).  Returns a dict."""
+    import ythip as yt
+    w = _workloads()[name]
+    flat = w["make"]()
+    ctx = open_context(device, flat)
+    p = yt.trace_params(sampler="path", resolution=w["resolution"], bounces=8, clamp=10.0,
+                        samples=1 << 30, batch=w["spp"])
+    width, height = ctx.make_trace_state(flat, p)
+    cnt = None
+    if count:
+        ctx.set_profiling(2)
+        ctx.reset_stats()
+        ctx.trace_samples(p)
+        cnt = ctx.get_stats()
+        ctx.set_profiling(0)
+    for _ in range(warmup):
+        ctx.trace_samples(p)
+    ctx.set_profiling(1)
+    ctx.reset_stats()
+    for _ in range(steps):
+        ctx.trace_samples(p)
+    st = ctx.get_stats()
+    ctx.set_profiling(0)
+    sizes = ctx.bvh_baked_sizes()
+    ctx.close()
+    ms = st["trace_ms"] / max(st["trace_launches"], 1)
+    out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"],
+           "ms_per_launch": ms, "launches": st["trace_launches"], "samples_per_launch": width * height * w["spp"]}
+    if cnt is not None:
+        nsamp = max(cnt["samples"], 1)
+        out["bytes_per_sample"] = yt.algorithmic_bytes(cnt) / nsamp
+        out["per_sample"] = {k: round(cnt[k] / nsamp, 3) for k in
+                             ["rays", "nodes", "triangles", "quads", "lines", "points", "instances", "shades"]}
+    if sizes:
+        out["baked_bytes"] = sizes
+    return out
+
+
+# ----------------------------------------------------------------------------
+# live counters: this script as a worker under rocprofv3 --pmc
+# ----------------------------------------------------------------------------
+PMC_PASSES = [
+    ["FETCH_SIZE", "TCC_REQ_sum", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+    ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"],
+]
+
+
+def rocprof_path():
+    for p in ("/opt/rocm/bin/rocprofv3", shutil.which("rocprofv3") or ""):
+        if p and os.path.exists(p):
+            return p
+    return None
+
+
+def collect_counters(name, device, timeout=240):
+    """Per-launch counter means of the workload's k_trace / k_pool launches, from separate
+    rocprofv3 --pmc passes of `bench.py --worker name` (counters only: never combined with
+    tracing).  Returns (dict counter -> per-launch mean, kernel name) or (None, reason)."""
+    prof = rocprof_path()
+    if prof is None:
+        return None, "rocprofv3 not found"
+    vals, kernel = {}, None
+    for counters in PMC_PASSES:
+        out = tempfile.mkdtemp(prefix="ythip_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--",
+                                            sys.executable, os.path.abspath(__file__), "--worker", name,
+                                            "--worker-device", str(device)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"rocprofv3 pass timed out after {timeout} s"
+        acc, disp = {}, {}
+        for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                if not (k.startswith("yt::k_trace") or k.startswith("yt::k_pool")):
+                    continue
+                kernel = k
+                acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                disp.setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])
+        shutil.rmtree(out, ignore_errors=True)
+        if not acc:
+            return None, f"rocprofv3 pass produced no counters (rc {r.returncode}): {r.stderr[-200:]}"
+        for c, v in acc.items():
+            vals[c] = v / len(disp[c])
+    return vals, kernel
+
+
+def valu_calibration():
+    """profiles/r02_valu_calib.json: cycles a wave64 VALU instruction occupies a SIMD at 4
+    waves/SIMD, per instruction class (measured by tools/microbench/valu_calib.hip), and the
+    mean over the static instruction mix of the dominant kernels (tools/valu_mix.py)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)["k_trace"]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_valu_calib.json")) as f:
+            return json.load(f)
     except Exception:
         return None
 
 
-def measured_valu_busy():
-    """Fraction of the VALU issue slots k_trace keeps busy, from the PMC pass of the
-    same command committed under profiles/ (SQ_ACTIVE_INST_VALU x 4 cycles per wave64
-    instruction / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)); None when no profile is
-    present.  What actually bounds the kernel: the working set is
-    cache-resident, so the algorithmic byte rate exceeds the HBM peak."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
-            d = json.load(f)
-        k = [v for n, v in d.items() if "k_trace<0, 0, false, true, true>" in n][0]
-        cycles = k["GRBM_GUI_ACTIVE"]["per_dispatch"] / 8.0  # summed over the 8 XCDs
-        return round(k["SQ_ACTIVE_INST_VALU"]["per_dispatch"] * 4.0 / (cycles * 1024.0), 4)
-    except Exception:
-        return None
+def roofline_of(run, counters, kernel, calib):
+    """Fractions of the roofs that can bind, from THIS workload's live counters."""
+    ms = run["ms_per_launch"]
+    sec = ms * 1e-3
+    roof = {"kernel": kernel, "launch_ms_avg": round(ms, 4)}
+    if "bytes_per_sample" in run:
+        alg = run["bytes_per_sample"] * run["samples_per_launch"]
+        roof["algorithmic_bytes_per_launch"] = int(alg)
+        roof["algorithmic_GBps"] = round(alg / sec / 1e9, 1)
+    if not counters:
+        roof.update({"bound": None, "frac": None, "traffic": None})
+        return roof
+    fr = {}
+    if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        hbm = 2 * counters["FETCH_SIZE"] * 1024 + counters["WRITE_SIZE"] * 1024  # KiB; gfx950 FETCH_SIZE x 2
+        roof["traffic"] = int(hbm)
+        roof["hbm_GBps"] = round(hbm / sec / 1e9, 1)
+        fr["hbm"] = hbm / sec / 1e9 / HBM_PEAK_GBS
+    if "TCC_REQ_sum" in counters:
+        l2 = counters["TCC_REQ_sum"] * L2_REQ_BYTES
+        roof["l2_GBps"] = round(l2 / sec / 1e9, 1)
+        fr["l2"] = l2 / sec / 1e9 / L2_PEAK_GBS
+        if "TCC_HIT_sum" in counters and "TCC_MISS_sum" in counters:
+            roof["l2_hit_rate"] = round(counters["TCC_HIT_sum"] / max(counters["TCC_HIT_sum"] + counters["TCC_MISS_sum"], 1), 4)
+    if "SQ_INSTS_VALU" in counters and "GRBM_GUI_ACTIVE" in counters and calib:
+        cyc = counters["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs; the profiled launch's own cycles
+        cpi = calib["mix_cycles_per_instruction"]
+        roof["valu_instructions_per_launch"] = int(counters["SQ_INSTS_VALU"])
+        roof["valu_cycles_per_instruction"] = cpi
+        fr["valu"] = counters["SQ_INSTS_VALU"] * cpi / (N_SIMD * cyc)
+    roof["fractions"] = {k: round(v, 4) for k, v in fr.items()}
+    roof["counters_per_launch"] = {k: float(f"{v:.6g}") for k, v in sorted(counters.items())}  # raw, to recompute from
+    if fr:
+        b = max(fr, key=fr.get)
+        roof["bound"] = b
+        roof["frac"] = round(fr[b], 4)
+        if b == "hbm":
+            roof.update(achieved=roof["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s")
+        elif b == "l2":
+            roof.update(achieved=roof["l2_GBps"], peak=L2_PEAK_GBS, unit="GB/s")
+        else:
+            ach = counters["SQ_INSTS_VALU"] / sec / 1e9
+            roof.update(achieved=round(ach, 1), peak=round(ach / fr["valu"], 1), unit="G wave-instructions/s")
+    else:
+        roof.update({"bound": None, "frac": None})
+    return roof
 
 
 def cpu_baseline(flat, params_kw, budget_s=15.0):
@@ -96,57 +270,29 @@ def cpu_baseline(flat, params_kw, budget_s=15.0):
                       f"reference trace_samples via oracle/_ref (g++ -O3, std::async x{cores})"}
 
 
-def other_configs(device, args):
-    """The other single-GPU BASELINE configs through the same path, short runs (their
-    parity lives in tests/test_gpu_baseline_configs.py): cfg2b — the north star's
-    "1M-triangle Cornell-box-style scene" (every ray hits, area-light
-    pdf walks) at 1024x1024x64spp — and configs[3], 10,000 instances of a
-    1,024-triangle mesh at 1920x1080x256spp.  One counting launch + 1 warm-up + 2 timed
-    steps each; algorithmic bytes by the same formula as the headline."""
-    import ythip as yt
-    import scenes as ysc
+def other_workloads(device, args, calib):
+    """The other single-GPU workloads through the same path, short runs (their parity lives in
+    tests/test_gpu_baseline_configs.py): 1 counting launch + 1 warm-up + 2 timed launches
+    each, then the live counter passes -> fractions of the roofs that can bind."""
     res = []
-    cornell = os.path.join(ROOT, "tests", "golden", "cornellbox.npz")  # make_cornellbox() as exported
-    for name, make, resolution, spp in [
-            ("cfg2b: Cornell box with 998,586 wall triangles, 1 area light",
-             lambda: ysc.cornell_1m_scene(ysc.load_scene(cornell)), 1024, 64),
-            ("configs[3]: 10,000 instances x 1,024-triangle sphere + constant env",
-             ysc.instanced_scene, 1920, 256)]:
-        flat = make()
-        ctx = yt.Context(device)
-        ctx.upload_scene(flat)
-        ctx.make_trace_bvh(flat)
-        ctx.make_trace_lights(flat)
-        p = yt.trace_params(sampler="path", resolution=resolution, bounces=8, clamp=10.0,
-                            samples=1 << 30, batch=spp)
-        w, h = ctx.make_trace_state(flat, p)
-        ctx.set_profiling(2)
-        ctx.reset_stats()
-        ctx.trace_samples(p)
-        cnt = ctx.get_stats()
-        ctx.set_profiling(0)
-        ctx.trace_samples(p)
-        ctx.set_profiling(1)
-        ctx.reset_stats()
-        steps = 2
-        for _ in range(steps):
-            ctx.trace_samples(p)
-        st = ctx.get_stats()
-        ctx.set_profiling(0)
-        ctx.close()
-        ms = st["trace_ms"] / steps
-        nsamp = max(cnt["samples"], 1)
-        bps = yt.algorithmic_bytes(cnt) / nsamp
-        res.append({"workload": f"{name}, {w}x{h}x{spp}spp, sampler=path bounces=8 clamp=10",
-                    "value": round(w * h * spp / ms / 1e3, 3), "unit": "Msamples/s",
-                    "ms_per_step": round(ms, 3), "steps": steps,
-                    "bytes_per_sample": round(bps, 1),
-                    "achieved_GBps": round(bps * w * h * spp / (ms * 1e-3) / 1e9, 1),
-                    "per_sample": {"rays": round(cnt["rays"] / nsamp, 3),
-                                   "nodes": round(cnt["nodes"] / nsamp, 3),
-                                   "triangles": round(cnt["triangles"] / nsamp, 3),
-                                   "instances": round(cnt["instances"] / nsamp, 3),
-                                   "shades": round(cnt["shades"] / nsamp, 3)}})
+    for name in ["cfg2b", "configs3", "configs4", "cornell9m"]:
+        try:
+            run = run_workload(name, device, steps=2, warmup=1)
+            counters, kernel = (None, "skipped") if args.no_counters else collect_counters(name, device)
+            roof = roofline_of(run, counters, kernel if counters else None, calib)
+            if counters is None and not args.no_counters:
+                roof["note"] = kernel
+            e = {"workload": f"{run['label']}, {run['width']}x{run['height']}x{run['spp']}spp, "
+                             f"sampler=path bounces=8 clamp=10",
+                 "value": round(run["samples_per_launch"] / run["ms_per_launch"] / 1e3, 3), "unit": "Msamples/s",
+                 "ms_per_step": round(run["ms_per_launch"], 3), "steps": run["launches"],
+                 "bytes_per_sample": round(run["bytes_per_sample"], 1), "per_sample": run["per_sample"],
+                 "roofline": roof}
+            if "baked_bytes" in run:
+                e["baked_bvh_bytes"] = run["baked_bytes"]
+            res.append(e)
+        except Exception as ex:  # reported, never required
+            res.append({"workload": name, "error": str(ex)[:300]})
     return res
 
 
@@ -154,15 +300,20 @@ def weak_resolution(base, world, tile=16):
     """Width of the weak-scaling frame: the same camera at `world` x the pixels of
     the `base`-wide frame, i.e. base * sqrt(world), rounded to a multiple of
     tile * world so every rank owns the same number of 16-pixel tile columns —
-    preferring a multiple of 8 (then 4, 2) tile columns per rank (measured: 57- and
-    58-column slices run 3-6 % slower per pixel than 56- and 80-column ones) — as
-    long as the pixel count stays within 5 % of world x base.
+    preferring a multiple of 8 (then 4, 2) tile columns per rank — as long as the pixel
+    count stays within 5 % of world x base.
     1280 -> 1792 / 2560 / 3584 for 2 / 4 / 8 ranks: 1.96x / 4x / 7.84x the pixels."""
     for m in (8, 4, 2, 1):
         q = tile * world * m
         w = max(q, int(round(base * world ** 0.5 / q)) * q)
         if abs(w * w / (base * base * world) - 1) <= 0.05 or m == 1:
             return w
+
+
+def worker_main(args):
+    """`--worker NAME`: one warm-up + one launch of the workload, nothing printed; run under
+    rocprofv3 --pmc by collect_counters()."""
+    run_workload(args.worker, args.worker_device, steps=1, warmup=1, count=False)
 
 
 def main():
@@ -174,13 +325,15 @@ def main():
     ap.add_argument("--resolution", type=int, default=1280)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true",
+                    help="skip the rocprofv3 --pmc worker passes (roofline fractions become null)")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="N=1: skip the short runs of the other BASELINE configs (other_configs)")
+                    help="N=1: skip the short runs of the other workloads")
     ap.add_argument("--sharding", choices=["columns", "rows"], default="columns")
-    ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
-                    help="N > 1: weak = frame grown to N x the pixels of configs[1] (primary "
-                         "line); strong = configs[2], the 1280x720 frame split N ways; both = "
-                         "weak as the primary line + configs2_strong inside it")
+    ap.add_argument("--scaling", choices=["strong", "weak", "both"], default="both",
+                    help="N > 1: strong = BASELINE configs[2], the 1280x720 frame split N ways (the "
+                         "primary line); weak = frame grown to N x the pixels of configs[1]; both = "
+                         "strong as the primary line + weak_scaling inside it")
     ap.add_argument("--overlap-gather", action="store_true",
                     help="experiment: gather a snapshot of the frame on a side stream while the "
                          "next step's kernel runs (measured slower than the default)")
@@ -191,7 +344,11 @@ def main():
     ap.add_argument("--as-rank", default=None, metavar="R/N",
                     help="single-GPU experiment: render only the slice rank R of N would "
                          "(no gather); the JSON line then describes that slice")
+    ap.add_argument("--worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--worker-device", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.worker:
+        return worker_main(args)
 
     import torch
     import ythip as yt
@@ -226,7 +383,6 @@ def main():
     # ---- workload: BASELINE.json configs[1] --------------------------------
     flat = ysc.plane_scene()  # 1,000,000 triangles, 501,501 vertices
     params_kw = dict(sampler="path", resolution=args.resolution, bounces=8, clamp=10.0)
-    params = yt.trace_params(samples=1 << 30, batch=args.spp, **params_kw)
     t0 = time.time()
     ctx = yt.Context(local)
     ctx.upload_scene(flat)
@@ -321,25 +477,26 @@ def main():
         return float(tmax.item()), (w, h), npix, stats_count, stats_time
 
     keep = []
-    weak = world > 1 and args.scaling in ("weak", "both") and not args.as_rank
-    resolution = weak_resolution(args.resolution, world) if weak else args.resolution
+    # the primary line: BASELINE configs[1] at N = 1, configs[2] (the same frame split N ways) at N > 1
+    primary_weak = world > 1 and args.scaling == "weak" and not args.as_rank
+    resolution = weak_resolution(args.resolution, world) if primary_weak else args.resolution
     dt, (w, h), npix, stats_count, stats_time = run(resolution, not args.no_roofline)
 
     total_samples = (npix if args.as_rank else w * h) * args.spp * args.steps
     value = total_samples / dt / 1e6
     if world == 1:
         what = "BASELINE configs[1]"
-    elif weak:
+    elif primary_weak:
         what = (f"configs[1] per GPU: the configs[1] camera at {world}x the pixels of "
                 f"{args.resolution}x{args.resolution * 9 // 16}")
     else:
-        what = "BASELINE configs[2]: the configs[1] frame split across the ranks"
+        what = "BASELINE configs[2]: the configs[1] frame tile-sharded across the ranks"
 
     out = {
         "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak" if (weak or world == 1) else "strong",
+        "scaling": "weak" if (primary_weak or world == 1) else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"1M-triangle plane + constant env, {w}x{h}x{args.spp}spp, "
                                f"sampler=path bounces=8 clamp=10 ({what})"
@@ -360,52 +517,50 @@ def main():
                                  "build_ms": round(build_info["build_ms"], 3),
                                  "bake_ms": round(build_info["bake_ms"], 3)}},
     }
+    if gathering:  # what the collective library itself reports
+        out["config"]["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+    calib = valu_calibration()
     if rank == 0 and stats_count is not None and stats_time["trace_launches"] > 0:
-        # The dominant (only) kernel is k_trace: one launch = one step.  Its
-        # ALGORITHMIC bytes are SURVEY.md §8(d)'s per-unit figures x the units
-        # counted in one step (all stages: traversal + shading + trace_state).
+        # The dominant (only) kernel is k_trace: one launch = one step.
         launches_per_step = stats_time["trace_launches"] / args.steps
-        bytes_step = yt.algorithmic_bytes(stats_count)
         k_ms = stats_time["trace_ms"] / stats_time["trace_launches"]
-        bytes_per_launch = bytes_step / launches_per_step
-        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
         nsamp = max(stats_count["samples"], 1)
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic() if world == 1 and not args.as_rank else None,
-            "valu_busy": measured_valu_busy() if world == 1 and not args.as_rank else None,
-            "launch_ms_avg": round(k_ms, 4), "launches_per_step": launches_per_step,
-            "bytes_per_launch": int(bytes_per_launch),
-            "traversal_bytes_per_launch": int(yt.traversal_bytes(stats_count) / launches_per_step),
-            "per_sample": {"rays": round(stats_count["rays"] / nsamp, 3),
-                           "nodes": round(stats_count["nodes"] / nsamp, 3),
-                           "triangles": round(stats_count["triangles"] / nsamp, 3),
-                           "instances": round(stats_count["instances"] / nsamp, 3),
-                           "shades": round(stats_count["shades"] / nsamp, 3),
-                           "bytes_all_stages": round(bytes_step / nsamp, 1)},
-        }
+        run1 = {"ms_per_launch": k_ms, "bytes_per_sample": yt.algorithmic_bytes(stats_count) / nsamp,
+                "samples_per_launch": nsamp / launches_per_step}
+        counters, kernel = None, None
+        if world == 1 and not args.as_rank and not args.no_counters and args.resolution == 1280 and args.spp == 64:
+            counters, kernel = collect_counters("configs1", local)
+        roof = roofline_of(run1, counters, kernel if counters else "k_trace", calib)
+        if counters is None:
+            roof["note"] = (kernel or "counters are collected at N = 1 on the default configs[1] workload only")
+        roof["launches_per_step"] = launches_per_step
+        roof["traversal_bytes_per_launch"] = int(yt.traversal_bytes(stats_count) / launches_per_step)
+        roof["per_sample"] = {"rays": round(stats_count["rays"] / nsamp, 3),
+                              "nodes": round(stats_count["nodes"] / nsamp, 3),
+                              "triangles": round(stats_count["triangles"] / nsamp, 3),
+                              "instances": round(stats_count["instances"] / nsamp, 3),
+                              "shades": round(stats_count["shades"] / nsamp, 3),
+                              "bytes_all_stages": round(run1["bytes_per_sample"], 1)}
         if world > 1:
-            out["roofline"]["note"] = "rank 0's launches (its slice of the frame)"
-    if weak and args.scaling == "both":
-        # BASELINE configs[2] exactly: the 1280x720 frame split N ways (total work
-        # fixed), same K steps between the same fences.  Reported, never required:
-        # a failure here (identical on every rank) must not cost the primary line.
+            roof["note"] = "rank 0's launches (its slice of the frame); counters are collected at N = 1 only"
+        out["roofline"] = roof
+    if world > 1 and args.scaling == "both" and not args.as_rank:
+        # weak scaling next to the primary (strong) line: the configs[1] camera at N x the pixels,
+        # same K steps between the same fences.  Reported, never required: a failure here
+        # (identical on every rank) must not cost the primary line.
         try:
-            dt2, (w2, h2), npix2, _, _ = run(args.resolution, False)
-            out["configs2_strong"] = {
+            dt2, (w2, h2), npix2, _, _ = run(weak_resolution(args.resolution, world), False)
+            out["weak_scaling"] = {
                 "value": round(w2 * h2 * args.spp * args.steps / dt2 / 1e6, 3), "unit": "Msamples/s",
-                "ms_per_step": round(dt2 / args.steps * 1e3, 3), "scaling": "strong",
+                "ms_per_step": round(dt2 / args.steps * 1e3, 3), "scaling": "weak",
                 "resolution": [w2, h2], "spp": args.spp, "pixels_per_rank": npix2,
-                "note": "a pixel's samples are sequential by contract (its PCG stream and running "
-                        "mean), so one pixel's 64-sample chain (~1.3 ms) bounds the step however "
-                        "few pixels a GPU holds (DESIGN.md §7)"}
+                "note": "one configs[1] frame of work per GPU (the frame grows with N at the same camera)"}
         except Exception as e:
-            out["configs2_strong"] = {"error": str(e)}
+            out["weak_scaling"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.as_rank and not args.no_other_configs:
         ctx.close()
         try:
-            out["other_configs"] = other_configs(local, args)
+            out["other_configs"] = other_workloads(local, args, calib)
         except Exception as e:  # reported, never required
             out["other_configs"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

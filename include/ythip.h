@@ -485,6 +485,11 @@ int ythip_intersect_batch(ythip_ctx* ctx, const ythip_ray* rays, int64_t n,
 /* intersect_instance_bvh for a batch (yocto_bvh.cpp:619-628). */
 int ythip_intersect_instance_batch(ythip_ctx* ctx, const int32_t* instances,
     const ythip_ray* rays, int64_t n, int find_any, ythip_hit* hits);
+/* The device's restatement of the reference platform's libm (yt_libm.h: glibc 2.35's sinf,
+ * cosf, expf, exp2f, logf, atanf, acosf, atan2f, powf — fn 0..8; 9 fmodf, 10 sqrtf, 11 x / y)
+ * evaluated on the device for n arguments (y may be NULL for the one-argument functions).
+ * Test entry: the results must equal the host's glibc bit for bit. */
+int ythip_test_libm(ythip_ctx* ctx, int fn, const float* x, const float* y, int64_t n, float* out);
 /* sample_camera for the next sample of every resident pixel
  * (yocto_trace.cpp:338-358,1467-1468) WITHOUT advancing the resident rngs;
  * writes width*(rows) rays.  Test entry. */

@@ -73,7 +73,7 @@ int main() {
     EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.rngs, gpu.rngs), "resume across back-ends differs");
   }
 
-  // 2. path: rng streams identical for >= 95 % of the pixels, image mean within 1 %
+  // 2. path: bit-identical trace_state
   {
     auto params       = trace_params{};
     params.resolution = 128;
@@ -86,15 +86,10 @@ int main() {
     while (cpu.samples < params.samples) trace_samples(cpu, scene, bvh, lights, params);
     while (gpu.samples < params.samples) hip::trace_samples_resident(gpu, scene, bvh, lights, params);
     hip::download_state(gpu);
-    auto   same = 0;
-    double mc = 0, mg = 0;
-    for (size_t k = 0; k < cpu.rngs.size(); k++) {
-      same += std::memcmp(&cpu.rngs[k], &gpu.rngs[k], sizeof(rng_state)) == 0;
-      mc += cpu.image[k].x + cpu.image[k].y + cpu.image[k].z;
-      mg += gpu.image[k].x + gpu.image[k].y + gpu.image[k].z;
-    }
-    EXPECT(same >= 0.95 * cpu.rngs.size(), "path: only %d of %zu rng streams agree", same, cpu.rngs.size());
-    EXPECT(std::fabs(mc - mg) <= 0.01 * std::fabs(mc), "path: image mean %g vs %g", mg, mc);
+    // the device evaluates the reference platform's libm (yt_libm.h): nothing to tolerate
+    EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.albedo, gpu.albedo) && same_bytes(cpu.normal, gpu.normal) &&
+               same_bytes(cpu.hits, gpu.hits) && same_bytes(cpu.rngs, gpu.rngs),
+        "path: trace_state differs from the CPU reference's");
     // camera edit between calls (apps/ytrace.cpp:189-204): only the camera is re-sent
     scene.cameras[0].frame.o.x += 0.25f;
     auto cpu2 = make_trace_state(scene, params);

@@ -1,0 +1,101 @@
+// libm_check.cpp — yt_libm.h (the device's restatement of the reference platform's libm)
+// compiled for the HOST and compared with the live glibc, bit for bit:
+//   * every one of the 2^32 float arguments for sinf, cosf, sincosf (both outputs), expf,
+//     exp2f, logf, atanf, acosf (mode "full"; "quick" strides through them);
+//   * seeded pairs + special values for atan2f and powf.
+// NaN results only have to be NaNs on both sides.  TEST INFRASTRUCTURE (tests/test_libm.py).
+// Build: g++ -O2 -std=c++17 -mfma -ffp-contract=off -pthread libm_check.cpp -lm
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <atomic>
+
+#include "../../yocto-gl_amd/csrc/yt_libm.h"
+
+static inline uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float    fl(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline bool     same(float a, float b) { return bits(a) == bits(b) || (std::isnan(a) && std::isnan(b)); }
+
+struct Fn1 { const char* name; float (*mine)(float); float (*ref)(float); };
+static float ref_sincos_s(float x) { float s, c; ::sincosf(x, &s, &c); return s; }
+static float ref_sincos_c(float x) { float s, c; ::sincosf(x, &s, &c); return c; }
+
+int main(int argc, char** argv) {
+  const bool full = argc > 1 && !strcmp(argv[1], "full");
+  const uint64_t stride = full ? 1 : 257;  // quick: 16.7M arguments per function, all exponents
+  const unsigned nthreads = std::max(1u, std::thread::hardware_concurrency());
+  Fn1 fns[] = {{"sinf", ytm::sinf, ::sinf}, {"cosf", ytm::cosf, ::cosf}, {"sincosf.sin", ytm::sinf, ref_sincos_s},
+      {"sincosf.cos", ytm::cosf, ref_sincos_c}, {"expf", ytm::expf, ::expf}, {"exp2f", ytm::exp2f, ::exp2f},
+      {"logf", ytm::logf, ::logf}, {"atanf", ytm::atanf, ::atanf}, {"acosf", ytm::acosf, ::acosf}};
+  int bad_total = 0;
+  for (auto& f : fns) {
+    std::atomic<uint64_t> bad{0}, first{~0ull};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; t++)
+      th.emplace_back([&, t] {
+        uint64_t lb = 0, lf = ~0ull;
+        for (uint64_t u = t * stride; u < (1ull << 32); u += nthreads * stride) {
+          float x = fl((uint32_t)u);
+          if (!same(f.mine(x), f.ref(x))) { lb++; if (u < lf) lf = u; }
+        }
+        bad += lb;
+        uint64_t cur = first.load();
+        while (lf < cur && !first.compare_exchange_weak(cur, lf)) {}
+      });
+    for (auto& t : th) t.join();
+    if (bad) {
+      float x = fl((uint32_t)first.load());
+      printf("MISMATCH %-12s %llu arguments differ; first x = %a (0x%08x): mine %a  glibc %a\n", f.name,
+          (unsigned long long)bad.load(), x, bits(x), f.mine(x), f.ref(x));
+      bad_total++;
+    } else {
+      printf("ok       %-12s %s\n", f.name, full ? "all 2^32 arguments" : "16.7M arguments (stride 257)");
+    }
+  }
+  // two-argument functions
+  {
+    const float special[] = {0.0f, -0.0f, 1.0f, -1.0f, 0.5f, -0.5f, 2.0f, -2.0f, 3.0f, -3.0f, 2.2f, 1.0f / 2.4f, 5.0f,
+        INFINITY, -INFINITY, NAN, 1e-45f, -1e-45f, 1e-38f, 3.4e38f, -3.4e38f, 1e30f, 1e-30f, 0.999999f, 1.000001f, 127.0f,
+        -149.0f, 1e10f, 88.7f, 16777216.0f, 16777217.0f, 0.7f, 0.3f};
+    const int ns = sizeof(special) / sizeof(float);
+    uint64_t badp = 0, bada = 0;
+    float    bx = 0, by = 0;
+    for (int a = 0; a < ns; a++)
+      for (int b = 0; b < ns; b++) {
+        if (!same(ytm::powf(special[a], special[b]), ::powf(special[a], special[b]))) { badp++; bx = special[a]; by = special[b]; }
+        if (!same(ytm::atan2f(special[a], special[b]), ::atan2f(special[a], special[b]))) bada++;
+      }
+    const uint64_t npairs = full ? (1ull << 30) : (1ull << 25);
+    std::atomic<uint64_t> bp{0}, ba{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; t++)
+      th.emplace_back([&, t] {
+        uint64_t s = 0x9E3779B97F4A7C15ull * (t + 1), lp = 0, la = 0;
+        auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+        for (uint64_t k = t; k < npairs; k += nthreads) {
+          uint64_t r = next();
+          float x = fl((uint32_t)r), y = fl((uint32_t)(r >> 32));
+          // half of the pairs in the ranges the tracer uses: bases in (0, 2), exponents in (0, 8)
+          if (k & 1) {
+            x = (float)((r & 0xffffff) / 8388608.0);
+            y = (float)(((r >> 24) & 0xffffff) / 2097152.0);
+          }
+          if (!same(ytm::powf(x, y), ::powf(x, y))) lp++;
+          if (!same(ytm::atan2f(x, y), ::atan2f(x, y))) la++;
+        }
+        bp += lp, ba += la;
+      });
+    for (auto& t : th) t.join();
+    badp += bp, bada += ba;
+    if (badp) { printf("MISMATCH powf   %llu pairs differ (e.g. %a ^ %a)\n", (unsigned long long)badp, bx, by); bad_total++; }
+    else printf("ok       powf         %d x %d special values + %llu seeded pairs\n", ns, ns, (unsigned long long)npairs);
+    if (bada) { printf("MISMATCH atan2f %llu pairs differ\n", (unsigned long long)bada); bad_total++; }
+    else printf("ok       atan2f       %d x %d special values + %llu seeded pairs\n", ns, ns, (unsigned long long)npairs);
+  }
+  printf(bad_total ? "libm_check: %d FUNCTIONS DIFFER\n" : "libm_check: OK\n", bad_total);
+  return bad_total ? 1 : 0;
+}

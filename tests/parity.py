@@ -313,6 +313,19 @@ def apply_edit_to_gpu(ctx, edited, shapes, instances):
 # ----------------------------------------------------------------------------
 # comparison
 # ----------------------------------------------------------------------------
+STATE_KEYS = ["image", "albedo", "normal", "hits", "rngs"]
+
+
+def assert_identical(a, b, what=""):
+    """The whole trace_state, bit for bit.  Since round 2 the device evaluates the reference
+    platform's libm (yt_libm.h), so every float of the path is the reference's and there is no
+    tolerance left to state: image, albedo, normal, hits and the rng streams are equal bytes."""
+    for k in STATE_KEYS:
+        if a[k].tobytes() != b[k].tobytes():
+            ne = a[k].reshape(len(a[k]), -1) != b[k].reshape(len(b[k]), -1)
+            raise AssertionError(f"{what}: {k} differs in {int(ne.any(1).sum())} of {len(a[k])} pixels")
+
+
 def image_stats(a, b):
     """Per-pixel relative differences between two radiance images (n,4)."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)

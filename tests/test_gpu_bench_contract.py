@@ -34,9 +34,16 @@ def test_default_line_carries_the_contract():
     # value = units / time
     assert abs(j["value"] - 1280 * 720 * 64 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
     r = j["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["launch_ms_avg"] * 1e-3) / 1e9) <= 1e-3 * r["achieved"]
+    # fractions of the roofs that can bind, from live counters of this workload: all <= 1, the
+    # largest is the bound
+    assert r["bound"] in ("hbm", "l2", "valu") and set(r["fractions"]) == {"hbm", "l2", "valu"}
+    assert all(0 < f <= 1 for f in r["fractions"].values()), r["fractions"]
+    assert r["frac"] == max(r["fractions"].values()) and r["fractions"][r["bound"]] == r["frac"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    assert r["traffic"] > 0 and abs(r["fractions"]["hbm"] - r["traffic"] / (r["launch_ms_avg"] * 1e-3) / 8e12) < 1e-3
+    # the algorithmic byte rate is reported next to it (it exceeds the HBM peak on this cache-resident scene)
+    assert abs(r["algorithmic_GBps"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms_avg"] * 1e-3) / 1e9) <= \
+        1e-3 * r["algorithmic_GBps"]
     assert 0 < r["launch_ms_avg"] <= j["ms_per_step"] * 1.05  # the kernel is the step
     # the counted work is the reference's (32.59 node pops, 3.35 triangle tests per sample)
     assert abs(r["per_sample"]["nodes"] - 32.592) < 0.01 and abs(r["per_sample"]["triangles"] - 3.348) < 0.01
@@ -44,9 +51,16 @@ def test_default_line_carries_the_contract():
     if "error" not in b:
         assert b["kind"] == "reference" and b["unit"] == "Msamples/s" and b["cores"] >= 1 and b["value"] > 0
         assert j["value"] > b["value"]
-    assert isinstance(j.get("other_configs"), list) and len(j["other_configs"]) == 2
+    # cfg2b, configs[3], configs[4] (hair) and the cache-exceeding Cornell box, each with its own fractions
+    assert isinstance(j.get("other_configs"), list) and len(j["other_configs"]) == 4
     for o in j["other_configs"]:
+        assert "error" not in o, o
         assert o["value"] > 0 and o["unit"] == "Msamples/s"
+        f = o["roofline"]["fractions"]
+        assert set(f) == {"hbm", "l2", "valu"} and all(0 < x <= 1 for x in f.values()), (o["workload"], f)
+    assert "800,000 line segments" in j["other_configs"][2]["workload"]
+    big = j["other_configs"][3]
+    assert big["baked_bvh_bytes"] > 400e6  # larger than the 256 MB Infinity Cache
 
 
 def test_slice_run_and_flags():
@@ -59,8 +73,9 @@ def test_two_rank_launch_rehearsed_with_gloo():
     """The N > 1 path of bench.py launched exactly as the driver launches it
     (torch.distributed.run, one process per rank) — rehearsed on this one GPU with the
     gloo backend (YTHIP_DIST_BACKEND; both ranks share the device, so the timings mean
-    nothing): weak-scaling frame, column sharding, framebuffer gather, MAX over ranks,
-    the configs2_strong leg, one JSON line from rank 0."""
+    nothing): BASELINE configs[2] (the frame split over the ranks) as the primary line,
+    column sharding, framebuffer gather, MAX over ranks, the weak-scaling leg, one JSON
+    line from rank 0."""
     env = dict(os.environ, YTHIP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     port = 29700 + os.getpid() % 200
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
@@ -71,11 +86,12 @@ def test_two_rank_launch_rehearsed_with_gloo():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 2
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 2
     w, h = j["config"]["resolution"]
-    assert (w, h) == (448, 252) and j["config"]["pixels_per_rank"] == w * h // 2  # weak_resolution(320, 2)
-    assert j["config"]["sharding"] == "columns/2"
+    assert (w, h) == (320, 180) and j["config"]["pixels_per_rank"] == w * h // 2  # the SAME frame, split
+    assert "configs[2]" in j["config"]["workload"] and j["config"]["sharding"] == "columns/2"
+    assert j["config"]["collective"] == {"backend": "gloo", "ranks": 2}
     assert abs(j["value"] - w * h * 4 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
-    s = j["configs2_strong"]
-    assert s["resolution"] == [320, 180] and s["pixels_per_rank"] == 320 * 180 // 2 and s["value"] > 0
+    s = j["weak_scaling"]
+    assert s["resolution"] == [448, 252] and s["pixels_per_rank"] == 448 * 252 // 2 and s["value"] > 0  # weak_resolution(320, 2)
     assert "cpu_baseline" not in j and "other_configs" not in j  # rank 0 at N=1 only

@@ -106,8 +106,7 @@ def test_refitted_scene_traces_like_a_fresh_upload_of_the_same_tree_and_like_the
         ref = st.get()
         assert img["rngs"].tobytes() == ref["rngs"].tobytes()
         assert img["hits"].tobytes() == ref["hits"].tobytes()
-        s = P.image_stats(img["image"], ref["image"])
-        assert s["frac_1e4"] >= 0.999, s
+        P.assert_identical(img, ref, "render of the refitted scene")
 
 
 def test_update_keeps_working_over_several_edits_and_rejects_bad_arguments():

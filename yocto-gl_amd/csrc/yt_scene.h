@@ -142,7 +142,7 @@ YT_FN ray3f sample_camera(const ythip_camera& camera, int i, int j, int width, i
 // ---------------------------------------------------------------------------
 YT_FN float srgb_to_rgb(float srgb) {  // yocto_color.h:235 (double-typed threshold)
   return ((double)srgb <= 0.04045) ? srgb / 12.92f
-                                   : powf((srgb + 0.055f) / (1.0f + 0.055f), 2.4f);
+                                   : ytm::powf((srgb + 0.055f) / (1.0f + 0.055f), 2.4f);
 }
 YT_FN vec3f srgb_to_rgb(vec3f c) { return {srgb_to_rgb(c.x), srgb_to_rgb(c.y), srgb_to_rgb(c.z)}; }
 YT_FN vec4f lookup_texture(const DScene& sc, const ythip_texture& t, int i, int j, bool as_linear) {
@@ -475,7 +475,7 @@ YT_FN vec3f eval_environment(const DScene& sc, int env, vec3f direction) {
   }
   auto inv      = ldframe(sc.env_inv + 12 * env);
   auto wl       = transform_direction(inv, direction);
-  auto texcoord = vec2f{atan2f(wl.z, wl.x) / (2 * pif), acosf(clamp_(wl.y, -1.0f, 1.0f)) / pif};
+  auto texcoord = vec2f{ytm::atan2f(wl.z, wl.x) / (2 * pif), ytm::acosf(clamp_(wl.y, -1.0f, 1.0f)) / pif};
   if (texcoord.x < 0) texcoord.x += 1;
   return emission * xyz(eval_texture(sc, environment.emission_tex, texcoord, false));
 }

@@ -18,7 +18,7 @@ YT_FN bool same_hemisphere(vec3f normal, vec3f outgoing, vec3f incoming) {
 YT_FN vec3f fresnel_schlick(vec3f specular, vec3f normal, vec3f outgoing) {
   if (specular == vec3f{0, 0, 0}) return {0, 0, 0};
   auto cosine = dot(normal, outgoing);
-  return specular + (1 - specular) * powf(clamp_(1 - fabs_(cosine), 0.0f, 1.0f), 5.0f);
+  return specular + (1 - specular) * ytm::powf(clamp_(1 - fabs_(cosine), 0.0f, 1.0f), 5.0f);
 }
 // fresnel_dielectric — :318-338
 YT_FN float fresnel_dielectric(float eta, vec3f normal, vec3f outgoing) {
@@ -90,8 +90,8 @@ YT_FN float microfacet_shadowing(float roughness, vec3f normal, vec3f halfway, v
 // sample_microfacet (ggx) — :458-471
 YT_FN vec3f sample_microfacet(float roughness, vec3f normal, vec2f rn) {
   auto phi   = 2 * pif * rn.x;
-  auto theta = atanf(roughness * sqrt_(rn.y / (1 - rn.y)));
-  auto local_half_vector = vec3f{cosf(phi) * sinf(theta), sinf(phi) * sinf(theta), cosf(theta)};
+  auto theta = ytm::atanf(roughness * sqrt_(rn.y / (1 - rn.y)));
+  auto local_half_vector = vec3f{ytm::cosf(phi) * ytm::sinf(theta), ytm::sinf(phi) * ytm::sinf(theta), ytm::cosf(theta)};
   return transform_direction(basis_fromz(normal), local_half_vector);
 }
 // sample_microfacet_pdf — :474-479
@@ -333,7 +333,7 @@ YT_FN vec3f eval_refractive(vec3f color, float ior, float roughness, vec3f norma
     return vec3f{1, 1, 1} *
            fabs_((dot(outgoing, halfway) * dot(incoming, halfway)) /
                  (dot(outgoing, normal) * dot(incoming, normal))) *
-           (1 - F) * D * G / powf(rel_ior * dot(halfway, incoming) + dot(halfway, outgoing), 2.0f) *
+           (1 - F) * D * G / sqr_(rel_ior * dot(halfway, incoming) + dot(halfway, outgoing)) *
            fabs_(dot(normal, incoming));
   }
 }
@@ -366,7 +366,7 @@ YT_FN float sample_refractive_pdf(vec3f color, float ior, float roughness, vec3f
     // [Walter 2007] equation 17
     return (1 - fresnel_dielectric(rel_ior, halfway, outgoing)) *
            sample_microfacet_pdf(roughness, up_normal, halfway) * fabs_(dot(halfway, incoming)) /
-           powf(rel_ior * dot(halfway, incoming) + dot(halfway, outgoing), 2.0f);
+           sqr_(rel_ior * dot(halfway, incoming) + dot(halfway, outgoing));
   }
 }
 // ---- refractive (delta) — :959-1005 (`abs(ior-1) < 1e-3` compares in double) ---
@@ -423,7 +423,7 @@ YT_FN vec3f eval_transmittance(vec3f density, float distance) { return exp_(-den
 YT_FN float sample_transmittance(vec3f density, float max_distance, float rl, float rd) {
   auto channel  = clamp_((int)(rl * 3), 0, 2);
   auto dch      = at(density, channel);
-  auto distance = (dch == 0) ? flt_max : -logf(1 - rd) / dch;
+  auto distance = (dch == 0) ? flt_max : -ytm::logf(1 - rd) / dch;
   return min_(distance, max_distance);
 }
 YT_FN float sample_transmittance_pdf(vec3f density, float distance, float max_distance) {
@@ -448,7 +448,7 @@ YT_FN vec3f sample_phasefunction(float anisotropy, vec3f outgoing, vec2f rn) {
   }
   auto sin_theta      = sqrt_(max_(0.0f, 1 - cos_theta * cos_theta));
   auto phi            = 2 * pif * rn.x;
-  auto local_incoming = vec3f{sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta};
+  auto local_incoming = vec3f{sin_theta * ytm::cosf(phi), sin_theta * ytm::sinf(phi), cos_theta};
   return basis_fromz(-outgoing) * local_incoming;
 }
 

@@ -1671,6 +1671,51 @@ int ythip_intersect_instance_batch(ythip_ctx* ctx, const int32_t* instances, con
   return intersect_impl(ctx, instances, rays, n, find_any, hits);
 }
 
+namespace {
+__global__ void __launch_bounds__(256) k_test_libm(int fn, const float* x, const float* y, long long n, float* out) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = x[i], b = y ? y[i] : 0.0f, r = 0;
+  switch (fn) {
+    case 0: r = ytm::sinf(a); break;
+    case 1: r = ytm::cosf(a); break;
+    case 2: r = ytm::expf(a); break;
+    case 3: r = ytm::exp2f(a); break;
+    case 4: r = ytm::logf(a); break;
+    case 5: r = ytm::atanf(a); break;
+    case 6: r = ytm::acosf(a); break;
+    case 7: r = ytm::atan2f(a, b); break;
+    case 8: r = ytm::powf(a, b); break;
+    case 9: r = fmodf(a, b); break;
+    case 10: r = sqrt_(a); break;
+    case 11: r = a / b; break;
+  }
+  out[i] = r;
+}
+}  // namespace
+
+int ythip_test_libm(ythip_ctx* ctx, int fn, const float* x, const float* y, int64_t n, float* out) {
+  if (!ctx || !x || !out || n < 0 || fn < 0 || fn > 11) return fail(ctx, YTHIP_ERR_INVALID, "bad argument");
+  if (n == 0) return YTHIP_OK;
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<void*> tmp;
+  float *            dx = nullptr, *dy = nullptr, *dout = nullptr;
+  int                rc;
+  if ((rc = dalloc(ctx, tmp, &dx, (size_t)n)) || (rc = dalloc(ctx, tmp, &dout, (size_t)n)) ||
+      (y && (rc = dalloc(ctx, tmp, &dy, (size_t)n)))) {
+    free_all(tmp);
+    return rc;
+  }
+  auto e = hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (y && e == hipSuccess) e = hipMemcpyAsync(dy, y, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+  hipLaunchKernelGGL(k_test_libm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, dx, dy, (long long)n, dout);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  free_all(tmp);
+  if (e != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "test_libm failed: %s", hipGetErrorString(e));
+  return YTHIP_OK;
+}
+
 int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params, ythip_ray* rays) {
   if (!ctx || !params || !rays) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "scene and state must be resident");

@@ -192,3 +192,37 @@ def cornell_1m_scene(base, n=316):
     for inst in base.instances:
         sc.add_instance(int(inst["shape"]), int(inst["material"]), inst["frame"])
     return sc
+
+
+def hair_scene_synthetic(strands=100000, steps=8, length=0.2, radius=(0.002, 0.001), seed=7):
+    """BASELINE configs[4] for bench.py: `strands` straight hairs of `steps`
+    segments grown along the normals of a unit sphere (what make_hair(make_sphere(32, 1),
+    {8, 100000}, {0.2, 0.2}, {0.002, 0.001}) builds, yocto_shape.cpp:1264-1334, without
+    noise / clumping) — 800,000 line segments, 900,000 vertices with radii — over a matte
+    base sphere, subsurface hair material, constant environment, the camera of the parity
+    tests.  The strand roots are seeded numpy draws, not the reference's sample_shape
+    stream (whose geometry is compiler-dependent): the parity
+    tests (tests/test_gpu_baseline_configs.py) use the reference's own arrays, this
+    generator keeps bench.py free of anything under oracle/."""
+    rng = np.random.default_rng(seed)
+    sc = FlatScene()
+    sc.add_camera(lookat_frame((0, 0.5, 3.2), (0, 0, 0)), lens=0.035, film=0.036, aspect=16 / 9,
+                  focus=float(np.sqrt(0.25 + 3.2 * 3.2)), aperture=0.0)
+    base = triangulated(make_uvsphere((64, 32), 1.0))
+    s_base = add_shape(sc, base)
+    z = rng.uniform(-1, 1, strands)
+    phi = rng.uniform(0, 2 * np.pi, strands)
+    rxy = np.sqrt(1 - z * z)
+    nrm = np.stack([rxy * np.cos(phi), z, rxy * np.sin(phi)], -1).astype(f32)
+    u = (np.arange(steps + 1, dtype=f32) / f32(steps))
+    pos = (nrm[:, None, :] * (f32(1) + u[None, :, None] * f32(length))).reshape(-1, 3).astype(f32)
+    rad = np.tile((f32(radius[0]) * (f32(1) - u) + f32(radius[1]) * u).astype(f32), strands)
+    k = (np.arange(strands, dtype=np.int32) * (steps + 1))[:, None] + np.arange(steps, dtype=np.int32)[None, :]
+    lines = np.stack([k, k + 1], -1).reshape(-1, 2).astype(np.int32)
+    s_hair = sc.add_shape(pos, lines=lines, normals=np.repeat(nrm, steps + 1, 0), radius=rad)
+    m_base = sc.add_material(type="matte", color=(0.7, 0.7, 0.7))
+    m_hair = sc.add_material(type="subsurface", color=(0.8, 0.6, 0.4), roughness=0.3, scattering=(0.5, 0.5, 0.5))
+    sc.add_instance(s_base, m_base)
+    sc.add_instance(s_hair, m_hair)
+    sc.add_environment((1, 1, 1))
+    return sc

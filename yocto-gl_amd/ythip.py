@@ -448,6 +448,7 @@ _SIGNATURES = {
     "ythip_state_set_samples": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_trace_samples": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_void_p]),
     "ythip_trace_samples_async": (C.c_int, [C.c_void_p, C.POINTER(CParams)]),
+    "ythip_test_libm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ythip_cancel": (C.c_int, [C.c_void_p]),
     "ythip_poll": (C.c_int, [C.c_void_p]),
     "ythip_state_get_samples": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -674,6 +675,13 @@ class Context:
         self._check(self.lib.ythip_bvh_build_info(self.h, C.byref(info)), "bvh_build_info")
         return {k: getattr(info, k) for k, _ in CBuildInfo._fields_}
 
+    def bvh_baked_sizes(self):
+        """Bytes of the baked traversal data: pair records (64 B) + quad records (128 B) +
+        leaf data (16 B per float4)."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.ythip_bvh_baked_sizes(self.h, C.byref(a), C.byref(b)), "bvh_baked_sizes")
+        return int(a.value) * (64 + 128) + int(b.value) * 16
+
     def download_baked_bvh(self):
         """The traversal layout: pairs [n, 16] f4, leafdata [m, 4] f4."""
         n, m = C.c_int64(), C.c_int64()
@@ -808,6 +816,19 @@ class Context:
     def trace_sample(self, params, i, j, sample):
         """trace_sample (yocto_trace.cpp:1461-1492): one sample of frame pixel (i, j)."""
         self._check(self.lib.ythip_trace_sample(self.h, C.byref(params), i, j, sample), "trace_sample")
+
+    LIBM_FUNCTIONS = ["sinf", "cosf", "expf", "exp2f", "logf", "atanf", "acosf", "atan2f", "powf", "fmodf", "sqrtf",
+                      "div"]
+
+    def test_libm(self, fn, x, y=None):
+        """yt_libm.h's restatement of glibc's `fn` evaluated on the device (test entry)."""
+        x = np.ascontiguousarray(x, np.float32)
+        y = None if y is None else np.ascontiguousarray(y, np.float32)
+        out = np.zeros_like(x)
+        self._check(self.lib.ythip_test_libm(self.h, self.LIBM_FUNCTIONS.index(fn), x.ctypes.data,
+                                             None if y is None else y.ctypes.data, x.size, out.ctypes.data),
+                    "test_libm")
+        return out
 
     def cancel(self):
         self._check(self.lib.ythip_cancel(self.h), "cancel")
