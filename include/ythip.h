@@ -240,6 +240,16 @@ int ythip_sync(ythip_ctx* ctx);
  * (yocto_cutrace.cpp:564-702).  Host pointers; copied. */
 int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* scene);
 
+/* Scene ingest straight into the flat layout (the loaders of
+ * yocto_sceneio.cpp produce vector-of-vectors scene_data): ythip_scene_staging allocates
+ * PINNED host pools sized by counts->num_* and returns them in *staged (same struct, pointers
+ * now writable: cast the const away); the loader fills cameras, instances, environments,
+ * materials, textures, the per-shape descriptors and the concatenated pools IN PLACE — one
+ * pass over the source, no intermediate copy —, then ythip_upload_scene_staged() sends them
+ * by asynchronous DMA and keeps the pools as the host copies the BVH / light builders read.
+ * Equivalent to ythip_upload_scene() of the same content (tested byte for byte). */
+int ythip_scene_staging(ythip_ctx* ctx, const ythip_scene* counts, ythip_scene* staged);
+int ythip_upload_scene_staged(ythip_ctx* ctx);
 /* Re-upload only the cameras of the resident scene (num must equal the resident
  * count).  The interactive loop edits scene.cameras[params.camera] between
  * trace_samples calls (apps/ytrace.cpp:189-204, 248-254) without touching the
@@ -454,15 +464,17 @@ int ythip_set_early_miss(ythip_ctx* ctx, int enable);
  * (10 % faster on BASELINE configs[1]); 0: always the general kernel. */
 int ythip_set_specialization(ythip_ctx* ctx, int enable);
 
-/* The pool scheduler (no reference equivalent; results do not depend on it).  mode 0:
- * every batch runs on k_trace (one wavefront per 16x4-pixel tile, lock-step rounds);
- * mode 1: whole-slice batches of the `path` / `pathtest` samplers run on k_pool
- * (yt_pool.h): persistent wavefronts that each own up to 256 pixels, fetch rays
- * dynamically inside the BVH walk and take tiles from a global counter; mode 2
- * (default): chosen per resident scene by a short timed probe of both kernels on a
- * scratch state.  waves / target / refill_min / shade_min / tile_mul tune k_pool
- * (0 keeps the current value; see yt_pool.h DPool).  YTHIP_POOL=0/1/2 sets the default
- * of new contexts. */
+/* The pool scheduler (no reference equivalent; results do not depend on it) — an
+ * EXPERIMENT, off by default.  mode 0 (default): every batch runs on k_trace (one
+ * wavefront per 16x4-pixel tile, lock-step extend / shade rounds); mode 1: whole-slice
+ * batches of the `path` / `pathtest` samplers run on k_pool (yt_pool.h): persistent
+ * wavefronts that each own up to 256 pixels, fetch rays dynamically inside the BVH walk,
+ * park their walks around out-of-line shade passes and take tiles from a global counter.
+ * Bit-identical trace_state (tests/test_gpu_round2.py); measured 0.75-0.9x k_trace's
+ * speed on the incoherent BASELINE scenes and 0.45x on configs[1], hence
+ * not the default.  waves / target / refill_min / shade_min / tile_mul tune it (0 keeps
+ * the current value; see yt_pool.h DPool).  YTHIP_POOL=0/1 sets the default of new
+ * contexts. */
 int ythip_set_pool(ythip_ctx* ctx, int mode, int waves, int target, int refill_min,
     int shade_min, int tile_mul);
 /* Diagnostics of the last k_pool launch: per-wavefront debug words (yt_pool.h

@@ -81,6 +81,29 @@ struct Stack {
 };
 #define YT_STACK_INIT(stack, s_stack) (stack).lds = (lds_entry*)&(s_stack)[0][threadIdx.x]
 
+// LDS staging of the top of the largest tree (north star: "BVH nodes ... staged through LDS").
+// A workgroup copies the root's quad record and the quad records of its (up to) 4 + 16
+// internal grandchildren — the top four tree levels, 21 x 128 B — into LDS once, and rewrites
+// the refs inside the copies so that a ref to a staged record carries its slot in bits 24-29
+// ((slot + 1) << 24; pair ids must be < 2^24).  The wide walk then reads a record from LDS
+// whenever the ref it holds is tagged — no lookup, the tag travels with the ref through the
+// stack — and from global memory otherwise.  Same records, same order: same hit records.
+// MEASURED AND REJECTED: bit-identical, and 15-18 % slower on every BASELINE scene
+// (the 2.7 KB cost a quarter of the resident workgroups, and the top of the tree is L1-resident
+// anyway); no gain on the latency-bound N = 8 slice either.  Compiled in only with -DYT_LDS_TOP
+// (tools/devbuild.sh NAME -DYT_LDS_TOP, YTHIP_LDS_TOP=1 at run time).
+#ifdef YT_LDS_TOP
+constexpr bool TOP_STAGING = true;
+#else
+constexpr bool TOP_STAGING = false;
+#endif
+constexpr int TOP_SLOTS = 21, TOP_TAG_SHIFT = 24, TOP_ID_MASK = (1 << TOP_TAG_SHIFT) - 1;
+typedef __attribute__((address_space(3))) float4 lds_float4;
+struct TopLds {
+  const float* rec;  // LDS: TOP_SLOTS records of 8 float4 (nullptr: staging off)
+  int          root; // pair id of the staged root
+};
+
 struct Hit {
   int   instance, element;
   float u, v, distance;
@@ -236,7 +259,7 @@ constexpr int HIT_ABORT = -2;  // Hit::instance of a wide walk that met an irreg
 // with their stack columns live.
 template <bool COUNT, bool WIDE = false, bool TRI = false, int LDSD = YT_LDS_DEPTH>
 YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
-    Counters& cnt) {
+    Counters& cnt, const TopLds* top = nullptr) {
   constexpr int LDS_LEVELS = LDSD, SPILL_LEVELS = 128 - LDSD;
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   Hit best = {-1, -1, 0, 0, 0, false};
@@ -299,6 +322,9 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     int4          m5 = reinterpret_cast<const int4*>(ti)[5];
     int           root = __float_as_int(m4.z);
     if (root == REF_NONE) return REF_NONE;
+    if constexpr (WIDE) {
+      if (TOP_STAGING && top && root == top->root) root |= 1 << TOP_TAG_SHIFT;  // its quad record is staged in LDS
+    }
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
     vec3f   io   = transform_point(inv, wo);
     vec3f   id   = transform_vector(inv, wd);
@@ -345,6 +371,9 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     float t0;
     if (!(slab<false>(o, dinv, tmin, sc.tlas_bmin, sc.tlas_bmax, t0) && t0 <= tmaxk)) return best;
     cur = sc.tlas_ref;
+    if constexpr (WIDE) {
+      if (TOP_STAGING && top && cur == top->root) cur |= 1 << TOP_TAG_SHIFT;
+    }
   }
 
   auto accept = [&](int element, const PrimHit& h) {
@@ -382,8 +411,17 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       if constexpr (WIDE) {
         // internal node, two levels at once: its grandchildren in the order the
         // reference's walk reaches them, each pushed with its own pop-time test
-        const float4* Qp = sc.wide + 8 * (int64_t)cur;
-        float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
+        float4 a0, a1, b0, b1, c0, c1, d0, d1;
+        if (TOP_STAGING && top && (cur >> TOP_TAG_SHIFT)) {  // a staged record: from LDS
+          const lds_float4* Ql = (const lds_float4*)top->rec + 8 * ((cur >> TOP_TAG_SHIFT) - 1);
+          a0 = {Ql[0].x, Ql[0].y, Ql[0].z, Ql[0].w}, a1 = {Ql[1].x, Ql[1].y, Ql[1].z, Ql[1].w};
+          b0 = {Ql[2].x, Ql[2].y, Ql[2].z, Ql[2].w}, b1 = {Ql[3].x, Ql[3].y, Ql[3].z, Ql[3].w};
+          c0 = {Ql[4].x, Ql[4].y, Ql[4].z, Ql[4].w}, c1 = {Ql[5].x, Ql[5].y, Ql[5].z, Ql[5].w};
+          d0 = {Ql[6].x, Ql[6].y, Ql[6].z, Ql[6].w}, d1 = {Ql[7].x, Ql[7].y, Ql[7].z, Ql[7].w};
+        } else {
+          const float4* Qp = sc.wide + 8 * (int64_t)cur;
+          a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
+        }
         cnt.steps++;
         float ta, tb, tc, td;
         // per slot {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axes}, like the pair records
@@ -490,8 +528,18 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       const float4* L = sc.leafdata + (leafbias + first * 3);
       // two triangles per round trip (the pool is padded, over-reads are ignored)
       for (int k0 = 0; k0 < num; k0 += 2) {
+#ifdef YT_NT_LEAF  // development builds: leaf data as a non-temporal stream (keeps trace_state lines in L2?)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        auto ntl = [](const float4* p) {
+          v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+          return float4{v.x, v.y, v.z, v.w};
+        };
+        float4 a0 = ntl(&L[3 * k0]), b0 = ntl(&L[3 * k0 + 1]), c0 = ntl(&L[3 * k0 + 2]);
+        float4 a1 = ntl(&L[3 * k0 + 3]), b1 = ntl(&L[3 * k0 + 4]), c1 = ntl(&L[3 * k0 + 5]);
+#else
         float4 a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
         float4 a1 = L[3 * k0 + 3], b1 = L[3 * k0 + 4], c1 = L[3 * k0 + 5];
+#endif
         if (COUNT) cnt.triangles++;
         auto h = intersect_triangle(o, d, tmin, tmax, {a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x});
         if (h.hit) accept(__float_as_int(c0.y), h);
@@ -751,7 +799,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
 // (irregular at world or instance level, find_any) — the same hit record either way.
 template <bool COUNT, bool WIDE, bool TRI = false>
 YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
-    Counters& cnt) {
+    Counters& cnt, const TopLds* top = nullptr) {
   if constexpr (WIDE && !COUNT) {
 #ifdef YT_PHASED
     if (!find_any) {
@@ -759,7 +807,7 @@ YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, b
       if (h.instance != HIT_ABORT) return h;
     }
 #else
-    Hit h = traverse<false, true, TRI>(sc, wray, only_instance, find_any, st, cnt);
+    Hit h = traverse<false, true, TRI>(sc, wray, only_instance, find_any, st, cnt, top);
     if (h.instance != HIT_ABORT) return h;
 #endif
   }

@@ -99,6 +99,7 @@ struct KParams {
   float clamp;
   int   nocaustics, envhidden, tentfilter;
   int   has_env;  // !scene.environments.empty()
+  int   lds_top;  // 1: stage the top of the largest tree in LDS (k_trace's dynamic LDS, TopLds)
   int   hold;     // scheduling policy of k_trace (0 off, 1 hold back partial primary wavefronts)
   int   peek;     // resolve a continuing path's root-box miss in place (resolve_step), 0 off
 };
@@ -226,8 +227,10 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
       const auto& tex = sc.textures[environment.emission_tex];
       auto        idx = sample_discrete(sc.cdf + light.cdf_offset, light.cdf_count, rel);
       auto        uv  = vec2f{((idx % tex.width) + 0.5f) / tex.width, ((idx / tex.width) + 0.5f) / tex.height};
-      return transform_direction(ldframe(environment.frame),
-          {ytm::cosf(uv.x * 2 * pif) * ytm::sinf(uv.y * pif), ytm::cosf(uv.y * pif), ytm::sinf(uv.x * 2 * pif) * ytm::sinf(uv.y * pif)});
+      float sx, cx, sy, cy;
+      ytm::sincosf(uv.x * 2 * pif, &sx, &cx);
+      ytm::sincosf(uv.y * pif, &sy, &cy);
+      return transform_direction(ldframe(environment.frame), {cx * sy, cy, sx * sy});
     } else {
       return sample_sphere(ruv);
     }
@@ -375,8 +378,13 @@ YT_FN int step_tail(Path& P) {
 // trace_path / trace_pathdirect / trace_pathmis / trace_pathtest — one iteration
 // of the bounce loop after the intersection (yocto_trace.cpp:453-1029)
 // ---------------------------------------------------------------------------
-template <int SAMPLER, int LP, bool MATTE = false>
+// CLS: what is known about the resident scene (checked at upload; the assignments below only
+// tell the compiler, the arithmetic on the live path is the same): 0 nothing; 1 "simple scene" —
+// every material matte and untextured, every shape a triangle mesh; 2 no material references
+// a texture (any material types, any shapes: the hair scene of configs[4]).
+template <int SAMPLER, int LP, int CLS = 0>
 YT_FN int step_path(ShadeEnv& E, Path& P) {
+  constexpr bool MATTE = CLS == 1, NOTEX = CLS >= 1;
   const auto& sc = E.sc;
   const auto& kp = E.kp;
   constexpr bool DIRECT  = SAMPLER == YTHIP_SAMPLER_PATHDIRECT;
@@ -412,8 +420,8 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     auto outgoing = -P.d;
     auto s        = load_surface<MATTE>(sc, isec.instance, isec.element, {isec.u, isec.v});
     auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
-    auto normal   = eval_shading_normal<MATTE>(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
-    auto material = eval_material<MATTE>(sc, s.shc, *s.mat, s.e, s.uv);
+    auto normal   = eval_shading_normal<NOTEX>(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
+    auto material = eval_material<NOTEX>(sc, s.shc, *s.mat, s.e, s.uv);
     count_shade(E.st);
 #ifdef YT_TIMING
     asm volatile("" ::"v"(position.x), "v"(normal.x), "v"(material.color.x), "v"(material.roughness));
@@ -543,7 +551,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     // update volume stack
     if (VOLUMES && is_volumetric(*s.mat) && dot(normal, outgoing) * dot(normal, incoming) < 0) {
       if (!(P.flags & PF_VOLUME)) {
-        auto vmat = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
+        auto vmat = eval_material<NOTEX>(sc, s.shc, *s.mat, s.e, s.uv);
         store_volume(E.st, E.slot, vmat);
         P.flags |= PF_VOLUME;
       } else {
@@ -983,8 +991,9 @@ YT_FN int max_bounces_of(const KParams& kp) {
 #ifndef YT_WAVES_PER_EU  // development builds: occupancy experiments
 #define YT_WAVES_PER_EU 4
 #endif
-template <int SAMPLER, int LP, bool COUNT, bool WIDE, bool MATTE = false>
+template <int SAMPLER, int LP, bool COUNT, bool WIDE, int CLS = 0>
 __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, DState st, KParams kp) {
+  constexpr bool MATTE = CLS == 1;
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   // root-box misses of continuing paths resolved in place (resolve_step); the counting
@@ -1003,6 +1012,39 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
   if (lb < 0) return;
   if (stop_requested(st.stop)) return;  // cancelled before this tile started
   const int tid = threadIdx.x;
+  // LDS staging of the top four levels of the largest tree (dynamic LDS, only when asked for)
+  extern __shared__ float4 s_top[];
+  TopLds topl = {nullptr, -1};
+  if constexpr (WIDE && TOP_STAGING) {
+    if (kp.lds_top && sc.top_root >= 0) {
+      // slot 0: the root's record; slots 1-4: its internal grandchildren; slots 5-20: theirs
+      for (int k = tid; k < TOP_SLOTS * 8; k += YT_BLOCK) s_top[k] = {0, 0, __int_as_float(REF_NONE), 0};
+      __syncthreads();
+      if (tid < 8) s_top[tid] = sc.wide[8 * (int64_t)sc.top_root + tid];
+      __syncthreads();
+      for (int level = 0; level < 2; level++) {
+        const int nsrc = level == 0 ? 1 : 4, src0 = level == 0 ? 0 : 1, dst0 = level == 0 ? 1 : 5;
+        // (source slot s, child c) -> destination slot dst0 + 4 (s - src0) + c
+        for (int k = tid; k < nsrc * 4 * 8; k += YT_BLOCK) {
+          const int s = k / 32, c = (k / 8) & 3, part = k & 7;
+          const int ref = __float_as_int(s_top[(src0 + s) * 8 + 2 * c + 1].z);
+          if (ref >= 0 && ref < REF_INST && ref <= TOP_ID_MASK)
+            s_top[(dst0 + 4 * s + c) * 8 + part] = sc.wide[8 * (int64_t)ref + part];
+        }
+        __syncthreads();
+        // tag the refs of the source slots whose targets are now staged
+        for (int k = tid; k < nsrc * 4; k += YT_BLOCK) {
+          const int s = k / 4, c = k & 3;
+          float4&   r = s_top[(src0 + s) * 8 + 2 * c + 1];
+          const int ref = __float_as_int(r.z);
+          if (ref >= 0 && ref < REF_INST && ref <= TOP_ID_MASK) r.z = __int_as_float(ref | ((dst0 + 4 * s + c + 1) << TOP_TAG_SHIFT));
+        }
+        __syncthreads();
+      }
+      topl = {reinterpret_cast<const float*>(s_top), sc.top_root};
+    }
+  }
+  const TopLds* top = topl.rec ? &topl : nullptr;
   Stack     stack;
   YT_STACK_INIT(stack, s_stack);
   Counters  cnt         = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1088,7 +1130,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
       } else {
         ray3f          ray = make_ray(P.o, P.d);
         const unsigned s0  = cnt.steps;
-        P.isec             = traverse_any<COUNT, WIDE, MATTE>(sc, ray, -1, false, stack, cnt);
+        P.isec             = traverse_any<COUNT, WIDE, MATTE>(sc, ray, -1, false, stack, cnt, top);
         work               = cnt.steps - s0 + 1;
       }
 #ifdef YT_TIMING
@@ -1104,7 +1146,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
       } else {
         ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
         if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
-          step = step_path<SAMPLER, LP, MATTE>(E, P);
+          step = step_path<SAMPLER, LP, CLS>(E, P);
 #ifdef YT_TIMING
           tmG = E.t_geo;
 #endif

@@ -35,8 +35,14 @@
 #ifdef __HIPCC__
 #define YT_LIBM_FN __device__ __forceinline__
 #define YT_LIBM_TABLE static __device__ const
+#ifdef YT_LIBM_OUTLINE  // development builds: the large functions as real calls (register pressure experiment)
+#define YT_LIBM_BIG __device__ __noinline__
+#else
+#define YT_LIBM_BIG __device__ __forceinline__
+#endif
 #else
 #define YT_LIBM_FN static inline
+#define YT_LIBM_BIG static inline
 #define YT_LIBM_TABLE static const
 #endif
 
@@ -52,17 +58,15 @@ YT_LIBM_FN float    nanf_() { return asfloat(0x7fc00000u); }
 // ---------------------------------------------------------------------------
 // sinf / cosf — sincosf.h, s_sinf.c, s_cosf.c
 // ---------------------------------------------------------------------------
-// sincos_t as laid out in that libm: sign[4], hpi_inv, hpi, c0, c1, s1, c2, s2, c3, s3, c4
-YT_LIBM_TABLE double sincos_tab[2][14] = {
-    {0x1.0000000000000p+0, -0x1.0000000000000p+0, -0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.45f306dc9c883p+23,
-        0x1.921fb54442d18p+0, 0x1.0000000000000p+0, -0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3,
-        0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7, -0x1.6c087e89a359dp-10, -0x1.994eb3774cf24p-13,
-        0x1.99343027bf8c3p-16},
-    {0x1.0000000000000p+0, -0x1.0000000000000p+0, -0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.45f306dc9c883p+23,
-        0x1.921fb54442d18p+0, -0x1.0000000000000p+0, 0x1.ffffffd0c621cp-2, -0x1.555545995a603p-3,
-        -0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7, 0x1.6c087e89a359dp-10, -0x1.994eb3774cf24p-13,
-        -0x1.99343027bf8c3p-16}};
-enum { SC_HPI_INV = 4, SC_HPI = 5, SC_C0 = 6, SC_C1 = 7, SC_S1 = 8, SC_C2 = 9, SC_S2 = 10, SC_C3 = 11, SC_S3 = 12, SC_C4 = 13 };
+// __sincosf_table[0] (sincos_t: sign[4] = {1, -1, -1, 1}, hpi_inv, hpi, c0..c4, s1..s3).
+// __sincosf_table[1] is the same with the cosine coefficients negated — it is selected
+// when n & 2 — and IEEE arithmetic is sign-symmetric, so evaluating the cosine with table 0
+// and negating the result gives the same bits; likewise sign[n & 3] is -1 exactly when
+// (n + 1) & 2.  That keeps every constant a literal: no table loads in the dependency chain.
+constexpr double SC_HPI_INV = 0x1.45f306dc9c883p+23, SC_HPI = 0x1.921fb54442d18p+0;
+constexpr double SC_C0 = 0x1.0000000000000p+0, SC_C1 = -0x1.ffffffd0c621cp-2, SC_C2 = 0x1.55553e1068f19p-5,
+                 SC_C3 = -0x1.6c087e89a359dp-10, SC_C4 = 0x1.99343027bf8c3p-16;
+constexpr double SC_S1 = -0x1.555545995a603p-3, SC_S2 = 0x1.1107605230bc4p-7, SC_S3 = -0x1.994eb3774cf24p-13;
 // 4/PI as 24 overlapping 32-bit words (__inv_pio4)
 YT_LIBM_TABLE uint32_t inv_pio4[24] = {0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
     0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db,
@@ -70,29 +74,29 @@ YT_LIBM_TABLE uint32_t inv_pio4[24] = {0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf98
 
 YT_LIBM_FN uint32_t abstop12(float x) { return (asuint(x) >> 20) & 0x7ff; }
 
-// sinf_poly: sine of x (x2 = x * x) for even n, cosine for odd n, as fused in the _fma build
-YT_LIBM_FN float sinf_poly(double x, double x2, const double* p, int n) {
-  if ((n & 1) == 0) {
-    double x3 = x * x2;
-    double s1 = fma_(x2, p[SC_S3], p[SC_S2]);
-    double x7 = x3 * x2;
-    double s  = fma_(x3, p[SC_S1], x);
-    return (float)fma_(s1, x7, s);
-  } else {
-    double x4 = x2 * x2;
-    double c1 = fma_(x2, p[SC_C1], p[SC_C0]);
-    double c2 = fma_(x2, p[SC_C4], p[SC_C3]);
-    double x6 = x4 * x2;
-    double c  = fma_(x4, p[SC_C2], c1);
-    return (float)fma_(c2, x6, c);
-  }
+// sinf_poly's two branches, as fused in the _fma build: the sine polynomial of x (x2 = x * x) ...
+YT_LIBM_FN double sin_poly(double x, double x2) {
+  double x3 = x * x2;
+  double s1 = fma_(x2, SC_S3, SC_S2);
+  double x7 = x3 * x2;
+  double s  = fma_(x3, SC_S1, x);
+  return fma_(s1, x7, s);
+}
+// ... and the cosine polynomial (table 0)
+YT_LIBM_FN double cos_poly(double x2) {
+  double x4 = x2 * x2;
+  double c1 = fma_(x2, SC_C1, SC_C0);
+  double c2 = fma_(x2, SC_C4, SC_C3);
+  double x6 = x4 * x2;
+  double c  = fma_(x4, SC_C2, c1);
+  return fma_(c2, x6, c);
 }
 // reduce_fast: |x| < 120
-YT_LIBM_FN double reduce_fast(double x, const double* p, int* np) {
-  double r = x * p[SC_HPI_INV];
+YT_LIBM_FN double reduce_fast(double x, int* np) {
+  double r = x * SC_HPI_INV;
   int    n = ((int32_t)r + 0x800000) >> 24;
   *np      = n;
-  return fma_(-(double)n, p[SC_HPI], x);
+  return fma_(-(double)n, SC_HPI, x);
 }
 // reduce_large: 120 <= |x| < inf
 YT_LIBM_FN double reduce_large(uint32_t xi, int* np) {
@@ -112,52 +116,58 @@ YT_LIBM_FN double reduce_large(uint32_t xi, int* np) {
   *np      = (int)n;
   return x * 0x1.921fb54442d18p-62;
 }
-
-YT_LIBM_FN float sinf(float y) {
-  double        x = y, s;
-  int           n;
-  const double* p = sincos_tab[0];
-  if (abstop12(y) < 0x3f4) {  // |y| < pi/4
-    s = x * x;
-    if (abstop12(y) < 0x398) return y;  // |y| < 2^-12
-    return sinf_poly(x, s, p, 0);
-  } else if (abstop12(y) < 0x42f) {  // |y| < 120
-    x = reduce_fast(x, p, &n);
-    s = p[n & 3];
-    if (n & 2) p = sincos_tab[1];
-    return sinf_poly(x * s, x * x, p, n);
+// the argument reduction shared by sinf / cosf / sincosf: x reduced to [-pi/4, pi/4] times the
+// quadrant sign, n the quadrant (n & 1: swap sine and cosine; m & 2, m = n (+ sign): negate the cosine)
+YT_LIBM_FN bool sincos_reduce(float y, double* xs, double* x2, int* n, int* m) {
+  double x = y;
+  if (abstop12(y) < 0x42f) {  // |y| < 120
+    x  = reduce_fast(x, n);
+    *m = *n;
   } else if (abstop12(y) < 0x7f8) {
-    uint32_t xi   = asuint(y);
-    int      sign = (int)(xi >> 31);
-    x             = reduce_large(xi, &n);
-    s             = p[(n + sign) & 3];
-    if ((n + sign) & 2) p = sincos_tab[1];
-    return sinf_poly(x * s, x * x, p, n);
+    uint32_t xi = asuint(y);
+    x           = reduce_large(xi, n);
+    *m          = *n + (int)(xi >> 31);
+  } else {
+    return false;
   }
-  return nanf_();
+  *xs = ((*m + 1) & 2) ? -x : x;  // x * sign[m & 3]
+  *x2 = x * x;
+  return true;
+}
+
+// (glibc branches off |y| < pi/4 (no reduction) and |y| < 2^-12 (sinf returns y, cosf 1) first.
+// Both are what the general path computes anyway — there n = 0, x - 0 * hpi = x exactly and the
+// polynomials round to y / 1 — so the wavefront runs ONE path for every argument below 120
+// instead of diverging; equality with glibc is checked over all 2^32 arguments.)
+YT_LIBM_FN float sinf(float y) {
+  double xs, x2;
+  int    n, m;
+  if (!sincos_reduce(y, &xs, &x2, &n, &m)) return nanf_();
+  if ((asuint(y) << 1) == 0) return y;  // sin(-0) = -0 (the polynomial would give +0)
+  double c = cos_poly(x2), sv = sin_poly(xs, x2);
+  return (float)((n & 1) ? ((m & 2) ? -c : c) : sv);
 }
 YT_LIBM_FN float cosf(float y) {
-  double        x = y, s;
-  int           n;
-  const double* p = sincos_tab[0];
-  if (abstop12(y) < 0x3f4) {
-    double x2 = x * x;
-    if (abstop12(y) < 0x398) return 1.0f;
-    return sinf_poly(x, x2, p, 1);
-  } else if (abstop12(y) < 0x42f) {
-    x = reduce_fast(x, p, &n);
-    s = p[n & 3];
-    if (n & 2) p = sincos_tab[1];
-    return sinf_poly(x * s, x * x, p, n ^ 1);
-  } else if (abstop12(y) < 0x7f8) {
-    uint32_t xi   = asuint(y);
-    int      sign = (int)(xi >> 31);
-    x             = reduce_large(xi, &n);
-    s             = p[(n + sign) & 3];
-    if ((n + sign) & 2) p = sincos_tab[1];
-    return sinf_poly(x * s, x * x, p, n ^ 1);
+  double xs, x2;
+  int    n, m;
+  if (!sincos_reduce(y, &xs, &x2, &n, &m)) return nanf_();
+  double c = cos_poly(x2), sv = sin_poly(xs, x2);
+  return (float)((n & 1) ? sv : ((m & 2) ? -c : c));
+}
+// sincosf: glibc's gives exactly sinf's and cosf's values (same reduction, same
+// polynomials; checked over all 2^32 arguments) — one reduction for both
+YT_LIBM_FN void sincosf(float y, float* sinp, float* cosp) {
+  double xs, x2;
+  int    n, m;
+  if (!sincos_reduce(y, &xs, &x2, &n, &m)) {
+    *sinp = *cosp = nanf_();
+    return;
   }
-  return nanf_();
+  double c  = cos_poly(x2);
+  float  sv = (float)sin_poly(xs, x2), cv = (float)((m & 2) ? -c : c);
+  if ((asuint(y) << 1) == 0) sv = y;  // sin(-0) = -0
+  *sinp = (n & 1) ? cv : sv;
+  *cosp = (n & 1) ? sv : cv;
 }
 
 // ---------------------------------------------------------------------------
@@ -179,7 +189,7 @@ YT_LIBM_FN float oflowf(uint32_t sign) { return (sign ? -0x1p97f : 0x1p97f) * 0x
 YT_LIBM_FN float uflowf(uint32_t sign) { return (sign ? -0x1p-95f : 0x1p-95f) * 0x1p-95f; }
 YT_LIBM_FN float may_uflowf(uint32_t sign) { return (sign ? -0x1.4p-75f : 0x1.4p-75f) * 0x1.4p-75f; }
 
-YT_LIBM_FN float expf(float x) {
+YT_LIBM_BIG float expf(float x) {
   double   xd     = (double)x;
   uint32_t abstop = abstop12(x);
   if (abstop >= 0x42b) {  // |x| >= 88 or x is nan
@@ -204,7 +214,7 @@ YT_LIBM_FN float expf(float x) {
   y         = y * s;
   return (float)y;
 }
-YT_LIBM_FN float exp2f(float x) {
+YT_LIBM_BIG float exp2f(float x) {
   double   xd     = (double)x;
   uint32_t abstop = abstop12(x);
   if (abstop >= 0x430) {  // |x| >= 128 or x is nan
@@ -243,7 +253,7 @@ YT_LIBM_TABLE double logf_tab[16][2] = {{0x1.661ec79f8f3bep+0, -0x1.57bf7808caad
 constexpr double LOGF_LN2 = 0x1.62e42fefa39efp-1, LOGF_A0 = -0x1.00ea348b88334p-2, LOGF_A1 = 0x1.5575b0be00b6ap-2,
                  LOGF_A2 = -0x1.ffffef20a4123p-2;
 
-YT_LIBM_FN float logf(float x) {
+YT_LIBM_BIG float logf(float x) {
   uint32_t ix = asuint(x);
   if (ix == 0x3f800000u) return 0.0f;
   if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
@@ -332,7 +342,7 @@ YT_LIBM_FN int powf_checkint(uint32_t iy) {
 }
 YT_LIBM_FN bool powf_zeroinfnan(uint32_t ix) { return 2 * ix - 1 >= 2u * 0x7f800000u - 1; }
 
-YT_LIBM_FN float powf(float x, float y) {
+YT_LIBM_BIG float powf(float x, float y) {
   uint32_t sign_bias = 0;
   uint32_t ix = asuint(x), iy = asuint(y);
   if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) {
@@ -385,7 +395,7 @@ YT_LIBM_FN float powf(float x, float y) {
 // ---------------------------------------------------------------------------
 YT_LIBM_FN float fabsf_(float x) { return asfloat(asuint(x) & 0x7fffffffu); }
 
-YT_LIBM_FN float atanf(float x) {
+YT_LIBM_BIG float atanf(float x) {
   const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
   const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
   const float aT[11]    = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f,
@@ -430,7 +440,7 @@ YT_LIBM_FN float atanf(float x) {
   return (hx < 0) ? -z : z;
 }
 
-YT_LIBM_FN float atan2f(float y, float x) {
+YT_LIBM_BIG float atan2f(float y, float x) {
   const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
               pi_lo = -8.7422776573e-08f;
   float   z;
@@ -483,7 +493,7 @@ YT_LIBM_FN float atan2f(float y, float x) {
 
 YT_LIBM_FN float sqrtf_(float x) { return __builtin_sqrtf(x); }
 
-YT_LIBM_FN float acosf(float x) {
+YT_LIBM_BIG float acosf(float x) {
   const float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f,
               pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
               pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f,

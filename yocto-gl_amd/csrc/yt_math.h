@@ -208,14 +208,18 @@ YT_FN vec3f rand3f(rng_state& rng) {
 YT_FN vec3f sample_sphere(vec2f ruv) {  // :277
   auto z   = 2 * ruv.y - 1;
   auto r   = sqrt_(clamp_(1 - z * z, 0.0f, 1.0f));
-  auto phi = 2 * pif * ruv.x;
-  return {r * ytm::cosf(phi), r * ytm::sinf(phi), z};
+  auto  phi = 2 * pif * ruv.x;
+  float sp, cp;
+  ytm::sincosf(phi, &sp, &cp);  // (glibc's sincosf == its sinf and cosf: one argument reduction)
+  return {r * cp, r * sp, z};
 }
 YT_FN vec3f sample_hemisphere_cos(vec3f normal, vec2f ruv) {  // :297
   auto z               = sqrt_(ruv.y);
   auto r               = sqrt_(1 - z * z);
   auto phi             = 2 * pif * ruv.x;
-  auto local_direction = vec3f{r * ytm::cosf(phi), r * ytm::sinf(phi), z};
+  float sp, cp;
+  ytm::sincosf(phi, &sp, &cp);
+  auto local_direction = vec3f{r * cp, r * sp, z};
   return transform_direction(basis_fromz(normal), local_direction);
 }
 YT_FN float sample_hemisphere_cos_pdf(vec3f normal, vec3f direction) {  // :304
@@ -225,7 +229,9 @@ YT_FN float sample_hemisphere_cos_pdf(vec3f normal, vec3f direction) {  // :304
 YT_FN vec2f sample_disk(vec2f ruv) {  // :339
   auto r   = sqrt_(ruv.y);
   auto phi = 2 * pif * ruv.x;
-  return {ytm::cosf(phi) * r, ytm::sinf(phi) * r};
+  float sp, cp;
+  ytm::sincosf(phi, &sp, &cp);
+  return {cp * r, sp * r};
 }
 YT_FN vec2f sample_triangle(vec2f ruv) {  // :354
   return {1 - sqrt_(ruv.x), ruv.y * sqrt_(ruv.x)};

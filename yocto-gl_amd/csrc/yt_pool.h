@@ -275,7 +275,7 @@ __device__ __noinline__ PoolQ pool_heavy(PoolQ qin, int nactive_in, unsigned lds
         int  ij;
         load_slot(s, P, ij);
         ShadeEnv E    = {sc, st, kp, nullptr, nullptr, gbase + s};
-        int      step = step_path<SAMPLER, LP, MATTE>(E, P);
+        int      step = step_path<SAMPLER, LP, MATTE ? 1 : 0>(E, P);
         cls           = pool_resolve<PEEK>(sc, st, kp, P, ij, step, max_bounces, q.stopped != 0);
         if (cls != OUT_DEAD) store_slot(s, P, ij);
       }

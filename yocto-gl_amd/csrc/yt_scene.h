@@ -70,6 +70,7 @@ struct DScene {
   const int*        tlas_prims; // instance ids in TLAS leaf order
   const DInstanceT* tinst;      // per instance
   int               tlas_ref;   // ref of the TLAS root, REF_NONE if empty
+  int               top_root;   // pair id of the root record of the largest tree (LDS staging of its top), -1 none
   vec3f             tlas_bmin, tlas_bmax;
   // lights
   const DLight* lights;

@@ -91,7 +91,10 @@ YT_FN float microfacet_shadowing(float roughness, vec3f normal, vec3f halfway, v
 YT_FN vec3f sample_microfacet(float roughness, vec3f normal, vec2f rn) {
   auto phi   = 2 * pif * rn.x;
   auto theta = ytm::atanf(roughness * sqrt_(rn.y / (1 - rn.y)));
-  auto local_half_vector = vec3f{ytm::cosf(phi) * ytm::sinf(theta), ytm::sinf(phi) * ytm::sinf(theta), ytm::cosf(theta)};
+  float sp, cp, st, ct;
+  ytm::sincosf(phi, &sp, &cp);
+  ytm::sincosf(theta, &st, &ct);
+  auto local_half_vector = vec3f{cp * st, sp * st, ct};
   return transform_direction(basis_fromz(normal), local_half_vector);
 }
 // sample_microfacet_pdf — :474-479
@@ -448,7 +451,9 @@ YT_FN vec3f sample_phasefunction(float anisotropy, vec3f outgoing, vec2f rn) {
   }
   auto sin_theta      = sqrt_(max_(0.0f, 1 - cos_theta * cos_theta));
   auto phi            = 2 * pif * rn.x;
-  auto local_incoming = vec3f{sin_theta * ytm::cosf(phi), sin_theta * ytm::sinf(phi), cos_theta};
+  float sp, cp;
+  ytm::sincosf(phi, &sp, &cp);
+  auto local_incoming = vec3f{sin_theta * cp, sin_theta * sp, cos_theta};
   return basis_fromz(-outgoing) * local_incoming;
 }
 

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ythip.h"
@@ -38,6 +39,29 @@ struct DevBuf {
 
 }  // namespace
 
+// A host-side pool of the flat scene layout: either a copy the context owns, or a view of
+// the pinned staging pool the loader filled directly (ythip_scene_staging).
+template <typename T>
+struct HostPool {
+  std::vector<T> own;
+  T*             ext = nullptr;
+  size_t         n   = 0;
+  T*             data() { return ext ? ext : own.data(); }
+  const T*       data() const { return ext ? ext : own.data(); }
+  size_t         size() const { return ext ? n : own.size(); }
+  bool           empty() const { return size() == 0; }
+  T&             operator[](size_t i) { return data()[i]; }
+  const T&       operator[](size_t i) const { return data()[i]; }
+  void           assign(const T* a, const T* b) {
+    ext = nullptr, n = 0;
+    own.assign(a, b);
+  }
+  void adopt(T* p, size_t count) {
+    std::vector<T>().swap(own);
+    ext = p, n = count;
+  }
+};
+
 struct ythip_ctx {
   int         device     = 0;
   hipStream_t own_stream = nullptr;
@@ -49,11 +73,17 @@ struct ythip_ctx {
   // host copies kept for BVH baking / light building
   std::vector<ythip_shape>    h_shapes;
   std::vector<ythip_instance> h_instances;
-  std::vector<int32_t>        h_points, h_lines, h_triangles, h_quads;
-  std::vector<float>          h_positions, h_radius;
+  HostPool<int32_t>           h_points, h_lines, h_triangles, h_quads;
+  HostPool<float>             h_positions, h_radius;
+  // scene ingest straight into the flat layout: pinned pools the
+  // loader fills in place; they become the context's host copies and the DMA source
+  std::vector<void*>          staging_allocs;
+  ythip_scene                 staged      = {};
+  bool                        have_staged = false;
   bool                        may_retry = false;  // opacity < 1 possible → bounce loop may exceed `bounces`
   bool                        has_volumes = false;
   bool                        all_matte   = false;  // "simple scene": matte untextured materials, triangle meshes only
+  bool                        no_textures = false;  // no material references a texture
   int                         specialize  = 1;
   int                         num_cameras = 0;
 
@@ -91,18 +121,27 @@ struct ythip_ctx {
   float4*                                      nhit_a   = nullptr;
   int*                                         nhit_e   = nullptr;
 
-  // k_pool (yt_pool.h): 0 never, 1 always (where it applies), 2 by the scene (see pool_applies)
+  // k_pool (yt_pool.h, experimental): 0 never (default), 1 wherever it applies (pool_applies)
   int                pool_mode = 0;
   DPool              pool      = {};
   std::vector<void*> pool_allocs;
   int                pool_waves = 0, pool_target = 0, pool_refill = 16, pool_shade_min = 64, pool_max_iters = 1 << 28;
   unsigned           pool_tile_mul = 1;
   int                pool_rounds   = 0, pool_phase_min = 1, pool_heavy_min = 64;
+  int                lds_top       = 0;  // stage the top of the largest tree in LDS (k_trace)
   int*               d_stop        = nullptr;  // device-visible cancel flag polled by the kernels
   hipStream_t        side_stream   = nullptr;  // raises the flag while the kernel runs on `stream`
   hipEvent_t         done_event    = nullptr;
   std::atomic<bool>  stop_raised{false};
 };
+
+static void free_staging(ythip_ctx* ctx) {
+  for (auto p : ctx->staging_allocs)
+    if (p) (void)hipHostFree(p);
+  ctx->staging_allocs.clear();
+  ctx->have_staged = false;
+  ctx->staged      = {};
+}
 
 // The wide walk halves a ray's chain of dependent fetches and costs a little more
 // arithmetic per level.  It pays when the waves have the machine to themselves
@@ -174,6 +213,7 @@ KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
   k.tentfilter = p->tentfilter;
   k.has_env    = ctx->ds.num_environments > 0;
   k.hold       = ctx->hold_policy;
+  k.lds_top    = ctx->lds_top;
   k.peek       = ctx->peek_policy;
   return k;
 }
@@ -428,8 +468,15 @@ int bake_bvh(ythip_ctx* ctx) {
   ctx->ds.wide     = d_quads;
   ctx->ds.leafdata = d_leaf;
   ctx->largest_tree = 0;
-  for (int t = 0; t < ntrees; t++)
-    ctx->largest_tree = std::max<int64_t>(ctx->largest_tree, b.prim_offset[t + 1] - b.prim_offset[t]);
+  ctx->ds.top_root  = -1;
+  for (int t = 0; t < ntrees; t++) {
+    const int64_t np = b.prim_offset[t + 1] - b.prim_offset[t];
+    if (np > ctx->largest_tree) {
+      ctx->largest_tree = np;
+      // the tree whose top the kernels may stage in LDS: its root's pair id (internal roots only)
+      ctx->ds.top_root = (roots[t].ref >= 0 && roots[t].ref < (1 << 24) && npairs < (1 << 24)) ? roots[t].ref : -1;
+    }
+  }
   ctx->num_pairs   = npairs;
   ctx->num_leaf4   = nleaf4;
   if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tlas_prims, b.prims.data() + b.prim_offset[nshapes],
@@ -564,10 +611,11 @@ int upload_lights_impl(ythip_ctx* ctx) {
 template <int S, int LP>
 void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
   dim3 grid(ctx->st.nblocks), block(YT_BLOCK);  // one persistent one-wave workgroup per 16x4 tile
+  const size_t dyn = TOP_STAGING && kp.lds_top && ctx->ds.top_root >= 0 ? (size_t)TOP_SLOTS * 8 * sizeof(float4) : 0;
   if (count)  // the counting launch walks binary: its counts are the reference's
     hipLaunchKernelGGL((k_trace<S, LP, true, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
   else if (ctx->use_wide())
-    hipLaunchKernelGGL((k_trace<S, LP, false, true>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
+    hipLaunchKernelGGL((k_trace<S, LP, false, true>), grid, block, dyn, ctx->stream, ctx->ds, ctx->st, kp);
   else
     hipLaunchKernelGGL((k_trace<S, LP, false, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
 }
@@ -581,12 +629,23 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
         // the default sampler on an all-matte scene: the variant compiled without the
         // other material lobes and the volume code (same results, fewer registers)
         dim3 grid(ctx->st.nblocks), block(YT_BLOCK);
+        const size_t dyn = TOP_STAGING && kp.lds_top && ctx->ds.top_root >= 0 ? (size_t)TOP_SLOTS * 8 * sizeof(float4) : 0;
         if (lp == LP_DEFER)
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, true>), grid, block, 0, ctx->stream,
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 1>), grid, block, dyn, ctx->stream,
               ctx->ds, ctx->st, kp);
         else
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, true>), grid, block, 0, ctx->stream,
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 1>), grid, block, dyn, ctx->stream,
               ctx->ds, ctx->st, kp);
+      } else if (!count && ctx->no_textures && ctx->specialize && ctx->use_wide()) {
+        // no material references a texture (any material types, any primitive kinds): the
+        // variant compiled without the texture lookups and the normal-map code
+        dim3 grid(ctx->st.nblocks), block(YT_BLOCK);
+        if (lp == LP_DEFER)
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 2>), grid, block, 0, ctx->stream, ctx->ds,
+              ctx->st, kp);
+        else
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 2>), grid, block, 0, ctx->stream, ctx->ds,
+              ctx->st, kp);
       } else if (lp == LP_DEFER)
         launch_trace<YTHIP_SAMPLER_PATH, LP_DEFER>(ctx, kp, count);
       else
@@ -811,6 +870,11 @@ void classify_scene(ythip_ctx* ctx, const ythip_material* materials, int num_mat
   }
   for (auto& sh : ctx->h_shapes)  // ... and every shape a triangle mesh
     if (sh.num_points || sh.num_lines || sh.num_quads) ctx->all_matte = false;
+  ctx->no_textures = true;
+  for (int k = 0; k < num_materials; k++) {
+    const auto& m = materials[k];
+    if ((m.emission_tex & m.color_tex & m.roughness_tex & m.scattering_tex & m.normal_tex) != YTHIP_INVALIDID) ctx->no_textures = false;
+  }
   ctx->may_retry = false;
   for (int k = 0; k < num_materials; k++)
     if (materials[k].opacity < 1 || materials[k].color_tex != YTHIP_INVALIDID) ctx->may_retry = true;
@@ -843,6 +907,7 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_HOLD")) ctx->hold_policy = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_PEEK")) ctx->peek_policy = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL")) ctx->pool_mode = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_LDS_TOP")) ctx->lds_top = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL_WAVES")) ctx->pool_waves = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL_TARGET")) ctx->pool_target = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL_REFILL")) ctx->pool_refill = std::atoi(e);
@@ -878,6 +943,7 @@ void ythip_destroy(ythip_ctx* ctx) {
   }
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_stop) (void)hipFree(ctx->d_stop);
+  free_staging(ctx);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
   free_all(ctx->pool_allocs);
@@ -901,8 +967,71 @@ int ythip_sync(ythip_ctx* ctx) {
   return YTHIP_OK;
 }
 
+namespace {
+int upload_scene_impl(ythip_ctx* ctx, const ythip_scene* sc, bool from_staging);
+}  // namespace
+
 int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* sc) {
   if (!ctx || !sc) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  int rc = upload_scene_impl(ctx, sc, false);
+  if (rc == YTHIP_OK) free_staging(ctx);  // (a staged scene that was never uploaded is dropped)
+  return rc;
+}
+
+// Pinned host pools sized by `counts` (its num_* fields; pointers ignored): the loader writes
+// cameras, instances, ..., the concatenated vertex / element / texel pools and the per-shape
+// descriptors straight into them — no intermediate copy —, then ythip_upload_scene_staged()
+// sends them (asynchronous DMA from pinned memory) and keeps them as the host copies the BVH
+// and light builders read.
+int ythip_scene_staging(ythip_ctx* ctx, const ythip_scene* counts, ythip_scene* staged) {
+  if (!ctx || !counts || !staged) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  free_staging(ctx);
+  ythip_scene v = *counts;
+  auto pin = [&](auto*& field, size_t count) -> int {
+    using T = std::remove_const_t<std::remove_pointer_t<std::remove_reference_t<decltype(field)>>>;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess)
+      return fail(ctx, YTHIP_ERR_HIP, "pinned staging allocation of %zu bytes failed", count * sizeof(T));
+    ctx->staging_allocs.push_back(p);
+    field = (T*)p;
+    return YTHIP_OK;
+  };
+  int rc;
+#define PIN(field, count) \
+  if ((rc = pin(v.field, (size_t)(count)))) { free_staging(ctx); return rc; }
+  PIN(cameras, v.num_cameras);
+  PIN(instances, v.num_instances);
+  PIN(environments, v.num_environments);
+  PIN(shapes, v.num_shapes);
+  PIN(textures, v.num_textures);
+  PIN(materials, v.num_materials);
+  PIN(points, v.num_points);
+  PIN(lines, v.num_lines * 2);
+  PIN(triangles, v.num_triangles * 3);
+  PIN(quads, v.num_quads * 4);
+  PIN(positions, v.num_positions * 3);
+  PIN(normals, v.num_normals * 3);
+  PIN(texcoords, v.num_texcoords * 2);
+  PIN(colors, v.num_colors * 4);
+  PIN(radius, v.num_radius);
+  PIN(pixelsf, v.num_pixelsf * 4);
+  PIN(pixelsb, v.num_pixelsb * 4);
+#undef PIN
+  ctx->staged      = v;
+  ctx->have_staged = true;
+  *staged          = v;
+  return YTHIP_OK;
+}
+
+int ythip_upload_scene_staged(ythip_ctx* ctx) {
+  if (!ctx) return YTHIP_ERR_INVALID;
+  if (!ctx->have_staged) return fail(ctx, YTHIP_ERR_STATE, "ythip_scene_staging first");
+  return upload_scene_impl(ctx, &ctx->staged, true);
+}
+
+namespace {
+int upload_scene_impl(ythip_ctx* ctx, const ythip_scene* sc, bool from_staging) {
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   // validation (the reference would index out of bounds)
   for (int k = 0; k < sc->num_instances; k++) {
@@ -975,17 +1104,27 @@ int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* sc) {
   // host copies for BVH baking
   ctx->h_shapes.assign(sc->shapes, sc->shapes + sc->num_shapes);
   ctx->h_instances.assign(sc->instances, sc->instances + sc->num_instances);
-  ctx->h_points.assign(sc->points, sc->points + sc->num_points);
-  ctx->h_lines.assign(sc->lines, sc->lines + sc->num_lines * 2);
-  ctx->h_triangles.assign(sc->triangles, sc->triangles + sc->num_triangles * 3);
-  ctx->h_quads.assign(sc->quads, sc->quads + sc->num_quads * 4);
-  ctx->h_positions.assign(sc->positions, sc->positions + sc->num_positions * 3);
-  ctx->h_radius.assign(sc->radius, sc->radius + sc->num_radius);
+  if (from_staging) {  // the pinned pools ARE the host copies
+    ctx->h_points.adopt((int32_t*)sc->points, (size_t)sc->num_points);
+    ctx->h_lines.adopt((int32_t*)sc->lines, (size_t)sc->num_lines * 2);
+    ctx->h_triangles.adopt((int32_t*)sc->triangles, (size_t)sc->num_triangles * 3);
+    ctx->h_quads.adopt((int32_t*)sc->quads, (size_t)sc->num_quads * 4);
+    ctx->h_positions.adopt((float*)sc->positions, (size_t)sc->num_positions * 3);
+    ctx->h_radius.adopt((float*)sc->radius, (size_t)sc->num_radius);
+  } else {
+    ctx->h_points.assign(sc->points, sc->points + sc->num_points);
+    ctx->h_lines.assign(sc->lines, sc->lines + sc->num_lines * 2);
+    ctx->h_triangles.assign(sc->triangles, sc->triangles + sc->num_triangles * 3);
+    ctx->h_quads.assign(sc->quads, sc->quads + sc->num_quads * 4);
+    ctx->h_positions.assign(sc->positions, sc->positions + sc->num_positions * 3);
+    ctx->h_radius.assign(sc->radius, sc->radius + sc->num_radius);
+  }
   classify_scene(ctx, sc->materials, sc->num_materials);
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_scene = true;
   return YTHIP_OK;
 }
+}  // namespace
 
 // In-place edits of the small pools (what the reference's GUI does between batches: it
 // reads the scene fresh on every trace_samples call).  Counts must match the resident scene.
@@ -1753,7 +1892,7 @@ int ythip_set_specialization(ythip_ctx* ctx, int enable) {
 }
 
 int ythip_set_pool(ythip_ctx* ctx, int mode, int waves, int target, int refill_min, int shade_min, int tile_mul) {
-  if (!ctx || mode < 0 || mode > 2) return fail(ctx, YTHIP_ERR_INVALID, "pool mode must be 0, 1 or 2");
+  if (!ctx || mode < 0 || mode > 1) return fail(ctx, YTHIP_ERR_INVALID, "pool mode must be 0 or 1");
   ctx->pool_mode = mode;
   if (waves > 0) ctx->pool_waves = waves;
   if (target > 0) ctx->pool_target = target;

@@ -323,6 +323,8 @@ struct residency {
   int          dev_samples = -1;       // state.samples the device arrays correspond to
   bool         host_stale  = false;    // device ahead of the host vectors (trace_samples_resident)
   std::vector<shadow_state> shadows;
+  ythip_scene  staged      = {};       // rank 0's pinned staging pools (the flat scene, filled in place)
+  bool         have_staged = false;
   ythip_ctx*   ctx(int r = 0) { return ythip_multi_ctx(multi, r); }
 };
 residency& cache() {
@@ -369,21 +371,116 @@ void ensure_context(residency& r) {
   r.ranks = ythip_multi_size(r.multi);
 }
 
-// the scene's device mirrors (uploads what the stamp says changed)
-void ensure_scene(residency& r, const scene_data& scene, flat_scene* keep = nullptr) {
+// Scene ingest: scene_data's vector-of-vectors go straight into
+// libythip's pinned staging pools — one pass over the source, no intermediate flat copy, the
+// upload is a DMA from the pools and the library keeps them as its host copies (flatten()
+// above + ythip_upload_scene made three copies of the geometry; this makes one).  The layout
+// written is flatten()'s, byte for byte (ingest_selfcheck()).
+void count_scene(const scene_data& s, ythip_scene& v) {
+  v                  = {};
+  v.num_cameras      = (int)s.cameras.size();
+  v.num_instances    = (int)s.instances.size();
+  v.num_environments = (int)s.environments.size();
+  v.num_shapes       = (int)s.shapes.size();
+  v.num_textures     = (int)s.textures.size();
+  v.num_materials    = (int)s.materials.size();
+  for (auto& sh : s.shapes) {
+    v.num_points += (int64_t)sh.points.size(), v.num_lines += (int64_t)sh.lines.size();
+    v.num_triangles += (int64_t)sh.triangles.size(), v.num_quads += (int64_t)sh.quads.size();
+    v.num_positions += (int64_t)sh.positions.size(), v.num_normals += (int64_t)sh.normals.size();
+    v.num_texcoords += (int64_t)sh.texcoords.size(), v.num_colors += (int64_t)sh.colors.size();
+    v.num_radius += (int64_t)sh.radius.size();
+  }
+  for (auto& t : s.textures) {
+    if (t.pixelsf.empty())
+      v.num_pixelsb += (int64_t)t.pixelsb.size();
+    else
+      v.num_pixelsf += (int64_t)t.pixelsf.size();
+  }
+}
+// fills pools sized by count_scene (the pointers of `v` are writable staging memory)
+void fill_scene(const scene_data& s, const ythip_scene& v) {
+  auto cameras = (ythip_camera*)v.cameras;
+  for (size_t k = 0; k < s.cameras.size(); k++) cameras[k] = flat(s.cameras[k]);
+  auto instances = (ythip_instance*)v.instances;
+  for (size_t k = 0; k < s.instances.size(); k++)
+    instances[k] = {flat(s.instances[k].frame), s.instances[k].shape, s.instances[k].material};
+  auto environments = (ythip_environment*)v.environments;
+  for (size_t k = 0; k < s.environments.size(); k++) {
+    auto& e         = s.environments[k];
+    environments[k] = {flat(e.frame), {e.emission.x, e.emission.y, e.emission.z}, e.emission_tex};
+  }
+  static_assert(sizeof(ythip_material) == sizeof(material_data), "material layout drifted");
+  if (!s.materials.empty())
+    std::memcpy((void*)v.materials, (const void*)s.materials.data(), s.materials.size() * sizeof(ythip_material));
+  // a cursor per pool, in elements; put() copies one source vector and returns its offset (-1: empty)
+  auto put = [](auto* pool, int64_t& cursor, const auto& src) -> int64_t {
+    if (src.empty()) return -1;
+    auto off = cursor;
+    std::memcpy((void*)((char*)pool + (size_t)cursor * sizeof(src[0])), (const void*)src.data(), src.size() * sizeof(src[0]));
+    cursor += (int64_t)src.size();
+    return off;
+  };
+  int64_t cf = 0, cb = 0;
+  auto    textures = (ythip_texture*)v.textures;
+  for (size_t k = 0; k < s.textures.size(); k++) {
+    auto&         t  = s.textures[k];
+    ythip_texture ft = {t.width, t.height, t.linear ? 1 : 0, t.nearest ? 1 : 0, t.clamp ? 1 : 0,
+        t.pixelsf.empty() ? 0 : 1, 0};
+    auto off  = t.pixelsf.empty() ? put(v.pixelsb, cb, t.pixelsb) : put(v.pixelsf, cf, t.pixelsf);
+    ft.offset = off < 0 ? 0 : off;
+    textures[k] = ft;
+  }
+  int64_t c_points = 0, c_lines = 0, c_triangles = 0, c_quads = 0, c_positions = 0, c_normals = 0, c_texcoords = 0,
+          c_colors = 0, c_radius = 0;
+  auto shapes = (ythip_shape*)v.shapes;
+  for (size_t k = 0; k < s.shapes.size(); k++) {
+    auto&       sh      = s.shapes[k];
+    ythip_shape fs      = {};
+    fs.points_offset    = put(v.points, c_points, sh.points);
+    fs.lines_offset     = put(v.lines, c_lines, sh.lines);
+    fs.triangles_offset = put(v.triangles, c_triangles, sh.triangles);
+    fs.quads_offset     = put(v.quads, c_quads, sh.quads);
+    fs.positions_offset = put(v.positions, c_positions, sh.positions);
+    fs.normals_offset   = put(v.normals, c_normals, sh.normals);
+    fs.texcoords_offset = put(v.texcoords, c_texcoords, sh.texcoords);
+    fs.colors_offset    = put(v.colors, c_colors, sh.colors);
+    fs.radius_offset    = put(v.radius, c_radius, sh.radius);
+    fs.num_points       = (int)sh.points.size();
+    fs.num_lines        = (int)sh.lines.size();
+    fs.num_triangles    = (int)sh.triangles.size();
+    fs.num_quads        = (int)sh.quads.size();
+    fs.num_positions    = (int)sh.positions.size();
+    fs.num_normals      = (int)sh.normals.size();
+    fs.num_texcoords    = (int)sh.texcoords.size();
+    fs.num_colors       = (int)sh.colors.size();
+    fs.num_radius       = (int)sh.radius.size();
+    shapes[k]           = fs;
+  }
+}
+void ingest(residency& r, const scene_data& scene) {
+  ythip_scene counts;
+  count_scene(scene, counts);
+  r.have_staged = false;
+  check(r.ctx(0), ythip_scene_staging(r.ctx(0), &counts, &r.staged));
+  fill_scene(scene, r.staged);
+  check(r.ctx(0), ythip_upload_scene_staged(r.ctx(0)));
+  r.have_staged = true;
+  // the other ranks read rank 0's pinned pools (replicated scene: SURVEY.md §8e)
+  for (int k = 1; k < r.ranks; k++) check(r.ctx(k), ythip_upload_scene(r.ctx(k), &r.staged));
+}
+
+// the scene's device mirrors (uploads what the stamp says changed); with `need_view` the
+// flat view r.staged is valid on return (make_trace_bvh reads the geometry through it)
+void ensure_scene(residency& r, const scene_data& scene, bool need_view = false) {
   ensure_context(r);
   auto ss    = stamp_of(scene);
   bool whole = !r.scene.valid || ss.who != r.scene.who || ss.layout != r.scene.layout;
-  if (whole || keep) {
-    flat_scene  local;
-    flat_scene& f = keep ? *keep : local;
-    flatten(scene, f);
-    if (whole) {
-      on_all(r, [&](ythip_ctx* c) { return ythip_upload_scene(c, &f.view); });
-      r.scene = ss;
-      r.bvh = r.lights = 0;
-      return;
-    }
+  if (whole || (need_view && !r.have_staged)) {
+    ingest(r, scene);
+    r.scene = ss;
+    if (whole) r.bvh = r.lights = 0;
+    return;
   }
   if (ss.cameras != r.scene.cameras) {
     std::vector<ythip_camera> cams;
@@ -545,6 +642,50 @@ int hip_device_count() {
   return r.ranks;
 }
 
+// Test hook: ingests `scene` into staging pools and compares every pool, byte for byte, with
+// the copy-based flatten() the first round shipped.  Returns "" when identical.
+std::string ingest_selfcheck(const scene_data& scene) {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  ensure_context(r);
+  ingest(r, scene);
+  r.scene = stamp_of(scene);
+  r.bvh = r.lights = 0;
+  flat_scene f;
+  flatten(scene, f);
+  auto& a = f.view;
+  auto& b = r.staged;
+  if (a.num_cameras != b.num_cameras || a.num_instances != b.num_instances || a.num_environments != b.num_environments ||
+      a.num_shapes != b.num_shapes || a.num_textures != b.num_textures || a.num_materials != b.num_materials ||
+      a.num_points != b.num_points || a.num_lines != b.num_lines || a.num_triangles != b.num_triangles ||
+      a.num_quads != b.num_quads || a.num_positions != b.num_positions || a.num_normals != b.num_normals ||
+      a.num_texcoords != b.num_texcoords || a.num_colors != b.num_colors || a.num_radius != b.num_radius ||
+      a.num_pixelsf != b.num_pixelsf || a.num_pixelsb != b.num_pixelsb)
+    return "counts";
+  auto same = [](const void* x, const void* y, size_t bytes) { return bytes == 0 || std::memcmp(x, y, bytes) == 0; };
+#define YT_SAME(field, bytes) \
+  if (!same(a.field, b.field, (size_t)(bytes))) return #field;
+  YT_SAME(cameras, a.num_cameras * sizeof(ythip_camera));
+  YT_SAME(instances, a.num_instances * sizeof(ythip_instance));
+  YT_SAME(environments, a.num_environments * sizeof(ythip_environment));
+  YT_SAME(shapes, a.num_shapes * sizeof(ythip_shape));
+  YT_SAME(textures, a.num_textures * sizeof(ythip_texture));
+  YT_SAME(materials, a.num_materials * sizeof(ythip_material));
+  YT_SAME(points, a.num_points * 4);
+  YT_SAME(lines, a.num_lines * 8);
+  YT_SAME(triangles, a.num_triangles * 12);
+  YT_SAME(quads, a.num_quads * 16);
+  YT_SAME(positions, a.num_positions * 12);
+  YT_SAME(normals, a.num_normals * 12);
+  YT_SAME(texcoords, a.num_texcoords * 8);
+  YT_SAME(colors, a.num_colors * 16);
+  YT_SAME(radius, a.num_radius * 4);
+  YT_SAME(pixelsf, a.num_pixelsf * 16);
+  YT_SAME(pixelsb, a.num_pixelsb * 4);
+#undef YT_SAME
+  return "";
+}
+
 void invalidate() {
   auto& r    = cache();
   auto  lock = std::lock_guard{r.mutex};
@@ -607,9 +748,8 @@ trace_bvh make_trace_bvh(const scene_data& scene, const trace_params& params) {
   if (params.highqualitybvh) return yocto::make_trace_bvh(scene, params);
   auto&      r    = cache();
   auto       lock = std::lock_guard{r.mutex};
-  flat_scene f;
-  ensure_scene(r, scene, &f);
-  on_all(r, [&](ythip_ctx* c) { return ythip_build_bvh(c, &f.view, 0); });  // deterministic: the same tree on every rank
+  ensure_scene(r, scene, true);
+  on_all(r, [&](ythip_ctx* c) { return ythip_build_bvh(c, &r.staged, 0); });  // deterministic: the same tree on every rank
   int32_t ntrees = 0;
   int64_t nnodes = 0, nprims = 0;
   check(r.ctx(), ythip_bvh_sizes(r.ctx(), &ntrees, &nnodes, &nprims));
@@ -942,6 +1082,8 @@ void release() {
   r.dev_samples    = -1;
   r.host_stale     = false;
   r.shadows.clear();
+  r.staged      = {};
+  r.have_staged = false;
 }
 
 }  // namespace yocto::hip

@@ -26,6 +26,8 @@
 #ifndef YOCTO_HIPTRACE_H
 #define YOCTO_HIPTRACE_H
 
+#include <string>
+
 #include <yocto/yocto_image.h>
 #include <yocto/yocto_scene.h>
 #include <yocto/yocto_trace.h>
@@ -48,6 +50,12 @@ int hip_device_count();
 // update_trace_bvh, a few texels repainted) is announced with invalidate(): the next
 // call uploads scene, bvh and lights again.
 void invalidate();
+
+// Scene ingest goes straight from scene_data into libythip's pinned staging pools
+// (ythip_scene_staging: one copy of the geometry instead of three, DMA upload).  This test
+// hook ingests `scene` and compares every pool with the copy-based flatten, byte for byte;
+// returns "" when identical, else the name of the first pool that differs.
+std::string ingest_selfcheck(const scene_data& scene);
 
 // yocto_trace.h:160-168.  State and lights: libythip's host builders (the image-size
 // rule + the serial master rng stream; the light CDFs).  make_trace_bvh: built by libythip (device for shapes >= 16384

@@ -400,6 +400,8 @@ _SIGNATURES = {
     "ythip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_sync": (C.c_int, [C.c_void_p]),
     "ythip_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(CScene)]),
+    "ythip_scene_staging": (C.c_int, [C.c_void_p, C.POINTER(CScene), C.POINTER(CScene)]),
+    "ythip_upload_scene_staged": (C.c_int, [C.c_void_p]),
     "ythip_update_cameras": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ythip_update_materials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ythip_update_environments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -871,7 +873,7 @@ class Context:
         self._check(self.lib.ythip_set_early_miss(self.h, int(enable)), "set_early_miss")
 
     def set_pool(self, mode, waves=0, target=0, refill_min=0, shade_min=0, tile_mul=0):
-        """Scheduler: 0 k_trace, 1 k_pool (path samplers), 2 chosen per scene (default)."""
+        """Scheduler: 0 k_trace (default), 1 the experimental k_pool (path samplers)."""
         self._check(self.lib.ythip_set_pool(self.h, int(mode), waves, target, refill_min, shade_min, tile_mul),
                     "set_pool")
 
