@@ -398,6 +398,30 @@ int ythip_get_normal_image(ythip_ctx* ctx, float* image);
  * (apps/ytrace.cpp:206-216) then moves 4 B/pixel per refresh. */
 int ythip_tonemap_image(ythip_ctx* ctx, float exposure, int filmic, int srgb,
     float* ldr, uint8_t* ldr_bytes);
+
+/* denoise_image (yocto_trace.cpp:1794-1872) and the hand-off at the end of trace_samples
+ * (:1615-1618) — SURVEY.md §8(f) rank 3.  The reference's filter is Intel OIDN (a neural
+ * network, not vendored) or, in the default build, a copy; its interface — HDR colour plus the
+ * first-hit albedo / normal means — is what this keeps.  The filter is an edge-avoiding à-trous
+ * wavelet on the albedo-demodulated colour driven by those guides (csrc/yt_denoise.h has the
+ * complete definition; tests restate it in numpy).  NOT a parity feature: there is no
+ * reference output to match.  `params` NULL = ythip_denoise_default_params.
+ *   ythip_denoise_image: host buffers in the reference's layouts (render vec4f, albedo vec3f,
+ *     normal vec3f, denoised vec4f; width*height each), any context.
+ *   ythip_denoise_state: on the resident whole-frame trace_state (a sliced state is refused:
+ *     gather first); the result stays on the device (ythip_state_device_denoised) until the
+ *     state changes and is also copied to `denoised` when that is not NULL. */
+typedef struct ythip_denoise_params {
+  int32_t levels;        /* à-trous levels, tap spacing 1, 2, 4, ...  (default 5) */
+  float   sigma_color;   /* tolerance on the relative colour distance, halved per level (4) */
+  float   sigma_normal;  /* tolerance on |n_p - n_q|  (0.35) */
+  float   sigma_albedo;  /* tolerance on |albedo_p - albedo_q|  (0.1) */
+} ythip_denoise_params;
+void ythip_denoise_default_params(ythip_denoise_params* params);
+int  ythip_denoise_image(ythip_ctx* ctx, const ythip_denoise_params* params, int32_t width, int32_t height,
+     const float* render, const float* albedo, const float* normal, float* denoised);
+int  ythip_denoise_state(ythip_ctx* ctx, const ythip_denoise_params* params, float* denoised);
+int  ythip_state_device_denoised(ythip_ctx* ctx, void** image);
 /* Use caller-owned DEVICE buffers (e.g. torch tensors) for the state arrays,
  * so that the framebuffer gather can run on them directly (RCCL). */
 int ythip_state_bind_device(ythip_ctx* ctx, void* image, void* albedo,

@@ -10,6 +10,7 @@
 #include <yocto/yocto_shape.h>
 #include <yocto/yocto_trace.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -364,6 +365,22 @@ int main() {
       auto what = hip::ingest_selfcheck(*sc);
       EXPECT(what.empty(), "staged ingest differs from flatten in pool '%s'", what.c_str());
     }
+    {  // a million-triangle shape (BASELINE configs[1]'s geometry): the two routes timed
+      auto big   = scene_data{};
+      big.cameras.push_back(scene.cameras[0]);
+      auto& sh     = big.shapes.emplace_back();
+      auto  quads  = make_recty({1000, 500}, {10, 10});
+      sh.positions = quads.positions, sh.normals = quads.normals, sh.texcoords = quads.texcoords;
+      sh.triangles = quads_to_triangles(quads.quads);
+      big.materials.emplace_back();
+      auto& inst = big.instances.emplace_back();
+      inst.shape = 0, inst.material = 0;
+      double staged = 0, copy = 0;
+      hip::ingest_selfcheck(big);  // (first touch of the pinned pools)
+      auto what = hip::ingest_selfcheck(big, &staged, &copy);
+      EXPECT(what.empty(), "staged ingest of the 1M-triangle plane differs in pool '%s'", what.c_str());
+      std::printf("ingest 1M triangles: staged %.2f ms, flatten+upload %.2f ms\n", staged, copy);
+    }
     auto params       = trace_params{};
     params.sampler    = trace_sampler_type::path;
     params.resolution = 96;
@@ -381,6 +398,61 @@ int main() {
     auto hbvh = hip::make_trace_bvh(rich, params);
     EXPECT(hbvh.bvh.bvh.nodes.size() == rbvh.bvh.bvh.nodes.size(), "make_trace_bvh over the staged view");
     hip::invalidate();
+  }
+
+  // 4c. the denoiser slot.  Default: the reference's default build
+  //     (state.denoised = state.image).  With set_device_denoiser(true): libythip's filter on
+  //     the resident state = hip::denoise_image on the same state's host vectors, bit for bit;
+  //     it must reduce the error of a 4 spp render against a 256 spp one.
+  {
+    auto params       = trace_params{};
+    params.sampler    = trace_sampler_type::path;
+    params.resolution = 128;
+    params.samples    = 4;
+    params.batch      = 4;
+    params.denoise    = true;
+    auto bvh          = make_trace_bvh(scene, params);
+    auto lights       = make_trace_lights(scene, params);
+    auto a = make_trace_state(scene, params), b = hip::make_trace_state(scene, params);
+    EXPECT(!b.denoised.empty() && b.denoised.size() == a.denoised.size(), "make_trace_state with denoise");
+    trace_samples(a, scene, bvh, lights, params);
+    hip::trace_samples(b, scene, bvh, lights, params);
+    EXPECT(same_bytes(a.image, b.image) && same_bytes(a.denoised, b.denoised), "default denoise hand-off is the reference's copy");
+    hip::set_device_denoiser(true);
+    auto c = hip::make_trace_state(scene, params);
+    hip::trace_samples(c, scene, bvh, lights, params);
+    hip::set_device_denoiser(false);
+    EXPECT(same_bytes(c.image, a.image), "the render itself does not depend on the denoiser");
+    auto d = std::vector<vec4f>(c.image.size());
+    hip::denoise_image(d, c.width, c.height, c.image, c.albedo, c.normal);
+    EXPECT(same_bytes(d, c.denoised), "resident hand-off differs from hip::denoise_image on the same state");
+    auto many    = params;
+    many.samples = many.batch = 256;
+    many.denoise              = false;
+    auto ref                  = make_trace_state(scene, many);
+    hip::trace_samples(ref, scene, bvh, lights, many);
+    auto rmse = [&](const std::vector<vec4f>& x) {
+      double acc = 0;
+      for (size_t k = 0; k < x.size(); k++) {
+        auto u = xyz(x[k]), v = xyz(ref.image[k]);
+        for (auto ch : {0, 1, 2}) {
+          auto e = std::pow(std::min(u[ch], 1.0f), 1 / 2.2f) - std::pow(std::min(v[ch], 1.0f), 1 / 2.2f);
+          acc += (double)e * e;
+        }
+      }
+      return std::sqrt(acc / (3 * x.size()));
+    };
+    auto e_raw = rmse(c.image), e_den = rmse(c.denoised);
+    std::printf("denoiser: RMSE vs 256 spp  raw %.4f  filtered %.4f\n", e_raw, e_den);
+    EXPECT(e_den < 0.6 * e_raw, "the filter must reduce the error (%.4f -> %.4f)", e_raw, e_den);
+    bool threw = false;
+    try {
+      auto small = std::vector<vec4f>(3);
+      hip::denoise_image(small, c.width, c.height, c.image, c.albedo, c.normal);
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    EXPECT(threw, "denoise_image must reject mismatched sizes like the reference");
   }
 
   // 5. in-place edits between batches (the reference reads the scene fresh on every call):

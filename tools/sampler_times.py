@@ -22,6 +22,8 @@ elif SCENE == "cornell1m":  # cfg2b: the Cornell box with 1M-triangle walls
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import parity as P
     flat = P.scene_cornell_1m()
+elif SCENE == "cornell9m":  # bench.py's cache-exceeding scene: 8,987,066 wall triangles
+    flat = ysc.cornell_1m_scene(ysc.load_scene(os.path.join(ROOT, "tests", "golden", "cornellbox.npz")), n=948)
 else:
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import parity as P

@@ -797,19 +797,24 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
 
 // The production entry: the wide walk, and the binary walk for the rays it declines
 // (irregular at world or instance level, find_any) — the same hit record either way.
-template <bool COUNT, bool WIDE, bool TRI = false>
+#ifdef YT_PHASED
+constexpr bool PHASED_DEFAULT = true;
+#else
+constexpr bool PHASED_DEFAULT = false;
+#endif
+template <bool COUNT, bool WIDE, bool TRI = false, bool PHASED = PHASED_DEFAULT>
 YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt, const TopLds* top = nullptr) {
   if constexpr (WIDE && !COUNT) {
-#ifdef YT_PHASED
-    if (!find_any) {
-      Hit h = traverse_phased<TRI>(sc, wray, only_instance, st, cnt);
+    if constexpr (PHASED) {
+      if (!find_any) {
+        Hit h = traverse_phased<TRI>(sc, wray, only_instance, st, cnt);
+        if (h.instance != HIT_ABORT) return h;
+      }
+    } else {
+      Hit h = traverse<false, true, TRI>(sc, wray, only_instance, find_any, st, cnt, top);
       if (h.instance != HIT_ABORT) return h;
     }
-#else
-    Hit h = traverse<false, true, TRI>(sc, wray, only_instance, find_any, st, cnt, top);
-    if (h.instance != HIT_ABORT) return h;
-#endif
   }
   return traverse<COUNT, false, TRI>(sc, wray, only_instance, find_any, st, cnt);
 }

@@ -994,6 +994,16 @@ YT_FN int max_bounces_of(const KParams& kp) {
 template <int SAMPLER, int LP, bool COUNT, bool WIDE, int CLS = 0>
 __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, DState st, KParams kp) {
   constexpr bool MATTE = CLS == 1;
+  // majority-phase scene walk (yt_bvh.h::traverse_phased) for the kernels where it wins:
+  // simple scenes with area lights (closed rooms: every ray hits, bounce rays as long as
+  // camera rays).  Measured, DESIGN.md §6.
+#if defined(YT_PHASED_LP_ALL)
+  constexpr bool PHASED_SCENE = PHASED_DEFAULT || LP == LP_DEFER;
+#elif !defined(YT_NO_PHASED_LP)
+  constexpr bool PHASED_SCENE = PHASED_DEFAULT || (MATTE && LP == LP_DEFER);
+#else
+  constexpr bool PHASED_SCENE = PHASED_DEFAULT;
+#endif
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   // root-box misses of continuing paths resolved in place (resolve_step); the counting
@@ -1130,7 +1140,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
       } else {
         ray3f          ray = make_ray(P.o, P.d);
         const unsigned s0  = cnt.steps;
-        P.isec             = traverse_any<COUNT, WIDE, MATTE>(sc, ray, -1, false, stack, cnt, top);
+        P.isec             = traverse_any<COUNT, WIDE, MATTE, PHASED_SCENE>(sc, ray, -1, false, stack, cnt, top);
         work               = cnt.steps - s0 + 1;
       }
 #ifdef YT_TIMING

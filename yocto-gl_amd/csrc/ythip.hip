@@ -24,6 +24,7 @@
 #include "yt_build.h"
 #include "yt_gpubuild.h"
 #include "yt_kernels.h"
+#include "yt_denoise.h"
 #include "yt_pool.h"
 
 using namespace yt;
@@ -77,6 +78,11 @@ struct ythip_ctx {
   HostPool<float>             h_positions, h_radius;
   // scene ingest straight into the flat layout: pinned pools the
   // loader fills in place; they become the context's host copies and the DMA source
+  // on-device denoiser (yt_denoise.h): working images for a w x h frame, result in dn_out
+  std::vector<void*>          denoise_allocs;
+  float4 *                    dn_a = nullptr, *dn_b = nullptr, *dn_gn = nullptr, *dn_ga = nullptr, *dn_out = nullptr;
+  size_t                      dn_pixels    = 0;
+  bool                        have_denoised = false;  // dn_out holds the filtered image of the resident state
   std::vector<void*>          staging_allocs;
   ythip_scene                 staged      = {};
   bool                        have_staged = false;
@@ -800,6 +806,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   if (params->camera < 0 || params->camera >= ctx->num_cameras)
     return fail(ctx, YTHIP_ERR_INVALID, "camera index %d out of range [0,%d)", params->camera, ctx->num_cameras);
   if (params->batch < 1) return fail(ctx, YTHIP_ERR_INVALID, "batch must be >= 1");
+  ctx->have_denoised = false;
   if (only_pix < 0 && ctx->samples >= params->samples) return YTHIP_OK;  // yocto_trace.cpp:1598
   if (stop && *stop) return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
 
@@ -944,6 +951,7 @@ void ythip_destroy(ythip_ctx* ctx) {
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_stop) (void)hipFree(ctx->d_stop);
   free_staging(ctx);
+  free_all(ctx->denoise_allocs);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
   free_all(ctx->pool_allocs);
@@ -1501,8 +1509,9 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
         col_first, col_stride, width);
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   free_all(ctx->state_allocs);
-  ctx->have_state  = false;
-  ctx->state_bound = false;
+  ctx->have_state    = false;
+  ctx->have_denoised = false;
+  ctx->state_bound   = false;
   auto& st         = ctx->st;
   st               = DState{};
   st.width         = width;
@@ -1549,6 +1558,7 @@ int ythip_state_upload(ythip_ctx* ctx, const float* image, const float* albedo, 
     const int32_t* hits, const uint64_t* rngs, int samples) {
   if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  ctx->have_denoised = false;
   size_t n = (size_t)ctx->st.npix;
   if (image) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.image, image, n * 16, hipMemcpyHostToDevice, ctx->stream));
   if (albedo) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.albedo, albedo, n * 12, hipMemcpyHostToDevice, ctx->stream));
@@ -1631,6 +1641,115 @@ int ythip_tonemap_image(ythip_ctx* ctx, float exposure, int filmic, int srgb, fl
   auto e3 = hipStreamSynchronize(ctx->stream);
   free_all(tmp);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "tonemap_image failed");
+  return YTHIP_OK;
+}
+
+// ---- denoiser (yt_denoise.h; the slot of denoise_image, yocto_trace.cpp:1794-1872) ---------
+void ythip_denoise_default_params(ythip_denoise_params* p) {
+  if (!p) return;
+  p->levels       = 5;
+  p->sigma_color  = 4.0f;
+  p->sigma_normal = 0.35f;
+  p->sigma_albedo = 0.1f;
+}
+namespace {
+int denoise_buffers(ythip_ctx* ctx, size_t n) {
+  if (ctx->dn_pixels == n && ctx->dn_a) return YTHIP_OK;
+  free_all(ctx->denoise_allocs);
+  ctx->dn_a = ctx->dn_b = ctx->dn_gn = ctx->dn_ga = ctx->dn_out = nullptr;
+  ctx->dn_pixels = 0;
+  int rc;
+  if ((rc = dalloc(ctx, ctx->denoise_allocs, &ctx->dn_a, n))) return rc;
+  if ((rc = dalloc(ctx, ctx->denoise_allocs, &ctx->dn_b, n))) return rc;
+  if ((rc = dalloc(ctx, ctx->denoise_allocs, &ctx->dn_gn, n))) return rc;
+  if ((rc = dalloc(ctx, ctx->denoise_allocs, &ctx->dn_ga, n))) return rc;
+  if ((rc = dalloc(ctx, ctx->denoise_allocs, &ctx->dn_out, n))) return rc;
+  ctx->dn_pixels = n;
+  return YTHIP_OK;
+}
+// image / albedo / normal on the device (trace_state layout) → ctx->dn_out
+int denoise_run(ythip_ctx* ctx, const ythip_denoise_params* up, int width, int height, const float4* image,
+    const float* albedo, const float* normal) {
+  ythip_denoise_params dp;
+  ythip_denoise_default_params(&dp);
+  if (up) dp = *up;
+  if (dp.levels < 0 || dp.levels > 16) return fail(ctx, YTHIP_ERR_INVALID, "denoise levels %d outside [0,16]", dp.levels);
+  if (!(dp.sigma_color > 0) || !(dp.sigma_normal > 0) || !(dp.sigma_albedo > 0))
+    return fail(ctx, YTHIP_ERR_INVALID, "denoise sigmas must be positive");
+  const size_t n = (size_t)width * height;
+  int          rc;
+  if ((rc = denoise_buffers(ctx, n))) return rc;
+  ytdn::Params p = {width, height, dp.levels, 1.0f / (dp.sigma_normal * dp.sigma_normal),
+      1.0f / (dp.sigma_albedo * dp.sigma_albedo), 1.0f / (dp.sigma_color * dp.sigma_color)};
+  const int  threads = ytdn::BX * ytdn::BY;
+  const dim3 flat((unsigned)((n + threads - 1) / threads));
+  const dim3 grid((unsigned)((width + ytdn::BX - 1) / ytdn::BX), (unsigned)((height + ytdn::BY - 1) / ytdn::BY));
+  hipLaunchKernelGGL(ytdn::k_prep, flat, dim3(threads), 0, ctx->stream, image, albedo, normal, (int)n, ctx->dn_a,
+      ctx->dn_gn, ctx->dn_ga);
+  float4 *src = ctx->dn_a, *dst = ctx->dn_b;
+  float   scale = 1;  // 4^l: the colour tolerance halves per level (Dammertz et al. 2010, §3)
+  for (int l = 0; l < dp.levels; l++) {
+    hipLaunchKernelGGL(ytdn::k_atrous, grid, dim3(threads), 0, ctx->stream, src, ctx->dn_gn, ctx->dn_ga, dst, p, 1 << l,
+        p.inv_sc2 * scale);
+    std::swap(src, dst);
+    scale *= 4;
+  }
+  hipLaunchKernelGGL(ytdn::k_finish, flat, dim3(threads), 0, ctx->stream, src, ctx->dn_ga, (int)n, ctx->dn_out);
+  HIPCHECK(ctx, hipGetLastError());
+  return YTHIP_OK;
+}
+}  // namespace
+
+int ythip_denoise_image(ythip_ctx* ctx, const ythip_denoise_params* params, int32_t width, int32_t height,
+    const float* render, const float* albedo, const float* normal, float* denoised) {
+  if (!ctx || !render || !albedo || !normal || !denoised) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (width <= 0 || height <= 0) return fail(ctx, YTHIP_ERR_INVALID, "bad image size %d x %d", width, height);
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  const size_t       n = (size_t)width * height;
+  std::vector<void*> tmp;
+  float4*            d_img = nullptr;
+  float *            d_alb = nullptr, *d_nrm = nullptr;
+  int                rc;
+  if ((rc = dalloc(ctx, tmp, &d_img, n)) || (rc = dalloc(ctx, tmp, &d_alb, 3 * n)) || (rc = dalloc(ctx, tmp, &d_nrm, 3 * n))) {
+    free_all(tmp);
+    return rc;
+  }
+  auto e1 = hipMemcpyAsync(d_img, render, n * 16, hipMemcpyHostToDevice, ctx->stream);
+  auto e2 = hipMemcpyAsync(d_alb, albedo, n * 12, hipMemcpyHostToDevice, ctx->stream);
+  auto e3 = hipMemcpyAsync(d_nrm, normal, n * 12, hipMemcpyHostToDevice, ctx->stream);
+  rc      = (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) ? fail(ctx, YTHIP_ERR_HIP, "denoise upload failed")
+                                                                        : denoise_run(ctx, params, width, height, d_img, d_alb, d_nrm);
+  ctx->have_denoised = false;  // dn_out no longer belongs to the resident state
+  if (rc == YTHIP_OK) {
+    auto e4 = hipMemcpyAsync(denoised, ctx->dn_out, n * 16, hipMemcpyDeviceToHost, ctx->stream);
+    auto e5 = hipStreamSynchronize(ctx->stream);
+    if (e4 != hipSuccess || e5 != hipSuccess) rc = fail(ctx, YTHIP_ERR_HIP, "denoise download failed");
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  free_all(tmp);
+  return rc;
+}
+
+int ythip_denoise_state(ythip_ctx* ctx, const ythip_denoise_params* params, float* denoised) {
+  if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  const auto& st = ctx->st;
+  if (st.lwidth != st.width || st.col_stride != 1 || st.row_begin != 0 || st.rows != st.height)
+    return fail(ctx, YTHIP_ERR_STATE, "denoise needs the whole frame on one device (this state is a slice: gather, then "
+                                      "ythip_denoise_image)");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  int rc = denoise_run(ctx, params, st.width, st.height, st.image, st.albedo, st.normal);
+  if (rc != YTHIP_OK) return rc;
+  ctx->have_denoised = true;
+  if (denoised) HIPCHECK(ctx, hipMemcpyAsync(denoised, ctx->dn_out, (size_t)st.npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return YTHIP_OK;
+}
+
+int ythip_state_device_denoised(ythip_ctx* ctx, void** image) {
+  if (!ctx || !image || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
+  if (!ctx->have_denoised) return fail(ctx, YTHIP_ERR_STATE, "ythip_denoise_state first");
+  *image = ctx->dn_out;
   return YTHIP_OK;
 }
 
@@ -1737,6 +1856,7 @@ int ythip_trace_sample(ythip_ctx* ctx, const ythip_params* params, int i, int j,
   if (!ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
   auto& st = ctx->st;
   if (sample < 0) return fail(ctx, YTHIP_ERR_INVALID, "sample must be >= 0");
+  ctx->have_denoised = false;
   int tc = i / YT_TILE, dc = tc - st.col_first;
   if (i < 0 || i >= st.width || j < st.row_begin || j >= st.row_begin + st.rows || dc < 0 || dc % st.col_stride)
     return fail(ctx, YTHIP_ERR_INVALID, "pixel (%d,%d) is not in this slice of the %dx%d frame", i, j, st.width,

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <future>
 #include <mutex>
@@ -331,6 +332,11 @@ residency& cache() {
   static residency r;
   return r;
 }
+// params.denoise hand-off: false = the reference's default build (a copy), true = libythip's filter
+std::atomic<bool>& device_denoiser() {
+  static std::atomic<bool> on{false};
+  return on;
+}
 
 [[noreturn]] void raise(const std::string& msg, int code) {
   if (code == YTHIP_ERR_SAMPLER) throw std::runtime_error("sampler unknown");  // yocto_trace.cpp:1437
@@ -617,8 +623,18 @@ void trace_impl(trace_state& state, const scene_data& scene, const trace_bvh& bv
   r.host_stale  = true;
   if (download) pull_state(r, state);
   if (params.denoise && !state.denoised.empty()) {  // yocto_trace.cpp:1615-1618
+    if (device_denoiser().load() && r.ranks == 1) {
+      // the filter runs on the resident image + guides; only the result (16 B/pixel) comes back
+      check(r.ctx(), ythip_denoise_state(r.ctx(), nullptr, (float*)state.denoised.data()));
+      return;
+    }
     if (r.host_stale) pull_state(r, state);
-    denoise_image(state.denoised, state.width, state.height, state.image, state.albedo, state.normal);
+    if (device_denoiser().load())
+      check(r.ctx(), ythip_denoise_image(r.ctx(), nullptr, state.width, state.height, (const float*)state.image.data(),
+                         (const float*)state.albedo.data(), (const float*)state.normal.data(),
+                         (float*)state.denoised.data()));
+    else
+      yocto::denoise_image(state.denoised, state.width, state.height, state.image, state.albedo, state.normal);
   }
 }
 
@@ -644,15 +660,23 @@ int hip_device_count() {
 
 // Test hook: ingests `scene` into staging pools and compares every pool, byte for byte, with
 // the copy-based flatten() the first round shipped.  Returns "" when identical.
-std::string ingest_selfcheck(const scene_data& scene) {
+std::string ingest_selfcheck(const scene_data& scene, double* ms_staged, double* ms_copy) {
   auto& r    = cache();
   auto  lock = std::lock_guard{r.mutex};
   ensure_context(r);
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms  = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  flat_scene f;
+  auto       t0 = now();
+  flatten(scene, f);
+  on_all(r, [&](ythip_ctx* c) { return ythip_upload_scene(c, &f.view); });
+  auto t1 = now();
   ingest(r, scene);
+  auto t2 = now();
+  if (ms_copy) *ms_copy = ms(t0, t1);
+  if (ms_staged) *ms_staged = ms(t1, t2);
   r.scene = stamp_of(scene);
   r.bvh = r.lights = 0;
-  flat_scene f;
-  flatten(scene, f);
   auto& a = f.view;
   auto& b = r.staged;
   if (a.num_cameras != b.num_cameras || a.num_instances != b.num_instances || a.num_environments != b.num_environments ||
@@ -978,6 +1002,36 @@ image_data get_denoised_image(const trace_state& state) {
   auto image = make_image(state.width, state.height, true);
   hip::get_denoised_image(image, state);
   return image;
+}
+
+// denoise_image — yocto_trace.cpp:1794-1872, on the device (libythip's guide-driven à-trous
+// filter in the slot the reference gives to OIDN).  Same argument checks as the reference.
+void set_device_denoiser(bool on) { device_denoiser().store(on); }
+void denoise_image(vector<vec4f>& denoised, int width, int height, const vector<vec4f>& render,
+    const vector<vec3f>& albedo, const vector<vec3f>& normal) {
+  auto n = (size_t)width * (size_t)height;
+  if (width <= 0 || height <= 0 || denoised.size() != n || render.size() != n || albedo.size() != n || normal.size() != n)
+    throw std::invalid_argument{"image should have the same size"};  // check_image, yocto_trace.cpp:1843-1846
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  ensure_context(r);
+  check(r.ctx(), ythip_denoise_image(r.ctx(), nullptr, width, height, (const float*)render.data(),
+                     (const float*)albedo.data(), (const float*)normal.data(), (float*)denoised.data()));
+}
+void denoise_image(image_data& denoised, const image_data& render, const image_data& albedo, const image_data& normal) {
+  auto n = (size_t)render.width * (size_t)render.height;
+  if (denoised.width != render.width || denoised.height != render.height || albedo.width != render.width ||
+      albedo.height != render.height || normal.width != render.width || normal.height != render.height ||
+      denoised.pixels.size() != n || albedo.pixels.size() != n || normal.pixels.size() != n)
+    throw std::invalid_argument{"image should have the same size"};  // yocto_trace.cpp:1802-1804
+  auto a3 = vector<vec3f>(n), n3 = vector<vec3f>(n);
+  for (size_t k = 0; k < n; k++) a3[k] = xyz(albedo.pixels[k]), n3[k] = xyz(normal.pixels[k]);
+  hip::denoise_image(denoised.pixels, render.width, render.height, render.pixels, a3, n3);
+}
+image_data denoise_image(const image_data& render, const image_data& albedo, const image_data& normal) {
+  auto denoised = make_image(render.width, render.height, render.linear);
+  hip::denoise_image(denoised, render, albedo, normal);
+  return denoised;
 }
 
 namespace {

@@ -54,8 +54,9 @@ void invalidate();
 // Scene ingest goes straight from scene_data into libythip's pinned staging pools
 // (ythip_scene_staging: one copy of the geometry instead of three, DMA upload).  This test
 // hook ingests `scene` and compares every pool with the copy-based flatten, byte for byte;
-// returns "" when identical, else the name of the first pool that differs.
-std::string ingest_selfcheck(const scene_data& scene);
+// returns "" when identical, else the name of the first pool that differs.  The two out
+// parameters receive the wall time of each route (flatten + ythip_upload_scene / staged).
+std::string ingest_selfcheck(const scene_data& scene, double* ms_staged = nullptr, double* ms_copy = nullptr);
 
 // yocto_trace.h:160-168.  State and lights: libythip's host builders (the image-size
 // rule + the serial master rng stream; the light CDFs).  make_trace_bvh: built by libythip (device for shapes >= 16384
@@ -120,6 +121,19 @@ image_data get_normal_image(const trace_state& state);
 void       get_normal_image(image_data& image, const trace_state& state);
 image_data get_denoised_image(const trace_state& state);
 void       get_denoised_image(image_data& image, const trace_state& state);
+// denoise_image (yocto_trace.h:193-199, yocto_trace.cpp:1794-1872) on the device.  The
+// reference's filter is OIDN when built with YOCTO_DENOISE (not vendored) and a copy
+// otherwise; this is libythip's guide-driven edge-avoiding à-trous filter on the same
+// three inputs (include/ythip.h: ythip_denoise_image) — NOT a parity feature.
+// set_device_denoiser(true) makes the `params.denoise` hand-off at the end of
+// trace_samples / trace_start use it on the resident state (default: the reference's
+// default-build behaviour, state.denoised = state.image).
+void       set_device_denoiser(bool on);
+void       denoise_image(vector<vec4f>& denoised, int width, int height, const vector<vec4f>& render,
+          const vector<vec3f>& albedo, const vector<vec3f>& normal);
+void       denoise_image(image_data& denoised, const image_data& render, const image_data& albedo,
+          const image_data& normal);
+image_data denoise_image(const image_data& render, const image_data& albedo, const image_data& normal);
 // tonemap_image (yocto_image.h:104-112) of the resident render, computed ON THE
 // DEVICE: exposure, optional filmic curve, sRGB encoding.  The float version is
 // what a viewer uploads to its display; the byte version what save_image writes

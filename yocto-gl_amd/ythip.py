@@ -75,6 +75,11 @@ FALSECOLORS = ["position", "normal", "frontfacing", "gnormal", "gfrontfacing",
 # ----------------------------------------------------------------------------
 # ctypes structs
 # ----------------------------------------------------------------------------
+class CDenoiseParams(C.Structure):
+    _fields_ = [("levels", C.c_int32), ("sigma_color", C.c_float), ("sigma_normal", C.c_float),
+                ("sigma_albedo", C.c_float)]
+
+
 class CScene(C.Structure):
     _fields_ = [
         ("num_cameras", C.c_int32), ("num_instances", C.c_int32),
@@ -446,6 +451,11 @@ _SIGNATURES = {
     "ythip_get_normal_image": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_trace_sample": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_int, C.c_int, C.c_int]),
     "ythip_tonemap_image": (C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ythip_denoise_default_params": (None, [C.c_void_p]),
+    "ythip_denoise_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "ythip_denoise_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ythip_state_device_denoised": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ythip_state_bind_device": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     "ythip_state_set_samples": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_trace_samples": (C.c_int, [C.c_void_p, C.POINTER(CParams), C.c_void_p]),
@@ -804,6 +814,38 @@ class Context:
         self._check(self.lib.ythip_tonemap_image(self.h, exposure, int(filmic), int(srgb),
                                                  ldr.ctypes.data, ldrb.ctypes.data), "tonemap_image")
         return ldr, ldrb
+
+    # denoiser (csrc/yt_denoise.h; the slot of denoise_image, yocto_trace.cpp:1794-1872) -------
+    def denoise_params(self, **kw):
+        p = CDenoiseParams()
+        self.lib.ythip_denoise_default_params(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown denoise parameter {k}")
+            setattr(p, k, v)
+        return p
+
+    def denoise_image(self, render, albedo, normal, **kw):
+        """Host images (render [h, w, 4], albedo / normal [h, w, 3], float32) -> denoised [h, w, 4]."""
+        render = np.ascontiguousarray(render, "f4")
+        albedo = np.ascontiguousarray(albedo, "f4")
+        normal = np.ascontiguousarray(normal, "f4")
+        h, w = render.shape[:2]
+        if render.shape != (h, w, 4) or albedo.shape != (h, w, 3) or normal.shape != (h, w, 3):
+            raise ValueError("denoise_image: render [h,w,4], albedo [h,w,3], normal [h,w,3]")
+        out = np.zeros((h, w, 4), "f4")
+        p = self.denoise_params(**kw)
+        self._check(self.lib.ythip_denoise_image(self.h, C.byref(p), w, h, render.ctypes.data, albedo.ctypes.data,
+                                                 normal.ctypes.data, out.ctypes.data), "denoise_image")
+        return out
+
+    def denoise_state(self, download=True, **kw):
+        """The resident whole-frame state's image, filtered on the device; [h, w, 4] or None."""
+        out = np.zeros((self.height, self.width, 4), "f4") if download else None
+        p = self.denoise_params(**kw)
+        self._check(self.lib.ythip_denoise_state(self.h, C.byref(p), out.ctypes.data if download else None),
+                    "denoise_state")
+        return out
 
     def bind_device_state(self, image, albedo, normal, hits, rngs):
         self._check(self.lib.ythip_state_bind_device(self.h, image, albedo, normal,
