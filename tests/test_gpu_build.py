@@ -18,14 +18,14 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 
-def build_both(flat, min_prims=8):
+def build_both(flat, min_prims=8, highquality=False):
     """(device-built, host-built) downloads + baked arrays of the same scene."""
     out = []
     for mode in ["device", "host"]:
         ctx = yt.Context(0)
         ctx.upload_scene(flat)
         ctx.set_bvh_builder(mode, min_prims)
-        ctx.make_trace_bvh(flat)
+        ctx.make_trace_bvh(flat, highquality)
         out.append((ctx.download_bvh(), ctx.download_baked_bvh(), ctx.bvh_build_info()))
         ctx.close()
     return out
@@ -160,3 +160,62 @@ def test_hits_and_images_do_not_depend_on_the_builder():
     assert res[0][0].tobytes() == res[1][0].tobytes()
     for k in ["image", "albedo", "normal", "hits", "rngs"]:
         assert res[0][1][k].tobytes() == res[1][1][k].tobytes(), k
+
+
+# ---- highqualitybvh: split_sah (yocto_bvh.cpp:108-164) on the device --------------------------
+@pytest.mark.parametrize("name", list(P.SCENES))
+def test_device_sah_tree_equals_host_and_reference(name):
+    flat = P.SCENES[name]()
+    dev, host = build_both(flat, min_prims=5, highquality=True)
+    assert dev[2]["device_trees"] >= 1 and dev[2]["fallbacks"] == 0 and host[2]["device_trees"] == 0
+    assert_same(dev, host, name + " sah")
+    if P.have_ref():
+        ref = ry.RefBvh(ry.RefScene.from_flat(flat), True).flat()
+        assert dev[0].nodes.tobytes() == ref.nodes.tobytes()
+        assert dev[0].primitives.tobytes() == ref.primitives.tobytes()
+    # and it is not the split_middle tree
+    mid = build_both(flat, min_prims=5)[0]
+    assert mid[0].nodes.tobytes() != dev[0].nodes.tobytes()
+
+
+@pytest.mark.parametrize("kind", ["triangles", "quads", "lines", "points"])
+@pytest.mark.parametrize("variant", ["uniform", "clustered", "grid"])
+def test_device_sah_on_random_soups(kind, variant):
+    """Every branch of split_sah: empty bins and one-sided candidates (0 * inf = NaN costs that
+    never win), degenerate axes (csize 0 on one axis), many equal centroids (grid: candidates
+    that cannot split fall to the break-in-half rule), very unbalanced clusters."""
+    flat = _soup(kind, 30011, seed=len(kind) * 5 + len(variant), clustered=variant == "clustered",
+                 grid=variant == "grid")
+    dev, host = build_both(flat, highquality=True)
+    assert dev[2]["device_trees"] == 1 and dev[2]["fallbacks"] == 0
+    assert_same(dev, host, f"sah {kind}/{variant}")
+    if P.have_ref() and kind == "triangles":
+        ref = ry.RefBvh(ry.RefScene.from_flat(flat), True).flat()
+        assert dev[0].nodes.tobytes() == ref.nodes.tobytes()
+        assert dev[0].primitives.tobytes() == ref.primitives.tobytes()
+
+
+def test_device_sah_degenerate_inputs():
+    dev, host = build_both(_soup("triangles", 4099, seed=3, dup=True), highquality=True)
+    assert dev[2]["device_trees"] == 1
+    assert_same(dev, host, "sah dup")
+    flat = _soup("points", 6000, seed=4)  # all centroids on a line: two axes without extent
+    pos = flat.positions.copy()
+    pos[:, 1] = 0.25
+    pos[:, 2] = -1.5
+    flat.positions = pos
+    dev, host = build_both(flat, highquality=True)
+    assert dev[2]["device_trees"] == 1
+    assert_same(dev, host, "sah line")
+
+
+def test_baseline_cfg2_sah_tree_on_device():
+    """1,000,000 triangles with highqualitybvh: the host builder's tree (itself the
+    reference's, tests/test_host.py) bit for bit; renders from it equal the host-built one."""
+    flat = ysc.plane_scene()
+    t0 = time.time()
+    dev, host = build_both(flat, min_prims=16384, highquality=True)
+    print("cfg2 SAH build info device:", dev[2], "host:", host[2], "wall", time.time() - t0)
+    assert dev[2]["device_trees"] == 1 and dev[2]["device_prims"] == 1_000_000 and dev[2]["fallbacks"] == 0
+    assert_same(dev, host, "cfg2 sah")
+    assert dev[2]["build_ms"] < host[2]["build_ms"]

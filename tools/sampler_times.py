@@ -29,7 +29,7 @@ else:
     import parity as P
     flat = P.SCENES[SCENE]()
 ctx = yt.Context(0)
-ctx.upload_scene(flat); ctx.make_trace_bvh(flat); ctx.make_trace_lights(flat)
+ctx.upload_scene(flat); ctx.make_trace_bvh(flat, bool(int(os.environ.get('HQ', '0')))); ctx.make_trace_lights(flat)  # HQ=1: highqualitybvh (split_sah)
 if os.environ.get('TRAVERSAL'):
     ctx.set_traversal(os.environ['TRAVERSAL'])
 spp = int(os.environ.get('SPP', '64'))

@@ -31,7 +31,8 @@ struct DeviceTree {
 
 enum { BUILD_OK = 0, BUILD_FALLBACK = 1, BUILD_ERROR = 2 };
 
-// make_shape_bvh (yocto_bvh.cpp:321-362) for one shape, split_middle only.
+// make_shape_bvh (yocto_bvh.cpp:321-362) for one shape: split_middle, or split_sah
+// (yocto_bvh.cpp:108-164, trace_params::highqualitybvh) with `highquality`.
 // `elems` / `positions` / `radius` are DEVICE pointers already offset to the
 // shape's first element / vertex; kind is the BVH dispatch kind (1 points,
 // 2 lines, 3 triangles, 4 quads).  Returns BUILD_FALLBACK (nothing allocated)
@@ -39,7 +40,7 @@ enum { BUILD_OK = 0, BUILD_FALLBACK = 1, BUILD_ERROR = 2 };
 // ties between box faces — see the .hip) and the caller must use the host
 // builder, BUILD_ERROR on a HIP failure (message in *err).
 int build_shape_tree(hipStream_t stream, int kind, const int32_t* elems, const float* positions,
-    const float* radius, int64_t num_prims, DeviceTree* out, std::string* err);
+    const float* radius, int64_t num_prims, bool highquality, DeviceTree* out, std::string* err);
 void free_tree(DeviceTree* tree);
 
 // Device bake of one BLAS into the traversal layout of yt_bvh.h (what

@@ -1,6 +1,7 @@
 // yt_gpubuild.hip — make_bvh on the device.
 //
-// Restates libs/yocto/yocto_bvh.cpp:202-302 (make_bvh + split_middle) and
+// Restates libs/yocto/yocto_bvh.cpp:202-302 (make_bvh + split_middle), :108-164
+// (split_sah, the `highqualitybvh` build: 16 bins x 3 axes per node, see k_bin) and
 // :321-362 (make_shape_bvh's primitive bounds) so that the result is the SAME
 // tree the reference builds — node order, `primitives` permutation, boxes —
 // which is what keeps hit records bit-identical.
@@ -65,6 +66,15 @@ struct BNode {
   float bmin[3], bmax[3];
   int   icount;      // internal nodes in the subtree
   int   rank, id;    // processing rank among internal nodes / reference node index
+  int   sah;         // split_sah: index of the node's bin set in this level's Bins array, -1 = none
+  float cmin[3], csize[3];  // centroid box (split_sah's cbbox.min, csize)
+};
+// split_sah's 16 bins per axis (yocto_bvh.cpp:120-148): primitive boxes merged per bin +
+// counts.  Bin k of an axis holds the primitives whose centre is >= k of the 15 candidate
+// planes; a candidate's left / right box is the merge of the bins below / from it.
+constexpr int NBINS = 16, BIN_WORDS = 7, BINSET = 3 * NBINS * BIN_WORDS;  // 336 words per node
+struct Bins {
+  unsigned v[BINSET];  // [axis][bin]{min.x, min.y, min.z, ~max.x, ~max.y, ~max.z (sortable keys), count}
 };
 // Range accumulators: 12 keys reduced with min (max values are stored negated)
 // + the signed-zero flags.  [0..2] box min, [3..5] ~box max, [6..8] centroid min,
@@ -193,7 +203,8 @@ __global__ void k_reduce(int n, const int* prim, const float4* bbmin, const floa
 
 // Leaf / internal decision and split plane of every node of the level
 // (yocto_bvh.cpp:269-291, split_middle :202-221).
-__global__ void k_decide(BNode* nodes, const Acc* acc, int lb, int le, int* ambiguous) {
+__global__ void k_decide(BNode* nodes, const Acc* acc, int lb, int le, int* ambiguous, int highquality, Bins* bins,
+    int* bin_counter) {
   int x = lb + blockIdx.x * BLK + threadIdx.x;
   if (x >= le) return;
   const unsigned* a  = acc[x].v;
@@ -214,7 +225,7 @@ __global__ void k_decide(BNode* nodes, const Acc* acc, int lb, int le, int* ambi
   }
   nd->bmin[0] = bmin0, nd->bmin[1] = bmin1, nd->bmin[2] = bmin2;
   nd->bmax[0] = bmax0, nd->bmax[1] = bmax1, nd->bmax[2] = bmax2;
-  int   left = -1, needpart = 0, axis = 0, mid = start;
+  int   left = -1, needpart = 0, axis = 0, mid = start, sah = -1;
   float split = 0;
   if (size > MAX_PRIMS) {
     float cmin0 = fkey_inv(a[6]), cmin1 = fkey_inv(a[7]), cmin2 = fkey_inv(a[8]);
@@ -223,6 +234,13 @@ __global__ void k_decide(BNode* nodes, const Acc* acc, int lb, int le, int* ambi
     left = -2;  // internal, children allocated by k_mid
     if (cs0 == 0 && cs1 == 0 && cs2 == 0) {
       mid = (start + end) / 2;
+    } else if (highquality) {  // split_sah: plane chosen by k_sah_decide once the bins are filled
+      sah = atomicAdd(bin_counter, 1);
+      unsigned* b = bins[sah].v;
+      for (int k = 0; k < BINSET; k++) b[k] = (k % BIN_WORDS == BIN_WORDS - 1) ? 0u : 0xffffffffu;
+      nd->cmin[0] = cmin0, nd->cmin[1] = cmin1, nd->cmin[2] = cmin2;
+      nd->csize[0] = cs0, nd->csize[1] = cs1, nd->csize[2] = cs2;
+      needpart = 1;
     } else {
       if (cs0 >= cs1 && cs0 >= cs2) axis = 0;
       if (cs1 >= cs0 && cs1 >= cs2) axis = 1;
@@ -234,6 +252,145 @@ __global__ void k_decide(BNode* nodes, const Acc* acc, int lb, int le, int* ambi
     }
   }
   nd->left = left, nd->K = 0, nd->needpart = needpart, nd->axis = axis, nd->mid = mid, nd->split = split;
+  nd->sah  = sah;
+}
+
+// ---- split_sah (yocto_bvh.cpp:108-164) ------------------------------------------------
+// candidate plane b of an axis: cbbox.min[axis] + b * csize[axis] / nbins, as the reference writes it
+__device__ __forceinline__ float sah_plane(float cmin, float csize, int b) { return cmin + (float)b * csize / (float)NBINS; }
+
+// Binning pass of the level: every primitive of a split_sah node adds its box and one count to
+// one bin per axis.  The planes are non-decreasing in b (a rounded monotonic function), so
+// "centre < plane b" holds exactly for b > k: the bin index k is the number of planes the
+// centre is not below.  A block covers BIN_ITEMS * BLK consecutive primitives; the first
+// BIN_SLOTS ranges it meets are accumulated in LDS and flushed with one set of atomics per
+// block (at the top of the tree all primitives share a few nodes), the rest go straight to
+// global atomics (deep levels: few primitives per node, no contention).
+constexpr int BIN_ITEMS = 8, BIN_SLOTS = 4;
+__global__ void __launch_bounds__(BLK) k_bin(int n, const int* prim, const float4* bbmin, const float4* bbmax,
+    const int* node_of, const BNode* nodes, Bins* bins) {
+  __shared__ unsigned s_bins[BIN_SLOTS][BINSET];
+  __shared__ int      s_set[BIN_SLOTS];
+  __shared__ int      s_wave[BLK / 64];
+  const int tid = threadIdx.x, base = blockIdx.x * (BLK * BIN_ITEMS), first = base + tid * BIN_ITEMS;
+  for (int k = tid; k < BIN_SLOTS * BINSET; k += BLK)
+    (&s_bins[0][0])[k] = (k % BIN_WORDS == BIN_WORDS - 1) ? 0u : 0xffffffffu;
+  if (tid < BIN_SLOTS) s_set[tid] = -1;
+  // slot of an element = number of range changes between the block's first element and it
+  int nd[BIN_ITEMS], changes = 0;
+  int prev = (first > base && first - 1 < n) ? node_of[first - 1] : -3;
+#pragma unroll
+  for (int it = 0; it < BIN_ITEMS; it++) {
+    int i  = first + it;
+    nd[it] = i < n ? node_of[i] : -2;
+    if (i < n && i > base && nd[it] != prev) changes++;
+    prev = nd[it];
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  int       incl = changes;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int slot = incl - changes;
+  for (int w = 0; w < wave; w++) slot += s_wave[w];
+  prev = (first > base && first - 1 < n) ? node_of[first - 1] : -3;
+#pragma unroll
+  for (int it = 0; it < BIN_ITEMS; it++) {
+    int i = first + it;
+    if (i >= n) break;
+    if (i > base && nd[it] != prev) slot++;
+    prev = nd[it];
+    if (nd[it] < 0) continue;
+    const BNode& node = nodes[nd[it]];
+    const int    set  = node.sah;
+    if (set < 0) continue;
+    int    p  = prim[i];
+    float4 mn = bbmin[p], mx = bbmax[p];
+    float  c[3] = {(mn.x + mx.x) / 2, (mn.y + mx.y) / 2, (mn.z + mx.z) / 2};  // centers[] = center(bbox), :247
+    unsigned key[6] = {fkey(mn.x), fkey(mn.y), fkey(mn.z), ~fkey(mx.x), ~fkey(mx.y), ~fkey(mx.z)};
+    unsigned* dst;
+    const bool in_lds = slot < BIN_SLOTS;
+    if (in_lds) {
+      s_set[slot] = set;
+      dst         = s_bins[slot];
+    } else {
+      dst = bins[set].v;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      int k = 0;
+      for (int b = 1; b < NBINS; b++) k += (c[a] < sah_plane(node.cmin[a], node.csize[a], b)) ? 0 : 1;
+      unsigned* bin = dst + (a * NBINS + k) * BIN_WORDS;
+#pragma unroll
+      for (int w = 0; w < 6; w++) atomicMin(&bin[w], key[w]);
+      atomicAdd(&bin[6], 1u);
+    }
+  }
+  __syncthreads();
+  for (int sl = 0; sl < BIN_SLOTS; sl++) {
+    const int set = s_set[sl];
+    if (set < 0) continue;
+    for (int k = tid; k < BINSET; k += BLK) {
+      unsigned v = s_bins[sl][k];
+      if (k % BIN_WORDS == BIN_WORDS - 1) {
+        if (v) atomicAdd(&bins[set].v[k], v);
+      } else if (v != 0xffffffffu) {
+        atomicMin(&bins[set].v[k], v);
+      }
+    }
+  }
+}
+
+// The 45 candidates of split_sah in its own order (axis outer, plane inner), the cost in its
+// own float expression, the first strict minimum wins (yocto_bvh.cpp:119-148).
+__global__ void k_sah_decide(BNode* nodes, int lb, int le, const Bins* bins) {
+  int x = lb + blockIdx.x * BLK + threadIdx.x;
+  if (x >= le) return;
+  BNode* nd = &nodes[x];
+  if (nd->sah < 0) return;
+  const unsigned* B = bins[nd->sah].v;
+  struct Box {
+    float lo[3], hi[3];
+  };
+  const float flt_max = 3.402823466e+38f;
+  auto invalid = [&]() { return Box{{flt_max, flt_max, flt_max}, {-flt_max, -flt_max, -flt_max}}; };
+  auto area = [](const Box& b) {  // bbox_area, :124-128
+    float sx = b.hi[0] - b.lo[0], sy = b.hi[1] - b.lo[1], sz = b.hi[2] - b.lo[2];
+    return 1e-12f + 2 * sx * sy + 2 * sx * sz + 2 * sy * sz;
+  };
+  auto merge_bin = [&](Box& b, int& count, int a, int k) {
+    const unsigned* bin = B + (a * NBINS + k) * BIN_WORDS;
+    if (bin[6] == 0) return;
+    count += (int)bin[6];
+    for (int c = 0; c < 3; c++) {
+      b.lo[c] = fmin_(b.lo[c], fkey_inv(bin[c]));
+      b.hi[c] = fmax_(b.hi[c], fkey_inv(~bin[3 + c]));
+    }
+  };
+  // bbox_area(cbbox): size = cbbox.max - cbbox.min = csize
+  const float carea = 1e-12f + 2 * nd->csize[0] * nd->csize[1] + 2 * nd->csize[0] * nd->csize[2] +
+                      2 * nd->csize[1] * nd->csize[2];
+  int   axis = 0;
+  float split = 0.0f, min_cost = flt_max;
+  for (int a = 0; a < 3; a++) {
+    for (int b = 1; b < NBINS; b++) {
+      Box left = invalid(), right = invalid();
+      int nl = 0, nr = 0;
+      for (int k = 0; k < b; k++) merge_bin(left, nl, a, k);
+      for (int k = b; k < NBINS; k++) merge_bin(right, nr, a, k);
+      float cost = 1 + nl * area(left) / carea + nr * area(right) / carea;
+      if (cost < min_cost) {
+        min_cost = cost;
+        split    = sah_plane(nd->cmin[a], nd->csize[a], b);
+        axis     = a;
+      }
+    }
+  }
+  nd->axis = axis, nd->split = split;
 }
 
 // predicate of std::partition, negated: 1 where centers[primitive][axis] < split is FALSE
@@ -616,7 +773,7 @@ void free_tree(DeviceTree* t) {
 }
 
 int build_shape_tree(hipStream_t s, int kind, const int32_t* elems, const float* positions, const float* radius,
-    int64_t num_prims, DeviceTree* out, std::string* err) {
+    int64_t num_prims, bool highquality, DeviceTree* out, std::string* err) {
   *out = DeviceTree{};
   if (num_prims <= MAX_PRIMS || num_prims > (1ll << 28) || kind < 1 || kind > 4) return BUILD_FALLBACK;
   if ((kind == 1 || kind == 2) && !radius) return BUILD_FALLBACK;
@@ -635,7 +792,10 @@ int build_shape_tree(hipStream_t s, int kind, const int32_t* elems, const float*
   size_t o_nodeof = carve(n * sizeof(int)), o_flag = carve(n * sizeof(int)), o_G = carve((n + 1) * sizeof(int));
   size_t o_A = carve(n * sizeof(int)), o_B = carve(n * sizeof(int)), o_tiles = carve((ntiles + 1) * sizeof(int));
   size_t o_nodes = carve(max_nodes * sizeof(BNode)), o_acc = carve(max_nodes * sizeof(Acc));
-  size_t o_ctr = carve(2 * sizeof(int));
+  size_t o_ctr = carve(4 * sizeof(int));
+  // split_sah: one bin set per internal node of a level; internal nodes hold > 4 primitives each
+  const size_t max_binsets = highquality ? (size_t)n / (MAX_PRIMS + 1) + 2 : 0;
+  size_t       o_bins      = carve(max_binsets * sizeof(Bins));
   char*  scratch = nullptr;
   int*   prim    = nullptr;
   ythip_bvh_node* out_nodes = nullptr;
@@ -664,6 +824,8 @@ int build_shape_tree(hipStream_t s, int kind, const int32_t* elems, const float*
   auto* acc     = (Acc*)(scratch + o_acc);
   auto* counter = (int*)(scratch + o_ctr);
   auto* ambig   = counter + 1;
+  auto* binctr  = counter + 2;
+  auto* bins    = (Bins*)(scratch + o_bins);
 
   GCHECK(hipEventRecord(ev0, s));
   hipLaunchKernelGGL(k_init, dim3(grid(n)), dim3(BLK), 0, s, kind, elems, positions, radius, n, bbmin, bbmax, prim,
@@ -680,7 +842,14 @@ int build_shape_tree(hipStream_t s, int kind, const int32_t* elems, const float*
     int lb = level_base[level];
     hipLaunchKernelGGL(k_reduce, dim3(grid((n + RED_ITEMS - 1) / RED_ITEMS)), dim3(BLK), 0, s, n, prim, bbmin, bbmax,
         node_of, acc);
-    hipLaunchKernelGGL(k_decide, dim3(grid(le - lb)), dim3(BLK), 0, s, nodes, acc, lb, le, ambig);
+    if (highquality) GCHECK(hipMemsetAsync(binctr, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_decide, dim3(grid(le - lb)), dim3(BLK), 0, s, nodes, acc, lb, le, ambig, highquality ? 1 : 0,
+        bins, binctr);
+    if (highquality) {
+      hipLaunchKernelGGL(k_bin, dim3(grid((n + BIN_ITEMS - 1) / BIN_ITEMS)), dim3(BLK), 0, s, n, prim, bbmin, bbmax,
+          node_of, nodes, bins);
+      hipLaunchKernelGGL(k_sah_decide, dim3(grid(le - lb)), dim3(BLK), 0, s, nodes, lb, le, bins);
+    }
     hipLaunchKernelGGL(k_flags, dim3(grid(n)), dim3(BLK), 0, s, n, prim, bbmin, bbmax, node_of, nodes, flag);
     exclusive_scan(s, flag, G, tiles, n);
     hipLaunchKernelGGL(k_mid, dim3(grid(le - lb)), dim3(BLK), 0, s, nodes, acc, lb, le, G, counter);

@@ -347,6 +347,9 @@ YT_FN void set_first_hit(const DState& s, const Path& P, vec3f albedo, vec3f nor
   auto weight = 1.0f / (s.sample_base + P.sidx + 1);
   auto alb    = lerp_(ld3(s.albedo, P.pix), albedo, weight);
   auto nrm    = lerp_(ld3(s.normal, P.pix), normal, weight);
+#ifdef YT_EXP_LASTSTORE  // ceiling experiment: accumulator stores only in the batch's last sample — WRONG results
+  if (P.sidx + 1 < s.batch) return;
+#endif
   s.albedo[3 * P.pix] = alb.x, s.albedo[3 * P.pix + 1] = alb.y, s.albedo[3 * P.pix + 2] = alb.z;
   s.normal[3 * P.pix] = nrm.x, s.normal[3 * P.pix + 1] = nrm.y, s.normal[3 * P.pix + 2] = nrm.z;
 }
@@ -843,10 +846,15 @@ YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Pa
   const int pix    = P.pix;
   float4    im     = st.image[pix];
   vec4f     image  = {im.x, im.y, im.z, im.w};
+#ifdef YT_EXP_LASTSTORE
+  const bool store = P.sidx + 1 >= st.batch;
+#else
+  constexpr bool store = true;
+#endif
   if (hit) {
     // albedo / normal were folded in at the first hit (set_first_hit)
     image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
-    st.hits[pix] += 1;
+    if (store) st.hits[pix] += 1;
   } else {
     // no surface was hit: the path never left the camera ray's direction
     // (opacity skips only move the origin), so -P.d is -camera_ray.d
@@ -857,16 +865,18 @@ YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Pa
       image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
       alb   = lerp_(alb, vec3f{1, 1, 1}, weight);
       nrm   = lerp_(nrm, normal, weight);
-      st.hits[pix] += 1;
+      if (store) st.hits[pix] += 1;
     } else {
       image = lerp_(image, vec4f{0, 0, 0, 0}, weight);
       alb   = lerp_(alb, vec3f{0, 0, 0}, weight);
       nrm   = lerp_(nrm, normal, weight);
     }
-    st.albedo[3 * pix] = alb.x, st.albedo[3 * pix + 1] = alb.y, st.albedo[3 * pix + 2] = alb.z;
-    st.normal[3 * pix] = nrm.x, st.normal[3 * pix + 1] = nrm.y, st.normal[3 * pix + 2] = nrm.z;
+    if (store) {
+      st.albedo[3 * pix] = alb.x, st.albedo[3 * pix + 1] = alb.y, st.albedo[3 * pix + 2] = alb.z;
+      st.normal[3 * pix] = nrm.x, st.normal[3 * pix + 1] = nrm.y, st.normal[3 * pix + 2] = nrm.z;
+    }
   }
-  st.image[pix] = {image.x, image.y, image.z, image.w};
+  if (store) st.image[pix] = {image.x, image.y, image.z, image.w};
   count_lanes(st.counters, CNT_SAMPLES);
 }
 

@@ -536,14 +536,14 @@ int build_bvh_mixed(ythip_ctx* ctx, const ythip_scene& sc, bool highquality, boo
     out.node_offset.push_back((int64_t)out.nodes.size());
     out.prim_offset.push_back((int64_t)out.prims.size());
     bool built = false;
-    if (use_device && !highquality && nprim >= ctx->device_build_min_prims) {
+    if (use_device && nprim >= ctx->device_build_min_prims) {
       const int* el = kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
                       : kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
                       : kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
                                              : ctx->ds.points + sh.points_offset;
       std::string err;
       int rc = ytgpu::build_shape_tree(ctx->stream, kind, el, ctx->ds.positions + 3 * sh.positions_offset,
-          sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, nprim,
+          sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, nprim, highquality,
           &ctx->d_trees[k], &err);
       if (rc == ytgpu::BUILD_ERROR) return fail(ctx, YTHIP_ERR_HIP, "device bvh build failed: %s", err.c_str());
       if (rc == ytgpu::BUILD_OK) {

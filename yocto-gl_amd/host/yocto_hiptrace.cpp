@@ -766,14 +766,14 @@ trace_lights make_trace_lights(const scene_data& scene, const trace_params& para
 // make_trace_bvh — yocto_trace.cpp:88-96.  Large shapes are built on the device
 // (ythip_build_bvh, yt_gpubuild.hip: the reference's tree node for node), the
 // result stays resident for trace_samples AND comes back as the reference's own
-// value type, so either back-end can use it.  SAH builds stay on the host.
+// value type, so either back-end can use it.  params.highqualitybvh selects the
+// reference's binned-SAH split (split_sah), built on the device as well.
 trace_bvh make_trace_bvh(const scene_data& scene, const trace_params& params) {
   if (params.embreebvh) throw std::invalid_argument("yocto::hip::make_trace_bvh: embreebvh has no device mirror");
-  if (params.highqualitybvh) return yocto::make_trace_bvh(scene, params);
   auto&      r    = cache();
   auto       lock = std::lock_guard{r.mutex};
   ensure_scene(r, scene, true);
-  on_all(r, [&](ythip_ctx* c) { return ythip_build_bvh(c, &r.staged, 0); });  // deterministic: the same tree on every rank
+  on_all(r, [&](ythip_ctx* c) { return ythip_build_bvh(c, &r.staged, params.highqualitybvh ? 1 : 0); });  // deterministic: the same tree on every rank
   int32_t ntrees = 0;
   int64_t nnodes = 0, nprims = 0;
   check(r.ctx(), ythip_bvh_sizes(r.ctx(), &ntrees, &nnodes, &nprims));

@@ -60,7 +60,7 @@ std::string ingest_selfcheck(const scene_data& scene, double* ms_staged = nullpt
 
 // yocto_trace.h:160-168.  State and lights: libythip's host builders (the image-size
 // rule + the serial master rng stream; the light CDFs).  make_trace_bvh: built by libythip (device for shapes >= 16384
-// primitives, host otherwise; params.highqualitybvh → the reference's SAH build),
+// primitives, host otherwise; split_middle or, with params.highqualitybvh, the reference's binned-SAH split_sah),
 // left resident, and returned in the reference's layout.
 trace_state  make_trace_state(const scene_data& scene, const trace_params& params);
 trace_lights make_trace_lights(const scene_data& scene, const trace_params& params);
