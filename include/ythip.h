@@ -269,10 +269,11 @@ int ythip_update_environments(ythip_ctx* ctx, const ythip_environment* environme
 int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* scene, int highquality);
 /* Where make_bvh runs.  mode 1 (default): shapes with >= min_prims primitives
  * (default 16384; <= 0 keeps the current value) are built ON THE DEVICE by a
- * level-synchronous restatement of make_bvh + split_middle that reproduces the
- * reference's node order, `primitives` permutation and boxes bit for bit
- * (yocto_bvh.cpp:202-302); small shapes, the instance
- * tree and highquality (SAH) builds use the host builder.  mode 0: host only.
+ * level-synchronous restatement of make_bvh + split_middle / split_sah
+ * (`highquality`) that reproduces the reference's node order, `primitives`
+ * permutation and boxes bit for bit (yocto_bvh.cpp:108-164, 202-302; SURVEY.md
+ * §8(f) rank 1); small shapes and the instance tree use the host builder (same
+ * trees).  mode 0: host only.
  * Either way ythip_bvh_download returns the reference's tree. */
 int ythip_set_bvh_builder(ythip_ctx* ctx, int mode, int64_t min_prims);
 /* What the last ythip_build_bvh did (zeroed by ythip_upload_bvh). */

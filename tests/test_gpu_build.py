@@ -219,3 +219,24 @@ def test_baseline_cfg2_sah_tree_on_device():
     assert dev[2]["device_trees"] == 1 and dev[2]["device_prims"] == 1_000_000 and dev[2]["fallbacks"] == 0
     assert_same(dev, host, "cfg2 sah")
     assert dev[2]["build_ms"] < host[2]["build_ms"]
+
+
+@pytest.mark.skipif(not P.have_ref(), reason="oracle/_ref did not travel")
+@pytest.mark.parametrize("name", ["cornellbox", "materials", "lines_points", "cornell1m"])
+def test_render_on_the_device_built_sah_tree_equals_the_reference_with_highqualitybvh(name):
+    """trace_params::highqualitybvh end to end: tree built on the device, `path` render =
+    the reference's render on ITS split_sah tree, whole trace_state byte for byte (the two
+    trees order equidistant hits differently from the split_middle ones, so this is a
+    parity case of its own)."""
+    flat = P.scene_cornell_1m() if name == "cornell1m" else P.SCENES[name]()
+    p = yt.trace_params(sampler="path", resolution=192, samples=4, batch=2)
+    ctx = yt.Context(0)
+    ctx.upload_scene(flat)
+    ctx.set_bvh_builder("device", 5)
+    ctx.make_trace_bvh(flat, True)
+    ctx.make_trace_lights(flat)
+    assert ctx.bvh_build_info()["device_trees"] >= 1
+    gpu = P.gpu_render(ctx, flat, p)
+    ctx.close()
+    ref = P.RefBundle(flat, highquality=True).render(p)
+    P.assert_identical(gpu, ref, name + " highqualitybvh")
