@@ -180,8 +180,9 @@ YT_FN void count_lanes(unsigned long long* c, int idx) {
 
 // Out-of-line traversal for LP_INLINE shading (several call sites, one copy).
 __device__ __noinline__ Hit trace_ray(const DScene& sc, vec3f o, vec3f d, int only_instance, Stack& st,
-    Counters& cnt) {
+    Counters& cnt, bool wide) {
   ray3f ray = make_ray(o, d);
+  if (wide) return traverse_any<false, true>(sc, ray, only_instance, false, st, cnt);  // same hit record (tested)
   return traverse<true>(sc, ray, only_instance, false, st, cnt);
 }
 // ---------------------------------------------------------------------------
@@ -243,7 +244,8 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
 // inline with their stack in scratch only (k_pool: the LDS stack columns belong to
 // suspended scene walks).
 template <int WALK>
-YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt) {
+YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt,
+    bool wide = false) {
   auto pdf = 0.0f;
   for (int l = 0; l < sc.num_lights; l++) {
     const auto& light = sc.lights[l];
@@ -258,7 +260,7 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
         for (auto bounce = 0; bounce < 100; bounce++) {
           Hit isec;
           if constexpr (WALK == 1) {
-            isec = trace_ray(sc, next_position, direction, light.instance, *st, *cnt);
+            isec = trace_ray(sc, next_position, direction, light.instance, *st, *cnt, wide);
           } else if constexpr (WALK == 3) {
             ray3f ray = make_ray(next_position, direction);
             isec      = traverse<true, false, false, 0>(sc, ray, light.instance, false, *st, *cnt);
@@ -325,6 +327,7 @@ struct ShadeEnv {
   Stack*         stack;  // LP_INLINE only
   Counters*      cnt;    // LP_INLINE only
   int            slot;
+  bool           wide = false;  // LP_INLINE: the out-of-line walks may use the wide records
 #ifdef YT_TIMING
   long long t_geo = 0;  // cycle counter after the shading point has been evaluated
 #endif
@@ -466,10 +469,10 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
         auto rel      = rand1f(P.rng);
         auto rl       = rand1f(P.rng);
         auto incoming = sample_lights(sc, position, rl, rel, ruv);
-        auto pdf      = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt);
+        auto pdf      = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt, E.wide);
         auto bsdfcos  = eval_bsdfcos(material, normal, outgoing, incoming);
         if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
-          auto nisec    = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt);
+          auto nisec    = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt, E.wide);
           auto emission = nee_emission(sc, nisec, incoming);
           P.radiance += P.weight * bsdfcos * emission / pdf;
         }
@@ -499,7 +502,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           }
           if (incoming == vec3f{0, 0, 0}) break;
           auto bsdfcos    = eval_bsdfcos(material, normal, outgoing, incoming);
-          auto light_pdf  = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt);
+          auto light_pdf  = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt, E.wide);
           auto bsdf_pdf   = sample_bsdfcos_pdf(material, normal, outgoing, incoming);
           auto heur       = [](float this_pdf, float other_pdf) {
             return (this_pdf * this_pdf) / (this_pdf * this_pdf + other_pdf * other_pdf);
@@ -507,7 +510,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           auto mis_weight = sample_light ? heur(light_pdf, bsdf_pdf) / light_pdf
                                          : heur(bsdf_pdf, light_pdf) / bsdf_pdf;
           if (bsdfcos != vec3f{0, 0, 0} && mis_weight != 0) {
-            auto nisec = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt);
+            auto nisec = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt, E.wide);
             if (!sample_light) {
               // next_intersection = intersection (persists across bounces)
               E.st.nhit_a[E.slot] = {nisec.u, nisec.v, nisec.distance, __int_as_float(nisec.hit ? nisec.instance : -1)};
@@ -1002,7 +1005,15 @@ YT_FN int max_bounces_of(const KParams& kp) {
 #define YT_WAVES_PER_EU 4
 #endif
 template <int SAMPLER, int LP, bool COUNT, bool WIDE, int CLS = 0>
-__global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, DState st, KParams kp) {
+// The NEE samplers (pathdirect, pathmis: LP_INLINE) evaluate lobes, light pdfs (walks) and a
+// second emission inside one shade step; at 128 VGPRs they spill 1300-1600 registers.  Two
+// waves per SIMD (256 VGPRs, 250-290 spilled) is 14 % (pathdirect) to 28-40 % (pathmis)
+// faster; three (168) was miscompiled by ROCm 7.2 (a wrong constant in image.z), DESIGN.md §6.
+#ifndef YT_WAVES_PER_EU_NEE
+#define YT_WAVES_PER_EU_NEE 2
+#endif
+__global__ void __launch_bounds__(YT_BLOCK, (LP == LP_INLINE ? YT_WAVES_PER_EU_NEE : YT_WAVES_PER_EU))
+    k_trace(DScene sc, DState st, KParams kp) {
   constexpr bool MATTE = CLS == 1;
   // majority-phase scene walk (yt_bvh.h::traverse_phased) for the kernels where it wins:
   // simple scenes with area lights (closed rooms: every ray hits, bounce rays as long as
@@ -1161,7 +1172,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU) k_trace(DScene sc, 
       P.flags &= ~PF_SKIPEXTEND;
       int step;
       if constexpr (LP == LP_INLINE) {
-        ShadeEnv E = {sc, st, kp, &stack, &cnt, slot};
+        ShadeEnv E = {sc, st, kp, &stack, &cnt, slot, WIDE && !COUNT};
         step       = step_path<SAMPLER, LP>(E, P);
       } else {
         ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};

@@ -663,7 +663,7 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
       else
         launch_trace<YTHIP_SAMPLER_PATHTEST, LP_NONE>(ctx, kp, count);
       break;
-#ifndef YT_DEV_ONLY_PATH  // development builds: compile the path / pathtest / naive kernels only (10x faster)
+#if !defined(YT_DEV_ONLY_PATH) || defined(YT_DEV_NEE)  // development builds: compile the path / pathtest / naive kernels only (10x faster; -DYT_DEV_NEE adds these two)
     case YTHIP_SAMPLER_PATHDIRECT: launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_INLINE>(ctx, kp, count); break;
     case YTHIP_SAMPLER_PATHMIS: launch_trace<YTHIP_SAMPLER_PATHMIS, LP_INLINE>(ctx, kp, count); break;
 #endif
