@@ -47,6 +47,22 @@ def test_device_filter_equals_its_numpy_restatement(h, w, kw):
     assert _close(got[..., :3], want[..., :3]), float(np.max(np.abs(got - want)))
 
 
+@pytest.mark.parametrize("h,w,levels", [(37, 53, 5), (64, 129, 5), (200, 333, 6), (9, 70, 4), (1080 // 4, 1920 // 4, 5)])
+def test_lds_tiled_levels_equal_the_untiled_kernel(h, w, levels, monkeypatch):
+    """k_atrous_lds (residue-class tiles staged through LDS, spacings <= 16) runs the same taps
+    in the same order as k_atrous: byte-identical output, ragged sizes, a level beyond 16."""
+    render, albedo, normal = _random_inputs(h, w, 3 * h + w)
+    out = []
+    for simple in ["0", "1"]:
+        monkeypatch.setenv("YTHIP_DENOISE_SIMPLE", simple)
+        ctx = yt.Context(0)
+        try:
+            out.append(ctx.denoise_image(render, albedo, normal, levels=levels))
+        finally:
+            ctx.close()
+    assert out[0].tobytes() == out[1].tobytes()
+
+
 def test_properties():
     ctx = yt.Context(0)
     try:

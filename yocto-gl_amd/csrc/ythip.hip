@@ -83,6 +83,7 @@ struct ythip_ctx {
   float4 *                    dn_a = nullptr, *dn_b = nullptr, *dn_gn = nullptr, *dn_ga = nullptr, *dn_out = nullptr;
   size_t                      dn_pixels    = 0;
   bool                        have_denoised = false;  // dn_out holds the filtered image of the resident state
+  bool                        denoise_simple = false; // YTHIP_DENOISE_SIMPLE=1: the untiled kernel for every level (cross-check)
   std::vector<void*>          staging_allocs;
   ythip_scene                 staged      = {};
   bool                        have_staged = false;
@@ -915,6 +916,7 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_PEEK")) ctx->peek_policy = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL")) ctx->pool_mode = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LDS_TOP")) ctx->lds_top = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_DENOISE_SIMPLE")) ctx->denoise_simple = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_POOL_WAVES")) ctx->pool_waves = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL_TARGET")) ctx->pool_target = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL_REFILL")) ctx->pool_refill = std::atoi(e);
@@ -1689,8 +1691,17 @@ int denoise_run(ythip_ctx* ctx, const ythip_denoise_params* up, int width, int h
   float4 *src = ctx->dn_a, *dst = ctx->dn_b;
   float   scale = 1;  // 4^l: the colour tolerance halves per level (Dammertz et al. 2010, §3)
   for (int l = 0; l < dp.levels; l++) {
-    hipLaunchKernelGGL(ytdn::k_atrous, grid, dim3(threads), 0, ctx->stream, src, ctx->dn_gn, ctx->dn_ga, dst, p, 1 << l,
-        p.inv_sc2 * scale);
+    const int step = 1 << l;
+    if (step <= 16 && !ctx->denoise_simple) {
+      // one workgroup per tile of one residue class's sub-image (class 0 has the most tiles)
+      const int sw = (width + step - 1) / step, sh = (height + step - 1) / step;
+      const dim3 g((unsigned)((sw + ytdn::TX - 1) / ytdn::TX), (unsigned)((sh + ytdn::TY - 1) / ytdn::TY),
+          (unsigned)(step * step));
+      hipLaunchKernelGGL(ytdn::k_atrous_lds, g, dim3(ytdn::TX * ytdn::TY), 0, ctx->stream, src, ctx->dn_gn, ctx->dn_ga, dst,
+          p, step, p.inv_sc2 * scale);
+    } else
+      hipLaunchKernelGGL(ytdn::k_atrous, grid, dim3(threads), 0, ctx->stream, src, ctx->dn_gn, ctx->dn_ga, dst, p, step,
+          p.inv_sc2 * scale);
     std::swap(src, dst);
     scale *= 4;
   }
