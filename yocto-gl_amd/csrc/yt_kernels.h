@@ -1012,7 +1012,11 @@ template <int SAMPLER, int LP, bool COUNT, bool WIDE, int CLS = 0>
 #ifndef YT_WAVES_PER_EU_NEE
 #define YT_WAVES_PER_EU_NEE 2
 #endif
-__global__ void __launch_bounds__(YT_BLOCK, (LP == LP_INLINE ? YT_WAVES_PER_EU_NEE : YT_WAVES_PER_EU))
+#ifndef YT_WAVES_PER_EU_GENERAL  // experiment: occupancy of the general-class kernels
+#define YT_WAVES_PER_EU_GENERAL YT_WAVES_PER_EU
+#endif
+__global__ void __launch_bounds__(YT_BLOCK,
+    (LP == LP_INLINE ? YT_WAVES_PER_EU_NEE : (CLS == 0 && !COUNT ? YT_WAVES_PER_EU_GENERAL : YT_WAVES_PER_EU)))
     k_trace(DScene sc, DState st, KParams kp) {
   constexpr bool MATTE = CLS == 1;
   // majority-phase scene walk (yt_bvh.h::traverse_phased) for the kernels where it wins:

@@ -353,8 +353,11 @@ int ythip_multi_get_image(ythip_multi* m, float* image) {
       if (rc) return mfail(m, YTHIP_ERR_HIP, "ncclCommInitAll: %s", m->rccl.GetErrorString(rc));
       m->rccl.CommCount(m->comms[0], &m->comm_ranks);
     }
+    // rank 0's own slice never leaves its device
+    MHIP(m, hipMemcpyAsync(m->d_gathered + m->offset[0], src[0], (size_t)m->lwidth[0] * m->height * sizeof(float4),
+                hipMemcpyDeviceToDevice, m->streams[0]));
     ncclResult_t rc = m->rccl.GroupStart();
-    for (int r = 0; r < n && !rc; r++) {
+    for (int r = 1; r < n && !rc; r++) {
       if (m->lwidth[r] == 0) continue;
       size_t count = (size_t)m->lwidth[r] * m->height * 4;
       rc           = m->rccl.Send(src[r], count, ncclFloat32, 0, m->comms[r], m->streams[r]);
