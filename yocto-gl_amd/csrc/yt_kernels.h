@@ -87,6 +87,12 @@ struct DState {
   // cancellation: a device-visible flag the host raises when the caller's `stop` goes up
   // (yocto_trace.cpp:1636-1637 polls context.stop per sample); may be null
   const int* stop;
+  // XCD-banded tile queues (experiment): tiles grouped into 8 compact bands, one
+  // per XCD (= per L2); a workgroup takes the next tile of its own XCD's band and steals from
+  // the others when that is empty.  null: identity mapping.
+  const int* tile_order;   // nblocks tile ids, band after band
+  int*       band_next;    // 8 counters, zeroed before the launch
+  int        band_start[9];
 };
 YT_FN bool stop_requested(const int* stop) {
   return stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -132,6 +138,19 @@ YT_FN int logical_block(const DState& st) {
   if (st.only_pix >= 0) {  // trace_sample(): a one-workgroup launch on the pixel's tile
     int jl = st.only_pix / st.lwidth, il = st.only_pix - jl * st.lwidth;
     return b == 0 ? (jl / YT_TILE_H) * st.tiles_x + il / YT_TILE : -1;
+  }
+  if (st.tile_order) {  // (one wavefront per workgroup: lane 0 claims, everybody reads)
+    int tile = -1;
+    if (threadIdx.x == 0) {
+      const int xcd = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);  // HW_REG_XCC_ID[3:0]
+      for (int k = 0; k < 8 && tile < 0; k++) {
+        const int band = (xcd + k) & 7, size = st.band_start[band + 1] - st.band_start[band];
+        if (size <= 0) continue;
+        const int t = atomicAdd(&st.band_next[band], 1);
+        if (t < size) tile = st.tile_order[st.band_start[band] + t];
+      }
+    }
+    return __builtin_amdgcn_readfirstlane(tile);
   }
   return b;
 }

@@ -83,6 +83,9 @@ struct ythip_ctx {
   float4 *                    dn_a = nullptr, *dn_b = nullptr, *dn_gn = nullptr, *dn_ga = nullptr, *dn_out = nullptr;
   size_t                      dn_pixels    = 0;
   bool                        have_denoised = false;  // dn_out holds the filtered image of the resident state
+  int                         xcd_map = 0;  // YTHIP_XCD: 0 identity, 1 4x2 blocks, 2 8 row bands, 3 8 column bands, 4 2x4 blocks
+  int*                        d_tile_order = nullptr;
+  int*                        d_band_next  = nullptr;
   bool                        denoise_simple = false; // YTHIP_DENOISE_SIMPLE=1: the untiled kernel for every level (cross-check)
   std::vector<void*>          staging_allocs;
   ythip_scene                 staged      = {};
@@ -853,6 +856,11 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
 
   // one launch renders the whole batch: every workgroup loops over its tile
   // until its pixels have taken `batch` samples (k_trace)
+  ctx->st.tile_order = nullptr, ctx->st.band_next = nullptr;
+  if (ctx->d_tile_order && only_pix < 0) {
+    HIPCHECK(ctx, hipMemsetAsync(ctx->d_band_next, 0, 8 * sizeof(int), ctx->stream));
+    ctx->st.tile_order = ctx->d_tile_order, ctx->st.band_next = ctx->d_band_next;
+  }
   {
     EvScope ev(ctx, 0);
     int     rc = pool_applies(ctx, params, count, only_pix) ? launch_pool_any(ctx, kp, lp)
@@ -916,6 +924,7 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_PEEK")) ctx->peek_policy = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL")) ctx->pool_mode = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LDS_TOP")) ctx->lds_top = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_XCD")) ctx->xcd_map = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_DENOISE_SIMPLE")) ctx->denoise_simple = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_POOL_WAVES")) ctx->pool_waves = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL_TARGET")) ctx->pool_target = std::atoi(e);
@@ -1553,6 +1562,25 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
   ctx->nhit_e     = nullptr;
   ctx->samples    = 0;
   ctx->have_state = true;
+  ctx->d_tile_order = nullptr, ctx->d_band_next = nullptr;
+  if (ctx->xcd_map > 0) {  // XCD-banded tile queues (experiment): tiles grouped by band, band after band
+    const int gx = ctx->xcd_map == 1 ? 4 : ctx->xcd_map == 2 ? 1 : ctx->xcd_map == 3 ? 8 : 2, gy = 8 / gx;
+    std::vector<std::vector<int>> bands(8);
+    for (int ty = 0; ty < st.tiles_y; ty++)
+      for (int tx = 0; tx < st.tiles_x; tx++) {
+        int bx = std::min(gx - 1, tx * gx / std::max(st.tiles_x, 1)), by = std::min(gy - 1, ty * gy / std::max(st.tiles_y, 1));
+        bands[by * gx + bx].push_back(ty * st.tiles_x + tx);
+      }
+    std::vector<int> order;
+    for (int b = 0; b < 8; b++) {
+      st.band_start[b] = (int)order.size();
+      order.insert(order.end(), bands[b].begin(), bands[b].end());
+    }
+    st.band_start[8] = (int)order.size();
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_order, order.size()))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_band_next, 8))) return rc;
+    HIPCHECK(ctx, hipMemcpy(ctx->d_tile_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   return YTHIP_OK;
 }
 
