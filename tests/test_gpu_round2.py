@@ -276,3 +276,22 @@ def test_multi_device_api_errors():
     assert lib.ythip_multi_state_create(m, 16, 16) == 0  # one tile column for two ranks: rank 1 sits out
     assert lib.ythip_multi_get_image(m, None) != 0
     lib.ythip_destroy_multi(m)
+
+
+# ---- NEE samplers: deferred walks (default) vs the inline kernels -------------------------------
+@pytest.mark.parametrize("sampler", ["pathdirect", "pathmis"])
+@pytest.mark.parametrize("scene", ["cornellbox", "materials", "lines_points"])
+def test_deferred_nee_equals_inline_nee(sampler, scene, monkeypatch):
+    """pathdirect / pathmis run their light-pdf walks, NEE rays and NEE emission in the walk
+    stage of k_trace (LP_DEFER) by default; YTHIP_NEE_INLINE=1 selects the kernels that do
+    them inside the shade step.  Same draws in the same order, same sums: identical state
+    (and both equal the reference: tests/test_gpu_parity.py runs the default)."""
+    flat = P.SCENES[scene]()
+    p = yt.trace_params(sampler=sampler, resolution=160, samples=6, batch=3)
+    out = []
+    for inline in ["0", "1"]:
+        monkeypatch.setenv("YTHIP_NEE_INLINE", inline)
+        ctx = P.gpu_context(flat)
+        out.append(P.gpu_render(ctx, flat, p))
+        ctx.close()
+    P.assert_identical(out[0], out[1], f"{sampler} {scene}")

@@ -82,6 +82,12 @@ struct DState {
   float4* nhit_a;   // pathmis next_intersection: u, v, distance, instance
   int*    nhit_e;   // pathmis next_intersection: element
   float4* pend;     // deferred light pdf: bsdfcos.xyz (or scattering), bsdf pdf
+  // deferred NEE (pathdirect, pathmis with LP_DEFER), per slot:
+  //   pathdirect: nee_a = light direction xyz, state (0 none, 1 pending, 2 pending + path ends); nee_b = its bsdfcos
+  //   pathmis:    nee_a / nee_b = light-sampled direction + bsdf pdf / its bsdfcos + flags (1 pass 0 ran, 2 pass 1 ran,
+  //               4 volume event: `pend` holds the mixture terms instead); nee_c / nee_d = the same for the
+  //               bsdf-sampled direction; nee_e = the weight factor of the continuation
+  float4 *nee_a, *nee_b, *nee_c, *nee_d, *nee_e;
   // work counters (ythip_stats), may be null
   unsigned long long* counters;
   // cancellation: a device-visible flag the host raises when the caller's `stop` goes up
@@ -416,7 +422,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
   constexpr bool MIS     = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   constexpr bool TEST    = SAMPLER == YTHIP_SAMPLER_PATHTEST;
   constexpr bool VOLUMES = !TEST && !MATTE;
-  static_assert(!(DIRECT || MIS) || LP == LP_INLINE, "NEE samplers trace inline");
+  static_assert(!(DIRECT || MIS) || LP != LP_NONE, "NEE samplers: NEE inline (LP_INLINE) or deferred (LP_DEFER)");
   const bool next_emission = !(P.flags & PF_NOEMIT);
 
   auto& isec = P.isec;
@@ -482,18 +488,28 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     if ((!DIRECT && !MIS) || next_emission) P.radiance += P.weight * eval_emission(material, normal, outgoing);
 
     // direct (pathdirect) — yocto_trace.cpp:670-693
+    int nee_pending = 0;  // pathdirect with deferred NEE (LP_DEFER): the NEE ray waits for the walk stage
     if constexpr (DIRECT) {
       if (!is_delta(material)) {
         auto ruv      = rand2f(P.rng);  // g++ order: ruv, rel, rl
         auto rel      = rand1f(P.rng);
         auto rl       = rand1f(P.rng);
         auto incoming = sample_lights(sc, position, rl, rel, ruv);
-        auto pdf      = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt, E.wide);
-        auto bsdfcos  = eval_bsdfcos(material, normal, outgoing, incoming);
-        if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
-          auto nisec    = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt, E.wide);
-          auto emission = nee_emission(sc, nisec, incoming);
-          P.radiance += P.weight * bsdfcos * emission / pdf;
+        if constexpr (LP == LP_DEFER) {
+          // the light pdf (walks), the NEE ray and its emission have no rng draws and touch
+          // nothing but P.radiance: they run in the walk stage, before the weight update
+          auto bsdfcos       = eval_bsdfcos(material, normal, outgoing, incoming);
+          E.st.nee_a[E.slot] = {incoming.x, incoming.y, incoming.z, __int_as_float(1)};
+          E.st.nee_b[E.slot] = {bsdfcos.x, bsdfcos.y, bsdfcos.z, 0};
+          nee_pending        = 1;
+        } else {
+          auto pdf     = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt, E.wide);
+          auto bsdfcos = eval_bsdfcos(material, normal, outgoing, incoming);
+          if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
+            auto nisec    = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt, E.wide);
+            auto emission = nee_emission(sc, nisec, incoming);
+            P.radiance += P.weight * bsdfcos * emission / pdf;
+          }
         }
         P.flags |= PF_NOEMIT;
       } else {
@@ -505,7 +521,41 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     auto incoming = vec3f{0, 0, 0};
     bool deferred = false;
     if (!is_delta(material)) {
-      if constexpr (MIS) {
+      if constexpr (MIS && LP == LP_DEFER) {
+        // direct with MIS — yocto_trace.cpp:853-892 — with the walks deferred: both directions are
+        // drawn and their lobe terms evaluated here (all the rng draws, in order); the light pdfs,
+        // the two NEE rays, next_intersection and the emission run in the walk stage
+        float4 ma = {0, 0, 0, 0}, mb = {0, 0, 0, 0}, mc = {0, 0, 0, 0}, md = {0, 0, 0, 0};
+        int    mflags = 0;
+        for (int pass = 0; pass < 2; pass++) {
+          if (pass == 0) {
+            auto ruv = rand2f(P.rng);
+            auto rel = rand1f(P.rng);
+            auto rl  = rand1f(P.rng);
+            incoming = sample_lights(sc, position, rl, rel, ruv);
+          } else {
+            auto rn  = rand2f(P.rng);  // g++ order: rn, rnl
+            auto rnl = rand1f(P.rng);
+            incoming = sample_bsdfcos(material, normal, outgoing, rnl, rn);
+          }
+          if (incoming == vec3f{0, 0, 0}) break;
+          auto bsdfcos  = eval_bsdfcos(material, normal, outgoing, incoming);
+          auto bsdf_pdf = sample_bsdfcos_pdf(material, normal, outgoing, incoming);
+          if (pass == 0)
+            ma = {incoming.x, incoming.y, incoming.z, bsdf_pdf}, mb = {bsdfcos.x, bsdfcos.y, bsdfcos.z, 0};
+          else
+            mc = {incoming.x, incoming.y, incoming.z, bsdf_pdf}, md = {bsdfcos.x, bsdfcos.y, bsdfcos.z, 0};
+          mflags |= 1 << pass;
+        }
+        // indirect: the factor of the weight update, applied after the NEE contributions
+        auto wfac = eval_bsdfcos(material, normal, outgoing, incoming) /
+                    sample_bsdfcos_pdf(material, normal, outgoing, incoming);
+        mb.w               = __int_as_float(mflags);
+        E.st.nee_a[E.slot] = ma, E.st.nee_b[E.slot] = mb, E.st.nee_c[E.slot] = mc, E.st.nee_d[E.slot] = md;
+        E.st.nee_e[E.slot] = {wfac.x, wfac.y, wfac.z, 0};
+        deferred           = true;
+        P.flags |= PF_NOEMIT;
+      } else if constexpr (MIS) {
         // direct with MIS — yocto_trace.cpp:853-892
         for (int pass = 0; pass < 2; pass++) {
           const bool sample_light = pass == 0;
@@ -554,7 +604,14 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           auto rl  = rand1f(P.rng);
           incoming = sample_lights(sc, position, rl, rel, ruv);
         }
-        if (incoming == vec3f{0, 0, 0}) return STEP_END;
+        if (incoming == vec3f{0, 0, 0}) {
+          if (DIRECT && LP == LP_DEFER && nee_pending) {  // the path ends, its NEE contribution is still owed
+            E.st.nee_a[E.slot].w = __int_as_float(2);
+            P.o                  = position;
+            return STEP_DEFER;
+          }
+          return STEP_END;
+        }
         auto f     = eval_bsdfcos(material, normal, outgoing, incoming);
         auto pdf_a = sample_bsdfcos_pdf(material, normal, outgoing, incoming);
         if constexpr (LP == LP_DEFER) {
@@ -612,6 +669,8 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     P.d        = incoming;
     if constexpr (LP == LP_DEFER) {
       E.st.pend[E.slot] = {f.x, f.y, f.z, pdf_a};
+      if constexpr (DIRECT) E.st.nee_a[E.slot].w = __int_as_float(0);  // no NEE at a scattering event
+      if constexpr (MIS) E.st.nee_b[E.slot].w = __int_as_float(4);     // the mixture terms of `pend` apply
       return STEP_DEFER;
     } else {
       P.weight *= f / (0.5f * pdf_a + 0.5f * sample_lights_pdf<LP == LP_INLINE ? 1 : 0>(
@@ -1199,7 +1258,8 @@ __global__ void __launch_bounds__(YT_BLOCK,
         step       = step_path<SAMPLER, LP>(E, P);
       } else {
         ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
-        if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST) {
+        if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST ||
+                      SAMPLER == YTHIP_SAMPLER_PATHDIRECT || SAMPLER == YTHIP_SAMPLER_PATHMIS) {
           step = step_path<SAMPLER, LP, CLS>(E, P);
 #ifdef YT_TIMING
           tmG = E.t_geo;
@@ -1281,11 +1341,66 @@ __global__ void __launch_bounds__(YT_BLOCK,
           slot = Q.lqueue[tid];
           Path P;
           load_path(st, W, slot, P);
-          float4 pd = st.pend[slot];
-          // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
-          auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
-          P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
-          int step = step_tail(P);
+          int nee = 0;
+          if constexpr (SAMPLER == YTHIP_SAMPLER_PATHDIRECT) {
+            // the NEE half of the loop body (yocto_trace.cpp:670-693) for the light direction
+            // the shade stage drew: pdf walks, the NEE ray, the emission it finds
+            float4 na = st.nee_a[slot];
+            nee       = __float_as_int(na.w);
+            if (nee) {
+              float4 nb      = st.nee_b[slot];
+              vec3f  inc     = {na.x, na.y, na.z}, bsdfcos = {nb.x, nb.y, nb.z};
+              auto   pdf     = sample_lights_pdf<2>(sc, P.o, inc, &stack, &cnt);
+              if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
+                ray3f nray     = make_ray(P.o, inc);
+                Hit   nisec    = traverse_any<COUNT, WIDE>(sc, nray, -1, false, stack, cnt);
+                auto  emission = nee_emission(sc, nisec, inc);
+                P.radiance += P.weight * bsdfcos * emission / pdf;
+              }
+            }
+          }
+          int step = STEP_END;
+          if constexpr (SAMPLER == YTHIP_SAMPLER_PATHMIS) {
+            // the walk half of the MIS loop body (yocto_trace.cpp:853-892)
+            const float4 mb     = st.nee_b[slot];
+            const int    mflags = __float_as_int(mb.w);
+            if (!(mflags & 4)) {
+              nee = 2;  // (the mixture update below does not apply)
+              for (int pass = 0; pass < 2; pass++) {
+                if (!(mflags & (1 << pass))) break;
+                const float4 a = pass == 0 ? st.nee_a[slot] : st.nee_c[slot];
+                const float4 b = pass == 0 ? mb : st.nee_d[slot];
+                const vec3f  inc = {a.x, a.y, a.z}, bsdfcos = {b.x, b.y, b.z};
+                const float  bsdf_pdf  = a.w;
+                const float  light_pdf = sample_lights_pdf<2>(sc, P.o, inc, &stack, &cnt);
+                auto         heur      = [](float this_pdf, float other_pdf) {
+                  return (this_pdf * this_pdf) / (this_pdf * this_pdf + other_pdf * other_pdf);
+                };
+                const float mis_weight = pass == 0 ? heur(light_pdf, bsdf_pdf) / light_pdf
+                                                   : heur(bsdf_pdf, light_pdf) / bsdf_pdf;
+                if (bsdfcos != vec3f{0, 0, 0} && mis_weight != 0) {
+                  ray3f nray  = make_ray(P.o, inc);
+                  Hit   nisec = traverse_any<COUNT, WIDE>(sc, nray, -1, false, stack, cnt);
+                  if (pass == 1) {  // next_intersection = intersection (persists across bounces)
+                    st.nhit_a[slot] = {nisec.u, nisec.v, nisec.distance, __int_as_float(nisec.hit ? nisec.instance : -1)};
+                    st.nhit_e[slot] = nisec.element;
+                  }
+                  auto emission = nee_emission(sc, nisec, inc);
+                  P.radiance += P.weight * bsdfcos * emission * mis_weight;
+                }
+              }
+              const float4 wf = st.nee_e[slot];
+              P.weight *= vec3f{wf.x, wf.y, wf.z};
+              step = step_tail(P);
+            }
+          }
+          if (nee != 2) {
+            float4 pd = st.pend[slot];
+            // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
+            auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
+            P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
+            step = step_tail(P);
+          }
           cls      = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
           store_path(W, slot, P);
         }

@@ -128,6 +128,8 @@ struct ythip_ctx {
   std::vector<std::pair<int, int>>             ev_used;  // (pool index, kind 0 extend / 1 shade)
   size_t                                       ev_next = 0;
   ythip_stats                                  stats   = {};
+  float4 *nee_a = nullptr, *nee_b = nullptr, *nee_c = nullptr, *nee_d = nullptr, *nee_e = nullptr;  // deferred NEE (per slot)
+  bool                                         nee_inline = false;  // YTHIP_NEE_INLINE=1: pathdirect with inline NEE walks (the round-1 kernel)
   float4*                                      nhit_a   = nullptr;
   int*                                         nhit_e   = nullptr;
 
@@ -668,8 +670,18 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
         launch_trace<YTHIP_SAMPLER_PATHTEST, LP_NONE>(ctx, kp, count);
       break;
 #if !defined(YT_DEV_ONLY_PATH) || defined(YT_DEV_NEE)  // development builds: compile the path / pathtest / naive kernels only (10x faster; -DYT_DEV_NEE adds these two)
-    case YTHIP_SAMPLER_PATHDIRECT: launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_INLINE>(ctx, kp, count); break;
-    case YTHIP_SAMPLER_PATHMIS: launch_trace<YTHIP_SAMPLER_PATHMIS, LP_INLINE>(ctx, kp, count); break;
+    case YTHIP_SAMPLER_PATHDIRECT:
+      if (ctx->nee_inline)
+        launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_INLINE>(ctx, kp, count);
+      else
+        launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER>(ctx, kp, count);
+      break;
+    case YTHIP_SAMPLER_PATHMIS:
+      if (ctx->nee_inline)
+        launch_trace<YTHIP_SAMPLER_PATHMIS, LP_INLINE>(ctx, kp, count);
+      else
+        launch_trace<YTHIP_SAMPLER_PATHMIS, LP_DEFER>(ctx, kp, count);
+      break;
 #endif
     case YTHIP_SAMPLER_NAIVE: launch_trace<YTHIP_SAMPLER_NAIVE, LP_NONE>(ctx, kp, count); break;
 #ifndef YT_DEV_ONLY_PATH
@@ -827,6 +839,19 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
     if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nhit_a, (size_t)npix))) return rc;
     if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nhit_e, (size_t)npix))) return rc;
   }
+  if ((params->sampler == YTHIP_SAMPLER_PATHDIRECT || mis) && !ctx->nee_a) {
+    int rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nee_a, (size_t)npix))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nee_b, (size_t)npix))) return rc;
+  }
+  if (mis && !ctx->nee_c) {
+    int rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nee_c, (size_t)npix))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nee_d, (size_t)npix))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->nee_e, (size_t)npix))) return rc;
+  }
+  ctx->st.nee_a = ctx->nee_a, ctx->st.nee_b = ctx->nee_b, ctx->st.nee_c = ctx->nee_c, ctx->st.nee_d = ctx->nee_d;
+  ctx->st.nee_e = ctx->nee_e;
   ctx->st.nhit_a      = mis ? ctx->nhit_a : nullptr;
   ctx->st.nhit_e      = mis ? ctx->nhit_e : nullptr;
   ctx->st.stop        = ctx->d_stop;
@@ -925,6 +950,7 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_POOL")) ctx->pool_mode = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LDS_TOP")) ctx->lds_top = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_XCD")) ctx->xcd_map = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_NEE_INLINE")) ctx->nee_inline = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_DENOISE_SIMPLE")) ctx->denoise_simple = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_POOL_WAVES")) ctx->pool_waves = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_POOL_TARGET")) ctx->pool_target = std::atoi(e);
@@ -1560,6 +1586,7 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->nhit_a     = nullptr;
   ctx->nhit_e     = nullptr;
+  ctx->nee_a = ctx->nee_b = ctx->nee_c = ctx->nee_d = ctx->nee_e = nullptr;
   ctx->samples    = 0;
   ctx->have_state = true;
   ctx->d_tile_order = nullptr, ctx->d_band_next = nullptr;
