@@ -1261,6 +1261,21 @@ __global__ void __launch_bounds__(YT_BLOCK,
         if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST ||
                       SAMPLER == YTHIP_SAMPLER_PATHDIRECT || SAMPLER == YTHIP_SAMPLER_PATHMIS) {
           step = step_path<SAMPLER, LP, CLS>(E, P);
+          if constexpr (MIS) {
+            // pathmis re-tests the SAME next_intersection against `opacity` with a fresh random
+            // number until it passes (yocto_trace.cpp:794-796 with :830-836; up to 128 times):
+            // the retry needs no ray, so it loops here instead of costing a wavefront iteration
+            // each.  Exactly what the next iteration would do: P.o moved by the step, the
+            // intersection re-read from next_intersection (the volume branch edits isec.distance).
+#ifndef YT_MIS_RETRY_BY_ITERATION
+            while (step == STEP_RETRY && (P.flags & PF_NOEMIT)) {
+              float4 ha   = st.nhit_a[slot];
+              int    inst = __float_as_int(ha.w);
+              P.isec      = {inst, st.nhit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
+              step        = step_path<SAMPLER, LP, CLS>(E, P);
+            }
+#endif
+          }
 #ifdef YT_TIMING
           tmG = E.t_geo;
 #endif
