@@ -485,7 +485,7 @@ void ensure_scene(residency& r, const scene_data& scene, bool need_view = false)
   if (whole || (need_view && !r.have_staged)) {
     ingest(r, scene);
     r.scene = ss;
-    if (whole) r.bvh = r.lights = 0;
+    r.bvh = r.lights = 0;  // a scene upload drops the device trees and lights
     return;
   }
   if (ss.cameras != r.scene.cameras) {
