@@ -295,3 +295,16 @@ def test_deferred_nee_equals_inline_nee(sampler, scene, monkeypatch):
         out.append(P.gpu_render(ctx, flat, p))
         ctx.close()
     P.assert_identical(out[0], out[1], f"{sampler} {scene}")
+
+
+# ---- random scenes x random parameters vs the live reference -------------------------------------
+@pytest.mark.skipif(not P.have_ref(), reason="oracle/_ref did not travel")
+def test_fuzz_random_scenes_against_the_live_reference():
+    """tools/fuzz_parity.py: 80 random scenes (all primitive kinds, material types, texture
+    slots, environments, non-rigid frames, cameras) x random trace_params (all samplers,
+    bounces 0-8, clamp, nocaustics, envhidden, tentfilter, batches, split_middle / split_sah):
+    whole trace_state byte for byte.  (profiles/r02_fuzz.txt: 4,000 cases, 0 failures.)"""
+    import subprocess, sys
+    tool = os.path.join(P.ROOT, "tools", "fuzz_parity.py")
+    r = subprocess.run([sys.executable, tool, "5000", "80"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "80 cases, 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
