@@ -308,3 +308,31 @@ def test_fuzz_random_scenes_against_the_live_reference():
     tool = os.path.join(P.ROOT, "tools", "fuzz_parity.py")
     r = subprocess.run([sys.executable, tool, "5000", "80"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "80 cases, 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ---- longest-tile-first launch order (yt_order.hip) ------------------------------------------------
+@pytest.mark.parametrize("scene,sampler", [("cornellbox", "path"), ("materials", "path"), ("lines_points", "pathdirect"),
+                                           ("instances", "naive")])
+def test_launch_order_by_measured_tile_cost_changes_nothing(scene, sampler, monkeypatch):
+    """From the second batch on k_trace hands out the tiles most expensive first (the costs
+    every workgroup recorded in the previous launch, sorted on the device).  Only the tile ->
+    workgroup assignment changes: progressive renders with the order on and off, a
+    trace_sample between batches and a column-sliced state all give the same bytes."""
+    flat = P.SCENES[scene]()
+    p = yt.trace_params(sampler=sampler, resolution=200, samples=8, batch=2)
+    out = []
+    for lpt in ["1", "0"]:
+        monkeypatch.setenv("YTHIP_LPT", lpt)
+        ctx = P.gpu_context(flat)
+        ctx.make_trace_state(flat, p)
+        ctx.trace_samples(p)
+        ctx.trace_samples(p)
+        ctx.trace_sample(p, 17, 5, 4)  # (single-pixel launches do not disturb the recorded costs)
+        ctx.trace_samples(p)
+        ctx.trace_samples(p)
+        full = ctx.download_state()
+        sl = P.gpu_render(ctx, flat, p, cols=(1, 3))
+        out.append((full, sl))
+        ctx.close()
+    P.assert_identical(out[0][0], out[1][0], f"{scene} {sampler} full frame")
+    P.assert_identical(out[0][1], out[1][1], f"{scene} {sampler} slice")

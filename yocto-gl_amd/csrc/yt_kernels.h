@@ -96,6 +96,10 @@ struct DState {
   // XCD-banded tile queues (experiment): tiles grouped into 8 compact bands, one
   // per XCD (= per L2); a workgroup takes the next tile of its own XCD's band and steals from
   // the others when that is empty.  null: identity mapping.
+  // longest-tile-first launch order (yt_order.hip): workgroup b renders tile tile_perm[b]; every
+  // workgroup records the cycles its tile took for the next launch's order.  null: off.
+  const int* tile_perm;
+  unsigned*  tile_cost;
   const int* tile_order;   // nblocks tile ids, band after band
   int*       band_next;    // 8 counters, zeroed before the launch
   int        band_start[9];
@@ -145,6 +149,7 @@ YT_FN int logical_block(const DState& st) {
     int jl = st.only_pix / st.lwidth, il = st.only_pix - jl * st.lwidth;
     return b == 0 ? (jl / YT_TILE_H) * st.tiles_x + il / YT_TILE : -1;
   }
+  if (st.tile_perm) return st.tile_perm[b];
   if (st.tile_order) {  // (one wavefront per workgroup: lane 0 claims, everybody reads)
     int tile = -1;
     if (threadIdx.x == 0) {
@@ -1124,6 +1129,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
   const int lb = logical_block(st);
   if (lb < 0) return;
   if (stop_requested(st.stop)) return;  // cancelled before this tile started
+  const long long t_tile0 = st.tile_cost ? (long long)__builtin_readcyclecounter() : 0;
   const int tid = threadIdx.x;
   // LDS staging of the top four levels of the largest tree (dynamic LDS, only when asked for)
   extern __shared__ float4 s_top[];
@@ -1425,6 +1431,10 @@ __global__ void __launch_bounds__(YT_BLOCK,
     }
   }
   if (COUNT || LP != LP_NONE) flush_counters(st.counters, cnt);
+  if (st.tile_cost && threadIdx.x == 0) {
+    const long long dt = ((long long)__builtin_readcyclecounter() - t_tile0) >> 6;  // 64-cycle units fit 32 bits
+    st.tile_cost[lb]   = (unsigned)(dt < 0 ? 0 : (dt > 0xffffffffll ? 0xffffffffll : dt));
+  }
 }
 
 // Test/parity entries ---------------------------------------------------------

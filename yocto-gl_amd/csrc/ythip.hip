@@ -25,6 +25,7 @@
 #include "yt_gpubuild.h"
 #include "yt_kernels.h"
 #include "yt_denoise.h"
+#include "yt_order.h"
 #include "yt_pool.h"
 
 using namespace yt;
@@ -83,6 +84,13 @@ struct ythip_ctx {
   float4 *                    dn_a = nullptr, *dn_b = nullptr, *dn_gn = nullptr, *dn_ga = nullptr, *dn_out = nullptr;
   size_t                      dn_pixels    = 0;
   bool                        have_denoised = false;  // dn_out holds the filtered image of the resident state
+  // longest-tile-first launch order (yt_order.hip): 0 off, 1 on (YTHIP_LPT)
+  int                         lpt = 1;
+  unsigned *                  d_tile_cost = nullptr, *d_tile_keys = nullptr;
+  int *                       d_tile_perm = nullptr, *d_tile_iota = nullptr;
+  void*                       d_sort_temp = nullptr;
+  size_t                      sort_temp_bytes = 0;
+  bool                        have_tile_costs = false;  // d_tile_cost holds the previous whole-slice launch's costs
   int                         xcd_map = 0;  // YTHIP_XCD: 0 identity, 1 4x2 blocks, 2 8 row bands, 3 8 column bands, 4 2x4 blocks
   int*                        d_tile_order = nullptr;
   int*                        d_band_next  = nullptr;
@@ -881,6 +889,16 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
 
   // one launch renders the whole batch: every workgroup loops over its tile
   // until its pixels have taken `batch` samples (k_trace)
+  ctx->st.tile_perm = nullptr, ctx->st.tile_cost = nullptr;
+  const bool lpt = ctx->d_tile_cost && only_pix < 0 && !count && !ctx->d_tile_order;
+  if (lpt) {
+    if (ctx->have_tile_costs) {  // the previous batch's costs order this one (same pixels, same work)
+      HIPCHECK(ctx, ytorder::order_by_cost(ctx->stream, ctx->d_tile_cost, ctx->st.nblocks, ctx->d_tile_keys, ctx->d_tile_iota,
+                        ctx->d_tile_perm, ctx->d_sort_temp, ctx->sort_temp_bytes));
+      ctx->st.tile_perm = ctx->d_tile_perm;
+    }
+    ctx->st.tile_cost = ctx->d_tile_cost;
+  }
   ctx->st.tile_order = nullptr, ctx->st.band_next = nullptr;
   if (ctx->d_tile_order && only_pix < 0) {
     HIPCHECK(ctx, hipMemsetAsync(ctx->d_band_next, 0, 8 * sizeof(int), ctx->stream));
@@ -893,6 +911,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
     if (rc) return rc;
   }
   HIPCHECK(ctx, hipGetLastError());
+  if (lpt) ctx->have_tile_costs = true;
   if (only_pix < 0) ctx->samples += params->batch;  // yocto_trace.cpp:1614
   return YTHIP_OK;
 }
@@ -950,6 +969,7 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_POOL")) ctx->pool_mode = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LDS_TOP")) ctx->lds_top = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_XCD")) ctx->xcd_map = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_LPT")) ctx->lpt = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_NEE_INLINE")) ctx->nee_inline = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_DENOISE_SIMPLE")) ctx->denoise_simple = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_POOL_WAVES")) ctx->pool_waves = std::atoi(e);
@@ -1590,6 +1610,19 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
   ctx->samples    = 0;
   ctx->have_state = true;
   ctx->d_tile_order = nullptr, ctx->d_band_next = nullptr;
+  ctx->d_tile_cost = ctx->d_tile_keys = nullptr, ctx->d_tile_perm = ctx->d_tile_iota = nullptr, ctx->d_sort_temp = nullptr;
+  ctx->have_tile_costs = false;
+  if (ctx->lpt > 0 && st.nblocks > 1) {
+    const size_t nb = (size_t)st.nblocks;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_cost, nb))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_keys, nb))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_perm, nb))) return rc;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_iota, nb))) return rc;
+    ctx->sort_temp_bytes = ytorder::temp_bytes(st.nblocks);
+    unsigned char* tmp   = nullptr;
+    if ((rc = dalloc(ctx, ctx->state_allocs, &tmp, std::max<size_t>(ctx->sort_temp_bytes, 16)))) return rc;
+    ctx->d_sort_temp = tmp;
+  }
   if (ctx->xcd_map > 0) {  // XCD-banded tile queues (experiment): tiles grouped by band, band after band
     const int gx = ctx->xcd_map == 1 ? 4 : ctx->xcd_map == 2 ? 1 : ctx->xcd_map == 3 ? 8 : 2, gy = 8 / gx;
     std::vector<std::vector<int>> bands(8);
