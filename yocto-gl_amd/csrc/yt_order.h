@@ -6,6 +6,5 @@
 
 namespace ytorder {
 size_t     temp_bytes(int n);
-hipError_t order_by_cost(hipStream_t s, const unsigned* cost, int n, unsigned* keys_out, int* iota, int* perm,
-    void* temp, size_t temp_size);
+hipError_t order_by_cost(hipStream_t s, const unsigned* cost, int n, int* perm, void* temp, size_t temp_size);
 }  // namespace ytorder

@@ -86,11 +86,12 @@ struct ythip_ctx {
   bool                        have_denoised = false;  // dn_out holds the filtered image of the resident state
   // longest-tile-first launch order (yt_order.hip): 0 off, 1 on (YTHIP_LPT)
   int                         lpt = 1;
-  unsigned *                  d_tile_cost = nullptr, *d_tile_keys = nullptr;
-  int *                       d_tile_perm = nullptr, *d_tile_iota = nullptr;
+  unsigned*                   d_tile_cost = nullptr;
+  int*                        d_tile_perm = nullptr;
   void*                       d_sort_temp = nullptr;
   size_t                      sort_temp_bytes = 0;
   bool                        have_tile_costs = false;  // d_tile_cost holds the previous whole-slice launch's costs
+  int                         lpt_age = 0;              // launches since the order was last computed
   int                         xcd_map = 0;  // YTHIP_XCD: 0 identity, 1 4x2 blocks, 2 8 row bands, 3 8 column bands, 4 2x4 blocks
   int*                        d_tile_order = nullptr;
   int*                        d_band_next  = nullptr;
@@ -893,8 +894,11 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   const bool lpt = ctx->d_tile_cost && only_pix < 0 && !count && !ctx->d_tile_order;
   if (lpt) {
     if (ctx->have_tile_costs) {  // the previous batch's costs order this one (same pixels, same work)
-      HIPCHECK(ctx, ytorder::order_by_cost(ctx->stream, ctx->d_tile_cost, ctx->st.nblocks, ctx->d_tile_keys, ctx->d_tile_iota,
-                        ctx->d_tile_perm, ctx->d_sort_temp, ctx->sort_temp_bytes));
+      // costs are stable from batch to batch: the order is refreshed every 16th launch only
+      if (ctx->lpt_age % 16 == 0)
+        HIPCHECK(ctx, ytorder::order_by_cost(ctx->stream, ctx->d_tile_cost, ctx->st.nblocks, ctx->d_tile_perm, ctx->d_sort_temp,
+                          ctx->sort_temp_bytes));
+      ctx->lpt_age++;
       ctx->st.tile_perm = ctx->d_tile_perm;
     }
     ctx->st.tile_cost = ctx->d_tile_cost;
@@ -1610,14 +1614,13 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
   ctx->samples    = 0;
   ctx->have_state = true;
   ctx->d_tile_order = nullptr, ctx->d_band_next = nullptr;
-  ctx->d_tile_cost = ctx->d_tile_keys = nullptr, ctx->d_tile_perm = ctx->d_tile_iota = nullptr, ctx->d_sort_temp = nullptr;
+  ctx->d_tile_cost = nullptr, ctx->d_tile_perm = nullptr, ctx->d_sort_temp = nullptr;
   ctx->have_tile_costs = false;
+  ctx->lpt_age         = 0;
   if (ctx->lpt > 0 && st.nblocks > 1) {
     const size_t nb = (size_t)st.nblocks;
     if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_cost, nb))) return rc;
-    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_keys, nb))) return rc;
     if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_perm, nb))) return rc;
-    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_iota, nb))) return rc;
     ctx->sort_temp_bytes = ytorder::temp_bytes(st.nblocks);
     unsigned char* tmp   = nullptr;
     if ((rc = dalloc(ctx, ctx->state_allocs, &tmp, std::max<size_t>(ctx->sort_temp_bytes, 16)))) return rc;
