@@ -24,9 +24,17 @@ __device__ __forceinline__ int cost_class(unsigned cost) {  // larger cost -> sm
   return NBINS - 1 - (int)(k < (unsigned)NBINS ? k : (unsigned)NBINS - 1);
 }
 
+// (tiles of one frame fall into a handful of classes: the counts are gathered per block in LDS
+// first, so the global atomics are one per block and non-empty class, not one per tile)
 __global__ void __launch_bounds__(BLK) k_hist(const unsigned* cost, int n, int* bins) {
+  __shared__ int s_cnt[NBINS];
+  for (int k = threadIdx.x; k < NBINS; k += BLK) s_cnt[k] = 0;
+  __syncthreads();
   int i = blockIdx.x * BLK + threadIdx.x;
-  if (i < n) atomicAdd(&bins[cost_class(cost[i])], 1);
+  if (i < n) atomicAdd(&s_cnt[cost_class(cost[i])], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < NBINS; k += BLK)
+    if (s_cnt[k]) atomicAdd(&bins[k], s_cnt[k]);
 }
 // exclusive prefix sum of the 4096 class counts, one block
 __global__ void __launch_bounds__(1024) k_scan(int* bins) {
@@ -46,8 +54,18 @@ __global__ void __launch_bounds__(1024) k_scan(int* bins) {
   for (int k = 0; k < 4; k++) bins[4 * t + k] = run, run += v[k];
 }
 __global__ void __launch_bounds__(BLK) k_place(const unsigned* cost, int n, int* bins, int* perm) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i < n) perm[atomicAdd(&bins[cost_class(cost[i])], 1)] = i;
+  __shared__ int s_cnt[NBINS], s_base[NBINS];
+  for (int k = threadIdx.x; k < NBINS; k += BLK) s_cnt[k] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  const int c = i < n ? cost_class(cost[i]) : -1;
+  int       local = 0;
+  if (c >= 0) local = atomicAdd(&s_cnt[c], 1);  // rank inside this block's share of the class
+  __syncthreads();
+  for (int k = threadIdx.x; k < NBINS; k += BLK)
+    if (s_cnt[k]) s_base[k] = atomicAdd(&bins[k], s_cnt[k]);  // the block's range inside the class
+  __syncthreads();
+  if (c >= 0) perm[s_base[c] + local] = i;
 }
 
 size_t temp_bytes(int) { return NBINS * sizeof(int); }
