@@ -167,20 +167,22 @@ def collect_counters(name, device, timeout=240):
         except subprocess.TimeoutExpired:
             shutil.rmtree(out, ignore_errors=True)
             return None, f"rocprofv3 pass timed out after {timeout} s"
-        acc, disp = {}, {}
+        per = {}  # counter -> dispatch -> value (rows of one dispatch, e.g. per XCD, are summed)
         for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 k = row["Kernel_Name"].split("(")[0].replace("void ", "")
                 if not (k.startswith("yt::k_trace") or k.startswith("yt::k_pool")):
                     continue
                 kernel = k
-                acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-                disp.setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])
+                d = per.setdefault(row["Counter_Name"], {})
+                d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
         shutil.rmtree(out, ignore_errors=True)
-        if not acc:
+        if not per:
             return None, f"rocprofv3 pass produced no counters (rc {r.returncode}): {r.stderr[-200:]}"
-        for c, v in acc.items():
-            vals[c] = v / len(disp[c])
+        for c, d in per.items():
+            # GRBM_GUI_ACTIVE is a wall-clock cycle count of the dispatch window: anything else the
+            # device does meanwhile inflates it, so the quietest launch is the measurement
+            vals[c] = min(d.values()) if c == "GRBM_GUI_ACTIVE" else sum(d.values()) / len(d)
     return vals, kernel
 
 
