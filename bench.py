@@ -90,13 +90,22 @@ def open_context(device, flat):
     return ctx
 
 
+def progress(msg):
+    """Progress notes on stderr (stdout carries the one JSON line)."""
+    if os.environ.get("YTHIP_BENCH_PROGRESS", "1") != "0":
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def run_workload(name, device, steps, warmup, count=True):
     """One workload through the C ABI: optional counting launch, warm-up, `steps` timed
     launches (hipEvents on the launch stream).  Returns a dict."""
     import ythip as yt
     w = _workloads()[name]
+    progress(f"workload {name}: scene")
     flat = w["make"]()
+    progress(f"workload {name}: upload + bvh")
     ctx = open_context(device, flat)
+    progress(f"workload {name}: launches")
     p = yt.trace_params(sampler="path", resolution=w["resolution"], bounces=8, clamp=10.0,
                         samples=1 << 30, batch=w["spp"])
     width, height = ctx.make_trace_state(flat, p)
@@ -147,6 +156,11 @@ def rocprof_path():
 
 
 def collect_counters(name, device, timeout=240):
+    progress(f"counters {name}: rocprofv3 --pmc passes of a worker process")
+    return _collect_counters(name, device, timeout)
+
+
+def _collect_counters(name, device, timeout=240):
     """Per-launch counter means of the workload's k_trace / k_pool launches, from separate
     rocprofv3 --pmc passes of `bench.py --worker name` (counters only: never combined with
     tracing).  Returns (dict counter -> per-launch mean, kernel name) or (None, reason)."""
@@ -248,6 +262,7 @@ def roofline_of(run, counters, kernel, calib):
 def cpu_baseline(flat, params_kw, budget_s=15.0):
     """The reference itself (oracle/_ref, g++ -O3, all host cores) timed on a
     bounded sample of the same workload."""
+    progress("cpu_baseline: the reference on the host cores")
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import refyocto as ry
     import ythip as yt
@@ -276,26 +291,40 @@ def other_workloads(device, args, calib):
     """The other single-GPU workloads through the same path, short runs (their parity lives in
     tests/test_gpu_baseline_configs.py): 1 counting launch + 1 warm-up + 2 timed launches
     each, then the live counter passes -> fractions of the roofs that can bind."""
-    res = []
+    res, deferred = [], []
     for name in ["cfg2b", "configs3", "configs4", "cornell9m"]:
         try:
             run = run_workload(name, device, steps=2, warmup=1)
-            counters, kernel = (None, "skipped") if args.no_counters else collect_counters(name, device)
-            roof = roofline_of(run, counters, kernel if counters else None, calib)
-            if counters is None and not args.no_counters:
-                roof["note"] = kernel
             e = {"workload": f"{run['label']}, {run['width']}x{run['height']}x{run['spp']}spp, "
                              f"sampler=path bounces=8 clamp=10",
                  "value": round(run["samples_per_launch"] / run["ms_per_launch"] / 1e3, 3), "unit": "Msamples/s",
                  "ms_per_step": round(run["ms_per_launch"], 3), "steps": run["launches"],
                  "bytes_per_sample": round(run["bytes_per_sample"], 1), "per_sample": run["per_sample"],
-                 "roofline": roof}
+                 "roofline": roofline_of(run, None, None, calib)}
             if "baked_bytes" in run:
                 e["baked_bvh_bytes"] = run["baked_bytes"]
             res.append(e)
+            deferred.append((name, run, e))
         except Exception as ex:  # reported, never required
             res.append({"workload": name, "error": str(ex)[:300]})
-    return res
+    return res, deferred
+
+
+def fill_counters(deferred, device, calib):
+    """The live counter passes, AFTER every timed launch of this process is done and its
+    contexts are closed: each pass is a worker process of its own under rocprofv3 --pmc, so
+    nothing it does (or suffers) can touch the timed numbers already taken."""
+    for name, run, entry in deferred:
+        try:
+            counters, kernel = collect_counters(name, device)
+            roof = roofline_of(run, counters, kernel if counters else entry["roofline"].get("kernel"), calib)
+            if counters is None:
+                roof["note"] = kernel
+            for k, v in entry["roofline"].items():  # keep what the timed run already attached
+                roof.setdefault(k, v)
+            entry["roofline"] = roof
+        except Exception as ex:  # reported, never required
+            entry["roofline"]["note"] = f"counter passes failed: {str(ex)[:200]}"
 
 
 def weak_resolution(base, world, tile=16):
@@ -522,6 +551,7 @@ def main():
     if gathering:  # what the collective library itself reports
         out["config"]["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
     calib = valu_calibration()
+    deferred_counters = []  # (workload, timed run, entry whose "roofline" gets the live counters), filled last
     if rank == 0 and stats_count is not None and stats_time["trace_launches"] > 0:
         # The dominant (only) kernel is k_trace: one launch = one step.
         launches_per_step = stats_time["trace_launches"] / args.steps
@@ -529,12 +559,11 @@ def main():
         nsamp = max(stats_count["samples"], 1)
         run1 = {"ms_per_launch": k_ms, "bytes_per_sample": yt.algorithmic_bytes(stats_count) / nsamp,
                 "samples_per_launch": nsamp / launches_per_step}
-        counters, kernel = None, None
-        if world == 1 and not args.as_rank and not args.no_counters and args.resolution == 1280 and args.spp == 64:
-            counters, kernel = collect_counters("configs1", local)
-        roof = roofline_of(run1, counters, kernel if counters else "k_trace", calib)
-        if counters is None:
-            roof["note"] = (kernel or "counters are collected at N = 1 on the default configs[1] workload only")
+        want_counters = (world == 1 and not args.as_rank and not args.no_counters and args.resolution == 1280
+                         and args.spp == 64)
+        roof = roofline_of(run1, None, "k_trace", calib)
+        if not want_counters:
+            roof["note"] = "counters are collected at N = 1 on the default configs[1] workload only"
         roof["launches_per_step"] = launches_per_step
         roof["traversal_bytes_per_launch"] = int(yt.traversal_bytes(stats_count) / launches_per_step)
         roof["per_sample"] = {"rays": round(stats_count["rays"] / nsamp, 3),
@@ -546,6 +575,8 @@ def main():
         if world > 1:
             roof["note"] = "rank 0's launches (its slice of the frame); counters are collected at N = 1 only"
         out["roofline"] = roof
+        if want_counters:
+            deferred_counters.append(("configs1", run1, out))
     if world > 1 and args.scaling == "both" and not args.as_rank:
         # weak scaling next to the primary (strong) line: the configs[1] camera at N x the pixels,
         # same K steps between the same fences.  Reported, never required: a failure here
@@ -562,9 +593,14 @@ def main():
     if rank == 0 and world == 1 and not args.as_rank and not args.no_other_configs:
         ctx.close()
         try:
-            out["other_configs"] = other_workloads(local, args, calib)
+            out["other_configs"], more = other_workloads(local, args, calib)
+            if not args.no_counters:
+                deferred_counters.extend(more)
         except Exception as e:  # reported, never required
             out["other_configs"] = {"error": str(e)}
+    if rank == 0 and world == 1 and deferred_counters:
+        ctx.close()  # (idempotent) every timed launch is done: only now the profiled worker processes run
+        fill_counters(deferred_counters, local, calib)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(flat, params_kw)
