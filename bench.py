@@ -294,7 +294,7 @@ def other_workloads(device, args, calib):
     res, deferred = [], []
     for name in ["cfg2b", "configs3", "configs4", "cornell9m"]:
         try:
-            run = run_workload(name, device, steps=2, warmup=1)
+            run = run_workload_isolated(name, device)
             e = {"workload": f"{run['label']}, {run['width']}x{run['height']}x{run['spp']}spp, "
                              f"sampler=path bounces=8 clamp=10",
                  "value": round(run["samples_per_launch"] / run["ms_per_launch"] / 1e3, 3), "unit": "Msamples/s",
@@ -344,7 +344,25 @@ def weak_resolution(base, world, tile=16):
 def worker_main(args):
     """`--worker NAME`: one warm-up + one launch of the workload, nothing printed; run under
     rocprofv3 --pmc by collect_counters()."""
+    if args.worker_json:  # the timed run of one of the other workloads, in a process of its own
+        run = run_workload(args.worker, args.worker_device, steps=2, warmup=1)
+        print("YTHIP_RUN " + json.dumps(run), flush=True)
+        return
     run_workload(args.worker, args.worker_device, steps=1, warmup=1, count=False)
+
+
+def run_workload_isolated(name, device, timeout=420):
+    """run_workload(name) in a worker process: a failure there (a device fault kills the process
+    it happens in) costs that entry, not the line."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", name, "--worker-device", str(device),
+                        "--worker-json"], capture_output=True, text=True, timeout=timeout, env=env)
+    for line in r.stdout.splitlines():
+        if line.startswith("YTHIP_RUN "):
+            return json.loads(line[len("YTHIP_RUN "):])
+    raise RuntimeError(f"worker for {name} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}")
 
 
 def main():
@@ -377,9 +395,14 @@ def main():
                          "(no gather); the JSON line then describes that slice")
     ap.add_argument("--worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--worker-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--worker-json", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.worker:
         return worker_main(args)
+    # a sacrificial first GPU process per rank (yocto-gl_amd/preflight.py explains why)
+    sys.path.insert(0, os.path.join(ROOT, "yocto-gl_amd"))
+    import preflight
+    preflight.run(int(os.environ.get("LOCAL_RANK", "0")))
 
     import torch
     import ythip as yt
