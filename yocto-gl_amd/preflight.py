@@ -23,7 +23,10 @@ def _body(device):
     import ythip as yt
     import scenes as ysc
     flat = ysc.plane_scene()
-    ctx = yt.Context(device)
+    try:
+        ctx = yt.Context(device)
+    except yt.YthipError:
+        sys.exit(77)  # no device: nothing to warm up (and nothing to retry)
     ctx.upload_scene(flat)
     ctx.make_trace_bvh(flat)
     ctx.make_trace_lights(flat)
@@ -42,16 +45,21 @@ def run(device=0, timeout=300):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), str(device)], capture_output=True, text=True,
-                           timeout=timeout, env=env)
-        if r.returncode != 0:
-            print(f"[preflight] the sacrificial first GPU process ended with rc {r.returncode}: "
+    import time
+    rc = None
+    for attempt in range(3):  # (the process after a faulted one failed too, once: give the device a moment)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), str(device)], capture_output=True, text=True,
+                               timeout=timeout, env=env)
+            rc = r.returncode
+            if rc in (0, 77):
+                return rc
+            print(f"[preflight] attempt {attempt + 1}: the sacrificial GPU process ended with rc {rc}: "
                   f"{(r.stderr or '').strip().splitlines()[-1:] or ''}", file=sys.stderr, flush=True)
-        return r.returncode
-    except Exception as e:  # timeout, missing interpreter, ...
-        print(f"[preflight] {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-        return None
+        except Exception as e:  # timeout, missing interpreter, ...
+            print(f"[preflight] attempt {attempt + 1}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        time.sleep(5)
+    return rc
 
 
 if __name__ == "__main__":
