@@ -157,6 +157,14 @@ struct ythip_ctx {
 };
 
 static void free_staging(ythip_ctx* ctx) {
+  // host pools that view the staging memory go with it: the scene they belong to is no longer
+  // resident as far as the host-side builders are concerned (a new upload must follow)
+  bool viewed = false;
+  for (auto* pool : {&ctx->h_points, &ctx->h_lines, &ctx->h_triangles, &ctx->h_quads})
+    if (pool->ext) pool->ext = nullptr, pool->n = 0, viewed = true;
+  for (auto* pool : {&ctx->h_positions, &ctx->h_radius})
+    if (pool->ext) pool->ext = nullptr, pool->n = 0, viewed = true;
+  if (viewed) ctx->have_scene = ctx->have_bvh = ctx->have_lights = false;
   for (auto p : ctx->staging_allocs)
     if (p) (void)hipHostFree(p);
   ctx->staging_allocs.clear();
