@@ -273,7 +273,7 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
 // the scene, 1 = walks through the out-of-line trace_ray, 2 = walks inline, 3 = walks
 // inline with their stack in scratch only (k_pool: the LDS stack columns belong to
 // suspended scene walks).
-template <int WALK>
+template <int WALK, bool COUNT = true>
 YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt,
     bool wide = false) {
   auto pdf = 0.0f;
@@ -296,7 +296,7 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
             isec      = traverse<true, false, false, 0>(sc, ray, light.instance, false, *st, *cnt);
           } else {
             ray3f ray = make_ray(next_position, direction);
-            isec      = traverse<true>(sc, ray, light.instance, false, *st, *cnt);
+            isec      = traverse<COUNT>(sc, ray, light.instance, false, *st, *cnt);  // (counts only in the counting launch)
           }
           if (!isec.hit) break;
           auto e         = load_element(sc, sh, isec.element);
@@ -1371,7 +1371,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
             if (nee) {
               float4 nb      = st.nee_b[slot];
               vec3f  inc     = {na.x, na.y, na.z}, bsdfcos = {nb.x, nb.y, nb.z};
-              auto   pdf     = sample_lights_pdf<2>(sc, P.o, inc, &stack, &cnt);
+              auto   pdf     = sample_lights_pdf<2, COUNT>(sc, P.o, inc, &stack, &cnt);
               if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
                 ray3f nray     = make_ray(P.o, inc);
                 Hit   nisec    = traverse_any<COUNT, WIDE>(sc, nray, -1, false, stack, cnt);
@@ -1393,7 +1393,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
                 const float4 b = pass == 0 ? mb : st.nee_d[slot];
                 const vec3f  inc = {a.x, a.y, a.z}, bsdfcos = {b.x, b.y, b.z};
                 const float  bsdf_pdf  = a.w;
-                const float  light_pdf = sample_lights_pdf<2>(sc, P.o, inc, &stack, &cnt);
+                const float  light_pdf = sample_lights_pdf<2, COUNT>(sc, P.o, inc, &stack, &cnt);
                 auto         heur      = [](float this_pdf, float other_pdf) {
                   return (this_pdf * this_pdf) / (this_pdf * this_pdf + other_pdf * other_pdf);
                 };
@@ -1418,7 +1418,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
           if (nee != 2) {
             float4 pd = st.pend[slot];
             // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
-            auto lpdf = sample_lights_pdf<2>(sc, P.o, P.d, &stack, &cnt);
+            auto lpdf = sample_lights_pdf<2, COUNT>(sc, P.o, P.d, &stack, &cnt);
             P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
             step = step_tail(P);
           }
