@@ -532,7 +532,11 @@ int main() {
     auto t0 = std::chrono::steady_clock::now();
     hip::trace_cancel(context);
     auto ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    EXPECT(ms < 250.0, "trace_cancel took %.1f ms", ms);
+    // (ranks that share one physical device — the one-GPU rehearsal of YOCTO_HIP_DEVICES=0,0 — run their
+    // persistent kernels one after the other: the second rank's kernel only starts, and sees the flag, once
+    // the first has drained; half a second has been observed there)
+    const double bound = hip::hip_device_count() > 1 ? 2000.0 : 250.0;
+    EXPECT(ms < bound, "trace_cancel took %.1f ms", ms);
     EXPECT(!context.done && state.samples == 0, "cancelled batch: done %d samples %d", (int)context.done.load(), state.samples);
     std::printf("trace_cancel of a 1280x1280x4096spp batch returned in %.1f ms\n", ms);
     // the back-end keeps working after a cancel
