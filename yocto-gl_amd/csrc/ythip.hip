@@ -92,6 +92,8 @@ struct ythip_ctx {
   size_t                      sort_temp_bytes = 0;
   bool                        have_tile_costs = false;  // d_tile_cost holds the previous whole-slice launch's costs
   int                         lpt_age = 0;              // launches since the order was last computed
+  std::vector<void*>          order_allocs;             // the three buffers above: they outlive a state with the same tile grid
+  int                         order_tiles_x = 0, order_tiles_y = 0;
   int                         xcd_map = 0;  // YTHIP_XCD: 0 identity, 1 4x2 blocks, 2 8 row bands, 3 8 column bands, 4 2x4 blocks
   int*                        d_tile_order = nullptr;
   int*                        d_band_next  = nullptr;
@@ -1021,6 +1023,7 @@ void ythip_destroy(ythip_ctx* ctx) {
   if (ctx->d_stop) (void)hipFree(ctx->d_stop);
   free_staging(ctx);
   free_all(ctx->denoise_allocs);
+  free_all(ctx->order_allocs);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
   free_all(ctx->pool_allocs);
@@ -1622,18 +1625,26 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
   ctx->samples    = 0;
   ctx->have_state = true;
   ctx->d_tile_order = nullptr, ctx->d_band_next = nullptr;
-  ctx->d_tile_cost = nullptr, ctx->d_tile_perm = nullptr, ctx->d_sort_temp = nullptr;
-  ctx->have_tile_costs = false;
-  ctx->lpt_age         = 0;
-  if (ctx->lpt > 0 && st.nblocks > 1) {
-    const size_t nb = (size_t)st.nblocks;
-    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_cost, nb))) return rc;
-    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_perm, nb))) return rc;
-    ctx->sort_temp_bytes = ytorder::temp_bytes(st.nblocks);
-    unsigned char* tmp   = nullptr;
-    if ((rc = dalloc(ctx, ctx->state_allocs, &tmp, std::max<size_t>(ctx->sort_temp_bytes, 16)))) return rc;
-    ctx->d_sort_temp = tmp;
+  // A new state with the tile grid of the previous one (a viewer re-creates the state on every
+  // camera edit, apps/ytrace.cpp:189-204) keeps the recorded tile costs: its first batch is
+  // already launched most expensive tile first (the view changed a little, the costs did too).
+  const bool same_grid = ctx->d_tile_cost && ctx->order_tiles_x == st.tiles_x && ctx->order_tiles_y == st.tiles_y;
+  if (!same_grid) {
+    free_all(ctx->order_allocs);
+    ctx->d_tile_cost = nullptr, ctx->d_tile_perm = nullptr, ctx->d_sort_temp = nullptr;
+    ctx->have_tile_costs = false;
+    if (ctx->lpt > 0 && st.nblocks > 1) {
+      const size_t nb = (size_t)st.nblocks;
+      if ((rc = dalloc(ctx, ctx->order_allocs, &ctx->d_tile_cost, nb))) return rc;
+      if ((rc = dalloc(ctx, ctx->order_allocs, &ctx->d_tile_perm, nb))) return rc;
+      ctx->sort_temp_bytes = ytorder::temp_bytes(st.nblocks);
+      unsigned char* tmp   = nullptr;
+      if ((rc = dalloc(ctx, ctx->order_allocs, &tmp, std::max<size_t>(ctx->sort_temp_bytes, 16)))) return rc;
+      ctx->d_sort_temp = tmp;
+      ctx->order_tiles_x = st.tiles_x, ctx->order_tiles_y = st.tiles_y;
+    }
   }
+  ctx->lpt_age = 0;  // (the order is recomputed from the kept costs at the first launch)
   if (ctx->xcd_map > 0) {  // XCD-banded tile queues (experiment): tiles grouped by band, band after band
     const int gx = ctx->xcd_map == 1 ? 4 : ctx->xcd_map == 2 ? 1 : ctx->xcd_map == 3 ? 8 : 2, gy = 8 / gx;
     std::vector<std::vector<int>> bands(8);
