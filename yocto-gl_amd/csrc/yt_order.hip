@@ -26,12 +26,18 @@ __device__ __forceinline__ int cost_class(unsigned cost) {  // larger cost -> sm
 
 // (tiles of one frame fall into a handful of classes: the counts are gathered per block in LDS
 // first, so the global atomics are one per block and non-empty class, not one per tile)
-__global__ void __launch_bounds__(BLK) k_hist(const unsigned* cost, int n, int* bins) {
+// (the class of every tile is computed ONCE and kept: the placement pass must see exactly what the
+// histogram saw, or the result would not be a permutation — whatever happens to `cost` meanwhile)
+__global__ void __launch_bounds__(BLK) k_hist(const unsigned* cost, int n, int* bins, int* cls) {
   __shared__ int s_cnt[NBINS];
   for (int k = threadIdx.x; k < NBINS; k += BLK) s_cnt[k] = 0;
   __syncthreads();
   int i = blockIdx.x * BLK + threadIdx.x;
-  if (i < n) atomicAdd(&s_cnt[cost_class(cost[i])], 1);
+  if (i < n) {
+    const int c = cost_class(cost[i]);
+    cls[i]      = c;
+    atomicAdd(&s_cnt[c], 1);
+  }
   __syncthreads();
   for (int k = threadIdx.x; k < NBINS; k += BLK)
     if (s_cnt[k]) atomicAdd(&bins[k], s_cnt[k]);
@@ -53,12 +59,12 @@ __global__ void __launch_bounds__(1024) k_scan(int* bins) {
   int run = s_part[t] - sum;
   for (int k = 0; k < 4; k++) bins[4 * t + k] = run, run += v[k];
 }
-__global__ void __launch_bounds__(BLK) k_place(const unsigned* cost, int n, int* bins, int* perm) {
+__global__ void __launch_bounds__(BLK) k_place(const int* cls, int n, int* bins, int* perm) {
   __shared__ int s_cnt[NBINS], s_base[NBINS];
   for (int k = threadIdx.x; k < NBINS; k += BLK) s_cnt[k] = 0;
   __syncthreads();
   const int i = blockIdx.x * BLK + threadIdx.x;
-  const int c = i < n ? cost_class(cost[i]) : -1;
+  const int c = i < n ? cls[i] : -1;
   int       local = 0;
   if (c >= 0) local = atomicAdd(&s_cnt[c], 1);  // rank inside this block's share of the class
   __syncthreads();
@@ -68,17 +74,18 @@ __global__ void __launch_bounds__(BLK) k_place(const unsigned* cost, int n, int*
   if (c >= 0) perm[s_base[c] + local] = i;
 }
 
-size_t temp_bytes(int) { return NBINS * sizeof(int); }
+size_t temp_bytes(int n) { return (NBINS + (size_t)n) * sizeof(int); }  // class counts + one class per tile
 
 // perm[k] = a tile of the k-th most expensive cost class (any order inside a class)
 hipError_t order_by_cost(hipStream_t s, const unsigned* cost, int n, int* perm, void* temp, size_t temp_size) {
-  if (temp_size < NBINS * sizeof(int)) return hipErrorInvalidValue;
+  if (temp_size < (NBINS + (size_t)n) * sizeof(int)) return hipErrorInvalidValue;
   int*       bins = (int*)temp;
+  int*       cls  = bins + NBINS;
   hipError_t e    = hipMemsetAsync(bins, 0, NBINS * sizeof(int), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_hist, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, s, cost, n, bins);
+  hipLaunchKernelGGL(k_hist, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, s, cost, n, bins, cls);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, bins);
-  hipLaunchKernelGGL(k_place, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, s, cost, n, bins, perm);
+  hipLaunchKernelGGL(k_place, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, s, cls, n, bins, perm);
   return hipGetLastError();
 }
 
