@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <limits>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -1934,11 +1935,30 @@ int raise_stop(ythip_ctx* ctx) {
 }
 }  // namespace
 
+namespace {
+// A batch whose tile costs are not known yet (first batch of a tile grid) and that is long
+// enough to care is launched as 1 + (batch - 1) samples: the first launch records what every
+// tile costs, the second is handed out most expensive tile first (yt_order.hip).  Two launches
+// of a progressive render: the same samples in the same order, bit-identical (tested).
+int enqueue_batch(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop) {
+  const bool probe = ctx->lpt > 0 && ctx->d_tile_cost && !ctx->have_tile_costs && !ctx->d_tile_order &&
+                     (ctx->prof_mode & 2) == 0 && params->batch >= 8 && ctx->st.nblocks > 4096 &&
+                     ctx->samples < params->samples;
+  if (!probe) return enqueue_samples(ctx, params, stop);
+  ythip_params first = *params, rest = *params;
+  first.batch        = 1;
+  rest.batch         = params->batch - 1;
+  rest.samples       = std::numeric_limits<int>::max();  // (the whole batch runs, as in the reference: yocto_trace.cpp:1598 tests once)
+  int rc = enqueue_samples(ctx, &first, stop);
+  return rc ? rc : enqueue_samples(ctx, &rest, stop);
+}
+}  // namespace
+
 int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop) {
   if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   const int samples_before = ctx->samples;
-  int       rc             = enqueue_samples(ctx, params, stop);
+  int       rc             = enqueue_batch(ctx, params, stop);
   if (rc) return rc;
   bool cancelled = false;
   if (stop) {
@@ -1994,7 +2014,7 @@ int ythip_trace_sample(ythip_ctx* ctx, const ythip_params* params, int i, int j,
 int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params) {
   if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
-  return enqueue_samples(ctx, params, nullptr);
+  return enqueue_batch(ctx, params, nullptr);
 }
 
 static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_ray* rays, int64_t n,
