@@ -142,6 +142,7 @@ def run_workload(name, device, steps, warmup, count=True):
 # ----------------------------------------------------------------------------
 # live counters: this script as a worker under rocprofv3 --pmc
 # ----------------------------------------------------------------------------
+WORKER_STEPS = 2  # timed launches of a counter worker (after one warm-up)
 PMC_PASSES = [
     ["FETCH_SIZE", "TCC_REQ_sum", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"],
@@ -194,9 +195,12 @@ def _collect_counters(name, device, timeout=240):
         if not per:
             return None, f"rocprofv3 pass produced no counters (rc {r.returncode}): {r.stderr[-200:]}"
         for c, d in per.items():
+            # the worker's last WORKER_STEPS dispatches are its timed, full-size launches (what comes
+            # before is the warm-up, which a fresh tile grid runs as 1 + (batch - 1) samples).
             # GRBM_GUI_ACTIVE is a wall-clock cycle count of the dispatch window: anything else the
             # device does meanwhile inflates it, so the quietest launch is the measurement
-            vals[c] = min(d.values()) if c == "GRBM_GUI_ACTIVE" else sum(d.values()) / len(d)
+            last = [d[k] for k in sorted(d, key=int)[-WORKER_STEPS:]]
+            vals[c] = min(last) if c == "GRBM_GUI_ACTIVE" else sum(last) / len(last)
     return vals, kernel
 
 
@@ -342,13 +346,13 @@ def weak_resolution(base, world, tile=16):
 
 
 def worker_main(args):
-    """`--worker NAME`: one warm-up + one launch of the workload, nothing printed; run under
+    """`--worker NAME`: one warm-up + WORKER_STEPS launches of the workload, nothing printed; run under
     rocprofv3 --pmc by collect_counters()."""
     if args.worker_json:  # the timed run of one of the other workloads, in a process of its own
         run = run_workload(args.worker, args.worker_device, steps=2, warmup=1)
         print("YTHIP_RUN " + json.dumps(run), flush=True)
         return
-    run_workload(args.worker, args.worker_device, steps=1, warmup=1, count=False)
+    run_workload(args.worker, args.worker_device, steps=WORKER_STEPS, warmup=1, count=False)
 
 
 def run_workload_isolated(name, device, timeout=420):
