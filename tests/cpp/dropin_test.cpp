@@ -535,7 +535,10 @@ int main() {
     // (ranks that share one physical device — the one-GPU rehearsal of YOCTO_HIP_DEVICES=0,0 — run their
     // persistent kernels one after the other: the second rank's kernel only starts, and sees the flag, once
     // the first has drained; half a second has been observed there)
-    const double bound = hip::hip_device_count() > 1 ? 2000.0 : 250.0;
+    // What is asserted is the semantics: the batch (tens of seconds of work) is abandoned inside the
+    // launch.  Typical latency is 45-55 ms; 0.5-0.6 s has been observed on a loaded box (the host thread
+    // that relays the flag competes with 256 reference threads still winding down), hence the bound.
+    const double bound = 2000.0;
     EXPECT(ms < bound, "trace_cancel took %.1f ms", ms);
     EXPECT(!context.done && state.samples == 0, "cancelled batch: done %d samples %d", (int)context.done.load(), state.samples);
     std::printf("trace_cancel of a 1280x1280x4096spp batch returned in %.1f ms\n", ms);
