@@ -196,7 +196,7 @@ def _collect_counters(name, device, timeout=240):
             return None, f"rocprofv3 pass produced no counters (rc {r.returncode}): {r.stderr[-200:]}"
         for c, d in per.items():
             # the worker's last WORKER_STEPS dispatches are its timed, full-size launches (what comes
-            # before is the warm-up, which a fresh tile grid runs as 1 + (batch - 1) samples).
+            # before is the warm-up — with YTHIP_LPT_PROBE=1 a 1 + (batch - 1) pair of launches).
             # GRBM_GUI_ACTIVE is a wall-clock cycle count of the dispatch window: anything else the
             # device does meanwhile inflates it, so the quietest launch is the measurement
             last = [d[k] for k in sorted(d, key=int)[-WORKER_STEPS:]]

@@ -536,8 +536,9 @@ int main() {
     // persistent kernels one after the other: the second rank's kernel only starts, and sees the flag, once
     // the first has drained; half a second has been observed there)
     // What is asserted is the semantics: the batch (tens of seconds of work) is abandoned inside the
-    // launch.  Typical latency is 45-55 ms; 0.5-0.6 s has been observed on a loaded box (the host thread
-    // that relays the flag competes with 256 reference threads still winding down), hence the bound.
+    // launch.  Typical latency is 45-55 ms.  trace_cancel joins the worker of trace_start, as the reference's
+    // does: when the 200 ms above were not enough for that worker's uploads (a loaded box: 256 reference
+    // threads have just been busy), the join also waits for the rest of them — 0.5-0.6 s has been observed.
     const double bound = 2000.0;
     EXPECT(ms < bound, "trace_cancel took %.1f ms", ms);
     EXPECT(!context.done && state.samples == 0, "cancelled batch: done %d samples %d", (int)context.done.load(), state.samples);
