@@ -51,4 +51,6 @@ for sampler in (os.environ.get("SAMPLERS") or "falsecolor,eyelight,naive,pathtes
         for k in sorted(d):
             if hasattr(d[k], "tobytes"): h.update(d[k].tobytes())
         digest = " state " + h.hexdigest()[:12]
+    if os.environ.get("STACKSTATS"):  # -DYT_STACK_STATS builds: pushes / pushes beyond the LDS levels
+        print(f"[stack] pushes {s['quads']}  beyond LDS {s['lines']}  ({100.0 * s['lines'] / max(1, s['quads']):.1f} %)")
     print(f"{SCENE} {sampler:10s} {ms:8.3f} ms/step  {ctx.npixels*spp/ms/1e3:8.1f} Msamples/s{digest}", flush=True)

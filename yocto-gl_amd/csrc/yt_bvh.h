@@ -78,6 +78,7 @@ struct alignas(8) StackEntry {
 typedef __attribute__((address_space(3))) StackEntry lds_entry;
 struct Stack {
   lds_entry* lds;  // &s_stack[0][threadIdx.x]
+  unsigned   pf_zone = 0;  // YT_PREFETCH: LDS byte offset of the prefetch landing area (YT_BLOCK dwords)
 };
 #define YT_STACK_INIT(stack, s_stack) (stack).lds = (lds_entry*)&(s_stack)[0][threadIdx.x]
 
@@ -103,6 +104,74 @@ struct TopLds {
   const float* rec;  // LDS: TOP_SLOTS records of 8 float4 (nullptr: staging off)
   int          root; // pair id of the staged root
 };
+
+// push / pop of the per-lane stack (locals `lds`, `sp`, `spill`, `cnt` of the enclosing walk).
+//   default:        entries [0, L) in the lane's LDS column, [L, L + S) in scratch
+//   YT_RING_STACK:  the TOP L entries in LDS (a ring indexed by sp mod L), older ones evicted to
+//                   scratch one at a time — a depth-first walk works at the top of its stack, so
+//                   with deep trees the hot end stays in LDS instead of in scratch
+#ifdef YT_STACK_STATS  // development builds: pushes (Counters::quads) and pushes landing beyond the LDS levels (::lines)
+#define YT_STACK_STAT(L) cnt.quads++; if (sp >= (L)) cnt.lines++;
+#else
+#define YT_STACK_STAT(L)
+#endif
+#ifdef YT_RING_STACK
+#define YT_STACK_OPS(L, S)                                                                        \
+  static_assert(((L) & ((L)-1)) == 0 || (L) == 0, "ring stack: LDS levels must be a power of two"); \
+  int  lo   = 0; /* entries [lo, sp) are in LDS, [0, lo) in scratch */                            \
+  auto push = [&](int ref, float t0) {                                                            \
+    YT_STACK_STAT(L)                                                                              \
+    StackEntry v = {ref, __float_as_int(t0)};                                                     \
+    if ((L) == 0) {                                                                               \
+      if (sp < (S)) spill[sp] = v;                                                                \
+      sp++;                                                                                       \
+      return;                                                                                     \
+    }                                                                                             \
+    if (sp - lo == (L)) { /* ring full: the oldest LDS entry goes to scratch */                   \
+      if (lo < (S)) {                                                                             \
+        StackEntry e;                                                                             \
+        e.ref = lds[(lo & ((L)-1)) * YT_BLOCK].ref, e.t0 = lds[(lo & ((L)-1)) * YT_BLOCK].t0;     \
+        spill[lo] = e;                                                                            \
+        lo++;                                                                                     \
+      } else {                                                                                    \
+        return; /* beyond 128 entries: dropped (the reference's array<int,128> would overflow) */ \
+      }                                                                                           \
+    }                                                                                             \
+    lds[(sp & ((L)-1)) * YT_BLOCK].ref = v.ref, lds[(sp & ((L)-1)) * YT_BLOCK].t0 = v.t0;         \
+    sp++;                                                                                         \
+  };                                                                                              \
+  auto pop = [&]() -> StackEntry {                                                                \
+    sp--;                                                                                         \
+    if ((L) == 0) return sp < (S) ? spill[sp] : StackEntry{REF_EXIT, 0};                          \
+    if (sp < lo) { /* LDS part empty: the entry is in scratch */                                  \
+      lo = sp;                                                                                    \
+      return spill[sp];                                                                           \
+    }                                                                                             \
+    StackEntry v;                                                                                 \
+    v.ref = lds[(sp & ((L)-1)) * YT_BLOCK].ref, v.t0 = lds[(sp & ((L)-1)) * YT_BLOCK].t0;         \
+    return v;                                                                                     \
+  };
+#else
+#define YT_STACK_OPS(L, S)                                                                        \
+  auto push = [&](int ref, float t0) {                                                            \
+    YT_STACK_STAT(L)                                                                              \
+    StackEntry v = {ref, __float_as_int(t0)};                                                     \
+    if (sp < (L))                                                                                 \
+      lds[sp * YT_BLOCK].ref = v.ref, lds[sp * YT_BLOCK].t0 = v.t0;                               \
+    else if (sp < (L) + (S))                                                                      \
+      spill[sp - (L)] = v;                                                                        \
+    sp++; /* entries beyond 128 are dropped (the reference's array<int,128> would overflow) */    \
+  };                                                                                              \
+  auto pop = [&]() -> StackEntry {                                                                \
+    sp--;                                                                                         \
+    if (sp < (L)) {                                                                               \
+      StackEntry v;                                                                               \
+      v.ref = lds[sp * YT_BLOCK].ref, v.t0 = lds[sp * YT_BLOCK].t0;                               \
+      return v;                                                                                   \
+    }                                                                                             \
+    return (sp < (L) + (S)) ? spill[sp - (L)] : StackEntry{REF_EXIT, 0};                          \
+  };
+#endif
 
 struct Hit {
   int   instance, element;
@@ -249,6 +318,73 @@ YT_FN bool ray_is_tame(vec3f o, vec3f dinv, float tmin) {
          dinv.z != 0 && tmin == tmin;
 }
 
+// slab<true> on a baked box record {min.x, min.y, max.x, max.y} {min.z, max.z, ..}: the same six
+// subtractions and six multiplications, issued as v_pk_add_f32 / v_pk_mul_f32 pairs (CDNA3+ packed
+// fp32: two IEEE operations per lane and instruction, same rounding as the scalar forms).
+typedef float v2f __attribute__((ext_vector_type(2)));
+YT_FN bool slab_rec(vec3f o, vec3f dinv, float tmin, float4 r0, float4 r1, float& t0) {
+#ifdef YT_PK_SLAB
+  const v2f oxy = {o.x, o.y}, dxy = {dinv.x, dinv.y}, ozz = {o.z, o.z}, dzz = {dinv.z, dinv.z};
+  const v2f a = (v2f{r0.x, r0.y} - oxy) * dxy;  // it_min.xy
+  const v2f b = (v2f{r0.z, r0.w} - oxy) * dxy;  // it_max.xy
+  const v2f c = (v2f{r1.x, r1.y} - ozz) * dzz;  // it_min.z, it_max.z
+  auto vmin = [](float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto vmax = [](float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto vmin3 = [](float x, float y, float z) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
+  auto vmax3 = [](float x, float y, float z) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
+  float nx = vmin(a.x, b.x), ny = vmin(a.y, b.y), nz = vmin(c.x, c.y);
+  float fx = vmax(a.x, b.x), fy = vmax(a.y, b.y), fz = vmax(c.x, c.y);
+  t0       = vmax(vmax3(nx, ny, nz), tmin);
+  auto far = vmin3(fx, fy, fz);
+  return t0 <= far * BBOX_K;
+#else
+  return slab<true>(o, dinv, tmin, {r0.x, r0.y, r1.x}, {r0.z, r0.w, r1.y}, t0);
+#endif
+}
+
+// Software prefetch (YT_PREFETCH): gfx950 has no prefetch instruction, but a load that lands in
+// LDS (global_load_lds_dword: M0 = LDS byte offset, destination M0 + 4 * lane) needs no VGPR and
+// nobody has to wait for it; the line it touches is then in the L2 (and the CU's vector L1) when the
+// walk comes back for it.  `zone` = a 256-B landing area nobody reads.
+YT_FN void prefetch_line(const void* p, unsigned zone) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(p), "s"(zone) : "memory", "m0");
+}
+
+
+// prefetch of pushed nodes (YT_PREFETCH = 1: the entry pushed last — popped soonest; 2: every pushed entry)
+#if defined(YT_PREFETCH)
+#define YT_PF_DECL int pf_ref = REF_NONE;
+#if YT_PREFETCH >= 2
+#define YT_PF_NOTE(r) yt_prefetch_ref(sc, (r), cur_inst, kind, leafbias, st.pf_zone);
+#define YT_PF_ISSUE (void)pf_ref;
+#else
+#define YT_PF_NOTE(r) pf_ref = (r);
+#define YT_PF_ISSUE if (pf_ref != REF_NONE) yt_prefetch_ref(sc, pf_ref, cur_inst, kind, leafbias, st.pf_zone);
+#endif
+#else
+#define YT_PF_DECL
+#define YT_PF_NOTE(r)
+#define YT_PF_ISSUE
+#endif
+YT_FN void yt_prefetch_ref(const DScene& sc, int ref, int cur_inst, int kind, int leafbias, unsigned zone) {
+  if (ref >= 0) {  // internal node: its 128-B quad record
+    prefetch_line(sc.wide + 8 * (int64_t)ref, zone);
+  } else if (cur_inst >= 0) {  // BLAS leaf: the first line of its primitives
+    const int first = ref & 0x0fffffff;
+    prefetch_line(sc.leafdata + (leafbias + first * leaf_stride(kind)), zone);
+  }
+}
+
+#ifdef YT_WALK_PROFILE  // development builds: where the wavefronts of the (while-while) walk spend their cycles
+// [0] cycles in the descend phase  [1] lane-iterations of it (sum of active lanes per inner iteration)  [2] inner iterations
+// [3] cycles in the leaf / entry phase  [4] lanes holding a BLAS leaf at its start  [5] phase-2 rounds  [6] lanes holding an instance entry / exit
+// [7] primitive-test lane-rounds (sum over leaf rounds of lanes still testing)  [8] primitive-test rounds
+__device__ unsigned long long g_walkprof[16];
+#define YT_WP(i, v) do { if (wp_on) wp[i] += (unsigned long long)(v); } while (0)
+#else
+#define YT_WP(i, v)
+#endif
+
 // The traversal.  `only_instance` < 0: intersect_scene_bvh (yocto_bvh.cpp:554-617);
 // otherwise intersect_instance_bvh of that instance (yocto_bvh.cpp:619-628).
 constexpr int HIT_ABORT = -2;  // Hit::instance of a wide walk that met an irregular ray: redo it binary
@@ -293,23 +429,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   lds_entry* const lds = st.lds;
   int             sp  = 0;
   StackEntry      spill[SPILL_LEVELS];
-  auto push = [&](int ref, float t0) {
-    StackEntry v = {ref, __float_as_int(t0)};
-    if (sp < LDS_LEVELS)
-      lds[sp * YT_BLOCK].ref = v.ref, lds[sp * YT_BLOCK].t0 = v.t0;
-    else if (sp < LDS_LEVELS + SPILL_LEVELS)
-      spill[sp - LDS_LEVELS] = v;
-    sp++;  // entries beyond 128 are dropped (the reference's array<int,128> would overflow)
-  };
-  auto pop = [&]() -> StackEntry {
-    sp--;
-    if (sp < LDS_LEVELS) {
-      StackEntry v;
-      v.ref = lds[sp * YT_BLOCK].ref, v.t0 = lds[sp * YT_BLOCK].t0;
-      return v;
-    }
-    return (sp < LDS_LEVELS + SPILL_LEVELS) ? spill[sp - LDS_LEVELS] : StackEntry{REF_EXIT, 0};
-  };
+  YT_STACK_OPS(LDS_LEVELS, SPILL_LEVELS)
 
   // intersect_shape_bvh prologue for instance `inst`: transform_ray(inverse(frame,
   // true), ray) (yocto_geometry.h:441-443) and the pop + slab test of the BLAS
@@ -386,9 +506,19 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
 
   const float4* pairs = sc.pairs;
   bool          done  = false;
+#ifdef YT_WALK_PROFILE
+  unsigned long long wp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool         wp_on = WIDE && only_instance < 0;
+  const long long    wp_tstart = __builtin_readcyclecounter();
+#endif
   while (!done) {
+#ifdef YT_WALK_PROFILE
+    long long wp_t0 = __builtin_readcyclecounter();
+#endif
     // ---- (1) descend: until this lane holds a leaf / instance entry ----------
     while (true) {
+      YT_WP(1, __popcll(__ballot(1)));
+      YT_WP(2, 1);
       if (cur == REF_NONE) {
         if (sp == 0) {
           done = true;
@@ -407,7 +537,28 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
 #endif
         if (cur == REF_NONE) continue;
       }
-      if ((unsigned)cur >= (unsigned)REF_INST) break;  // leaf, instance entry or exit → phase 2
+      if ((unsigned)cur >= (unsigned)REF_INST) {
+#ifdef YT_EARLY_BOOKKEEPING  // measured, mixed (-6 ... +5 %), off: profiles/r03_traversal_experiments.txt
+        // the cheap bookkeeping stays in the descend phase (a lock-step round of phase 2 costs every
+        // lane of the wavefront the instance-entry and the leaf code): leaving an instance ...
+        if (cur == REF_EXIT) {
+          cur = REF_NONE;
+          if (exit_instance()) {
+            done = true;
+            break;
+          }
+          continue;
+        }
+        // ... and expanding a TLAS leaf into its continuation entries (yocto_bvh.cpp:600-609)
+        if (cur < 0 && cur_inst < 0) {
+          const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+          for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
+          cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
+          continue;
+        }
+#endif
+        break;  // BLAS leaf or instance entry → phase 2
+      }
       if constexpr (WIDE) {
         // internal node, two levels at once: its grandchildren in the order the
         // reference's walk reaches them, each pushed with its own pop-time test
@@ -425,10 +576,10 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         cnt.steps++;
         float ta, tb, tc, td;
         // per slot {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axes}, like the pair records
-        bool  fa = slab<true>(o, dinv, tmin, {a0.x, a0.y, a1.x}, {a0.z, a0.w, a1.y}, ta);
-        bool  fb = slab<true>(o, dinv, tmin, {b0.x, b0.y, b1.x}, {b0.z, b0.w, b1.y}, tb);
-        bool  fc = slab<true>(o, dinv, tmin, {c0.x, c0.y, c1.x}, {c0.z, c0.w, c1.y}, tc);
-        bool  fd = slab<true>(o, dinv, tmin, {d0.x, d0.y, d1.x}, {d0.z, d0.w, d1.y}, td);
+        bool  fa = slab_rec(o, dinv, tmin, a0, a1, ta);
+        bool  fb = slab_rec(o, dinv, tmin, b0, b1, tb);
+        bool  fc = slab_rec(o, dinv, tmin, c0, c1, tc);
+        bool  fd = slab_rec(o, dinv, tmin, d0, d1, td);
         // slots: a, b = children of child 0 (or child 0 itself, then b is empty); c, d likewise for child 1
         int ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
         int rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;
@@ -446,19 +597,21 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         // last to first: whatever passed is pushed, the nearest one becomes `cur`
         int   pr = REF_NONE;
         float pt = 0;
+        YT_PF_DECL
         if (v3r != REF_NONE) pr = v3r, pt = v3t;
         if (v2r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
+          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
           pr = v2r, pt = v2t;
         }
         if (v1r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
+          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
           pr = v1r, pt = v1t;
         }
         if (v0r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
+          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
           pr = v0r, pt = v0t;
         }
+        YT_PF_ISSUE
         cur = pr;
         continue;
       }
@@ -493,7 +646,17 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         cur = n2 ? r2 : REF_NONE;
       }
     }
+#ifdef YT_WALK_PROFILE
+    {
+      long long wp_t1 = __builtin_readcyclecounter();
+      YT_WP(0, wp_t1 - wp_t0);
+      wp_t0 = wp_t1;
+    }
+#endif
     if (done) break;
+    YT_WP(5, 1);
+    YT_WP(4, __popcll(__ballot(cur < 0 && cur_inst >= 0)));
+    YT_WP(6, __popcll(__ballot(cur >= REF_INST || (cur < 0 && cur_inst < 0))));
 
     // ---- (2) leaves, instance entries ----------------------------------------
     if (cur >= REF_INST) {
@@ -528,6 +691,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       const float4* L = sc.leafdata + (leafbias + first * 3);
       // two triangles per round trip (the pool is padded, over-reads are ignored)
       for (int k0 = 0; k0 < num; k0 += 2) {
+        YT_WP(7, __popcll(__ballot(1)));
+        YT_WP(8, 1);
 #ifdef YT_NT_LEAF  // development builds: leaf data as a non-temporal stream (keeps trace_state lines in L2?)
         typedef float v4f __attribute__((ext_vector_type(4)));
         auto ntl = [](const float4* p) {
@@ -552,6 +717,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     } else if (kind == KIND_QUADS) {
       const float4* L = sc.leafdata + (leafbias + first * 4);
       for (int k = 0; k < num; k++) {
+        YT_WP(7, __popcll(__ballot(1)));
+        YT_WP(8, 1);
         float4 a = L[4 * k], b = L[4 * k + 1], c = L[4 * k + 2], e4 = L[4 * k + 3];
         if (COUNT) cnt.quads++;
         auto h = intersect_quad(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, {c.y, c.z, c.w});
@@ -560,6 +727,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     } else if (kind == KIND_LINES) {
       const float4* L = sc.leafdata + (leafbias + first * 3);
       for (int k = 0; k < num; k++) {
+        YT_WP(7, __popcll(__ballot(1)));
+        YT_WP(8, 1);
         float4 a = L[3 * k], b = L[3 * k + 1], c = L[3 * k + 2];
         if (COUNT) cnt.lines++;
         auto h = intersect_line(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
@@ -568,6 +737,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     } else if (kind == KIND_POINTS) {
       const float4* L = sc.leafdata + (leafbias + first * 2);
       for (int k = 0; k < num; k++) {
+        YT_WP(7, __popcll(__ballot(1)));
+        YT_WP(8, 1);
         float4 a = L[2 * k], b = L[2 * k + 1];
         if (COUNT) cnt.points++;
         auto h = intersect_point(o, d, tmin, tmax, {a.x, a.y, a.z}, a.w);
@@ -581,6 +752,16 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       if (exit_instance()) done = true;
     }
   }
+#ifdef YT_WALK_PROFILE
+  if (wp_on) {
+    // (cycles of phase 2 = total - phase 1; every lane carries the same wave-uniform sums, the
+    //  first active lane reports them)
+    wp[3] = (unsigned long long)((long long)__builtin_readcyclecounter() - wp_tstart);  // the whole walk
+    const unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
+      for (int k = 0; k < 9; k++) atomicAdd(&g_walkprof[k], wp[k]);
+  }
+#endif
   return best;
 }
 
@@ -608,23 +789,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
   lds_entry* const lds = st.lds;
   int             sp  = 0;
   StackEntry      spill[YT_SPILL];
-  auto push = [&](int ref, float t0) {
-    StackEntry v = {ref, __float_as_int(t0)};
-    if (sp < YT_LDS_DEPTH)
-      lds[sp * YT_BLOCK].ref = v.ref, lds[sp * YT_BLOCK].t0 = v.t0;
-    else if (sp < YT_LDS_DEPTH + YT_SPILL)
-      spill[sp - YT_LDS_DEPTH] = v;
-    sp++;
-  };
-  auto pop = [&]() -> StackEntry {
-    sp--;
-    if (sp < YT_LDS_DEPTH) {
-      StackEntry v;
-      v.ref = lds[sp * YT_BLOCK].ref, v.t0 = lds[sp * YT_BLOCK].t0;
-      return v;
-    }
-    return (sp < YT_LDS_DEPTH + YT_SPILL) ? spill[sp - YT_LDS_DEPTH] : StackEntry{REF_EXIT, 0};
-  };
+  YT_STACK_OPS(YT_LDS_DEPTH, YT_SPILL)
   auto enter = [&](int inst) -> int {
     const float4* ti = reinterpret_cast<const float4*>(sc.tinst + inst);
     float4        m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
@@ -716,10 +881,10 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
         float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
         cnt.steps++;
         float ta, tb, tc, td;
-        bool  fa = slab<true>(o, dinv, tmin, {a0.x, a0.y, a1.x}, {a0.z, a0.w, a1.y}, ta);
-        bool  fb = slab<true>(o, dinv, tmin, {b0.x, b0.y, b1.x}, {b0.z, b0.w, b1.y}, tb);
-        bool  fc = slab<true>(o, dinv, tmin, {c0.x, c0.y, c1.x}, {c0.z, c0.w, c1.y}, tc);
-        bool  fd = slab<true>(o, dinv, tmin, {d0.x, d0.y, d1.x}, {d0.z, d0.w, d1.y}, td);
+        bool  fa = slab_rec(o, dinv, tmin, a0, a1, ta);
+        bool  fb = slab_rec(o, dinv, tmin, b0, b1, tb);
+        bool  fc = slab_rec(o, dinv, tmin, c0, c1, tc);
+        bool  fd = slab_rec(o, dinv, tmin, d0, d1, td);
         int   ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
         int   rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;
         int   rc = (fc && tc <= tmaxk) ? __float_as_int(c1.z) : REF_NONE;
@@ -733,19 +898,21 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
         float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
         int   pr = REF_NONE;
         float pt = 0;
+        YT_PF_DECL
         if (v3r != REF_NONE) pr = v3r, pt = v3t;
         if (v2r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
+          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
           pr = v2r, pt = v2t;
         }
         if (v1r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
+          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
           pr = v1r, pt = v1t;
         }
         if (v0r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
+          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
           pr = v0r, pt = v0t;
         }
+        YT_PF_ISSUE
         cur = pr;
       }
     } else if (nL > 0 && nL * YT_PHASE_L >= nL + nE) {

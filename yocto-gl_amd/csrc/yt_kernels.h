@@ -1166,6 +1166,10 @@ __global__ void __launch_bounds__(YT_BLOCK,
   const TopLds* top = topl.rec ? &topl : nullptr;
   Stack     stack;
   YT_STACK_INIT(stack, s_stack);
+#ifdef YT_PREFETCH
+  __shared__ int s_pf_zone[YT_BLOCK];  // landing area of the software prefetches (never read)
+  stack.pf_zone = (unsigned)(size_t)(__attribute__((address_space(3))) int*)s_pf_zone;
+#endif
   Counters  cnt         = {0, 0, 0, 0, 0, 0, 0, 0};
   const int max_bounces = max_bounces_of<SAMPLER>(kp);
 
@@ -1430,7 +1434,11 @@ __global__ void __launch_bounds__(YT_BLOCK,
       }
     }
   }
+#ifdef YT_STACK_STATS
+  flush_counters(st.counters, cnt);
+#else
   if (COUNT || LP != LP_NONE) flush_counters(st.counters, cnt);
+#endif
   if (st.tile_cost && threadIdx.x == 0) {
     const long long dt = ((long long)__builtin_readcyclecounter() - t_tile0) >> 6;  // 64-cycle units fit 32 bits
     st.tile_cost[lb]   = (unsigned)(dt < 0 ? 0 : (dt > 0xffffffffll ? 0xffffffffll : dt));
@@ -1438,8 +1446,11 @@ __global__ void __launch_bounds__(YT_BLOCK,
 }
 
 // Test/parity entries ---------------------------------------------------------
+#ifndef YT_IB_WAVES  // development builds: occupancy of the traversal-only kernel (tools/traversal_occupancy.py)
+#define YT_IB_WAVES 1
+#endif
 template <bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(YT_BLOCK) k_intersect_batch(DScene sc, const ythip_ray* rays,
+__global__ void __launch_bounds__(YT_BLOCK, YT_IB_WAVES) k_intersect_batch(DScene sc, const ythip_ray* rays,
     const int* instances, long long n, int find_any, ythip_hit* hits, unsigned long long* counters) {
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   long long      idx = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;

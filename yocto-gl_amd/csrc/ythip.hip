@@ -850,7 +850,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   auto kp          = to_kparams(ctx, params);
   bool count       = (ctx->prof_mode & 2) != 0;
   ctx->st.counters = count ? ctx->d_counters : nullptr;
-#ifdef YT_TIMING
+#if defined(YT_TIMING) || defined(YT_STACK_STATS)
   ctx->st.counters = ctx->d_counters;
 #endif
   int  npix        = ctx->st.nslots;  // path-state arrays are per slot
@@ -2051,6 +2051,8 @@ static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_
       hipMemcpyAsync(d_inst, instances, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
     return cleanup(fail(ctx, YTHIP_ERR_HIP, "instance upload failed"));
   bool count = (ctx->prof_mode & 2) != 0;
+  {
+  EvScope ev(ctx, 0);  // profiling bit 0: the kernel alone (ythip_get_stats: trace_ms / trace_launches)
   if (count)
     hipLaunchKernelGGL((k_intersect_batch<true, false>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
         d_rays, d_inst, (long long)n, find_any, d_hits, ctx->d_counters);
@@ -2060,6 +2062,7 @@ static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_
   else
     hipLaunchKernelGGL((k_intersect_batch<false, false>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
         d_rays, d_inst, (long long)n, find_any, d_hits, (unsigned long long*)nullptr);
+  }
   if (hipMemcpyAsync(hits, d_hits, n * sizeof(ythip_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess)
     return cleanup(fail(ctx, YTHIP_ERR_HIP, "intersect batch failed: %s", hipGetErrorString(hipGetLastError())));
@@ -2229,6 +2232,20 @@ int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
         100 * t[14] / tot, 100 * t[15] / tot, 100 * t[8] / tot);
     std::fprintf(stderr, "[timing] traversal lane utilisation (sum of lane steps / 64 x longest lane): %.1f%%\n",
         t[7] ? 100.0 * t[6] / t[7] : 0.0);
+  }
+#endif
+#ifdef YT_WALK_PROFILE
+  {
+    unsigned long long w[16] = {};
+    HIPCHECK(ctx, hipMemcpyFromSymbol(w, HIP_SYMBOL(yt::g_walkprof), sizeof(w)));
+    unsigned long long zero[16] = {};
+    HIPCHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(yt::g_walkprof), zero, sizeof(zero)));
+    if (w[3])
+      std::fprintf(stderr,
+          "[walk] descend phase %.1f%% of the walk cycles, %.1f of 64 lanes per inner iteration | leaf/entry phase %.1f%%: "
+          "%.1f lanes with a BLAS leaf + %.1f with an entry per round, %.1f lanes per primitive round (%.2f rounds per leaf round)\n",
+          100.0 * w[0] / w[3], w[2] ? (double)w[1] / w[2] : 0.0, 100.0 * (w[3] - w[0]) / w[3], w[5] ? (double)w[4] / w[5] : 0.0,
+          w[5] ? (double)w[6] / w[5] : 0.0, w[8] ? (double)w[7] / w[8] : 0.0, w[5] ? (double)w[8] / w[5] : 0.0);
   }
 #endif
   *stats           = ctx->stats;
