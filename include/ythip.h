@@ -489,23 +489,6 @@ int ythip_set_early_miss(ythip_ctx* ctx, int enable);
  * (10 % faster on BASELINE configs[1]); 0: always the general kernel. */
 int ythip_set_specialization(ythip_ctx* ctx, int enable);
 
-/* The pool scheduler (no reference equivalent; results do not depend on it) — an
- * EXPERIMENT, off by default.  mode 0 (default): every batch runs on k_trace (one
- * wavefront per 16x4-pixel tile, lock-step extend / shade rounds); mode 1: whole-slice
- * batches of the `path` / `pathtest` samplers run on k_pool (yt_pool.h): persistent
- * wavefronts that each own up to 256 pixels, fetch rays dynamically inside the BVH walk,
- * park their walks around out-of-line shade passes and take tiles from a global counter.
- * Bit-identical trace_state (tests/test_gpu_round2.py); measured 0.75-0.9x k_trace's
- * speed on the incoherent BASELINE scenes and 0.45x on configs[1], hence
- * not the default.  waves / target / refill_min / shade_min / tile_mul tune it (0 keeps
- * the current value; see yt_pool.h DPool).  YTHIP_POOL=0/1 sets the default of new
- * contexts. */
-int ythip_set_pool(ythip_ctx* ctx, int mode, int waves, int target, int refill_min,
-    int shade_min, int tile_mul);
-/* Diagnostics of the last k_pool launch: per-wavefront debug words (yt_pool.h
- * POOL_DBG_*), summed and maximised over the wavefronts.  sums / maxs: 16 words each. */
-int ythip_pool_stats(ythip_ctx* ctx, uint64_t* sums, uint64_t* maxs);
-
 /* Which BVH walk k_trace's extend stage and the test entries below use: 0 the
  * binary walk (one sibling pair per dependent fetch), 1 the wide walk (the four
  * grandchildren per fetch: half the fetch chain, yt_bvh.h), 2 (default) chosen by

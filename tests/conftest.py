@@ -20,16 +20,3 @@ def _built_library():
         import __graft_entry__ as g
         g.build()
     yield
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _gpu_preflight(request, _built_library):
-    """Before the first GPU test: a sacrificial first GPU process (yocto-gl_amd/preflight.py —
-    on this pool the first GPU process of a fresh box sometimes dies of a device memory
-    fault that no later process reproduces).  Only when GPU tests were selected."""
-    selected = any(item.get_closest_marker("gpu") for item in request.session.items)
-    if selected:
-        sys.path.insert(0, os.path.join(ROOT, "yocto-gl_amd"))
-        import preflight
-        preflight.run(0)
-    yield

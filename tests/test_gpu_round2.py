@@ -1,5 +1,4 @@
-"""Round-2 additions, on the GPU through the C ABI: the pool scheduler (k_pool) gives
-k_trace's trace_state bit for bit; bounces <= 0; cancellation inside a batch; in-place
+"""Round-2 additions, on the GPU through the C ABI: bounces <= 0; cancellation inside a batch; in-place
 material / environment edits; the one-process multi-device API (ythip_multi) sharded over
 two ranks of one GPU; the deep-tree guard."""
 import ctypes as C
@@ -20,50 +19,6 @@ STATE_KEYS = ["image", "albedo", "normal", "hits", "rngs"]
 
 def _same_state(a, b):
     return all(a[k].tobytes() == b[k].tobytes() for k in STATE_KEYS)
-
-
-# ---------------------------------------------------------------------------
-# k_pool == k_trace
-# ---------------------------------------------------------------------------
-@pytest.mark.parametrize("name,res,spp", [("plane", 320, 8), ("materials", 160, 6), ("lines_points", 128, 6),
-                                          ("instances", 192, 6), ("cornell1m", 192, 6)])
-@pytest.mark.parametrize("sampler", ["path", "pathtest"])
-def test_pool_scheduler_is_bit_identical(name, res, spp, sampler):
-    """Same per-path arithmetic, another schedule (yt_pool.h): dynamic ray fetch, parked
-    walks, out-of-line shade passes, tiles from a global counter — and the same state.
-    Few wavefronts (many tiles each), several refill / in-flight settings, progressive
-    batches; cornell1m has area lights (deferred light-pdf passes), materials every lobe +
-    textures + volumes (general kernel), lines_points the non-triangle leaf kinds."""
-    flat = P.scene_cornell_1m(n=64) if name == "cornell1m" else P.SCENES[name]()
-    params = yt.trace_params(sampler=sampler, resolution=res, samples=spp, batch=spp // 2)
-    ctx = P.gpu_context(flat)
-    ctx.set_traversal("wide")  # (k_pool is the wide walk; tiny test trees would otherwise stay binary)
-    ctx.set_pool(0)
-    base = P.gpu_render(ctx, flat, params)
-    for waves, target, refill, shade_min in [(0, 128, 16, 64), (24, 192, 4, 32), (7, 64, 64, 8)]:
-        ctx.set_pool(1, waves, target, refill, shade_min)
-        got = P.gpu_render(ctx, flat, params)
-        stats, _ = ctx.pool_stats()
-        assert stats["iters"] > 0, "k_pool did not run"
-        assert stats["watchdog"] == 0
-        assert _same_state(base, got), (name, sampler, waves, target, refill, shade_min)
-    ctx.close()
-
-
-def test_pool_scheduler_row_and_column_slices():
-    flat = P.SCENES["plane"]()
-    params = yt.trace_params(sampler="path", resolution=256, samples=4, batch=4)
-    w, h = yt.state_size(flat.cameras[0], params.resolution)
-    rngs = yt.make_rngs(params.seed, w * h)
-    ctx = P.gpu_context(flat)
-    ctx.set_traversal("wide")
-    for rows, cols in [((h // 3, h), None), (None, (1, 3))]:
-        ctx.set_pool(0)
-        a = P.gpu_render(ctx, flat, params, rows=rows, cols=cols, rngs=rngs)
-        ctx.set_pool(1, 16, 128, 8, 64)
-        b = P.gpu_render(ctx, flat, params, rows=rows, cols=cols, rngs=rngs)
-        assert _same_state(a, b)
-    ctx.close()
 
 
 # ---------------------------------------------------------------------------
@@ -96,8 +51,7 @@ def test_zero_bounces_match_the_reference(sampler, scene):
 # ---------------------------------------------------------------------------
 # cancellation inside a batch (VERDICT r1 #4a)
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("pool", [0, 1])
-def test_cancel_inside_a_batch(pool):
+def test_cancel_inside_a_batch():
     """A batch that would run for seconds (the instanced scene, 1920x1080 x 2048 spp) is
     cancelled through the caller's stop flag: the call returns YTHIP_ERR_CANCELLED within
     50 ms of the flag going up, state.samples does not advance, every pixel has taken
@@ -105,7 +59,6 @@ def test_cancel_inside_a_batch(pool):
     import scenes as ysc
     flat = ysc.instanced_scene()
     ctx = P.gpu_context(flat)
-    ctx.set_pool(pool)
     params = yt.trace_params(sampler="path", resolution=1920, samples=1 << 20, batch=2048)
     ctx.make_trace_state(flat, params)
     stop = np.zeros(1, np.int32)
@@ -128,12 +81,11 @@ def test_cancel_inside_a_batch(pool):
     assert st["samples"] == 0
     assert 0 <= st["hits"].min() and st["hits"].max() <= params.batch and st["hits"].max() > 0
     assert np.isfinite(st["image"]).all()
-    # the next batch lowers the flag again and renders as a fresh context does
+    # the next batch has another number (nothing has to lower the flag) and renders as a fresh context does
     p2 = yt.trace_params(sampler="path", resolution=160, samples=2, batch=2)
     a = P.gpu_render(ctx, flat, p2)
     ctx.close()
     ctx2 = P.gpu_context(flat)
-    ctx2.set_pool(pool)
     b = P.gpu_render(ctx2, flat, p2)
     ctx2.close()
     assert _same_state(a, b)
@@ -263,6 +215,23 @@ def test_multi_device_api_equals_one_context(nranks):
     assert mode == ("none (one rank)" if nranks == 1 else "device copies") and ranks == 0
 
 
+def test_rccl_send_recv_branch_executes_on_one_device(monkeypatch):
+    """The framebuffer gather's RCCL branch (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd,
+    yt_multi.hip) on the hardware there is: YTHIP_GATHER=rccl-self builds a one-rank communicator
+    on device 0 and sends rank 0's slice to itself inside the group.  The gathered frame equals a
+    single context's, and ythip_multi_gather_info reports the path that ran + RCCL's rank count."""
+    monkeypatch.setenv("YTHIP_GATHER", "rccl-self")
+    flat = P.SCENES["plane"]()
+    params = yt.trace_params(sampler="path", resolution=300, samples=4, batch=2)
+    ctx = P.gpu_context(flat)
+    one = P.gpu_render(ctx, flat, params)
+    ctx.close()
+    st, img, samples, mode, ranks = _multi_render(flat, params, [0])
+    assert samples == 4
+    assert img.tobytes() == one["image"].tobytes()
+    assert mode == "rccl send/recv (incl. rank 0 to itself)" and ranks == 1
+
+
 def test_multi_device_api_errors():
     lib = yt.load_library()
     m = C.c_void_p()
@@ -278,23 +247,63 @@ def test_multi_device_api_errors():
     lib.ythip_destroy_multi(m)
 
 
-# ---- NEE samplers: deferred walks (default) vs the inline kernels -------------------------------
-@pytest.mark.parametrize("sampler", ["pathdirect", "pathmis"])
-@pytest.mark.parametrize("scene", ["cornellbox", "materials", "lines_points"])
-def test_deferred_nee_equals_inline_nee(sampler, scene, monkeypatch):
-    """pathdirect / pathmis run their light-pdf walks, NEE rays and NEE emission in the walk
-    stage of k_trace (LP_DEFER) by default; YTHIP_NEE_INLINE=1 selects the kernels that do
-    them inside the shade step.  Same draws in the same order, same sums: identical state
-    (and both equal the reference: tests/test_gpu_parity.py runs the default)."""
-    flat = P.SCENES[scene]()
-    p = yt.trace_params(sampler=sampler, resolution=160, samples=6, batch=3)
-    out = []
-    for inline in ["0", "1"]:
-        monkeypatch.setenv("YTHIP_NEE_INLINE", inline)
-        ctx = P.gpu_context(flat)
-        out.append(P.gpu_render(ctx, flat, p))
-        ctx.close()
-    P.assert_identical(out[0], out[1], f"{sampler} {scene}")
+# ---- deep trees: the shared 128-entry stack ------------------------------------------------------
+def _chain_scene_and_tree(n):
+    """n well-separated triangles along x and a hand-made DEGENERATE tree over them: a chain in
+    which every internal node has one leaf child and one internal child (depth n) — what a
+    pathological builder could hand to upload_bvh."""
+    flat = yt.FlatScene()
+    flat.add_camera(yt.IDENTITY_FRAME)
+    x = np.arange(n, dtype="f4")[:, None] * 2.0
+    p0 = np.concatenate([x, np.zeros((n, 2), "f4")], 1)
+    positions = np.concatenate([p0, p0 + [1, 0, 0], p0 + [0, 1, 0]]).astype("f4")
+    tris = np.stack([np.arange(n), np.arange(n) + n, np.arange(n) + 2 * n], 1).astype("i4")
+    sh = flat.add_shape(positions, triangles=tris)
+    m = flat.add_material(color=(0.5, 0.5, 0.5))
+    flat.add_instance(sh, m)
+    flat.add_environment((1, 1, 1))
+    lo = np.minimum(np.minimum(positions[tris[:, 0]], positions[tris[:, 1]]), positions[tris[:, 2]])
+    hi = np.maximum(np.maximum(positions[tris[:, 0]], positions[tris[:, 1]]), positions[tris[:, 2]])
+    nodes = np.zeros(2 * n - 1, yt.node_dt)
+    # node 2k: internal (k < n - 1) covering triangles k..n-1; node 2k + 1: leaf of triangle k;
+    # the last internal node's second child is the leaf of triangle n - 1
+    for k in range(n - 1):
+        nd = nodes[2 * k]
+        nd["bbox_min"], nd["bbox_max"] = lo[k:].min(0), hi[k:].max(0)
+        nd["start"], nd["num"], nd["axis"], nd["internal"] = 2 * k + 1, 2, 0, 1
+        lf = nodes[2 * k + 1]
+        lf["bbox_min"], lf["bbox_max"], lf["start"], lf["num"] = lo[k], hi[k], k, 1
+    last = nodes[2 * n - 2]
+    last["bbox_min"], last["bbox_max"], last["start"], last["num"] = lo[n - 1], hi[n - 1], n - 1, 1
+    tl = np.zeros(1, yt.node_dt)
+    tl["bbox_min"], tl["bbox_max"], tl["start"], tl["num"] = lo.min(0), hi.max(0), 0, 1
+    bvh = yt.FlatBvh([0, 2 * n - 1, 2 * n], [0, n, n + 1], np.concatenate([nodes, tl]),
+                     np.concatenate([np.arange(n, dtype="i4"), np.zeros(1, "i4")]))
+    return flat, bvh
+
+
+def test_trees_too_deep_for_the_wide_walk_are_walked_binary_and_deeper_ones_refused():
+    """One 128-entry stack serves the instance tree and the shape tree.  A chain of depth 100 passes
+    the reference-shaped bound (100 + 1 + 5 <= 128) but not the wide walk's (3 pending siblings per
+    two levels: ADVICE r2) — it is walked binary, with the hit records of the builder's balanced
+    tree over the same triangles.  Depth 130 would overflow the reference's own stack: refused."""
+    flat, chain = _chain_scene_and_tree(100)
+    rays = P.random_rays(flat, 20000)
+    ctx = P.gpu_context(flat)
+    want = ctx.intersect_batch(rays)
+    ctx.upload_bvh(chain)
+    for mode in ["auto", "wide", "binary"]:
+        ctx.set_traversal(mode)
+        got = ctx.intersect_batch(rays)
+        assert P.hits_equal(want, got), mode
+    ctx.close()
+    assert int(want["hit"].sum()) > 100
+    flat, chain = _chain_scene_and_tree(130)
+    ctx = P.gpu_context(flat)
+    with pytest.raises(yt.YthipError) as e:
+        ctx.upload_bvh(chain)
+    assert "too deep" in str(e.value)
+    ctx.close()
 
 
 # ---- random scenes x random parameters vs the live reference -------------------------------------

@@ -82,28 +82,10 @@ struct Stack {
 };
 #define YT_STACK_INIT(stack, s_stack) (stack).lds = (lds_entry*)&(s_stack)[0][threadIdx.x]
 
-// LDS staging of the top of the largest tree (north star: "BVH nodes ... staged through LDS").
-// A workgroup copies the root's quad record and the quad records of its (up to) 4 + 16
-// internal grandchildren — the top four tree levels, 21 x 128 B — into LDS once, and rewrites
-// the refs inside the copies so that a ref to a staged record carries its slot in bits 24-29
-// ((slot + 1) << 24; pair ids must be < 2^24).  The wide walk then reads a record from LDS
-// whenever the ref it holds is tagged — no lookup, the tag travels with the ref through the
-// stack — and from global memory otherwise.  Same records, same order: same hit records.
-// MEASURED AND REJECTED: bit-identical, and 15-18 % slower on every BASELINE scene
-// (the 2.7 KB cost a quarter of the resident workgroups, and the top of the tree is L1-resident
-// anyway); no gain on the latency-bound N = 8 slice either.  Compiled in only with -DYT_LDS_TOP
-// (tools/devbuild.sh NAME -DYT_LDS_TOP, YTHIP_LDS_TOP=1 at run time).
-#ifdef YT_LDS_TOP
-constexpr bool TOP_STAGING = true;
-#else
-constexpr bool TOP_STAGING = false;
-#endif
-constexpr int TOP_SLOTS = 21, TOP_TAG_SHIFT = 24, TOP_ID_MASK = (1 << TOP_TAG_SHIFT) - 1;
+// (An LDS copy of the top four tree levels — north star: "BVH nodes staged through LDS" — was built and
+// measured 15-18 % slower on every BASELINE scene: the top of the tree is L1-resident anyway and the
+// staging costs a prologue per workgroup plus a branch per step.  tools/experiments/README.md.)
 typedef __attribute__((address_space(3))) float4 lds_float4;
-struct TopLds {
-  const float* rec;  // LDS: TOP_SLOTS records of 8 float4 (nullptr: staging off)
-  int          root; // pair id of the staged root
-};
 
 // push / pop of the per-lane stack (locals `lds`, `sp`, `spill`, `cnt` of the enclosing walk).
 //   default:        entries [0, L) in the lane's LDS column, [L, L + S) in scratch
@@ -390,12 +372,10 @@ __device__ unsigned long long g_walkprof[16];
 constexpr int HIT_ABORT = -2;  // Hit::instance of a wide walk that met an irregular ray: redo it binary
 
 // LDSD: stack entries per lane kept in the LDS column of `st` (the rest, up to the
-// reference's 128, in scratch).  0 = a walk that leaves the LDS stack alone — k_pool
-// runs sample_lights_pdf's walks that way while other lanes' scene walks are suspended
-// with their stack columns live.
+// reference's 128, in scratch).  0 = a walk that leaves the LDS stack alone.
 template <bool COUNT, bool WIDE = false, bool TRI = false, int LDSD = YT_LDS_DEPTH>
 YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
-    Counters& cnt, const TopLds* top = nullptr) {
+    Counters& cnt) {
   constexpr int LDS_LEVELS = LDSD, SPILL_LEVELS = 128 - LDSD;
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   Hit best = {-1, -1, 0, 0, 0, false};
@@ -442,9 +422,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     int4          m5 = reinterpret_cast<const int4*>(ti)[5];
     int           root = __float_as_int(m4.z);
     if (root == REF_NONE) return REF_NONE;
-    if constexpr (WIDE) {
-      if (TOP_STAGING && top && root == top->root) root |= 1 << TOP_TAG_SHIFT;  // its quad record is staged in LDS
-    }
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
     vec3f   io   = transform_point(inv, wo);
     vec3f   id   = transform_vector(inv, wd);
@@ -491,9 +468,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     float t0;
     if (!(slab<false>(o, dinv, tmin, sc.tlas_bmin, sc.tlas_bmax, t0) && t0 <= tmaxk)) return best;
     cur = sc.tlas_ref;
-    if constexpr (WIDE) {
-      if (TOP_STAGING && top && cur == top->root) cur |= 1 << TOP_TAG_SHIFT;
-    }
   }
 
   auto accept = [&](int element, const PrimHit& h) {
@@ -562,17 +536,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       if constexpr (WIDE) {
         // internal node, two levels at once: its grandchildren in the order the
         // reference's walk reaches them, each pushed with its own pop-time test
-        float4 a0, a1, b0, b1, c0, c1, d0, d1;
-        if (TOP_STAGING && top && (cur >> TOP_TAG_SHIFT)) {  // a staged record: from LDS
-          const lds_float4* Ql = (const lds_float4*)top->rec + 8 * ((cur >> TOP_TAG_SHIFT) - 1);
-          a0 = {Ql[0].x, Ql[0].y, Ql[0].z, Ql[0].w}, a1 = {Ql[1].x, Ql[1].y, Ql[1].z, Ql[1].w};
-          b0 = {Ql[2].x, Ql[2].y, Ql[2].z, Ql[2].w}, b1 = {Ql[3].x, Ql[3].y, Ql[3].z, Ql[3].w};
-          c0 = {Ql[4].x, Ql[4].y, Ql[4].z, Ql[4].w}, c1 = {Ql[5].x, Ql[5].y, Ql[5].z, Ql[5].w};
-          d0 = {Ql[6].x, Ql[6].y, Ql[6].z, Ql[6].w}, d1 = {Ql[7].x, Ql[7].y, Ql[7].z, Ql[7].w};
-        } else {
-          const float4* Qp = sc.wide + 8 * (int64_t)cur;
-          a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
-        }
+        const float4* Qp = sc.wide + 8 * (int64_t)cur;
+        float4        a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
         cnt.steps++;
         float ta, tb, tc, td;
         // per slot {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axes}, like the pair records
@@ -971,7 +936,7 @@ constexpr bool PHASED_DEFAULT = false;
 #endif
 template <bool COUNT, bool WIDE, bool TRI = false, bool PHASED = PHASED_DEFAULT>
 YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
-    Counters& cnt, const TopLds* top = nullptr) {
+    Counters& cnt) {
   if constexpr (WIDE && !COUNT) {
     if constexpr (PHASED) {
       if (!find_any) {
@@ -979,7 +944,7 @@ YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, b
         if (h.instance != HIT_ABORT) return h;
       }
     } else {
-      Hit h = traverse<false, true, TRI>(sc, wray, only_instance, find_any, st, cnt, top);
+      Hit h = traverse<false, true, TRI>(sc, wray, only_instance, find_any, st, cnt);
       if (h.instance != HIT_ABORT) return h;
     }
   }

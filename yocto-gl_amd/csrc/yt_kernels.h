@@ -49,8 +49,9 @@ enum {
 // How sample_lights_pdf's instance walks are executed
 enum {
   LP_NONE   = 0,  // scene has no area lights: no traversal needed
-  LP_INLINE = 1,  // walks (and NEE rays) inline in k_shade   (pathdirect / pathmis)
-  LP_DEFER  = 2,  // walks deferred to k_lightpdf             (path / pathtest with area lights)
+  LP_DEFER  = 2,  // walks (and the NEE rays of pathdirect / pathmis) run in the walk stage of k_trace
+  // (1 was LP_INLINE — walks inside the shade step, round 1's pathdirect / pathmis kernels: 1.2-1.4x
+  //  slower and 1300+ spilled registers; tools/experiments/README.md)
 };
 
 // Device mirror of trace_state (yocto_trace.h:147-157) + wavefront path state.
@@ -93,19 +94,14 @@ struct DState {
   // cancellation: a device-visible flag the host raises when the caller's `stop` goes up
   // (yocto_trace.cpp:1636-1637 polls context.stop per sample); may be null
   const int* stop;
-  // XCD-banded tile queues (experiment): tiles grouped into 8 compact bands, one
-  // per XCD (= per L2); a workgroup takes the next tile of its own XCD's band and steals from
-  // the others when that is empty.  null: identity mapping.
+  int        stop_gen;  // this batch's number: the batch stops when *stop equals it (ythip.hip, begin_batch)
   // longest-tile-first launch order (yt_order.hip): workgroup b renders tile tile_perm[b]; every
   // workgroup records the cycles its tile took for the next launch's order.  null: off.
   const int* tile_perm;
   unsigned*  tile_cost;
-  const int* tile_order;   // nblocks tile ids, band after band
-  int*       band_next;    // 8 counters, zeroed before the launch
-  int        band_start[9];
 };
-YT_FN bool stop_requested(const int* stop) {
-  return stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+YT_FN bool stop_requested(const int* stop, int gen) {
+  return stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen;
 }
 
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_QUADS, CNT_LINES, CNT_POINTS, CNT_INST, CNT_SHADES, CNT_SAMPLES, CNT_NUM };
@@ -115,7 +111,6 @@ struct KParams {
   float clamp;
   int   nocaustics, envhidden, tentfilter;
   int   has_env;  // !scene.environments.empty()
-  int   lds_top;  // 1: stage the top of the largest tree in LDS (k_trace's dynamic LDS, TopLds)
   int   hold;     // scheduling policy of k_trace (0 off, 1 hold back partial primary wavefronts)
   int   peek;     // resolve a continuing path's root-box miss in place (resolve_step), 0 off
 };
@@ -150,19 +145,6 @@ YT_FN int logical_block(const DState& st) {
     return b == 0 ? (jl / YT_TILE_H) * st.tiles_x + il / YT_TILE : -1;
   }
   if (st.tile_perm) return st.tile_perm[b];
-  if (st.tile_order) {  // (one wavefront per workgroup: lane 0 claims, everybody reads)
-    int tile = -1;
-    if (threadIdx.x == 0) {
-      const int xcd = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);  // HW_REG_XCC_ID[3:0]
-      for (int k = 0; k < 8 && tile < 0; k++) {
-        const int band = (xcd + k) & 7, size = st.band_start[band + 1] - st.band_start[band];
-        if (size <= 0) continue;
-        const int t = atomicAdd(&st.band_next[band], 1);
-        if (t < size) tile = st.tile_order[st.band_start[band] + t];
-      }
-    }
-    return __builtin_amdgcn_readfirstlane(tile);
-  }
   return b;
 }
 
@@ -208,13 +190,6 @@ YT_FN void count_lanes(unsigned long long* c, int idx) {
   if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&c[cnt_bank() + idx], (unsigned long long)__popcll(m));
 }
 
-// Out-of-line traversal for LP_INLINE shading (several call sites, one copy).
-__device__ __noinline__ Hit trace_ray(const DScene& sc, vec3f o, vec3f d, int only_instance, Stack& st,
-    Counters& cnt, bool wide) {
-  ray3f ray = make_ray(o, d);
-  if (wide) return traverse_any<false, true>(sc, ray, only_instance, false, st, cnt);  // same hit record (tested)
-  return traverse<true>(sc, ray, only_instance, false, st, cnt);
-}
 // ---------------------------------------------------------------------------
 // shading-point helpers
 // ---------------------------------------------------------------------------
@@ -270,12 +245,9 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
 }
 
 // sample_lights_pdf — yocto_trace.cpp:391-443.  WALK: 0 = no instance lights in
-// the scene, 1 = walks through the out-of-line trace_ray, 2 = walks inline, 3 = walks
-// inline with their stack in scratch only (k_pool: the LDS stack columns belong to
-// suspended scene walks).
+// the scene (no traversal code at all), 2 = the instance walks inline (the walk stage of k_trace).
 template <int WALK, bool COUNT = true>
-YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt,
-    bool wide = false) {
+YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt) {
   auto pdf = 0.0f;
   for (int l = 0; l < sc.num_lights; l++) {
     const auto& light = sc.lights[l];
@@ -288,16 +260,8 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
         auto        next_position = position;
         auto        area          = sc.cdf[light.cdf_offset + light.cdf_count - 1];
         for (auto bounce = 0; bounce < 100; bounce++) {
-          Hit isec;
-          if constexpr (WALK == 1) {
-            isec = trace_ray(sc, next_position, direction, light.instance, *st, *cnt, wide);
-          } else if constexpr (WALK == 3) {
-            ray3f ray = make_ray(next_position, direction);
-            isec      = traverse<true, false, false, 0>(sc, ray, light.instance, false, *st, *cnt);
-          } else {
-            ray3f ray = make_ray(next_position, direction);
-            isec      = traverse<COUNT>(sc, ray, light.instance, false, *st, *cnt);  // (counts only in the counting launch)
-          }
+          ray3f ray  = make_ray(next_position, direction);
+          Hit   isec = traverse<COUNT>(sc, ray, light.instance, false, *st, *cnt);  // (counts only in the counting launch)
           if (!isec.hit) break;
           auto e         = load_element(sc, sh, isec.element);
           auto lposition = eval_position(sc, frame, sh, e, {isec.u, isec.v});
@@ -354,10 +318,7 @@ struct ShadeEnv {
   const DScene&  sc;
   const DState&  st;
   const KParams& kp;
-  Stack*         stack;  // LP_INLINE only
-  Counters*      cnt;    // LP_INLINE only
   int            slot;
-  bool           wide = false;  // LP_INLINE: the out-of-line walks may use the wide records
 #ifdef YT_TIMING
   long long t_geo = 0;  // cycle counter after the shading point has been evaluated
 #endif
@@ -427,7 +388,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
   constexpr bool MIS     = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   constexpr bool TEST    = SAMPLER == YTHIP_SAMPLER_PATHTEST;
   constexpr bool VOLUMES = !TEST && !MATTE;
-  static_assert(!(DIRECT || MIS) || LP != LP_NONE, "NEE samplers: NEE inline (LP_INLINE) or deferred (LP_DEFER)");
+  static_assert(!(DIRECT || MIS) || LP == LP_DEFER, "the NEE samplers run their walks in the walk stage");
   const bool next_emission = !(P.flags & PF_NOEMIT);
 
   auto& isec = P.isec;
@@ -500,21 +461,13 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
         auto rel      = rand1f(P.rng);
         auto rl       = rand1f(P.rng);
         auto incoming = sample_lights(sc, position, rl, rel, ruv);
-        if constexpr (LP == LP_DEFER) {
+        {
           // the light pdf (walks), the NEE ray and its emission have no rng draws and touch
           // nothing but P.radiance: they run in the walk stage, before the weight update
           auto bsdfcos       = eval_bsdfcos(material, normal, outgoing, incoming);
           E.st.nee_a[E.slot] = {incoming.x, incoming.y, incoming.z, __int_as_float(1)};
           E.st.nee_b[E.slot] = {bsdfcos.x, bsdfcos.y, bsdfcos.z, 0};
           nee_pending        = 1;
-        } else {
-          auto pdf     = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt, E.wide);
-          auto bsdfcos = eval_bsdfcos(material, normal, outgoing, incoming);
-          if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
-            auto nisec    = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt, E.wide);
-            auto emission = nee_emission(sc, nisec, incoming);
-            P.radiance += P.weight * bsdfcos * emission / pdf;
-          }
         }
         P.flags |= PF_NOEMIT;
       } else {
@@ -526,7 +479,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     auto incoming = vec3f{0, 0, 0};
     bool deferred = false;
     if (!is_delta(material)) {
-      if constexpr (MIS && LP == LP_DEFER) {
+      if constexpr (MIS) {
         // direct with MIS — yocto_trace.cpp:853-892 — with the walks deferred: both directions are
         // drawn and their lobe terms evaluated here (all the rng draws, in order); the light pdfs,
         // the two NEE rays, next_intersection and the emission run in the walk stage
@@ -544,8 +497,9 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
             incoming = sample_bsdfcos(material, normal, outgoing, rnl, rn);
           }
           if (incoming == vec3f{0, 0, 0}) break;
-          auto bsdfcos  = eval_bsdfcos(material, normal, outgoing, incoming);
-          auto bsdf_pdf = sample_bsdfcos_pdf(material, normal, outgoing, incoming);
+          auto lobe     = eval_lobe(material, normal, outgoing, incoming);
+          auto bsdfcos  = lobe.f;
+          auto bsdf_pdf = lobe.pdf;
           if (pass == 0)
             ma = {incoming.x, incoming.y, incoming.z, bsdf_pdf}, mb = {bsdfcos.x, bsdfcos.y, bsdfcos.z, 0};
           else
@@ -553,50 +507,12 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           mflags |= 1 << pass;
         }
         // indirect: the factor of the weight update, applied after the NEE contributions
-        auto wfac = eval_bsdfcos(material, normal, outgoing, incoming) /
-                    sample_bsdfcos_pdf(material, normal, outgoing, incoming);
+        auto wl   = eval_lobe(material, normal, outgoing, incoming);
+        auto wfac = wl.f / wl.pdf;
         mb.w               = __int_as_float(mflags);
         E.st.nee_a[E.slot] = ma, E.st.nee_b[E.slot] = mb, E.st.nee_c[E.slot] = mc, E.st.nee_d[E.slot] = md;
         E.st.nee_e[E.slot] = {wfac.x, wfac.y, wfac.z, 0};
         deferred           = true;
-        P.flags |= PF_NOEMIT;
-      } else if constexpr (MIS) {
-        // direct with MIS — yocto_trace.cpp:853-892
-        for (int pass = 0; pass < 2; pass++) {
-          const bool sample_light = pass == 0;
-          if (sample_light) {
-            auto ruv = rand2f(P.rng);
-            auto rel = rand1f(P.rng);
-            auto rl  = rand1f(P.rng);
-            incoming = sample_lights(sc, position, rl, rel, ruv);
-          } else {
-            auto rn  = rand2f(P.rng);  // g++ order: rn, rnl
-            auto rnl = rand1f(P.rng);
-            incoming = sample_bsdfcos(material, normal, outgoing, rnl, rn);
-          }
-          if (incoming == vec3f{0, 0, 0}) break;
-          auto bsdfcos    = eval_bsdfcos(material, normal, outgoing, incoming);
-          auto light_pdf  = sample_lights_pdf<1>(sc, position, incoming, E.stack, E.cnt, E.wide);
-          auto bsdf_pdf   = sample_bsdfcos_pdf(material, normal, outgoing, incoming);
-          auto heur       = [](float this_pdf, float other_pdf) {
-            return (this_pdf * this_pdf) / (this_pdf * this_pdf + other_pdf * other_pdf);
-          };
-          auto mis_weight = sample_light ? heur(light_pdf, bsdf_pdf) / light_pdf
-                                         : heur(bsdf_pdf, light_pdf) / bsdf_pdf;
-          if (bsdfcos != vec3f{0, 0, 0} && mis_weight != 0) {
-            auto nisec = trace_ray(sc, position, incoming, -1, *E.stack, *E.cnt, E.wide);
-            if (!sample_light) {
-              // next_intersection = intersection (persists across bounces)
-              E.st.nhit_a[E.slot] = {nisec.u, nisec.v, nisec.distance, __int_as_float(nisec.hit ? nisec.instance : -1)};
-              E.st.nhit_e[E.slot] = nisec.element;
-            }
-            auto emission = nee_emission(sc, nisec, incoming);
-            P.radiance += P.weight * bsdfcos * emission * mis_weight;
-          }
-        }
-        // indirect
-        P.weight *= eval_bsdfcos(material, normal, outgoing, incoming) /
-                    sample_bsdfcos_pdf(material, normal, outgoing, incoming);
         P.flags |= PF_NOEMIT;
       } else {
         if (rand1f(P.rng) < 0.5f) {
@@ -610,21 +526,21 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
           incoming = sample_lights(sc, position, rl, rel, ruv);
         }
         if (incoming == vec3f{0, 0, 0}) {
-          if (DIRECT && LP == LP_DEFER && nee_pending) {  // the path ends, its NEE contribution is still owed
+          if (DIRECT && nee_pending) {  // the path ends, its NEE contribution is still owed
             E.st.nee_a[E.slot].w = __int_as_float(2);
             P.o                  = position;
             return STEP_DEFER;
           }
           return STEP_END;
         }
-        auto f     = eval_bsdfcos(material, normal, outgoing, incoming);
-        auto pdf_a = sample_bsdfcos_pdf(material, normal, outgoing, incoming);
+        auto lobe  = eval_lobe(material, normal, outgoing, incoming);  // f and its pdf from one evaluation (yt_shading.h)
+        auto f     = lobe.f;
+        auto pdf_a = lobe.pdf;
         if constexpr (LP == LP_DEFER) {
           E.st.pend[E.slot] = {f.x, f.y, f.z, pdf_a};
           deferred          = true;
         } else {
-          P.weight *= f / (0.5f * pdf_a + 0.5f * sample_lights_pdf<LP == LP_INLINE ? 1 : 0>(
-                                                     sc, position, incoming, E.stack, E.cnt));
+          P.weight *= f / (0.5f * pdf_a + 0.5f * sample_lights_pdf<0>(sc, position, incoming, nullptr, nullptr));
         }
       }
     } else {
@@ -668,8 +584,9 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
       if (MIS) P.flags &= ~PF_NOEMIT;
     }
     if (!MIS && incoming == vec3f{0, 0, 0}) return STEP_END;
-    auto f     = eval_scattering(vsdf, outgoing, incoming);
-    auto pdf_a = sample_scattering_pdf(vsdf, outgoing, incoming);
+    auto medium = eval_medium(vsdf, outgoing, incoming);
+    auto f      = medium.f;
+    auto pdf_a  = medium.pdf;
     P.o        = position;
     P.d        = incoming;
     if constexpr (LP == LP_DEFER) {
@@ -678,8 +595,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
       if constexpr (MIS) E.st.nee_b[E.slot].w = __int_as_float(4);     // the mixture terms of `pend` apply
       return STEP_DEFER;
     } else {
-      P.weight *= f / (0.5f * pdf_a + 0.5f * sample_lights_pdf<LP == LP_INLINE ? 1 : 0>(
-                                                 sc, position, incoming, E.stack, E.cnt));
+      P.weight *= f / (0.5f * pdf_a + 0.5f * sample_lights_pdf<0>(sc, position, incoming, nullptr, nullptr));
     }
   }
   return step_tail(P);
@@ -724,8 +640,8 @@ YT_FN int step_naive(ShadeEnv& E, Path& P) {
     auto rnl = rand1f(P.rng);
     incoming = sample_bsdfcos(material, normal, outgoing, rnl, rn);
     if (incoming == vec3f{0, 0, 0}) return STEP_END;
-    P.weight *= eval_bsdfcos(material, normal, outgoing, incoming) /
-                sample_bsdfcos_pdf(material, normal, outgoing, incoming);
+    auto lobe = eval_lobe(material, normal, outgoing, incoming);
+    P.weight *= lobe.f / lobe.pdf;
   } else {
     incoming = sample_delta(material, normal, outgoing, rand1f(P.rng));
     if (incoming == vec3f{0, 0, 0}) return STEP_END;
@@ -1088,18 +1004,11 @@ YT_FN int max_bounces_of(const KParams& kp) {
 #define YT_WAVES_PER_EU 4
 #endif
 template <int SAMPLER, int LP, bool COUNT, bool WIDE, int CLS = 0>
-// The NEE samplers (pathdirect, pathmis: LP_INLINE) evaluate lobes, light pdfs (walks) and a
-// second emission inside one shade step; at 128 VGPRs they spill 1300-1600 registers.  Two
-// waves per SIMD (256 VGPRs, 250-290 spilled) is 14 % (pathdirect) to 28-40 % (pathmis)
-// faster; three (168) was miscompiled by ROCm 7.2 (a wrong constant in image.z), DESIGN.md §6.
-#ifndef YT_WAVES_PER_EU_NEE
-#define YT_WAVES_PER_EU_NEE 2
-#endif
 #ifndef YT_WAVES_PER_EU_GENERAL  // experiment: occupancy of the general-class kernels
 #define YT_WAVES_PER_EU_GENERAL YT_WAVES_PER_EU
 #endif
 __global__ void __launch_bounds__(YT_BLOCK,
-    (LP == LP_INLINE ? YT_WAVES_PER_EU_NEE : (CLS == 0 && !COUNT ? YT_WAVES_PER_EU_GENERAL : YT_WAVES_PER_EU)))
+    (CLS == 0 && !COUNT ? YT_WAVES_PER_EU_GENERAL : YT_WAVES_PER_EU))
     k_trace(DScene sc, DState st, KParams kp) {
   constexpr bool MATTE = CLS == 1;
   // majority-phase scene walk (yt_bvh.h::traverse_phased) for the kernels where it wins:
@@ -1128,42 +1037,9 @@ __global__ void __launch_bounds__(YT_BLOCK,
 #endif
   const int lb = logical_block(st);
   if (lb < 0) return;
-  if (stop_requested(st.stop)) return;  // cancelled before this tile started
+  if (stop_requested(st.stop, st.stop_gen)) return;  // cancelled before this tile started
   const long long t_tile0 = st.tile_cost ? (long long)__builtin_readcyclecounter() : 0;
   const int tid = threadIdx.x;
-  // LDS staging of the top four levels of the largest tree (dynamic LDS, only when asked for)
-  extern __shared__ float4 s_top[];
-  TopLds topl = {nullptr, -1};
-  if constexpr (WIDE && TOP_STAGING) {
-    if (kp.lds_top && sc.top_root >= 0) {
-      // slot 0: the root's record; slots 1-4: its internal grandchildren; slots 5-20: theirs
-      for (int k = tid; k < TOP_SLOTS * 8; k += YT_BLOCK) s_top[k] = {0, 0, __int_as_float(REF_NONE), 0};
-      __syncthreads();
-      if (tid < 8) s_top[tid] = sc.wide[8 * (int64_t)sc.top_root + tid];
-      __syncthreads();
-      for (int level = 0; level < 2; level++) {
-        const int nsrc = level == 0 ? 1 : 4, src0 = level == 0 ? 0 : 1, dst0 = level == 0 ? 1 : 5;
-        // (source slot s, child c) -> destination slot dst0 + 4 (s - src0) + c
-        for (int k = tid; k < nsrc * 4 * 8; k += YT_BLOCK) {
-          const int s = k / 32, c = (k / 8) & 3, part = k & 7;
-          const int ref = __float_as_int(s_top[(src0 + s) * 8 + 2 * c + 1].z);
-          if (ref >= 0 && ref < REF_INST && ref <= TOP_ID_MASK)
-            s_top[(dst0 + 4 * s + c) * 8 + part] = sc.wide[8 * (int64_t)ref + part];
-        }
-        __syncthreads();
-        // tag the refs of the source slots whose targets are now staged
-        for (int k = tid; k < nsrc * 4; k += YT_BLOCK) {
-          const int s = k / 4, c = k & 3;
-          float4&   r = s_top[(src0 + s) * 8 + 2 * c + 1];
-          const int ref = __float_as_int(r.z);
-          if (ref >= 0 && ref < REF_INST && ref <= TOP_ID_MASK) r.z = __int_as_float(ref | ((dst0 + 4 * s + c + 1) << TOP_TAG_SHIFT));
-        }
-        __syncthreads();
-      }
-      topl = {reinterpret_cast<const float*>(s_top), sc.top_root};
-    }
-  }
-  const TopLds* top = topl.rec ? &topl : nullptr;
   Stack     stack;
   YT_STACK_INIT(stack, s_stack);
 #ifdef YT_PREFETCH
@@ -1217,7 +1093,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
     // as much (interiors) everything runs at once, which keeps the lanes full.  The
     // workgroup decides from the traversal work it has measured itself; results do
     // not depend on the decision (pixels are independent).
-    const bool stopped = stop_requested(st.stop);  // once per iteration = at most one sample late
+    const bool stopped = stop_requested(st.stop, st.stop_gen);  // once per iteration = at most one sample late
     bool wait = false;
     if (kp.hold && n.y > 0 && n.x > 0) {
       float wp = (float)Q.work[0], rp = (float)Q.rays[0], wb = (float)Q.work[1], rb_ = (float)Q.rays[1];
@@ -1253,7 +1129,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
       } else {
         ray3f          ray = make_ray(P.o, P.d);
         const unsigned s0  = cnt.steps;
-        P.isec             = traverse_any<COUNT, WIDE, MATTE, PHASED_SCENE>(sc, ray, -1, false, stack, cnt, top);
+        P.isec             = traverse_any<COUNT, WIDE, MATTE, PHASED_SCENE>(sc, ray, -1, false, stack, cnt);
         work               = cnt.steps - s0 + 1;
       }
 #ifdef YT_TIMING
@@ -1263,11 +1139,8 @@ __global__ void __launch_bounds__(YT_BLOCK,
       load_path_rest(st, W, slot, P, rb);
       P.flags &= ~PF_SKIPEXTEND;
       int step;
-      if constexpr (LP == LP_INLINE) {
-        ShadeEnv E = {sc, st, kp, &stack, &cnt, slot, WIDE && !COUNT};
-        step       = step_path<SAMPLER, LP>(E, P);
-      } else {
-        ShadeEnv E = {sc, st, kp, nullptr, nullptr, slot};
+      {
+        ShadeEnv E = {sc, st, kp, slot};
         if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST ||
                       SAMPLER == YTHIP_SAMPLER_PATHDIRECT || SAMPLER == YTHIP_SAMPLER_PATHMIS) {
           step = step_path<SAMPLER, LP, CLS>(E, P);

@@ -10,12 +10,22 @@
 // Do not "simplify" expressions here: association order is part of the spec.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#define YT_FN __device__ __forceinline__
+#else  // the same arithmetic compiled for the host: tests/cpp/shading_check.cpp (g++, against the reference's headers)
+#include <math.h>
+#include <string.h>
+#define YT_FN inline
+static inline float __uint_as_float(unsigned u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+#endif
 
 #include "yt_libm.h"  // the reference platform's libm (glibc 2.35), restated: ytm::sinf ... ytm::powf
-
-#define YT_FN __device__ __forceinline__
 
 namespace yt {
 

@@ -26,6 +26,8 @@
 #include <thread>
 #include <vector>
 
+#include "yt_xfer.h"
+
 #include "../../include/ythip.h"
 
 namespace {
@@ -106,6 +108,7 @@ struct ythip_multi {
   long long*              d_offset   = nullptr;
   int*                    d_lwidth   = nullptr;
   std::string             gather_mode = "none";
+  ytx::Bounce             xfer;  // the frame goes to the caller through pinned memory (yt_xfer.h), on devices[0]
 };
 
 namespace {
@@ -193,6 +196,10 @@ int ythip_create_multi(const int* device_ids, int n, ythip_multi** out) {
 void ythip_destroy_multi(ythip_multi* m) {
   if (!m) return;
   free_gather(m);
+  if (!m->devices.empty()) {
+    (void)hipSetDevice(m->devices[0]);
+    m->xfer.destroy();
+  }
   for (auto c : m->comms)
     if (c && m->rccl.CommDestroy) m->rccl.CommDestroy(c);
   for (int r = 0; r < m->n; r++) {
@@ -288,8 +295,11 @@ int ythip_multi_trace_samples(ythip_multi* m, const ythip_params* params, const 
   for (int r = 0; r < m->n; r++) {
     if (m->lwidth[r] == 0) continue;
     int rc = ythip_trace_samples_async(m->ctx[r], params);
-    if (rc) {
-      for (int q = 0; q < r; q++) (void)ythip_sync(m->ctx[q]);
+    if (rc) {  // all ranks or none: the ranks that did launch finish their batch and take it back
+      for (int q = 0; q < r; q++) {
+        (void)ythip_sync(m->ctx[q]);
+        if (m->lwidth[q]) (void)ythip_state_set_samples(m->ctx[q], samples_before[q]);
+      }
       return rank_fail(m, r, rc);
     }
   }
@@ -342,8 +352,14 @@ int ythip_multi_get_image(ythip_multi* m, float* image) {
     if (rc) return rank_fail(m, r, rc);
     src[r] = p;
   }
+  // YTHIP_GATHER=copy: device copies even between distinct devices.  YTHIP_GATHER=rccl-self: the RCCL
+  // branch on whatever distinct devices there are — with ONE device a one-rank communicator whose
+  // rank sends its slice to itself (a self send / recv inside the group), which is how a 1-GPU box
+  // executes this branch's ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd sequence at all
+  // (RCCL refuses a communicator that lists a device twice): tests/test_gpu_round2.py.
   const char* force = std::getenv("YTHIP_GATHER");
-  const bool  use_rccl = m->distinct && n > 1 && !(force && std::string(force) == "copy");
+  const bool  self  = force && std::string(force) == "rccl-self" && m->distinct;
+  const bool  use_rccl = self || (m->distinct && n > 1 && !(force && std::string(force) == "copy"));
   if (use_rccl) {
     if (m->comms.empty()) {
       std::string e;
@@ -353,11 +369,13 @@ int ythip_multi_get_image(ythip_multi* m, float* image) {
       if (rc) return mfail(m, YTHIP_ERR_HIP, "ncclCommInitAll: %s", m->rccl.GetErrorString(rc));
       m->rccl.CommCount(m->comms[0], &m->comm_ranks);
     }
-    // rank 0's own slice never leaves its device
-    MHIP(m, hipMemcpyAsync(m->d_gathered + m->offset[0], src[0], (size_t)m->lwidth[0] * m->height * sizeof(float4),
-                hipMemcpyDeviceToDevice, m->streams[0]));
+    // rank 0's own slice never leaves its device (a device copy; in the self-test mode it takes
+    // the send / recv path like everybody else's)
+    if (!self)
+      MHIP(m, hipMemcpyAsync(m->d_gathered + m->offset[0], src[0], (size_t)m->lwidth[0] * m->height * sizeof(float4),
+                  hipMemcpyDeviceToDevice, m->streams[0]));
     ncclResult_t rc = m->rccl.GroupStart();
-    for (int r = 1; r < n && !rc; r++) {
+    for (int r = self ? 0 : 1; r < n && !rc; r++) {
       if (m->lwidth[r] == 0) continue;
       size_t count = (size_t)m->lwidth[r] * m->height * 4;
       rc           = m->rccl.Send(src[r], count, ncclFloat32, 0, m->comms[r], m->streams[r]);
@@ -370,7 +388,7 @@ int ythip_multi_get_image(ythip_multi* m, float* image) {
       MHIP(m, hipStreamSynchronize(m->streams[r]));
     }
     MHIP(m, hipSetDevice(m->devices[0]));
-    m->gather_mode = "rccl send/recv";
+    m->gather_mode = self ? "rccl send/recv (incl. rank 0 to itself)" : "rccl send/recv";
   } else {
     for (int r = 0; r < n; r++) {
       if (m->lwidth[r] == 0) continue;
@@ -384,8 +402,7 @@ int ythip_multi_get_image(ythip_multi* m, float* image) {
   }
   hipLaunchKernelGGL(k_unstripe4, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, m->streams[0], m->d_gathered,
       m->d_offset, m->d_lwidth, n, m->width, m->height, m->d_frame);
-  MHIP(m, hipMemcpyAsync(image, m->d_frame, (size_t)npix * sizeof(float4), hipMemcpyDeviceToHost, m->streams[0]));
-  MHIP(m, hipStreamSynchronize(m->streams[0]));
+  MHIP(m, m->xfer.d2h(m->streams[0], image, m->d_frame, (size_t)npix * sizeof(float4)));  // (complete on return)
   return YTHIP_OK;
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "../../include/ythip.h"
+#include "yt_material.h"
 #include "yt_math.h"
 
 namespace yt {
@@ -70,7 +71,6 @@ struct DScene {
   const int*        tlas_prims; // instance ids in TLAS leaf order
   const DInstanceT* tinst;      // per instance
   int               tlas_ref;   // ref of the TLAS root, REF_NONE if empty
-  int               top_root;   // pair id of the root record of the largest tree (LDS staging of its top), -1 none
   vec3f             tlas_bmin, tlas_bmax;
   // lights
   const DLight* lights;
@@ -398,14 +398,7 @@ YT_FN vec3f eval_shading_normal(const DScene& sc, const frame3f& frame, const DS
 // ---------------------------------------------------------------------------
 // material_point / eval_material — yocto_scene.h:258-270, yocto_scene.cpp:531-581
 // ---------------------------------------------------------------------------
-struct material_point {
-  int   type;
-  vec3f emission, color;
-  float opacity, roughness, metallic, ior;
-  vec3f density, scattering;
-  float scanisotropy, trdepth;
-};
-constexpr float min_roughness = 0.03f * 0.03f;
+// (struct material_point: yt_material.h)
 
 // NOTEX: the caller knows that no material of the scene references a texture
 template <bool NOTEX = false>

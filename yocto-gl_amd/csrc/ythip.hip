@@ -17,17 +17,18 @@
 #include <cstdlib>
 #include <string>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <vector>
 
 #include "../../include/ythip.h"
 #include "yt_build.h"
+#include "yt_xfer.h"
 #include "yt_gpubuild.h"
 #include "yt_kernels.h"
 #include "yt_denoise.h"
 #include "yt_order.h"
-#include "yt_pool.h"
 
 using namespace yt;
 
@@ -93,12 +94,9 @@ struct ythip_ctx {
   size_t                      sort_temp_bytes = 0;
   bool                        have_tile_costs = false;  // d_tile_cost holds the previous whole-slice launch's costs
   int                         lpt_age = 0;              // launches since the order was last computed
-  bool                        lpt_probe = false;        // YTHIP_LPT_PROBE=1: split the first batch of a tile grid (see enqueue_batch)
+  bool                        lpt_probe = true;         // YTHIP_LPT_PROBE=0: do not split the first batch of a tile grid (see enqueue_batch)
   std::vector<void*>          order_allocs;             // the three buffers above: they outlive a state with the same tile grid
   int                         order_tiles_x = 0, order_tiles_y = 0;
-  int                         xcd_map = 0;  // YTHIP_XCD: 0 identity, 1 4x2 blocks, 2 8 row bands, 3 8 column bands, 4 2x4 blocks
-  int*                        d_tile_order = nullptr;
-  int*                        d_band_next  = nullptr;
   bool                        denoise_simple = false; // YTHIP_DENOISE_SIMPLE=1: the untiled kernel for every level (cross-check)
   std::vector<void*>          staging_allocs;
   ythip_scene                 staged      = {};
@@ -123,6 +121,7 @@ struct ythip_ctx {
   // work at hand — see use_wide()
   int     traversal_mode = 2;
   int64_t largest_tree   = 0;  // primitives of the largest tree of the resident BVH
+  bool    wide_stack_ok  = true;  // the wide walk's worst-case stack depth fits the 128 entries (bake_bvh)
   bool    use_wide() const;
   ythip_build_info               build_info             = {};
   int64_t                        num_pairs = 0, num_leaf4 = 0;
@@ -142,22 +141,20 @@ struct ythip_ctx {
   size_t                                       ev_next = 0;
   ythip_stats                                  stats   = {};
   float4 *nee_a = nullptr, *nee_b = nullptr, *nee_c = nullptr, *nee_d = nullptr, *nee_e = nullptr;  // deferred NEE (per slot)
-  bool                                         nee_inline = false;  // YTHIP_NEE_INLINE=1: pathdirect with inline NEE walks (the round-1 kernel)
   float4*                                      nhit_a   = nullptr;
   int*                                         nhit_e   = nullptr;
 
-  // k_pool (yt_pool.h, experimental): 0 never (default), 1 wherever it applies (pool_applies)
-  int                pool_mode = 0;
-  DPool              pool      = {};
-  std::vector<void*> pool_allocs;
-  int                pool_waves = 0, pool_target = 0, pool_refill = 16, pool_shade_min = 64, pool_max_iters = 1 << 28;
-  unsigned           pool_tile_mul = 1;
-  int                pool_rounds   = 0, pool_phase_min = 1, pool_heavy_min = 64;
-  int                lds_top       = 0;  // stage the top of the largest tree in LDS (k_trace)
   int*               d_stop        = nullptr;  // device-visible cancel flag polled by the kernels
   hipStream_t        side_stream   = nullptr;  // raises the flag while the kernel runs on `stream`
   hipEvent_t         done_event    = nullptr;
-  std::atomic<bool>  stop_raised{false};
+  // Cancellation by generation: every batch gets a number, the kernels stop when the
+  // word at d_stop EQUALS their batch's number, ythip_cancel writes the number of the batch in
+  // flight.  Nothing ever has to lower the flag, so a cancel that races with the next enqueue can
+  // neither be lost into it nor leak into it (the boolean of round 2 could end up raised with
+  // nobody left to lower it: every later tile then exited at once while `samples` kept advancing).
+  std::atomic<int>   stop_gen{0};
+  std::mutex         stop_mu;  // serialises concurrent ythip_cancel calls (they share the side stream)
+  ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
 };
 
 static void free_staging(ythip_ctx* ctx) {
@@ -181,6 +178,7 @@ static void free_staging(ythip_ctx* ctx) {
 // (small slices: one GPU of eight, previews) and on large trees; on scenes made of
 // tiny trees the 4-slot records are mostly empty.  Measured in DESIGN.md §6.
 bool ythip_ctx::use_wide() const {
+  if (!wide_stack_ok) return false;  // trees too deep for the wide walk's pushes (bake_bvh): the binary walk
   if (traversal_mode != 2) return traversal_mode == 1;
   return largest_tree >= 64;
 }
@@ -227,7 +225,7 @@ int dupload(ythip_ctx* ctx, std::vector<void*>& pool, const T** out, const T* sr
   T*  d  = nullptr;
   int rc = dalloc(ctx, pool, &d, count);
   if (rc) return rc;
-  if (count && src) HIPCHECK(ctx, hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  if (count && src) HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, d, src, count * sizeof(T)));
   *out = d;
   return YTHIP_OK;
 }
@@ -246,7 +244,6 @@ KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
   k.tentfilter = p->tentfilter;
   k.has_env    = ctx->ds.num_environments > 0;
   k.hold       = ctx->hold_policy;
-  k.lds_top    = ctx->lds_top;
   k.peek       = ctx->peek_policy;
   return k;
 }
@@ -375,8 +372,7 @@ int bake_bvh(ythip_ctx* ctx) {
           L[1]   = {__builtin_bit_cast(float, id), 0, 0, 0};
         }
       }
-      HIPCHECK(ctx, hipMemcpyAsync(d_leaf + leaf_base[t], leaf.data(), leaf.size() * sizeof(float4),
-                        hipMemcpyHostToDevice, ctx->stream));
+      HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, d_leaf + leaf_base[t], leaf.data(), leaf.size() * sizeof(float4)));
     }
     // pair ids of this tree, in node order
     std::vector<int32_t> pair_id((size_t)nn, -1);
@@ -407,8 +403,7 @@ int bake_bvh(ythip_ctx* ctx) {
                 __builtin_bit_cast(float, (int32_t)node.axis)};
         }
       }
-      HIPCHECK(ctx, hipMemcpyAsync(d_pairs + 4 * pair_base[t], pairs.data(), pairs.size() * sizeof(float4),
-                        hipMemcpyHostToDevice, ctx->stream));
+      HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, d_pairs + 4 * pair_base[t], pairs.data(), pairs.size() * sizeof(float4)));
       // grandchildren ("quad") records of the wide walk, same ids: slots 0,1 = children
       // of child 0 (or child 0 itself when it is a leaf, slot 1 empty), slots 2,3
       // likewise for child 1
@@ -441,8 +436,7 @@ int bake_bvh(ythip_ctx* ctx) {
         }
         Qr[1].w = __builtin_bit_cast(float, (int32_t)axes);
       }
-      HIPCHECK(ctx, hipMemcpyAsync(d_quads + 8 * pair_base[t], quads.data(), quads.size() * sizeof(float4),
-                        hipMemcpyHostToDevice, ctx->stream));
+      HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, d_quads + 8 * pair_base[t], quads.data(), quads.size() * sizeof(float4)));
     }
     if (nn > 0) {
       const auto& root = nodes[b.node_offset[t]];
@@ -478,6 +472,11 @@ int bake_bvh(ythip_ctx* ctx) {
       return fail(ctx, YTHIP_ERR_INVALID,
           "bvh too deep for the shared traversal stack: instance tree %d levels + deepest shape tree %d levels + 5 > 128",
           tlas_depth, deepest_blas);
+    // The wide walk advances two levels per step and can leave up to THREE pending siblings per
+    // step: 3 * ceil(depth / 2) entries per tree.  Trees between that bound and the
+    // binary one are walked binary — the reference renders them, so they are not refused.
+    auto wide_need      = [](int depth) { return 3 * ((depth + 1) / 2); };
+    ctx->wide_stack_ok = wide_need(tlas_depth) + wide_need(deepest_blas) + 5 <= 128;
   }
   // per-instance traversal records
   std::vector<DInstanceT> tinst(ctx->h_instances.size());
@@ -501,14 +500,9 @@ int bake_bvh(ythip_ctx* ctx) {
   ctx->ds.wide     = d_quads;
   ctx->ds.leafdata = d_leaf;
   ctx->largest_tree = 0;
-  ctx->ds.top_root  = -1;
   for (int t = 0; t < ntrees; t++) {
     const int64_t np = b.prim_offset[t + 1] - b.prim_offset[t];
-    if (np > ctx->largest_tree) {
-      ctx->largest_tree = np;
-      // the tree whose top the kernels may stage in LDS: its root's pair id (internal roots only)
-      ctx->ds.top_root = (roots[t].ref >= 0 && roots[t].ref < (1 << 24) && npairs < (1 << 24)) ? roots[t].ref : -1;
-    }
+    if (np > ctx->largest_tree) ctx->largest_tree = np;
   }
   ctx->num_pairs   = npairs;
   ctx->num_leaf4   = nleaf4;
@@ -532,10 +526,8 @@ int ensure_host_bvh(ythip_ctx* ctx) {
   for (size_t t = 0; t < ctx->d_trees.size(); t++) {
     auto& dt = ctx->d_trees[t];
     if (!dt.nodes || ctx->d_tree_on_host[t]) continue;
-    HIPCHECK(ctx, hipMemcpy(b.nodes.data() + b.node_offset[t], dt.nodes, (size_t)dt.num_nodes * sizeof(ythip_bvh_node),
-                      hipMemcpyDeviceToHost));
-    HIPCHECK(ctx, hipMemcpy(b.prims.data() + b.prim_offset[t], dt.prims, (size_t)dt.num_prims * sizeof(int32_t),
-                      hipMemcpyDeviceToHost));
+    HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, b.nodes.data() + b.node_offset[t], dt.nodes, (size_t)dt.num_nodes * sizeof(ythip_bvh_node)));
+    HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, b.prims.data() + b.prim_offset[t], dt.prims, (size_t)dt.num_prims * sizeof(int32_t)));
     ctx->d_tree_on_host[t] = 1;
   }
   return YTHIP_OK;
@@ -576,7 +568,7 @@ int build_bvh_mixed(ythip_ctx* ctx, const ythip_scene& sc, bool highquality, boo
       if (rc == ytgpu::BUILD_OK) {
         auto& dt = ctx->d_trees[k];
         ythip_bvh_node root;
-        HIPCHECK(ctx, hipMemcpy(&root, dt.nodes, sizeof(root), hipMemcpyDeviceToHost));
+        HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, &root, dt.nodes, sizeof(root)));
         roots[k].min = {root.bbox_min[0], root.bbox_min[1], root.bbox_min[2]};
         roots[k].max = {root.bbox_max[0], root.bbox_max[1], root.bbox_max[2]};
         empty[k]     = 0;
@@ -644,11 +636,10 @@ int upload_lights_impl(ythip_ctx* ctx) {
 template <int S, int LP>
 void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
   dim3 grid(ctx->st.nblocks), block(YT_BLOCK);  // one persistent one-wave workgroup per 16x4 tile
-  const size_t dyn = TOP_STAGING && kp.lds_top && ctx->ds.top_root >= 0 ? (size_t)TOP_SLOTS * 8 * sizeof(float4) : 0;
   if (count)  // the counting launch walks binary: its counts are the reference's
     hipLaunchKernelGGL((k_trace<S, LP, true, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
   else if (ctx->use_wide())
-    hipLaunchKernelGGL((k_trace<S, LP, false, true>), grid, block, dyn, ctx->stream, ctx->ds, ctx->st, kp);
+    hipLaunchKernelGGL((k_trace<S, LP, false, true>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
   else
     hipLaunchKernelGGL((k_trace<S, LP, false, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
 }
@@ -662,12 +653,11 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
         // the default sampler on an all-matte scene: the variant compiled without the
         // other material lobes and the volume code (same results, fewer registers)
         dim3 grid(ctx->st.nblocks), block(YT_BLOCK);
-        const size_t dyn = TOP_STAGING && kp.lds_top && ctx->ds.top_root >= 0 ? (size_t)TOP_SLOTS * 8 * sizeof(float4) : 0;
         if (lp == LP_DEFER)
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 1>), grid, block, dyn, ctx->stream,
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 1>), grid, block, 0, ctx->stream,
               ctx->ds, ctx->st, kp);
         else
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 1>), grid, block, dyn, ctx->stream,
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 1>), grid, block, 0, ctx->stream,
               ctx->ds, ctx->st, kp);
       } else if (!count && ctx->no_textures && ctx->specialize && ctx->use_wide()) {
         // no material references a texture (any material types, any primitive kinds): the
@@ -692,16 +682,10 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
       break;
 #if !defined(YT_DEV_ONLY_PATH) || defined(YT_DEV_NEE)  // development builds: compile the path / pathtest / naive kernels only (10x faster; -DYT_DEV_NEE adds these two)
     case YTHIP_SAMPLER_PATHDIRECT:
-      if (ctx->nee_inline)
-        launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_INLINE>(ctx, kp, count);
-      else
-        launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER>(ctx, kp, count);
+      launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER>(ctx, kp, count);
       break;
     case YTHIP_SAMPLER_PATHMIS:
-      if (ctx->nee_inline)
-        launch_trace<YTHIP_SAMPLER_PATHMIS, LP_INLINE>(ctx, kp, count);
-      else
-        launch_trace<YTHIP_SAMPLER_PATHMIS, LP_DEFER>(ctx, kp, count);
+      launch_trace<YTHIP_SAMPLER_PATHMIS, LP_DEFER>(ctx, kp, count);
       break;
 #endif
     case YTHIP_SAMPLER_NAIVE: launch_trace<YTHIP_SAMPLER_NAIVE, LP_NONE>(ctx, kp, count); break;
@@ -714,91 +698,6 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
     default: return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
   }
   return YTHIP_OK;
-}
-
-// ---------------------------------------------------------------------------
-// k_pool (yt_pool.h): the persistent pool kernel.  Applies to whole-slice batches of
-// the path samplers; everything else (trace_sample, counting launches, the NEE
-// samplers) stays on k_trace.  Same trace_state either way.
-// ---------------------------------------------------------------------------
-int ensure_pool(ythip_ctx* ctx, int nwaves) {
-  if (ctx->pool.wgt && ctx->pool.nwaves >= nwaves) return YTHIP_OK;
-  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-  free_all(ctx->pool_allocs);
-  ctx->pool = DPool{};
-  size_t n  = (size_t)nwaves * POOL_T;
-  int    rc;
-#define PAL(field, count) \
-  if ((rc = dalloc(ctx, ctx->pool_allocs, &ctx->pool.field, (size_t)(count)))) return rc;
-  PAL(wgt, n);
-  PAL(rad, n);
-  PAL(rng, n);
-  PAL(misc, n);
-  PAL(hit, n);
-  PAL(park, n);
-  PAL(vol_a, n);
-  PAL(vol_b, n);
-  PAL(pend, n);
-  PAL(tile_counter, 16);
-  PAL(dbg, (size_t)nwaves * POOL_DBG_STRIDE);
-#undef PAL
-  ctx->pool.nwaves = nwaves;
-  return YTHIP_OK;
-}
-
-template <int S, int LP, bool MATTE>
-int launch_pool(ythip_ctx* ctx, const KParams& kp) {
-  int per_cu = 0, cus = 0;
-  HIPCHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pool<S, LP, MATTE>, 64, 0));
-  HIPCHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-  const int ntiles = ctx->st.nblocks;
-  int       nwaves = ctx->pool_waves > 0 ? ctx->pool_waves : std::max(1, per_cu) * std::max(1, cus);
-  nwaves           = std::max(1, std::min(nwaves, ntiles));  // no more wavefronts than tiles
-  // rays a wavefront keeps in flight (queued or being walked) before it takes another tile
-  int target = ctx->pool_target > 0 ? ctx->pool_target : 128;
-  target     = std::max(1, std::min(POOL_T, target));
-  int rc     = ensure_pool(ctx, nwaves);
-  if (rc) return rc;
-  DPool pl      = ctx->pool;
-  pl.nwaves     = nwaves;
-  pl.ntiles     = ntiles;
-  pl.target     = target;
-  pl.refill_min = std::max(1, std::min(64, ctx->pool_refill));
-  pl.shade_min  = std::max(1, std::min(64, ctx->pool_shade_min));
-  pl.max_iters  = ctx->pool_max_iters;
-  pl.tile_mul   = ctx->pool_tile_mul ? ctx->pool_tile_mul : 1u;
-  pl.stop       = ctx->d_stop;
-  pl.rounds     = ctx->pool_rounds;
-  pl.phase_min  = std::max(1, std::min(64, ctx->pool_phase_min));
-  pl.heavy_min  = std::max(64, std::min(POOL_T, ctx->pool_heavy_min));
-  // a multiplier that is not coprime to the tile count would skip tiles
-  auto gcd = [](unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; };
-  while (gcd(pl.tile_mul, (unsigned)ntiles) != 1) pl.tile_mul++;
-  HIPCHECK(ctx, hipMemsetAsync(pl.tile_counter, 0, 16 * sizeof(unsigned), ctx->stream));
-  HIPCHECK(ctx, hipMemsetAsync(pl.dbg, 0, (size_t)nwaves * POOL_DBG_STRIDE * sizeof(unsigned long long), ctx->stream));
-  PoolLaunch launch = {ctx->ds, ctx->st, kp, pl};
-  launch.st.vol_a = pl.vol_a, launch.st.vol_b = pl.vol_b, launch.st.pend = pl.pend;  // per-slot arrays: the pool's
-  hipLaunchKernelGGL((k_pool<S, LP, MATTE>), dim3(nwaves), dim3(64), 0, ctx->stream, launch);
-  return YTHIP_OK;
-}
-
-bool pool_applies(const ythip_ctx* ctx, const ythip_params* params, bool count, int only_pix) {
-  if (ctx->pool_mode == 0 || count || only_pix >= 0 || !ctx->use_wide()) return false;
-  if (params->sampler != YTHIP_SAMPLER_PATH && params->sampler != YTHIP_SAMPLER_PATHTEST) return false;
-  if (params->bounces <= 0 || params->bounces >= 65536 || ctx->st.width >= 65536 || ctx->st.height >= 65536) return false;  // packed slot words
-  return true;
-}
-
-int launch_pool_any(ythip_ctx* ctx, const KParams& kp, int lp) {
-  if (kp.sampler == YTHIP_SAMPLER_PATH) {
-    if (ctx->all_matte && ctx->specialize)
-      return lp == LP_DEFER ? launch_pool<YTHIP_SAMPLER_PATH, LP_DEFER, true>(ctx, kp)
-                            : launch_pool<YTHIP_SAMPLER_PATH, LP_NONE, true>(ctx, kp);
-    return lp == LP_DEFER ? launch_pool<YTHIP_SAMPLER_PATH, LP_DEFER, false>(ctx, kp)
-                          : launch_pool<YTHIP_SAMPLER_PATH, LP_NONE, false>(ctx, kp);
-  }
-  return lp == LP_DEFER ? launch_pool<YTHIP_SAMPLER_PATHTEST, LP_DEFER, false>(ctx, kp)
-                        : launch_pool<YTHIP_SAMPLER_PATHTEST, LP_NONE, false>(ctx, kp);
 }
 
 // hipEvent bracketing of one launch (profiling mode bit 0)
@@ -876,10 +775,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   ctx->st.nhit_a      = mis ? ctx->nhit_a : nullptr;
   ctx->st.nhit_e      = mis ? ctx->nhit_e : nullptr;
   ctx->st.stop        = ctx->d_stop;
-  if (ctx->stop_raised) {  // a previous batch was cancelled: lower the flag (stream-ordered)
-    HIPCHECK(ctx, hipMemsetAsync(ctx->d_stop, 0, sizeof(int), ctx->stream));
-    ctx->stop_raised = false;
-  }
+  ctx->st.stop_gen    = ctx->stop_gen.load();  // (begin_batch() numbered this batch)
   ctx->st.sample_base = only_pix < 0 ? ctx->samples : sample;
   ctx->st.batch       = only_pix < 0 ? params->batch : 1;
   ctx->st.only_pix    = only_pix;
@@ -903,7 +799,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   // one launch renders the whole batch: every workgroup loops over its tile
   // until its pixels have taken `batch` samples (k_trace)
   ctx->st.tile_perm = nullptr, ctx->st.tile_cost = nullptr;
-  const bool lpt = ctx->d_tile_cost && only_pix < 0 && !count && !ctx->d_tile_order;
+  const bool lpt = ctx->d_tile_cost && only_pix < 0 && !count;
   if (lpt) {
     if (ctx->have_tile_costs) {  // the previous batch's costs order this one (same pixels, same work)
       // costs are stable from batch to batch: the order is refreshed every 16th launch only
@@ -915,15 +811,9 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
     }
     ctx->st.tile_cost = ctx->d_tile_cost;
   }
-  ctx->st.tile_order = nullptr, ctx->st.band_next = nullptr;
-  if (ctx->d_tile_order && only_pix < 0) {
-    HIPCHECK(ctx, hipMemsetAsync(ctx->d_band_next, 0, 8 * sizeof(int), ctx->stream));
-    ctx->st.tile_order = ctx->d_tile_order, ctx->st.band_next = ctx->d_band_next;
-  }
   {
     EvScope ev(ctx, 0);
-    int     rc = pool_applies(ctx, params, count, only_pix) ? launch_pool_any(ctx, kp, lp)
-                                                            : launch_trace_any(ctx, kp, lp, count);
+    int     rc = launch_trace_any(ctx, kp, lp, count);
     if (rc) return rc;
   }
   HIPCHECK(ctx, hipGetLastError());
@@ -964,6 +854,17 @@ void classify_scene(ythip_ctx* ctx, const ythip_material* materials, int num_mat
 // ===========================================================================
 extern "C" {
 
+// The cancel word is polled by every workgroup once per iteration and written by the command
+// processor while the batch runs.  Ordinary (coarse-grained) device memory is only coherent
+// between the eight XCDs' L2s at kernel boundaries: a workgroup's agent-scope load kept hitting
+// its XCD's stale line until the line happened to be evicted — the 45-55 ms cancel latency of
+// round 2.  Uncached device memory (MTYPE UC) is read at the memory side every time.
+static hipError_t alloc_stop_word(ythip_ctx* ctx) {
+  if (hipExtMallocWithFlags((void**)&ctx->d_stop, 64, hipDeviceMallocUncached) == hipSuccess) return hipSuccess;
+  (void)hipGetLastError();
+  return hipMalloc((void**)&ctx->d_stop, 64);
+}
+
 int ythip_create(int device, ythip_ctx** out) {
   if (!out) return fail(nullptr, YTHIP_ERR_INVALID, "out is null");
   *out       = nullptr;
@@ -982,25 +883,12 @@ int ythip_create(int device, ythip_ctx** out) {
   ctx->stream = ctx->own_stream;
   if (const char* e = std::getenv("YTHIP_HOLD")) ctx->hold_policy = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_PEEK")) ctx->peek_policy = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL")) ctx->pool_mode = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_LDS_TOP")) ctx->lds_top = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_XCD")) ctx->xcd_map = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LPT")) ctx->lpt = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LPT_PROBE")) ctx->lpt_probe = std::atoi(e) != 0;
-  if (const char* e = std::getenv("YTHIP_NEE_INLINE")) ctx->nee_inline = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_DENOISE_SIMPLE")) ctx->denoise_simple = std::atoi(e) != 0;
-  if (const char* e = std::getenv("YTHIP_POOL_WAVES")) ctx->pool_waves = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL_TARGET")) ctx->pool_target = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL_REFILL")) ctx->pool_refill = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL_SHADEMIN")) ctx->pool_shade_min = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL_TILEMUL")) ctx->pool_tile_mul = (unsigned)std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL_MAXITERS")) ctx->pool_max_iters = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL_ROUNDS")) ctx->pool_rounds = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL_PHASEMIN")) ctx->pool_phase_min = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_POOL_HEAVYMIN")) ctx->pool_heavy_min = std::atoi(e);
   if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void**)&ctx->d_stop, 64) != hipSuccess || hipMemset(ctx->d_stop, 0, 64) != hipSuccess ||
+      alloc_stop_word(ctx) != hipSuccess || hipMemset(ctx->d_stop, 0, 64) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return fail(nullptr, YTHIP_ERR_HIP, "context allocation failed");
@@ -1029,7 +917,7 @@ void ythip_destroy(ythip_ctx* ctx) {
   free_all(ctx->order_allocs);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
-  free_all(ctx->pool_allocs);
+  ctx->xfer.destroy();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -1224,8 +1112,7 @@ int ythip_update_materials(ythip_ctx* ctx, const ythip_material* materials, int 
         return fail(ctx, YTHIP_ERR_INVALID, "material %d references texture %d out of range", k, x);
   }
   HIPCHECK(ctx, hipSetDevice(ctx->device));
-  HIPCHECK(ctx, hipMemcpyAsync((void*)ctx->ds.materials, materials, (size_t)num * sizeof(ythip_material),
-                    hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)ctx->ds.materials, materials, (size_t)num * sizeof(ythip_material)));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   classify_scene(ctx, materials, num);  // the kernel specialisation follows the materials
   return YTHIP_OK;
@@ -1243,10 +1130,8 @@ int ythip_update_environments(ythip_ctx* ctx, const ythip_environment* environme
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   std::vector<float> env_inv((size_t)num * 12);
   for (int k = 0; k < num; k++) ythost::inverse_frame_rigid(environments[k].frame, env_inv.data() + 12 * k);
-  HIPCHECK(ctx, hipMemcpyAsync((void*)ctx->ds.environments, environments, (size_t)num * sizeof(ythip_environment),
-                    hipMemcpyHostToDevice, ctx->stream));
-  HIPCHECK(ctx, hipMemcpyAsync((void*)ctx->ds.env_inv, env_inv.data(), env_inv.size() * sizeof(float),
-                    hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)ctx->ds.environments, environments, (size_t)num * sizeof(ythip_environment)));
+  HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)ctx->ds.env_inv, env_inv.data(), env_inv.size() * sizeof(float)));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   return YTHIP_OK;
 }
@@ -1257,8 +1142,7 @@ int ythip_update_cameras(ythip_ctx* ctx, const ythip_camera* cameras, int num) {
   if (num != ctx->num_cameras)
     return fail(ctx, YTHIP_ERR_INVALID, "scene has %d cameras resident, %d given", ctx->num_cameras, num);
   HIPCHECK(ctx, hipSetDevice(ctx->device));
-  HIPCHECK(ctx, hipMemcpyAsync((void*)ctx->ds.cameras, cameras, (size_t)num * sizeof(ythip_camera),
-                    hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)ctx->ds.cameras, cameras, (size_t)num * sizeof(ythip_camera)));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   return YTHIP_OK;
 }
@@ -1289,17 +1173,14 @@ int ythip_update_shape_vertices(ythip_ctx* ctx, int32_t shape, const float* posi
         (long long)num_radius);
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   if (normals && num_normals > 0)  // shading data only: no host copy is kept
-    HIPCHECK(ctx, hipMemcpyAsync((void*)(ctx->ds.normals + 3 * sh.normals_offset), normals, (size_t)num_normals * 12,
-                      hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)(ctx->ds.normals + 3 * sh.normals_offset), normals, (size_t)num_normals * 12));
   if (positions && num_positions > 0) {
     std::memcpy(ctx->h_positions.data() + 3 * sh.positions_offset, positions, (size_t)num_positions * 12);
-    HIPCHECK(ctx, hipMemcpyAsync((void*)(ctx->ds.positions + 3 * sh.positions_offset), positions,
-                      (size_t)num_positions * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)(ctx->ds.positions + 3 * sh.positions_offset), positions, (size_t)num_positions * 12));
   }
   if (radius && num_radius > 0) {
     std::memcpy(ctx->h_radius.data() + sh.radius_offset, radius, (size_t)num_radius * 4);
-    HIPCHECK(ctx, hipMemcpyAsync((void*)(ctx->ds.radius + sh.radius_offset), radius, (size_t)num_radius * 4,
-                      hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)(ctx->ds.radius + sh.radius_offset), radius, (size_t)num_radius * 4));
   }
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffers are free again
   return YTHIP_OK;
@@ -1314,8 +1195,7 @@ int ythip_update_instance_frames(ythip_ctx* ctx, const int32_t* instances, int32
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   for (int k = 0; k < num; k++) {
     ctx->h_instances[instances[k]].frame = frames[k];
-    HIPCHECK(ctx, hipMemcpyAsync((void*)&ctx->ds.instances[instances[k]].frame, &frames[k], sizeof(ythip_frame),
-                      hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)&ctx->ds.instances[instances[k]].frame, &frames[k], sizeof(ythip_frame)));
   }
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   return YTHIP_OK;
@@ -1372,7 +1252,7 @@ int ythip_update_bvh(ythip_ctx* ctx, const int32_t* updated_instances, int32_t n
   for (int s = 0; s < nshapes; s++) {
     ythip_bvh_node root;
     if (on_device(s) && !ctx->d_tree_on_host[s]) {
-      HIPCHECK(ctx, hipMemcpy(&root, ctx->d_trees[s].nodes, sizeof(root), hipMemcpyDeviceToHost));
+      HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, &root, ctx->d_trees[s].nodes, sizeof(root)));
     } else {
       if (b.node_offset[s + 1] == b.node_offset[s]) continue;
       root = b.nodes[b.node_offset[s]];
@@ -1420,11 +1300,11 @@ int ythip_bvh_baked_download(ythip_ctx* ctx, float* pairs, float* leafdata, floa
   if (!ctx || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "no bvh resident");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   if (quads && ctx->num_pairs)
-    HIPCHECK(ctx, hipMemcpy(quads, ctx->ds.wide, (size_t)ctx->num_pairs * 128, hipMemcpyDeviceToHost));
+    HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, quads, ctx->ds.wide, (size_t)ctx->num_pairs * 128));
   if (pairs && ctx->num_pairs)
-    HIPCHECK(ctx, hipMemcpy(pairs, ctx->ds.pairs, (size_t)ctx->num_pairs * 64, hipMemcpyDeviceToHost));
+    HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, pairs, ctx->ds.pairs, (size_t)ctx->num_pairs * 64));
   if (leafdata && ctx->num_leaf4)
-    HIPCHECK(ctx, hipMemcpy(leafdata, ctx->ds.leafdata, (size_t)ctx->num_leaf4 * 16, hipMemcpyDeviceToHost));
+    HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, leafdata, ctx->ds.leafdata, (size_t)ctx->num_leaf4 * 16));
   return YTHIP_OK;
 }
 
@@ -1627,7 +1507,6 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
   ctx->nee_a = ctx->nee_b = ctx->nee_c = ctx->nee_d = ctx->nee_e = nullptr;
   ctx->samples    = 0;
   ctx->have_state = true;
-  ctx->d_tile_order = nullptr, ctx->d_band_next = nullptr;
   // A new state with the tile grid of the previous one (a viewer re-creates the state on every
   // camera edit, apps/ytrace.cpp:189-204) keeps the recorded tile costs: its first batch is
   // already launched most expensive tile first (the view changed a little, the costs did too).
@@ -1648,24 +1527,6 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
     }
   }
   ctx->lpt_age = 0;  // (the order is recomputed from the kept costs at the first launch)
-  if (ctx->xcd_map > 0) {  // XCD-banded tile queues (experiment): tiles grouped by band, band after band
-    const int gx = ctx->xcd_map == 1 ? 4 : ctx->xcd_map == 2 ? 1 : ctx->xcd_map == 3 ? 8 : 2, gy = 8 / gx;
-    std::vector<std::vector<int>> bands(8);
-    for (int ty = 0; ty < st.tiles_y; ty++)
-      for (int tx = 0; tx < st.tiles_x; tx++) {
-        int bx = std::min(gx - 1, tx * gx / std::max(st.tiles_x, 1)), by = std::min(gy - 1, ty * gy / std::max(st.tiles_y, 1));
-        bands[by * gx + bx].push_back(ty * st.tiles_x + tx);
-      }
-    std::vector<int> order;
-    for (int b = 0; b < 8; b++) {
-      st.band_start[b] = (int)order.size();
-      order.insert(order.end(), bands[b].begin(), bands[b].end());
-    }
-    st.band_start[8] = (int)order.size();
-    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_tile_order, order.size()))) return rc;
-    if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->d_band_next, 8))) return rc;
-    HIPCHECK(ctx, hipMemcpy(ctx->d_tile_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
-  }
   return YTHIP_OK;
 }
 
@@ -1675,11 +1536,11 @@ int ythip_state_upload(ythip_ctx* ctx, const float* image, const float* albedo, 
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   ctx->have_denoised = false;
   size_t n = (size_t)ctx->st.npix;
-  if (image) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.image, image, n * 16, hipMemcpyHostToDevice, ctx->stream));
-  if (albedo) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.albedo, albedo, n * 12, hipMemcpyHostToDevice, ctx->stream));
-  if (normal) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.normal, normal, n * 12, hipMemcpyHostToDevice, ctx->stream));
-  if (hits) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.hits, hits, n * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (rngs) HIPCHECK(ctx, hipMemcpyAsync(ctx->st.rngs, rngs, n * 16, hipMemcpyHostToDevice, ctx->stream));
+  if (image) HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, ctx->st.image, image, n * 16));
+  if (albedo) HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, ctx->st.albedo, albedo, n * 12));
+  if (normal) HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, ctx->st.normal, normal, n * 12));
+  if (hits) HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, ctx->st.hits, hits, n * 4));
+  if (rngs) HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, ctx->st.rngs, rngs, n * 16));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->samples = samples;
   return YTHIP_OK;
@@ -1690,11 +1551,11 @@ int ythip_state_download(ythip_ctx* ctx, float* image, float* albedo, float* nor
   if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   size_t n = (size_t)ctx->st.npix;
-  if (image) HIPCHECK(ctx, hipMemcpyAsync(image, ctx->st.image, n * 16, hipMemcpyDeviceToHost, ctx->stream));
-  if (albedo) HIPCHECK(ctx, hipMemcpyAsync(albedo, ctx->st.albedo, n * 12, hipMemcpyDeviceToHost, ctx->stream));
-  if (normal) HIPCHECK(ctx, hipMemcpyAsync(normal, ctx->st.normal, n * 12, hipMemcpyDeviceToHost, ctx->stream));
-  if (hits) HIPCHECK(ctx, hipMemcpyAsync(hits, ctx->st.hits, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (rngs) HIPCHECK(ctx, hipMemcpyAsync(rngs, ctx->st.rngs, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (image) HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, image, ctx->st.image, n * 16));
+  if (albedo) HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, albedo, ctx->st.albedo, n * 12));
+  if (normal) HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, normal, ctx->st.normal, n * 12));
+  if (hits) HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, hits, ctx->st.hits, n * 4));
+  if (rngs) HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, rngs, ctx->st.rngs, n * 16));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (samples) *samples = ctx->samples;
   return YTHIP_OK;
@@ -1704,7 +1565,7 @@ int ythip_get_image(ythip_ctx* ctx, float* image) {
   if (!ctx || !ctx->have_state) return fail(ctx, YTHIP_ERR_STATE, "state_create first");
   if (!image) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
-  HIPCHECK(ctx, hipMemcpyAsync(image, ctx->st.image, (size_t)ctx->st.npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, image, ctx->st.image, (size_t)ctx->st.npix * 16));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   return YTHIP_OK;
 }
@@ -1720,7 +1581,7 @@ int guide_image(ythip_ctx* ctx, const float* rgb, float* image) {
   int                rc;
   if ((rc = dalloc(ctx, tmp, &d, n))) return rc;
   hipLaunchKernelGGL(k_guide_image, dim3(grid_for((long long)n)), dim3(YT_BLOCK), 0, ctx->stream, rgb, (int)n, d);
-  auto e1 = hipMemcpyAsync(image, d, n * 16, hipMemcpyDeviceToHost, ctx->stream);
+  auto e1 = ctx->xfer.d2h(ctx->stream, image, d, n * 16);
   auto e2 = hipStreamSynchronize(ctx->stream);
   free_all(tmp);
   if (e1 != hipSuccess || e2 != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "guide image download failed");
@@ -1751,8 +1612,8 @@ int ythip_tonemap_image(ythip_ctx* ctx, float exposure, int filmic, int srgb, fl
   }
   hipLaunchKernelGGL(k_tonemap, dim3(grid_for((long long)n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->st.image, (int)n,
       exposure, filmic, srgb, d_f, d_b);
-  auto e1 = ldr ? hipMemcpyAsync(ldr, d_f, n * 16, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
-  auto e2 = ldr_bytes ? hipMemcpyAsync(ldr_bytes, d_b, n * 4, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+  auto e1 = ldr ? ctx->xfer.d2h(ctx->stream, ldr, d_f, n * 16) : hipSuccess;
+  auto e2 = ldr_bytes ? ctx->xfer.d2h(ctx->stream, ldr_bytes, d_b, n * 4) : hipSuccess;
   auto e3 = hipStreamSynchronize(ctx->stream);
   free_all(tmp);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "tonemap_image failed");
@@ -1838,14 +1699,14 @@ int ythip_denoise_image(ythip_ctx* ctx, const ythip_denoise_params* params, int3
     free_all(tmp);
     return rc;
   }
-  auto e1 = hipMemcpyAsync(d_img, render, n * 16, hipMemcpyHostToDevice, ctx->stream);
-  auto e2 = hipMemcpyAsync(d_alb, albedo, n * 12, hipMemcpyHostToDevice, ctx->stream);
-  auto e3 = hipMemcpyAsync(d_nrm, normal, n * 12, hipMemcpyHostToDevice, ctx->stream);
+  auto e1 = ctx->xfer.h2d(ctx->stream, d_img, render, n * 16);
+  auto e2 = ctx->xfer.h2d(ctx->stream, d_alb, albedo, n * 12);
+  auto e3 = ctx->xfer.h2d(ctx->stream, d_nrm, normal, n * 12);
   rc      = (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) ? fail(ctx, YTHIP_ERR_HIP, "denoise upload failed")
                                                                         : denoise_run(ctx, params, width, height, d_img, d_alb, d_nrm);
   ctx->have_denoised = false;  // dn_out no longer belongs to the resident state
   if (rc == YTHIP_OK) {
-    auto e4 = hipMemcpyAsync(denoised, ctx->dn_out, n * 16, hipMemcpyDeviceToHost, ctx->stream);
+    auto e4 = ctx->xfer.d2h(ctx->stream, denoised, ctx->dn_out, n * 16);
     auto e5 = hipStreamSynchronize(ctx->stream);
     if (e4 != hipSuccess || e5 != hipSuccess) rc = fail(ctx, YTHIP_ERR_HIP, "denoise download failed");
   } else {
@@ -1865,7 +1726,7 @@ int ythip_denoise_state(ythip_ctx* ctx, const ythip_denoise_params* params, floa
   int rc = denoise_run(ctx, params, st.width, st.height, st.image, st.albedo, st.normal);
   if (rc != YTHIP_OK) return rc;
   ctx->have_denoised = true;
-  if (denoised) HIPCHECK(ctx, hipMemcpyAsync(denoised, ctx->dn_out, (size_t)st.npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (denoised) HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, denoised, ctx->dn_out, (size_t)st.npix * 16));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   return YTHIP_OK;
 }
@@ -1923,29 +1784,40 @@ namespace {
 // Raise the device-visible cancel flag from the side stream (the batch's kernel polls it
 // once per sample boundary; yocto_trace.cpp:1636-1637).
 int raise_stop(ythip_ctx* ctx) {
-  ctx->stop_raised = true;
+  std::lock_guard<std::mutex> lock(ctx->stop_mu);
+  const int gen = ctx->stop_gen.load();  // the batch in flight (or the last one: then nobody is listening)
   // A write by the command processor: it needs neither a compute unit nor a DMA engine, so
   // it lands while the batch's persistent workgroups hold every CU (a copy that is executed
   // as a blit kernel would wait for one of them to retire — seconds for a long batch).
-  if (hipStreamWriteValue32(ctx->side_stream, ctx->d_stop, 1, 0) != hipSuccess) {
+  if (hipStreamWriteValue32(ctx->side_stream, ctx->d_stop, (uint32_t)gen, 0) != hipSuccess) {
     (void)hipGetLastError();
-    static const int one = 1;
-    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_stop, &one, sizeof(int), hipMemcpyHostToDevice, ctx->side_stream));
+    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_stop, &gen, sizeof(int), hipMemcpyHostToDevice, ctx->side_stream));
   }
-  HIPCHECK(ctx, hipStreamSynchronize(ctx->side_stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->side_stream));  // (`gen` is a local: the copy has been taken)
   return YTHIP_OK;
+}
+// every batch (and every trace_sample call) is numbered before its launches are enqueued
+void begin_batch(ythip_ctx* ctx) {
+  int g = ctx->stop_gen.load() + 1;
+  if (g <= 0) g = 1;  // (0 is what the word holds before the first cancel)
+  ctx->stop_gen.store(g);
 }
 }  // namespace
 
 namespace {
-// OPT-IN (YTHIP_LPT_PROBE=1; measured +12 % on a single 64-spp batch of Cornell-1M, but the split
-// batch still has to be reconciled with the latency bound of the in-batch cancellation tests):
-// a batch whose tile costs are not known yet (first batch of a tile grid) and that is long
+// On by default since round 3 (YTHIP_LPT_PROBE=0 switches it off; +12 % on a single 64-spp batch of
+// Cornell-1M).  Round 2 left it off because the in-batch cancellation test then missed its 50 ms
+// bound.  That was not the split: the cancel word lived in ordinary device memory, whose lines an
+// XCD's L2 keeps until they happen to be evicted — 45-55 ms on a busy device, with or without the
+// probe; the two extra small launches only pushed an already marginal latency over the bound.
+// The word is uncached memory now (alloc_stop_word) and both launches of a split batch carry the
+// same batch number (begin_batch), so one cancel stops both.
+// A batch whose tile costs are not known yet (first batch of a tile grid) and that is long
 // enough to care is launched as 1 + (batch - 1) samples: the first launch records what every
 // tile costs, the second is handed out most expensive tile first (yt_order.hip).  Two launches
 // of a progressive render: the same samples in the same order, bit-identical (tested).
 int enqueue_batch(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop) {
-  const bool probe = ctx->lpt_probe && ctx->lpt > 0 && ctx->d_tile_cost && !ctx->have_tile_costs && !ctx->d_tile_order &&
+  const bool probe = ctx->lpt_probe && ctx->lpt > 0 && ctx->d_tile_cost && !ctx->have_tile_costs &&
                      (ctx->prof_mode & 2) == 0 && params->batch >= 8 && ctx->st.nblocks > 4096 &&
                      ctx->samples < params->samples;
   if (!probe) return enqueue_samples(ctx, params, stop);
@@ -1962,6 +1834,7 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volati
   if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   const int samples_before = ctx->samples;
+  begin_batch(ctx);
   int       rc             = enqueue_batch(ctx, params, stop);
   if (rc) return rc;
   bool cancelled = false;
@@ -2008,6 +1881,7 @@ int ythip_trace_sample(ythip_ctx* ctx, const ythip_params* params, int i, int j,
         st.height);
   int pix = (j - st.row_begin) * st.lwidth + (dc / st.col_stride) * YT_TILE + i % YT_TILE;
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  begin_batch(ctx);
   int rc = enqueue_samples(ctx, params, nullptr, pix, sample);
   if (rc) return rc;
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2018,6 +1892,7 @@ int ythip_trace_sample(ythip_ctx* ctx, const ythip_params* params, int i, int j,
 int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params) {
   if (!ctx || !params) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  begin_batch(ctx);
   return enqueue_batch(ctx, params, nullptr);
 }
 
@@ -2045,10 +1920,10 @@ static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_
     free_all(tmp);
     return code;
   };
-  if (hipMemcpyAsync(d_rays, rays, n * sizeof(ythip_ray), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+  if (ctx->xfer.h2d(ctx->stream, d_rays, rays, n * sizeof(ythip_ray)) != hipSuccess)
     return cleanup(fail(ctx, YTHIP_ERR_HIP, "ray upload failed"));
   if (instances &&
-      hipMemcpyAsync(d_inst, instances, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      ctx->xfer.h2d(ctx->stream, d_inst, instances, n * sizeof(int)) != hipSuccess)
     return cleanup(fail(ctx, YTHIP_ERR_HIP, "instance upload failed"));
   bool count = (ctx->prof_mode & 2) != 0;
   {
@@ -2063,7 +1938,7 @@ static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_
     hipLaunchKernelGGL((k_intersect_batch<false, false>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
         d_rays, d_inst, (long long)n, find_any, d_hits, (unsigned long long*)nullptr);
   }
-  if (hipMemcpyAsync(hits, d_hits, n * sizeof(ythip_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+  if (ctx->xfer.d2h(ctx->stream, hits, d_hits, n * sizeof(ythip_hit)) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess)
     return cleanup(fail(ctx, YTHIP_ERR_HIP, "intersect batch failed: %s", hipGetErrorString(hipGetLastError())));
   return cleanup(YTHIP_OK);
@@ -2113,10 +1988,10 @@ int ythip_test_libm(ythip_ctx* ctx, int fn, const float* x, const float* y, int6
     free_all(tmp);
     return rc;
   }
-  auto e = hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (y && e == hipSuccess) e = hipMemcpyAsync(dy, y, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+  auto e = ctx->xfer.h2d(ctx->stream, dx, x, (size_t)n * 4);
+  if (y && e == hipSuccess) e = ctx->xfer.h2d(ctx->stream, dy, y, (size_t)n * 4);
   hipLaunchKernelGGL(k_test_libm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, dx, dy, (long long)n, dout);
-  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = ctx->xfer.d2h(ctx->stream, out, dout, (size_t)n * 4);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   free_all(tmp);
   if (e != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "test_libm failed: %s", hipGetErrorString(e));
@@ -2134,7 +2009,7 @@ int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params, ythip_ray* ray
   auto kp = to_kparams(ctx, params);
   hipLaunchKernelGGL(k_camera_rays, dim3(grid_for(ctx->st.npix)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds, ctx->st,
       kp, d_rays);
-  auto e1 = hipMemcpyAsync(rays, d_rays, (size_t)ctx->st.npix * sizeof(ythip_ray), hipMemcpyDeviceToHost, ctx->stream);
+  auto e1 = ctx->xfer.d2h(ctx->stream, rays, d_rays, (size_t)ctx->st.npix * sizeof(ythip_ray));
   auto e2 = hipStreamSynchronize(ctx->stream);
   free_all(tmp);
   if (e1 != hipSuccess || e2 != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "camera_rays failed");
@@ -2156,34 +2031,6 @@ int ythip_set_early_miss(ythip_ctx* ctx, int enable) {
 int ythip_set_specialization(ythip_ctx* ctx, int enable) {
   if (!ctx) return YTHIP_ERR_INVALID;
   ctx->specialize = enable ? 1 : 0;
-  return YTHIP_OK;
-}
-
-int ythip_set_pool(ythip_ctx* ctx, int mode, int waves, int target, int refill_min, int shade_min, int tile_mul) {
-  if (!ctx || mode < 0 || mode > 1) return fail(ctx, YTHIP_ERR_INVALID, "pool mode must be 0 or 1");
-  ctx->pool_mode = mode;
-  if (waves > 0) ctx->pool_waves = waves;
-  if (target > 0) ctx->pool_target = target;
-  if (refill_min > 0) ctx->pool_refill = refill_min;
-  if (shade_min > 0) ctx->pool_shade_min = shade_min;
-  if (tile_mul > 0) ctx->pool_tile_mul = (unsigned)tile_mul;
-  return YTHIP_OK;
-}
-
-int ythip_pool_stats(ythip_ctx* ctx, uint64_t* sums, uint64_t* maxs) {
-  if (!ctx || !sums || !maxs) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
-  for (int k = 0; k < POOL_DBG_STRIDE; k++) sums[k] = maxs[k] = 0;
-  if (!ctx->pool.dbg) return YTHIP_OK;
-  HIPCHECK(ctx, hipSetDevice(ctx->device));
-  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<unsigned long long> h((size_t)ctx->pool.nwaves * POOL_DBG_STRIDE);
-  HIPCHECK(ctx, hipMemcpy(h.data(), ctx->pool.dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  for (int w = 0; w < ctx->pool.nwaves; w++)
-    for (int k = 0; k < POOL_DBG_STRIDE; k++) {
-      auto v = h[(size_t)w * POOL_DBG_STRIDE + k];
-      sums[k] += v;
-      maxs[k] = std::max<uint64_t>(maxs[k], v);
-    }
   return YTHIP_OK;
 }
 
@@ -2215,7 +2062,7 @@ int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   harvest_events(ctx);
   unsigned long long banks[CNT_BANKS * CNT_STRIDE], c[CNT_NUM] = {};
-  HIPCHECK(ctx, hipMemcpy(banks, ctx->d_counters, sizeof(banks), hipMemcpyDeviceToHost));
+  HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, banks, ctx->d_counters, sizeof(banks)));
   for (int b = 0; b < CNT_BANKS; b++)
     for (int k = 0; k < CNT_NUM; k++) c[k] += banks[b * CNT_STRIDE + k];
 #ifdef YT_TIMING

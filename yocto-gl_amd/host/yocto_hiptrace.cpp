@@ -326,6 +326,13 @@ struct residency {
   std::vector<shadow_state> shadows;
   ythip_scene  staged      = {};       // rank 0's pinned staging pools (the flat scene, filled in place)
   bool         have_staged = false;
+  // trace_cancel's relay: the worker of trace_start hands this word to the library as the batch's
+  // `stop` flag (libythip polls it every 50 us while the batch runs and cancels the batch by its
+  // number); trace_cancel only stores to it — it touches nothing else of this struct, so it needs
+  // no lock and cannot race with ensure_context() / release()
+  std::atomic<int32_t> cancel{0};
+  static_assert(sizeof(std::atomic<int32_t>) == sizeof(int32_t) && std::atomic<int32_t>::is_always_lock_free,
+      "the relay word is read by libythip as a plain volatile int32_t");
   ythip_ctx*   ctx(int r = 0) { return ythip_multi_ctx(multi, r); }
 };
 residency& cache() {
@@ -467,6 +474,10 @@ void fill_scene(const scene_data& s, const ythip_scene& v) {
 void ingest(residency& r, const scene_data& scene) {
   ythip_scene counts;
   count_scene(scene, counts);
+  // ythip_scene_staging drops the resident scene before anything can fail: from here on nothing
+  // is resident as far as the stamps are concerned (a failed ingest is retried by the next call)
+  r.scene       = {};
+  r.bvh = r.lights = 0;
   r.have_staged = false;
   check(r.ctx(0), ythip_scene_staging(r.ctx(0), &counts, &r.staged));
   fill_scene(scene, r.staged);
@@ -476,18 +487,9 @@ void ingest(residency& r, const scene_data& scene) {
   for (int k = 1; k < r.ranks; k++) check(r.ctx(k), ythip_upload_scene(r.ctx(k), &r.staged));
 }
 
-// the scene's device mirrors (uploads what the stamp says changed); with `need_view` the
-// flat view r.staged is valid on return (make_trace_bvh reads the geometry through it)
-void ensure_scene(residency& r, const scene_data& scene, bool need_view = false) {
-  ensure_context(r);
-  auto ss    = stamp_of(scene);
-  bool whole = !r.scene.valid || ss.who != r.scene.who || ss.layout != r.scene.layout;
-  if (whole || (need_view && !r.have_staged)) {
-    ingest(r, scene);
-    r.scene = ss;
-    r.bvh = r.lights = 0;  // a scene upload drops the device trees and lights
-    return;
-  }
+// cameras / materials / environments: re-sent whenever their content hash differs from what is
+// resident (the GUI edits them in place between batches)
+void sync_small_pools(residency& r, const scene_data& scene, const scene_stamp& ss) {
   if (ss.cameras != r.scene.cameras) {
     std::vector<ythip_camera> cams;
     for (auto& c : scene.cameras) cams.push_back(flat(c));
@@ -505,6 +507,22 @@ void ensure_scene(residency& r, const scene_data& scene, bool need_view = false)
       envs.push_back({flat(e.frame), {e.emission.x, e.emission.y, e.emission.z}, e.emission_tex});
     on_all(r, [&](ythip_ctx* c) { return ythip_update_environments(c, envs.data(), (int)envs.size()); });
   }
+  r.scene.cameras = ss.cameras, r.scene.materials = ss.materials, r.scene.environments = ss.environments;
+}
+
+// the scene's device mirrors (uploads what the stamp says changed); with `need_view` the
+// flat view r.staged is valid on return (make_trace_bvh reads the geometry through it)
+void ensure_scene(residency& r, const scene_data& scene, bool need_view = false) {
+  ensure_context(r);
+  auto ss    = stamp_of(scene);
+  bool whole = !r.scene.valid || ss.who != r.scene.who || ss.layout != r.scene.layout;
+  if (whole || (need_view && !r.have_staged)) {
+    ingest(r, scene);
+    r.scene = ss;
+    r.bvh = r.lights = 0;  // a scene upload drops the device trees and lights
+    return;
+  }
+  sync_small_pools(r, scene, ss);
   r.scene = ss;
 }
 
@@ -608,9 +626,11 @@ void trace_impl(trace_state& state, const scene_data& scene, const trace_bvh& bv
   auto& r = cache();
   auto  lock = std::lock_guard{r.mutex};
   ensure_state(r, state, scene, bvh, lights);
-  auto p = flat(params);
-  mcheck(r, ythip_multi_trace_samples(r.multi, &p, nullptr));
-  if (stop && stop->load()) {
+  if (stop && stop->load()) return;  // cancelled during the uploads: nothing is launched
+  auto p  = flat(params);
+  auto rc = ythip_multi_trace_samples(r.multi, &p, stop ? reinterpret_cast<const volatile int32_t*>(&r.cancel) : nullptr);
+  if (rc != YTHIP_OK && rc != YTHIP_ERR_CANCELLED) mcheck(r, rc);
+  if (rc == YTHIP_ERR_CANCELLED || (stop && stop->load())) {
     // cancelled while the batch ran (trace_cancel raised the device flags): as in the
     // reference (yocto_trace.cpp:1636-1641) the pixels have taken different numbers of the
     // batch's samples and state.samples does not advance
@@ -815,6 +835,9 @@ void update_trace_bvh(trace_bvh& bvh, const scene_data& scene, const vector<int>
     r.bvh = bs;
   }
   if (!fresh_scene) {
+    // an edit of a camera / material / environment in the same frame (an animated camera plus a
+    // moving object) goes up too: the stamp taken below would otherwise call it resident
+    sync_small_pools(r, scene, stamp_of(scene));
     for (auto s : updated_shapes) {
       auto& sh = scene.shapes[s];
       on_all(r, [&](ythip_ctx* c) {
@@ -1082,6 +1105,7 @@ void trace_start(trace_context& context, trace_state& state, const scene_data& s
   if (state.samples >= params.samples) return;
   context.stop   = false;
   context.done   = false;
+  cache().cancel.store(0);
   context.worker = std::async(std::launch::async, [&]() {
     if (context.stop) return;
     trace_impl(state, scene, bvh, lights, params, false, &context.stop);  // includes the denoise hand-off
@@ -1095,11 +1119,7 @@ void trace_start(trace_context& context, trace_state& state, const scene_data& s
 // about one sample's time instead of running to its end.
 void trace_cancel(trace_context& context) {
   context.stop = true;
-  {
-    auto& r = cache();  // (no lock: the worker holds it while its batch runs; ythip_cancel is made for this)
-    if (r.multi)
-      for (int k = 0; k < r.ranks; k++) (void)ythip_cancel(r.ctx(k));
-  }
+  cache().cancel.store(1);  // the library relays it to the batch in flight (residency::cancel)
   if (context.worker.valid()) context.worker.get();
 }
 // trace_preview — yocto_trace.cpp:1660-1676

@@ -485,8 +485,6 @@ _SIGNATURES = {
     "ythip_set_scheduling": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_set_early_miss": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_set_specialization": (C.c_int, [C.c_void_p, C.c_int]),
-    "ythip_set_pool": (C.c_int, [C.c_void_p] + [C.c_int] * 6),
-    "ythip_pool_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ythip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_reset_stats": (C.c_int, [C.c_void_p]),
     "ythip_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CStats)]),
@@ -913,19 +911,6 @@ class Context:
 
     def set_early_miss(self, enable):
         self._check(self.lib.ythip_set_early_miss(self.h, int(enable)), "set_early_miss")
-
-    def set_pool(self, mode, waves=0, target=0, refill_min=0, shade_min=0, tile_mul=0):
-        """Scheduler: 0 k_trace (default), 1 the experimental k_pool (path samplers)."""
-        self._check(self.lib.ythip_set_pool(self.h, int(mode), waves, target, refill_min, shade_min, tile_mul),
-                    "set_pool")
-
-    def pool_stats(self):
-        names = ["iters", "watchdog", "rounds", "active", "shades", "shaded", "steps", "wsteps", "refills",
-                 "tiles", "cycles"]
-        s = np.zeros(16, np.uint64)
-        m = np.zeros(16, np.uint64)
-        self._check(self.lib.ythip_pool_stats(self.h, _ptr(s), _ptr(m)), "pool_stats")
-        return ({k: int(s[i]) for i, k in enumerate(names)}, {k: int(m[i]) for i, k in enumerate(names)})
 
     def set_traversal(self, mode):
         """"binary" | "wide" | "auto" (default): which BVH walk the kernels use."""
