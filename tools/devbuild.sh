@@ -6,9 +6,9 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/.."
 mkdir -p build/dev
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DYT_DEV_ONLY_PATH "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -ffp-contract=off -fPIC -DYT_DEV_ONLY_PATH "$@" \
   -c -o build/dev/ythip_$name.o yocto-gl_amd/csrc/ythip.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/gpubuild_$name.o yocto-gl_amd/csrc/yt_gpubuild.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/gpubuild_$name.o yocto-gl_amd/csrc/yt_gpubuild.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/multi_$name.o yocto-gl_amd/csrc/yt_multi.hip
 [ -f build/dev/order.o ] && [ build/dev/order.o -nt yocto-gl_amd/csrc/yt_order.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/order.o yocto-gl_amd/csrc/yt_order.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/dev/libythip_$name.so build/dev/ythip_$name.o build/dev/gpubuild_$name.o build/dev/multi_$name.o build/dev/order.o -ldl

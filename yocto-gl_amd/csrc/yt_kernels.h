@@ -93,8 +93,9 @@ struct DState {
   unsigned long long* counters;
   // cancellation: a device-visible flag the host raises when the caller's `stop` goes up
   // (yocto_trace.cpp:1636-1637 polls context.stop per sample); may be null
-  const int* stop;
-  int        stop_gen;  // this batch's number: the batch stops when *stop equals it (ythip.hip, begin_batch)
+  int*       stop;       // device word every workgroup polls once per iteration
+  const int* stop_host;  // pinned host word ythip_cancel writes; relayed into *stop by the kernel (ythip.hip, alloc_stop_word)
+  int        stop_gen;   // this batch's number: the batch stops when the word equals it (begin_batch)
   // longest-tile-first launch order (yt_order.hip): workgroup b renders tile tile_perm[b]; every
   // workgroup records the cycles its tile took for the next launch's order.  null: off.
   const int* tile_perm;
@@ -102,6 +103,12 @@ struct DState {
 };
 YT_FN bool stop_requested(const int* stop, int gen) {
   return stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen;
+}
+// the relay: one look at the host's word (a read over the fabric: rare by construction), passed on to the device word
+YT_FN bool relay_stop(const DState& st) {
+  if (!st.stop_host || __hip_atomic_load(st.stop_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != st.stop_gen) return false;
+  if (threadIdx.x == 0) __hip_atomic_store(st.stop, st.stop_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
 }
 
 enum { CNT_RAYS = 0, CNT_NODES, CNT_TRIS, CNT_QUADS, CNT_LINES, CNT_POINTS, CNT_INST, CNT_SHADES, CNT_SAMPLES, CNT_NUM };
@@ -1038,6 +1045,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
   const int lb = logical_block(st);
   if (lb < 0) return;
   if (stop_requested(st.stop, st.stop_gen)) return;  // cancelled before this tile started
+  if ((lb & 63) == 0 && relay_stop(st)) return;      // (one tile in 64 also asks the host's word: a batch cancelled before any workgroup ran)
   const long long t_tile0 = st.tile_cost ? (long long)__builtin_readcyclecounter() : 0;
   const int tid = threadIdx.x;
   Stack     stack;
@@ -1093,7 +1101,8 @@ __global__ void __launch_bounds__(YT_BLOCK,
     // as much (interiors) everything runs at once, which keeps the lanes full.  The
     // workgroup decides from the traversal work it has measured itself; results do
     // not depend on the decision (pixels are independent).
-    const bool stopped = stop_requested(st.stop, st.stop_gen);  // once per iteration = at most one sample late
+    // once per iteration = at most one sample late; every 64th iteration this workgroup is a relay
+    const bool stopped = stop_requested(st.stop, st.stop_gen) || (((iter + lb) & 63) == 63 && relay_stop(st));
     bool wait = false;
     if (kp.hold && n.y > 0 && n.x > 0) {
       float wp = (float)Q.work[0], rp = (float)Q.rays[0], wb = (float)Q.work[1], rb_ = (float)Q.rays[1];

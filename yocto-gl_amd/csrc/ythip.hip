@@ -3,9 +3,11 @@
 // (context / scene / bvh / lights / state — libs/yocto/yocto_cutrace.cpp:385-996)
 // but is written for HIP directly.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
-// (-ffp-contract=off is REQUIRED: bit parity with the g++-built reference, which
-// has no FMA contraction on baseline x86-64).
+// Build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -ffp-contract=off -fPIC -shared
+// (-ffp-contract=off is REQUIRED: bit parity with the g++-built reference, which has no FMA
+// contraction on baseline x86-64; -fno-slp-vectorize is REQUIRED too: with ROCm 7.2's SLP
+// vectorizer one k_trace instantiation is miscompiled and all of them are 5-40 % slower —
+// __graft_entry__.py, profiles/r03_slp_vectorizer.txt).
 
 #include <hip/hip_runtime.h>
 
@@ -144,8 +146,7 @@ struct ythip_ctx {
   float4*                                      nhit_a   = nullptr;
   int*                                         nhit_e   = nullptr;
 
-  int*               d_stop        = nullptr;  // device-visible cancel flag polled by the kernels
-  hipStream_t        side_stream   = nullptr;  // raises the flag while the kernel runs on `stream`
+  int*               d_stop        = nullptr;  // device-visible cancel word polled by the kernels
   hipEvent_t         done_event    = nullptr;
   // Cancellation by generation: every batch gets a number, the kernels stop when the
   // word at d_stop EQUALS their batch's number, ythip_cancel writes the number of the batch in
@@ -153,7 +154,8 @@ struct ythip_ctx {
   // neither be lost into it nor leak into it (the boolean of round 2 could end up raised with
   // nobody left to lower it: every later tile then exited at once while `samples` kept advancing).
   std::atomic<int>   stop_gen{0};
-  std::mutex         stop_mu;  // serialises concurrent ythip_cancel calls (they share the side stream)
+  int*               stop_host     = nullptr;  // pinned host word ythip_cancel stores the batch number into ...
+  const int*         stop_host_dev = nullptr;  // ... and its device address (the kernels relay it into d_stop)
   ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
 };
 
@@ -775,6 +777,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   ctx->st.nhit_a      = mis ? ctx->nhit_a : nullptr;
   ctx->st.nhit_e      = mis ? ctx->nhit_e : nullptr;
   ctx->st.stop        = ctx->d_stop;
+  ctx->st.stop_host   = ctx->stop_host_dev;
   ctx->st.stop_gen    = ctx->stop_gen.load();  // (begin_batch() numbered this batch)
   ctx->st.sample_base = only_pix < 0 ? ctx->samples : sample;
   ctx->st.batch       = only_pix < 0 ? params->batch : 1;
@@ -854,14 +857,30 @@ void classify_scene(ythip_ctx* ctx, const ythip_material* materials, int num_mat
 // ===========================================================================
 extern "C" {
 
-// The cancel word is polled by every workgroup once per iteration and written by the command
-// processor while the batch runs.  Ordinary (coarse-grained) device memory is only coherent
-// between the eight XCDs' L2s at kernel boundaries: a workgroup's agent-scope load kept hitting
-// its XCD's stale line until the line happened to be evicted — the 45-55 ms cancel latency of
-// round 2.  Uncached device memory (MTYPE UC) is read at the memory side every time.
+// Cancellation plumbing (measured: tools/cancel_latency.py, profiles/r03_cancel_latency.txt).
+//   * Every workgroup polls a DEVICE word once per iteration (one scalar load that hits the L2).
+//   * The host never touches that word.  It stores the batch number into a word of PINNED HOST memory
+//     — a plain store: no stream, no command processor, no copy engine, nothing that could queue
+//     behind the batch — and the kernel relays it: every 64th iteration (phase-shifted by tile) a
+//     workgroup also reads the host word over the fabric, and the first one that sees the batch's
+//     number writes it into the device word, which every other workgroup sees at its next iteration.
+//     With thousands of resident workgroups somebody looks within microseconds.
+//   Round 2 raised the device word with hipStreamWriteValue32 on a side stream: 1-40 ms on an idle
+//   queue, but 100-200 ms as soon as a batch was several launches (the longest-tile-first probe:
+//   1 + order kernels + (batch - 1)) — the write waited for queue arbitration.  Polling the host word
+//   directly from every workgroup every iteration is no alternative: configs[1] 5.3 -> 54 ms
+//   (100 M small reads per second over PCIe).
 static hipError_t alloc_stop_word(ythip_ctx* ctx) {
-  if (hipExtMallocWithFlags((void**)&ctx->d_stop, 64, hipDeviceMallocUncached) == hipSuccess) return hipSuccess;
-  (void)hipGetLastError();
+  void* h = nullptr;
+  hipError_t e = hipHostMalloc(&h, 64, hipHostMallocCoherent | hipHostMallocMapped);
+  if (e != hipSuccess) return e;
+  std::memset(h, 0, 64);
+  void* d = nullptr;
+  if ((e = hipHostGetDevicePointer(&d, h, 0)) != hipSuccess) {
+    (void)hipHostFree(h);
+    return e;
+  }
+  ctx->stop_host = (int*)h, ctx->stop_host_dev = (const int*)d;
   return hipMalloc((void**)&ctx->d_stop, 64);
 }
 
@@ -888,8 +907,7 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_DENOISE_SIMPLE")) ctx->denoise_simple = std::atoi(e) != 0;
   if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
-      alloc_stop_word(ctx) != hipSuccess || hipMemset(ctx->d_stop, 0, 64) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) {
+      alloc_stop_word(ctx) != hipSuccess || hipMemset(ctx->d_stop, 0, 64) != hipSuccess) {
     delete ctx;
     return fail(nullptr, YTHIP_ERR_HIP, "context allocation failed");
   }
@@ -911,11 +929,11 @@ void ythip_destroy(ythip_ctx* ctx) {
     (void)hipEventDestroy(ev.second);
   }
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->stop_host) (void)hipHostFree(ctx->stop_host);
   if (ctx->d_stop) (void)hipFree(ctx->d_stop);
   free_staging(ctx);
   free_all(ctx->denoise_allocs);
   free_all(ctx->order_allocs);
-  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->done_event) (void)hipEventDestroy(ctx->done_event);
   ctx->xfer.destroy();
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1784,16 +1802,9 @@ namespace {
 // Raise the device-visible cancel flag from the side stream (the batch's kernel polls it
 // once per sample boundary; yocto_trace.cpp:1636-1637).
 int raise_stop(ythip_ctx* ctx) {
-  std::lock_guard<std::mutex> lock(ctx->stop_mu);
-  const int gen = ctx->stop_gen.load();  // the batch in flight (or the last one: then nobody is listening)
-  // A write by the command processor: it needs neither a compute unit nor a DMA engine, so
-  // it lands while the batch's persistent workgroups hold every CU (a copy that is executed
-  // as a blit kernel would wait for one of them to retire — seconds for a long batch).
-  if (hipStreamWriteValue32(ctx->side_stream, ctx->d_stop, (uint32_t)gen, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    HIPCHECK(ctx, hipMemcpyAsync(ctx->d_stop, &gen, sizeof(int), hipMemcpyHostToDevice, ctx->side_stream));
-  }
-  HIPCHECK(ctx, hipStreamSynchronize(ctx->side_stream));  // (`gen` is a local: the copy has been taken)
+  // the number of the batch in flight (or of the last one: then nobody is listening) into the pinned
+  // host word; the kernels relay it (alloc_stop_word).  Callable from any thread, no HIP call.
+  __atomic_store_n(ctx->stop_host, ctx->stop_gen.load(), __ATOMIC_RELEASE);
   return YTHIP_OK;
 }
 // every batch (and every trace_sample call) is numbered before its launches are enqueued
@@ -1865,7 +1876,6 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volati
 
 int ythip_cancel(ythip_ctx* ctx) {
   if (!ctx) return YTHIP_ERR_INVALID;
-  HIPCHECK(ctx, hipSetDevice(ctx->device));
   return raise_stop(ctx);
 }
 
