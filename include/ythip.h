@@ -283,6 +283,8 @@ typedef struct ythip_build_info {
   double  device_ms; /* device time inside the builder kernels (hipEvents)        */
   double  build_ms;  /* wall time of the whole tree construction (all shapes+TLAS) */
   double  bake_ms;   /* wall time of baking pairs / leaf data / instance records   */
+  int32_t host_threads; /* worker threads that built the small shapes (0: the calling thread) */
+  int32_t device_tlas;  /* 1: the instance tree was built on the device                      */
 } ythip_build_info;
 int ythip_bvh_build_info(ythip_ctx* ctx, ythip_build_info* info);
 /* The baked traversal arrays, for tests: pairs are 64-B records
@@ -488,6 +490,31 @@ int ythip_set_early_miss(ythip_ctx* ctx, int enable);
  * other seven lobes, the volume and texture code and the quad / line / point paths
  * (10 % faster on BASELINE configs[1]); 0: always the general kernel. */
 int ythip_set_specialization(ythip_ctx* ctx, int enable);
+
+/* ---- the file formats either side of the path (host code, no device needed) ----
+ * trace_params <-> JSON: the reference's parameter files (libs/yocto/yocto_sceneio.cpp:5815-5852,
+ * load / save / update_trace_params :5933-5945): same keys, enums as their labels.
+ * ythip_params_default = trace_params{} (yocto_trace.h:95-113).  ythip_params_from_json has the
+ * reference's "update" semantics: a key that is absent keeps the value already in *params; `length`
+ * < 0 = strlen(text).  ythip_params_to_json returns the length of the text (writes at most
+ * `capacity` bytes incl. the terminator; call with NULL / 0 for the size), -1 on a bad enum value. */
+void    ythip_params_default(ythip_params* params);
+int     ythip_params_from_json(const char* text, int64_t length, ythip_params* params);
+int64_t ythip_params_to_json(const ythip_params* params, char* buffer, int64_t capacity);
+const char* ythip_io_last_error(void);
+/* PLY -> flat pools, without the reference's ply_model -> shape_data -> flatten() generations of
+ * copies (load_ply, libs/yocto/yocto_modelio.cpp:487-740; load_shape's getters,
+ * libs/yocto/yocto_sceneio.cpp:1017-1033 with yocto_modelio.h:548-817).  ythip_ply_open maps the file
+ * and reports in the num_* fields of `counts` what load_shape would produce from it (faces: quads if any
+ * face has four corners, else triangles, polygons fanned; "empty shape" is an error, as there); the
+ * caller sizes ythip_scene_staging from the counts of all its shapes and has ythip_ply_read convert the
+ * properties straight into the pools at the shape's offsets (NULL = skip that array; colors get alpha
+ * 1 when the file has none; flip_texcoord: v -> 1 - v, what load_shape is called with for scenes). */
+typedef struct ythip_ply ythip_ply;
+int  ythip_ply_open(const char* path, ythip_ply** ply, ythip_shape* counts);
+int  ythip_ply_read(ythip_ply* ply, int flip_texcoord, float* positions, float* normals, float* texcoords,
+    float* colors, float* radius, int32_t* points, int32_t* lines, int32_t* triangles, int32_t* quads);
+void ythip_ply_close(ythip_ply* ply);
 
 /* Which BVH walk k_trace's extend stage and the test entries below use: 0 the
  * binary walk (one sibling pair per dependent fetch), 1 the wide walk (the four

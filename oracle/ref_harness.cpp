@@ -732,6 +732,39 @@ void ref_rand1f(uint64_t* state, int n, float* out) {
   state[1] = rng.inc;
 }
 
+// save_trace_params / load_trace_params (yocto_sceneio.cpp:5933-5945): the reference's own
+// parameter files, for tests/test_io.py (ythip_params_to_json / _from_json must interoperate)
+int ref_params_save(const ythip_params* p, const char* filename) {
+  try {
+    auto params      = to_params(*p);
+    params.embreebvh = p->embreebvh != 0;
+    params.denoise   = p->denoise != 0;
+    save_trace_params(filename, params);
+  } catch (const std::exception& e) {
+    g_load_error = e.what();
+    return 1;
+  }
+  return 0;
+}
+int ref_params_load(const char* filename, ythip_params* p) {
+  try {
+    auto params = to_params(*p);  // (update semantics: absent keys keep the incoming values)
+    params.embreebvh = p->embreebvh != 0;
+    params.denoise   = p->denoise != 0;
+    update_trace_params(filename, params);
+    p->camera = params.camera, p->resolution = params.resolution, p->sampler = (int)params.sampler;
+    p->falsecolor = (int)params.falsecolor, p->samples = params.samples, p->bounces = params.bounces;
+    p->clamp = params.clamp, p->nocaustics = params.nocaustics, p->envhidden = params.envhidden;
+    p->tentfilter = params.tentfilter, p->seed = params.seed, p->embreebvh = params.embreebvh;
+    p->highqualitybvh = params.highqualitybvh, p->noparallel = params.noparallel, p->pratio = params.pratio;
+    p->denoise = params.denoise, p->batch = params.batch;
+  } catch (const std::exception& e) {
+    g_load_error = e.what();
+    return 1;
+  }
+  return 0;
+}
+
 int ref_hardware_concurrency() {
   return (int)std::thread::hardware_concurrency();
 }

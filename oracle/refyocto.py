@@ -80,6 +80,8 @@ def lib():
             "ref_make_rng": (None, [C.c_uint64, C.c_uint64, vp]),
             "ref_rand1f": (None, [vp, C.c_int, vp]),
             "ref_hardware_concurrency": (C.c_int, []),
+            "ref_params_save": (C.c_int, [C.POINTER(yt.CParams), C.c_char_p]),
+            "ref_params_load": (C.c_int, [C.c_char_p, C.POINTER(yt.CParams)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

@@ -240,3 +240,104 @@ def test_render_on_the_device_built_sah_tree_equals_the_reference_with_highquali
     ctx.close()
     ref = P.RefBundle(flat, highquality=True).render(p)
     P.assert_identical(gpu, ref, name + " highqualitybvh")
+
+
+# ---- round 3: the instance tree on the device, the small shapes on a host thread pool ---------------
+def _many_instances(grid, rotate=True, seed=5):
+    """grid x grid instances of a small sphere with random rigid + scaled frames (overlapping boxes)."""
+    flat = ysc.instanced_scene(grid=grid, sphere_steps=(8, 4))
+    if rotate:
+        rng = np.random.default_rng(seed)
+        n = len(flat.instances)
+        q = rng.normal(size=(n, 3, 3))
+        q, _ = np.linalg.qr(q)
+        s = (0.5 + rng.random((n, 1, 1))).astype(f32)
+        fr = flat.instances["frame"].copy()
+        fr[:, :9] = (q * s).astype(f32).reshape(n, 9)
+        flat.instances["frame"] = fr
+    return flat
+
+
+@pytest.mark.parametrize("highquality", [False, True])
+def test_instance_tree_built_on_the_device_equals_the_host_tree(highquality):
+    """40,000 instances (>= the device threshold): make_bvh over the instances' world bounds runs on
+    the GPU (kind 0 of yt_gpubuild.hip) — the same nodes, the same `primitives`, the same baked
+    pairs / quads as the host builder's, split_middle and split_sah; hits equal too."""
+    flat = _many_instances(200)
+    dev, host = build_both(flat, min_prims=16384, highquality=highquality)
+    assert dev[2]["device_tlas"] == 1 and host[2]["device_tlas"] == 0
+    assert_same(dev, host, "instance tree")
+
+
+def test_device_instance_tree_renders_refits_and_downloads():
+    flat = _many_instances(160)
+    ctx = yt.Context(0)
+    ctx.upload_scene(flat)
+    ctx.make_trace_bvh(flat)
+    assert ctx.bvh_build_info()["device_tlas"] == 1
+    rays = P.random_rays(flat, 50000)
+    got = ctx.intersect_batch(rays)
+    hctx = yt.Context(0)
+    hctx.upload_scene(flat)
+    hctx.set_bvh_builder("host")
+    hctx.make_trace_bvh(flat)
+    want = hctx.intersect_batch(rays)
+    assert P.hits_equal(want, got)
+    # moving instances: update_scene_bvh brings the device-built instance tree home and refits it there
+    ids = np.arange(0, len(flat.instances), 7, dtype=np.int32)
+    frames = flat.instances["frame"][ids].copy()
+    frames[:, 10] += f32(0.05)
+    for c in (ctx, hctx):
+        c.update_instance_frames(ids, frames)
+        c.update_bvh(updated_instances=ids)
+    a, b = ctx.download_bvh(), hctx.download_bvh()
+    assert a.nodes.tobytes() == b.nodes.tobytes() and a.primitives.tobytes() == b.primitives.tobytes()
+    assert P.hits_equal(hctx.intersect_batch(rays), ctx.intersect_batch(rays))
+    ctx.close()
+    hctx.close()
+
+
+def test_small_shapes_are_built_by_a_host_thread_pool(monkeypatch):
+    """1,500 shapes of 40-400 triangles each (all below the device threshold): the pool of host threads
+    (the reference's parallel_for over the shapes, yocto_bvh.cpp:369-378) produces the flat layout of the
+    one-thread build, byte for byte, and says how many threads it used."""
+    rng = np.random.default_rng(11)
+    flat = yt.FlatScene()
+    flat.add_camera(ysc.lookat_frame((0, 3, 8), (0, 0, 0)))
+    m = flat.add_material("matte", color=(0.6, 0.6, 0.6))
+    for k in range(1500):
+        n = int(rng.integers(40, 400))
+        p = (rng.random((3 * n, 3)) + rng.integers(-5, 5, 3)).astype(f32)
+        sh = flat.add_shape(p, triangles=np.arange(3 * n, dtype=np.int32).reshape(n, 3))
+        flat.add_instance(sh, m)
+    flat.add_environment((1, 1, 1))
+    out = []
+    for threads in ["0", "8"]:
+        monkeypatch.setenv("YTHIP_BUILD_THREADS", threads)
+        ctx = yt.Context(0)
+        ctx.upload_scene(flat)
+        ctx.make_trace_bvh(flat)
+        out.append((ctx.download_bvh(), ctx.download_baked_bvh(), ctx.bvh_build_info()))
+        ctx.close()
+    assert out[0][2]["host_threads"] == 0 and out[1][2]["host_threads"] == 8
+    assert out[0][2]["host_trees"] == out[1][2]["host_trees"] == 1500
+    assert_same(out[1], out[0], "thread pool")
+
+
+@pytest.mark.parametrize("name", list(P.SCENES))
+def test_batched_device_bake_of_host_trees_equals_the_host_bake(name, monkeypatch):
+    """Host-resident trees are baked into pair / quad / leaf records by ONE set of device launches
+    (ytgpu::bake_host_trees); YTHIP_HOST_BAKE=1 assembles the same records on the host, tree by tree:
+    byte-identical arrays, on every test scene (all primitive kinds, instances, empty shapes)."""
+    flat = P.SCENES[name]()
+    out = []
+    for env in ["0", "1"]:
+        monkeypatch.setenv("YTHIP_HOST_BAKE", env)
+        ctx = yt.Context(0)
+        ctx.upload_scene(flat)
+        ctx.set_bvh_builder("host")
+        ctx.make_trace_bvh(flat)
+        out.append(ctx.download_baked_bvh())
+        ctx.close()
+    for a, b, what in zip(out[0], out[1], ["pairs", "leaf data", "quads"]):
+        assert a.tobytes() == b.tobytes(), what

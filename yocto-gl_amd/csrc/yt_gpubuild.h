@@ -39,6 +39,8 @@ enum { BUILD_OK = 0, BUILD_FALLBACK = 1, BUILD_ERROR = 2 };
 // when the tree cannot be reproduced bit for bit on the device (signed-zero
 // ties between box faces — see the .hip) and the caller must use the host
 // builder, BUILD_ERROR on a HIP failure (message in *err).
+// kind 0: the primitives are boxes — `positions` holds {min.xyz, max.xyz} per box, `elems` and
+// `radius` are unused: make_bvh over instance bounds, the instance tree (yocto_bvh.cpp:381-393).
 int build_shape_tree(hipStream_t stream, int kind, const int32_t* elems, const float* positions,
     const float* radius, int64_t num_prims, bool highquality, DeviceTree* out, std::string* err);
 void free_tree(DeviceTree* tree);
@@ -53,6 +55,27 @@ void free_tree(DeviceTree* tree);
 int bake_shape_tree(hipStream_t stream, const DeviceTree& tree, int kind, const int32_t* elems,
     const float* positions, const float* radius, int64_t pair_base, int64_t prim_base, int64_t leaf_base,
     float4* pairs, float4* quads, float4* leafdata, float* root_out, std::string* err);
+
+// Batched device bake of HOST-resident trees (built by yt_build.h or uploaded by the caller): all of
+// them in one set of launches, whatever their number (a scene of thousands of small shapes bakes in
+// the time of one large one).  The caller uploads their nodes and primitives as compact arrays
+// (tree after tree) and a table that says where each tree starts and where its records go.
+struct HostTreeDesc {
+  long long    node_off;       // first node of the tree in the compact node array
+  long long    prim_off;       // first primitive of the tree in the compact primitive array
+  long long    pair_base;      // id of the tree's first sibling-pair / quad record
+  long long    ref_prim_base;  // added to a leaf's `start` in its ref: the tree's global primitive offset (0: instance tree)
+  long long    leaf_base;      // float4 index of the tree's leaf data
+  int          kind;           // 0 instance tree (no leaf data), 1 points, 2 lines, 3 triangles, 4 quads
+  int          pad_;
+  const int*   elems;          // the shape's elements / positions / radii on the device
+  const float* positions;
+  const float* radius;
+};
+// d_table: `ntrees` descriptors on the device, ascending node_off / prim_off.
+int bake_host_trees(hipStream_t stream, const ythip_bvh_node* d_nodes, long long num_nodes, const int32_t* d_prims,
+    long long num_prims, const HostTreeDesc* d_table, int ntrees, float4* pairs, float4* quads, float4* leafdata,
+    std::string* err);
 
 // refit_bvh (yocto_bvh.cpp:305-319) of a resident tree after the shape's vertices moved
 // (update_shape_bvh, yocto_bvh.cpp:398-431): every box recomputed bottom-up, topology

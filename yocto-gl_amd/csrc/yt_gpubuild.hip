@@ -95,7 +95,9 @@ __device__ __forceinline__ void prim_bounds(int kind, const int* elems, const fl
   auto mx2 = [](float3x a, float3x b) { return float3x{fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)}; };
   auto add = [](float3x a, float r) { return float3x{a.x + r, a.y + r, a.z + r}; };
   auto sub = [](float3x a, float r) { return float3x{a.x - r, a.y - r, a.z - r}; };
-  if (kind == 1) {  // point_bounds(p, r) = {min(p - r, p + r), max(p - r, p + r)}
+  if (kind == 0) {  // the boxes ARE the primitives (the instance tree: yocto_bvh.cpp:381-393): P holds {min, max} per box
+    lo = float3x{P[6 * i], P[6 * i + 1], P[6 * i + 2]}, hi = float3x{P[6 * i + 3], P[6 * i + 4], P[6 * i + 5]};
+  } else if (kind == 1) {  // point_bounds(p, r) = {min(p - r, p + r), max(p - r, p + r)}
     int  v = elems[i];
     auto p = ld(v);
     auto r = R[v];
@@ -775,7 +777,7 @@ void free_tree(DeviceTree* t) {
 int build_shape_tree(hipStream_t s, int kind, const int32_t* elems, const float* positions, const float* radius,
     int64_t num_prims, bool highquality, DeviceTree* out, std::string* err) {
   *out = DeviceTree{};
-  if (num_prims <= MAX_PRIMS || num_prims > (1ll << 28) || kind < 1 || kind > 4) return BUILD_FALLBACK;
+  if (num_prims <= MAX_PRIMS || num_prims > (1ll << 28) || kind < 0 || kind > 4) return BUILD_FALLBACK;
   if ((kind == 1 || kind == 2) && !radius) return BUILD_FALLBACK;
   const int n = (int)num_prims;
 
@@ -909,8 +911,9 @@ int bake_shape_tree(hipStream_t s, const DeviceTree& tree, int kind, const int32
       (long long)prim_base, pairs);
   hipLaunchKernelGGL(k_bake_quads, dim3(grid(n)), dim3(BLK), 0, s, tree.nodes, n, pid, (long long)pair_base,
       (long long)prim_base, quads);
-  hipLaunchKernelGGL(k_bake_leaf, dim3(grid(np)), dim3(BLK), 0, s, kind, elems, positions, radius, tree.prims, np,
-      leafdata + leaf_base);
+  if (kind != 0)  // (the instance tree has no leaf data: its leaves index tlas_prims)
+    hipLaunchKernelGGL(k_bake_leaf, dim3(grid(np)), dim3(BLK), 0, s, kind, elems, positions, radius, tree.prims, np,
+        leafdata + leaf_base);
   ythip_bvh_node root;
   GCHECK(hipMemcpyAsync(&root, tree.nodes, sizeof(root), hipMemcpyDeviceToHost, s));
   GCHECK(hipStreamSynchronize(s));
@@ -919,6 +922,138 @@ int bake_shape_tree(hipStream_t s, const DeviceTree& tree, int kind, const int32
   int ref = root.internal ? (int)pair_base
                           : (int)(0x80000000u | ((unsigned)(root.num & 7) << 28) | (unsigned)(prim_base + root.start));
   std::memcpy(&root_out[6], &ref, 4);
+  cleanup();
+  return BUILD_OK;
+}
+
+// ---- batched bake of host-resident trees ---------------------------------------------------
+namespace {
+__device__ __forceinline__ int tree_of_node(const HostTreeDesc* T, int nt, long long i) {
+  int lo = 0, hi = nt - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (T[mid].node_off <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__device__ __forceinline__ int tree_of_prim(const HostTreeDesc* T, int nt, long long k) {
+  int lo = 0, hi = nt - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (T[mid].prim_off <= k) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+// pair id of compact node `cn` (an internal node of tree t): the tree's base + its rank among the tree's internal nodes
+__device__ __forceinline__ int ref_of_all(const ythip_bvh_node& ch, long long cn, const int* scan, const HostTreeDesc& t) {
+  if (ch.internal) return (int)(t.pair_base + (scan[cn] - scan[t.node_off]));
+  return (int)(0x80000000u | ((unsigned)(ch.num & 7) << 28) | (unsigned)(t.ref_prim_base + ch.start));
+}
+__global__ void k_bake_all_nodes(const ythip_bvh_node* nodes, long long n, const int* scan, const HostTreeDesc* T, int nt,
+    float4* pairs, float4* quads) {
+  long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  ythip_bvh_node nd = nodes[i];
+  if (!nd.internal) return;
+  const HostTreeDesc t  = T[tree_of_node(T, nt, i)];
+  const long long    id = t.pair_base + (scan[i] - scan[t.node_off]);
+  float4*            P  = pairs + 4 * id;
+  float4*            Q  = quads + 8 * id;
+  int                axes = nd.axis & 3;
+  for (int h = 0; h < 2; h++) {
+    long long      cn = t.node_off + nd.start + h;
+    ythip_bvh_node ch = nodes[cn];
+    P[2 * h]          = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_max[0], ch.bbox_max[1]};
+    P[2 * h + 1]      = {ch.bbox_min[2], ch.bbox_max[2], __int_as_float(ref_of_all(ch, cn, scan, t)), __int_as_float((int)nd.axis)};
+    long long s0 = cn, s1 = -1;
+    if (ch.internal) {
+      s0 = t.node_off + ch.start, s1 = s0 + 1;
+      axes |= (ch.axis & 3) << (2 + 2 * h);
+    }
+    for (int k = 0; k < 2; k++) {
+      long long sn = k == 0 ? s0 : s1;
+      float4*   S  = Q + 2 * (2 * h + k);
+      if (sn < 0) {
+        S[0] = {0, 0, 0, 0};
+        S[1] = {0, 0, __int_as_float(0x7ffffffe), 0};  // REF_NONE
+        continue;
+      }
+      ythip_bvh_node g = nodes[sn];
+      S[0]             = {g.bbox_min[0], g.bbox_min[1], g.bbox_max[0], g.bbox_max[1]};
+      S[1]             = {g.bbox_min[2], g.bbox_max[2], __int_as_float(ref_of_all(g, sn, scan, t)), 0};
+    }
+  }
+  Q[1].w = __int_as_float(axes);
+}
+__global__ void k_bake_all_leaves(const int* prims, long long n, const HostTreeDesc* T, int nt, float4* leaf) {
+  long long k = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (k >= n) return;
+  const HostTreeDesc t = T[tree_of_prim(T, nt, k)];
+  if (t.kind == 0) return;  // the instance tree's primitives are instance ids (tlas_prims)
+  const int       id = prims[k];
+  const long long kl = k - t.prim_off;
+  const float*    P  = t.positions;
+  const float*    R  = t.radius;
+  auto pos = [&](int v) { return float3x{P[3 * v], P[3 * v + 1], P[3 * v + 2]}; };
+  if (t.kind == 3) {
+    auto    p0 = pos(t.elems[3 * id]), p1 = pos(t.elems[3 * id + 1]), p2 = pos(t.elems[3 * id + 2]);
+    float4* L  = leaf + t.leaf_base + 3 * kl;
+    L[0] = {p0.x, p0.y, p0.z, p1.x};
+    L[1] = {p1.y, p1.z, p2.x, p2.y};
+    L[2] = {p2.z, __int_as_float(id), 0, 0};
+  } else if (t.kind == 4) {
+    auto    p0 = pos(t.elems[4 * id]), p1 = pos(t.elems[4 * id + 1]), p2 = pos(t.elems[4 * id + 2]), p3 = pos(t.elems[4 * id + 3]);
+    float4* L  = leaf + t.leaf_base + 4 * kl;
+    L[0] = {p0.x, p0.y, p0.z, p1.x};
+    L[1] = {p1.y, p1.z, p2.x, p2.y};
+    L[2] = {p2.z, p3.x, p3.y, p3.z};
+    L[3] = {__int_as_float(id), 0, 0, 0};
+  } else if (t.kind == 2) {
+    int     a = t.elems[2 * id], b = t.elems[2 * id + 1];
+    auto    p0 = pos(a), p1 = pos(b);
+    float4* L  = leaf + t.leaf_base + 3 * kl;
+    L[0] = {p0.x, p0.y, p0.z, p1.x};
+    L[1] = {p1.y, p1.z, R ? R[a] : 0.0f, R ? R[b] : 0.0f};
+    L[2] = {__int_as_float(id), 0, 0, 0};
+  } else {
+    int     v = t.elems[id];
+    auto    p = pos(v);
+    float4* L = leaf + t.leaf_base + 2 * kl;
+    L[0] = {p.x, p.y, p.z, R ? R[v] : 0.0f};
+    L[1] = {__int_as_float(id), 0, 0, 0};
+  }
+}
+}  // namespace
+
+int bake_host_trees(hipStream_t s, const ythip_bvh_node* d_nodes, long long num_nodes, const int32_t* d_prims,
+    long long num_prims, const HostTreeDesc* d_table, int ntrees, float4* pairs, float4* quads, float4* leafdata,
+    std::string* err) {
+  if (num_nodes <= 0 || ntrees <= 0) return BUILD_OK;
+  if (num_nodes > 0x7fffffffll || num_prims > 0x7fffffffll) {
+    if (err) *err = "too many nodes for the batched bake";
+    return BUILD_ERROR;
+  }
+  const int n      = (int)num_nodes;
+  const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  int *     flag = nullptr, *scan = nullptr, *tiles = nullptr;
+  auto      cleanup = [&]() {
+    if (flag) (void)hipFree(flag);
+    if (scan) (void)hipFree(scan);
+    if (tiles) (void)hipFree(tiles);
+    flag = scan = tiles = nullptr;
+  };
+  GCHECK(hipMalloc((void**)&flag, (size_t)n * sizeof(int)));
+  GCHECK(hipMalloc((void**)&scan, ((size_t)n + 1) * sizeof(int)));
+  GCHECK(hipMalloc((void**)&tiles, ((size_t)ntiles + 1) * sizeof(int)));
+  hipLaunchKernelGGL(k_internal_flags, dim3(grid(n)), dim3(BLK), 0, s, d_nodes, n, flag);
+  exclusive_scan(s, flag, scan, tiles, n);
+  hipLaunchKernelGGL(k_bake_all_nodes, dim3(grid(n)), dim3(BLK), 0, s, d_nodes, (long long)n, scan, d_table, ntrees, pairs,
+      quads);
+  if (num_prims > 0)
+    hipLaunchKernelGGL(k_bake_all_leaves, dim3(grid((int)num_prims)), dim3(BLK), 0, s, d_prims, num_prims, d_table, ntrees,
+        leafdata);
+  GCHECK(hipStreamSynchronize(s));
+  GCHECK(hipGetLastError());
   cleanup();
   return BUILD_OK;
 }

@@ -311,13 +311,31 @@ int bake_bvh(ythip_ctx* ctx) {
     int   ref;
   };
   std::vector<Root>                roots(ntrees, Root{{0, 0, 0}, {0, 0, 0}, REF_NONE});
-  std::vector<std::vector<float4>> staging;  // host-baked slices, alive until the final sync
+  std::vector<std::vector<float4>> staging;  // host-baked slices (YTHIP_HOST_BAKE=1)
   bool                             bad_leaf = false;
+  // host-resident trees are baked by the device, all in one go (yt_gpubuild.hip: bake_host_trees)
+  const bool host_bake = [] { const char* e = std::getenv("YTHIP_HOST_BAKE"); return e && std::atoi(e) != 0; }();
+  struct Run {
+    int64_t node_begin, node_end, prim_begin, prim_end, cnode, cprim;
+  };
+  std::vector<ytgpu::HostTreeDesc> table;
+  std::vector<Run>                 runs;
+  int64_t                          compact_nodes = 0, compact_prims = 0;
 
   for (int t = 0; t < ntrees; t++) {
     const bool    blas  = t < nshapes;
     const int64_t nn    = b.node_offset[t + 1] - b.node_offset[t];
     const int64_t np    = b.prim_offset[t + 1] - b.prim_offset[t];
+    if (on_device(t) && !blas) {  // the instance tree, built on the device: pairs + quads, no leaf data
+      float       root7[7];
+      std::string err;
+      if (ytgpu::bake_shape_tree(ctx->stream, ctx->d_trees[t], 0, nullptr, nullptr, nullptr, pair_base[t], 0, 0, d_pairs,
+              d_quads, d_leaf, root7, &err) != ytgpu::BUILD_OK)
+        return fail(ctx, YTHIP_ERR_HIP, "device instance-tree bake failed: %s", err.c_str());
+      for (int c = 0; c < 3; c++) roots[t].bmin[c] = root7[c], roots[t].bmax[c] = root7[3 + c];
+      std::memcpy(&roots[t].ref, &root7[6], 4);
+      continue;
+    }
     if (on_device(t)) {
       const auto& sh   = ctx->h_shapes[t];
       int         kind = ythost::kind_bvh(sh);
@@ -335,7 +353,47 @@ int bake_bvh(ythip_ctx* ctx) {
       std::memcpy(&roots[t].ref, &root7[6], 4);
       continue;
     }
-    // ---- host bake of tree t ------------------------------------------------------
+    // ---- a host-resident tree (yt_build.h, or uploaded by the caller) ---------------------
+    if (!host_bake) {
+      // baked on the device together with every other host tree (ytgpu::bake_host_trees): here only
+      // its descriptor, its place in the compact upload and its root
+      ytgpu::HostTreeDesc d = {};
+      d.node_off      = compact_nodes;
+      d.prim_off      = compact_prims;
+      d.pair_base     = pair_base[t];
+      d.ref_prim_base = blas ? b.prim_offset[t] : 0;
+      d.leaf_base     = blas ? leaf_base[t] : 0;
+      d.kind          = 0;
+      if (blas) {
+        const auto& sh = ctx->h_shapes[t];
+        d.kind         = ythost::kind_bvh(sh);
+        d.elems        = d.kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
+                         : d.kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
+                         : d.kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
+                         : d.kind == KIND_POINTS  ? ctx->ds.points + sh.points_offset
+                                                  : nullptr;
+        d.positions    = ctx->ds.positions + 3 * sh.positions_offset;
+        d.radius       = sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr;
+        if (d.kind == KIND_NONE) d.kind = 0;  // (an element-less shape: a one-node tree with an empty leaf)
+      }
+      table.push_back(d);
+      if (!runs.empty() && runs.back().node_end == b.node_offset[t] && runs.back().prim_end == b.prim_offset[t])
+        runs.back().node_end = b.node_offset[t + 1], runs.back().prim_end = b.prim_offset[t + 1];
+      else
+        runs.push_back({b.node_offset[t], b.node_offset[t + 1], b.prim_offset[t], b.prim_offset[t + 1], compact_nodes, compact_prims});
+      compact_nodes += nn, compact_prims += np;
+      for (int64_t k = b.node_offset[t]; k < b.node_offset[t + 1]; k++)
+        if (!nodes[k].internal && (nodes[k].num < 0 || nodes[k].num > 7)) bad_leaf = true;
+      if (nn > 0) {
+        const auto& root = nodes[b.node_offset[t]];
+        roots[t].ref     = root.internal ? (int32_t)pair_base[t]
+                                         : (int32_t)(0x80000000u | ((uint32_t)(root.num & 7) << 28) |
+                                                     (uint32_t)((blas ? b.prim_offset[t] : 0) + root.start));
+        for (int c = 0; c < 3; c++) roots[t].bmin[c] = root.bbox_min[c], roots[t].bmax[c] = root.bbox_max[c];
+      }
+      continue;
+    }
+    // ---- YTHIP_HOST_BAKE=1: the same records assembled on the host (the cross-check of the kernels) ----
     if (blas && np > 0) {
       const auto&  sh     = ctx->h_shapes[t];
       int          kind   = ythost::kind_bvh(sh);
@@ -446,6 +504,35 @@ int bake_bvh(ythip_ctx* ctx) {
       for (int c = 0; c < 3; c++) roots[t].bmin[c] = root.bbox_min[c], roots[t].bmax[c] = root.bbox_max[c];
     }
   }
+  if (!table.empty()) {
+    // one compact upload of the host trees' nodes and primitives (run by run: host trees that sit next
+    // to each other in h_bvh travel together), the descriptor table, one set of launches for all of them
+    ythip_bvh_node*      d_nodes_c = nullptr;
+    int32_t*             d_prims_c = nullptr;
+    ytgpu::HostTreeDesc* d_table   = nullptr;
+    std::vector<void*>   tmp;
+    if ((rc = dalloc(ctx, tmp, &d_nodes_c, (size_t)compact_nodes)) || (rc = dalloc(ctx, tmp, &d_prims_c, (size_t)compact_prims)) ||
+        (rc = dalloc(ctx, tmp, &d_table, table.size()))) {
+      free_all(tmp);
+      return rc;
+    }
+    hipError_t e = ctx->xfer.h2d(ctx->stream, d_table, table.data(), table.size() * sizeof(ytgpu::HostTreeDesc));
+    for (auto& r : runs) {
+      if (e == hipSuccess && r.node_end > r.node_begin)
+        e = ctx->xfer.h2d(ctx->stream, d_nodes_c + r.cnode, b.nodes.data() + r.node_begin,
+            (size_t)(r.node_end - r.node_begin) * sizeof(ythip_bvh_node));
+      if (e == hipSuccess && r.prim_end > r.prim_begin)
+        e = ctx->xfer.h2d(ctx->stream, d_prims_c + r.cprim, b.prims.data() + r.prim_begin,
+            (size_t)(r.prim_end - r.prim_begin) * sizeof(int32_t));
+    }
+    std::string err;
+    int brc = e == hipSuccess ? ytgpu::bake_host_trees(ctx->stream, d_nodes_c, compact_nodes, d_prims_c, compact_prims, d_table,
+                                    (int)table.size(), d_pairs, d_quads, d_leaf, &err)
+                              : ytgpu::BUILD_ERROR;
+    free_all(tmp);
+    if (brc != ytgpu::BUILD_OK)
+      return fail(ctx, YTHIP_ERR_HIP, "bvh bake failed: %s", e != hipSuccess ? hipGetErrorString(e) : err.c_str());
+  }
   // One 128-entry stack serves the TLAS walk, the TLAS-leaf continuation entries, the exit
   // marker and the BLAS walk (yt_bvh.h), where the reference has 128 entries PER LEVEL
   // (yocto_bvh.cpp:470, 560): refuse trees so deep that the shared stack could overflow
@@ -508,8 +595,10 @@ int bake_bvh(ythip_ctx* ctx) {
   }
   ctx->num_pairs   = npairs;
   ctx->num_leaf4   = nleaf4;
-  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tlas_prims, b.prims.data() + b.prim_offset[nshapes],
-           (size_t)(b.prim_offset[nshapes + 1] - b.prim_offset[nshapes]))))
+  if (on_device(nshapes)) {
+    ctx->ds.tlas_prims = ctx->d_trees[nshapes].prims;  // (owned by the device tree, which outlives the bake)
+  } else if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tlas_prims, b.prims.data() + b.prim_offset[nshapes],
+                  (size_t)(b.prim_offset[nshapes + 1] - b.prim_offset[nshapes]))))
     return rc;
   if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tinst, tinst.data(), tinst.size()))) return rc;
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
@@ -549,66 +638,148 @@ int build_bvh_mixed(ythip_ctx* ctx, const ythip_scene& sc, bool highquality, boo
   ctx->d_tree_on_host.assign(nshapes, 0);
   auto roots = std::vector<ythost::bbox>(nshapes);
   auto empty = std::vector<char>(nshapes, 1);
+  auto prims_of = [&](const ythip_shape& sh) -> int64_t {
+    int kind = ythost::kind_bvh(sh);
+    return kind == KIND_POINTS ? sh.num_points : kind == KIND_LINES ? sh.num_lines
+           : kind == KIND_TRIANGLES ? sh.num_triangles : kind == KIND_QUADS ? sh.num_quads : 0;
+  };
+  // Shapes below the device threshold are built by a pool of host threads, as the reference does
+  // (make_scene_bvh's parallel_for over the shapes: yocto_bvh.cpp:369-378), WHILE this thread
+  // drives the device builds of the large ones.  Every tree is independent; they are concatenated
+  // in shape order afterwards, so the flat layout does not depend on who finished first.
+  std::vector<ythost::tree> host_trees(nshapes);
+  std::vector<char>         on_host(nshapes, 0);
+  for (int k = 0; k < nshapes; k++) on_host[k] = !(use_device && prims_of(sc.shapes[k]) >= ctx->device_build_min_prims);
+  std::atomic<int>         next_shape{0};
+  std::vector<std::thread> workers;
+  {
+    int64_t host_count = 0, host_prims = 0;
+    for (int k = 0; k < nshapes; k++)
+      if (on_host[k]) host_count++, host_prims += prims_of(sc.shapes[k]);
+    unsigned want = host_prims > 50000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), (unsigned)host_count) : 0;
+    if (const char* e = std::getenv("YTHIP_BUILD_THREADS")) want = (unsigned)std::max(0, std::atoi(e));
+    auto work = [&]() {
+      for (int k; (k = next_shape.fetch_add(1)) < nshapes;)
+        if (on_host[k]) host_trees[k] = ythost::make_shape_bvh(sc, sc.shapes[k], highquality);
+    };
+    for (unsigned t = 0; t < want; t++) workers.emplace_back(work);
+    ctx->build_info.host_threads = (int)want;
+    // (no pool: the host shapes are built below, on this thread, after the device ones)
+  }
+  auto join_workers = [&]() {
+    for (auto& w : workers) w.join();
+    workers.clear();
+  };
+  // the device builds (they synchronise once per tree level: the host threads run meanwhile)
   for (int k = 0; k < nshapes; k++) {
+    if (on_host[k]) continue;
     const auto& sh    = sc.shapes[k];
     int         kind  = ythost::kind_bvh(sh);
-    int64_t     nprim = kind == KIND_POINTS ? sh.num_points : kind == KIND_LINES ? sh.num_lines
-                        : kind == KIND_TRIANGLES ? sh.num_triangles : kind == KIND_QUADS ? sh.num_quads : 0;
+    int64_t     nprim = prims_of(sh);
+    const int*  el    = kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
+                        : kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
+                        : kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
+                                               : ctx->ds.points + sh.points_offset;
+    std::string err;
+    int rc = ytgpu::build_shape_tree(ctx->stream, kind, el, ctx->ds.positions + 3 * sh.positions_offset,
+        sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, nprim, highquality,
+        &ctx->d_trees[k], &err);
+    if (rc == ytgpu::BUILD_ERROR) {
+      join_workers();
+      return fail(ctx, YTHIP_ERR_HIP, "device bvh build failed: %s", err.c_str());
+    }
+    if (rc == ytgpu::BUILD_OK) {
+      auto& dt = ctx->d_trees[k];
+      ythip_bvh_node root;
+      if (auto e = ctx->xfer.d2h(ctx->stream, &root, dt.nodes, sizeof(root)); e != hipSuccess) {
+        join_workers();
+        return fail(ctx, YTHIP_ERR_HIP, "device bvh root readback failed: %s", hipGetErrorString(e));
+      }
+      roots[k].min = {root.bbox_min[0], root.bbox_min[1], root.bbox_min[2]};
+      roots[k].max = {root.bbox_max[0], root.bbox_max[1], root.bbox_max[2]};
+      empty[k]     = 0;
+      ctx->build_info.device_trees += 1;
+      ctx->build_info.device_prims += nprim;
+      ctx->build_info.device_ms += dt.build_ms;
+      ctx->build_info.max_depth = std::max(ctx->build_info.max_depth, dt.depth);
+    } else {  // (signed-zero tie: only the serial builder knows the answer)
+      ctx->build_info.fallbacks += 1;
+      host_trees[k] = ythost::make_shape_bvh(sc, sh, highquality);
+      on_host[k]    = 2;
+    }
+  }
+  if (workers.empty()) {
+    for (int k = 0; k < nshapes; k++)
+      if (on_host[k] == 1) host_trees[k] = ythost::make_shape_bvh(sc, sc.shapes[k], highquality);
+  }
+  join_workers();
+  // concatenate in shape order
+  for (int k = 0; k < nshapes; k++) {
     out.node_offset.push_back((int64_t)out.nodes.size());
     out.prim_offset.push_back((int64_t)out.prims.size());
-    bool built = false;
-    if (use_device && nprim >= ctx->device_build_min_prims) {
-      const int* el = kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
-                      : kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
-                      : kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
-                                             : ctx->ds.points + sh.points_offset;
-      std::string err;
-      int rc = ytgpu::build_shape_tree(ctx->stream, kind, el, ctx->ds.positions + 3 * sh.positions_offset,
-          sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, nprim, highquality,
-          &ctx->d_trees[k], &err);
-      if (rc == ytgpu::BUILD_ERROR) return fail(ctx, YTHIP_ERR_HIP, "device bvh build failed: %s", err.c_str());
-      if (rc == ytgpu::BUILD_OK) {
-        auto& dt = ctx->d_trees[k];
-        ythip_bvh_node root;
-        HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, &root, dt.nodes, sizeof(root)));
-        roots[k].min = {root.bbox_min[0], root.bbox_min[1], root.bbox_min[2]};
-        roots[k].max = {root.bbox_max[0], root.bbox_max[1], root.bbox_max[2]};
-        empty[k]     = 0;
-        out.nodes.resize(out.nodes.size() + (size_t)dt.num_nodes);  // filled by ensure_host_bvh()
-        out.prims.resize(out.prims.size() + (size_t)dt.num_prims);
-        ctx->build_info.device_trees += 1;
-        ctx->build_info.device_prims += nprim;
-        ctx->build_info.device_ms += dt.build_ms;
-        ctx->build_info.max_depth = std::max(ctx->build_info.max_depth, dt.depth);
-        built = true;
-      } else {
-        ctx->build_info.fallbacks += 1;
-      }
+    if (!on_host[k]) {  // device tree: its slice is filled by ensure_host_bvh() on demand
+      auto& dt = ctx->d_trees[k];
+      out.nodes.resize(out.nodes.size() + (size_t)dt.num_nodes);
+      out.prims.resize(out.prims.size() + (size_t)dt.num_prims);
+      continue;
     }
-    if (!built) {
-      auto t = ythost::make_shape_bvh(sc, sh, highquality);
-      if (!t.nodes.empty()) {
-        empty[k]     = 0;
-        auto& n      = t.nodes[0];
-        roots[k].min = {n.bbox_min[0], n.bbox_min[1], n.bbox_min[2]};
-        roots[k].max = {n.bbox_max[0], n.bbox_max[1], n.bbox_max[2]};
-      }
-      out.nodes.insert(out.nodes.end(), t.nodes.begin(), t.nodes.end());
-      out.prims.insert(out.prims.end(), t.prims.begin(), t.prims.end());
-      ctx->build_info.host_trees += 1;
+    auto& t = host_trees[k];
+    if (!t.nodes.empty()) {
+      empty[k]     = 0;
+      auto& n      = t.nodes[0];
+      roots[k].min = {n.bbox_min[0], n.bbox_min[1], n.bbox_min[2]};
+      roots[k].max = {n.bbox_max[0], n.bbox_max[1], n.bbox_max[2]};
     }
+    out.nodes.insert(out.nodes.end(), t.nodes.begin(), t.nodes.end());
+    out.prims.insert(out.prims.end(), t.prims.begin(), t.prims.end());
+    ythost::tree().nodes.swap(t.nodes);
+    ctx->build_info.host_trees += 1;
   }
-  // the instance tree — yocto_bvh.cpp:381-393
-  auto bboxes = std::vector<ythost::bbox>(sc.num_instances);
+  // the instance tree — yocto_bvh.cpp:381-393: make_bvh over the instances' world bounds.  With
+  // many instances it is built on the device like a large shape (kind 0: the boxes are the
+  // primitives); instances of empty shapes carry the invalid box, which stays with the host builder.
+  auto bboxes    = std::vector<ythost::bbox>(sc.num_instances);
+  bool any_empty = false;
   for (auto k = 0; k < sc.num_instances; k++) {
     auto& inst = sc.instances[k];
-    bboxes[k]  = empty[inst.shape] ? ythost::bbox{} : ythost::transform_bbox(inst.frame, roots[inst.shape]);
+    any_empty |= empty[inst.shape] != 0;
+    bboxes[k] = empty[inst.shape] ? ythost::bbox{} : ythost::transform_bbox(inst.frame, roots[inst.shape]);
   }
-  auto tlas = ythost::make_bvh(bboxes, highquality);
   out.node_offset.push_back((int64_t)out.nodes.size());
   out.prim_offset.push_back((int64_t)out.prims.size());
-  out.nodes.insert(out.nodes.end(), tlas.nodes.begin(), tlas.nodes.end());
-  out.prims.insert(out.prims.end(), tlas.prims.begin(), tlas.prims.end());
+  bool tlas_on_device = false;
+  if (use_device && !any_empty && sc.num_instances >= ctx->device_build_min_prims) {
+    static_assert(sizeof(ythost::bbox) == 6 * sizeof(float), "bbox is {min, max}");
+    float* d_boxes = nullptr;
+    HIPCHECK(ctx, hipMalloc((void**)&d_boxes, bboxes.size() * sizeof(ythost::bbox)));
+    auto e = ctx->xfer.h2d(ctx->stream, d_boxes, bboxes.data(), bboxes.size() * sizeof(ythost::bbox));
+    std::string err;
+    ctx->d_trees.push_back(ytgpu::DeviceTree{});
+    ctx->d_tree_on_host.push_back(0);
+    int rc = e == hipSuccess ? ytgpu::build_shape_tree(ctx->stream, 0, nullptr, d_boxes, nullptr, sc.num_instances,
+                                   highquality, &ctx->d_trees[nshapes], &err)
+                             : ytgpu::BUILD_ERROR;
+    (void)hipFree(d_boxes);
+    if (rc == ytgpu::BUILD_ERROR) return fail(ctx, YTHIP_ERR_HIP, "device instance-tree build failed: %s", err.c_str());
+    if (rc == ytgpu::BUILD_OK) {
+      auto& dt = ctx->d_trees[nshapes];
+      out.nodes.resize(out.nodes.size() + (size_t)dt.num_nodes);  // filled by ensure_host_bvh()
+      out.prims.resize(out.prims.size() + (size_t)dt.num_prims);
+      ctx->build_info.device_ms += dt.build_ms;
+      ctx->build_info.device_tlas = 1;
+      ctx->build_info.max_depth   = std::max(ctx->build_info.max_depth, dt.depth);
+      tlas_on_device              = true;
+    } else {
+      ctx->build_info.fallbacks += 1;
+      ctx->d_trees.pop_back();
+      ctx->d_tree_on_host.pop_back();
+    }
+  }
+  if (!tlas_on_device) {
+    auto tlas = ythost::make_bvh(bboxes, highquality);
+    out.nodes.insert(out.nodes.end(), tlas.nodes.begin(), tlas.nodes.end());
+    out.prims.insert(out.prims.end(), tlas.prims.begin(), tlas.prims.end());
+  }
   out.node_offset.push_back((int64_t)out.nodes.size());
   out.prim_offset.push_back((int64_t)out.prims.size());
   ctx->build_info.build_ms =
@@ -1283,6 +1454,13 @@ int ythip_update_bvh(ythip_ctx* ctx, const int32_t* updated_instances, int32_t n
   for (size_t k = 0; k < bboxes.size(); k++) {
     const auto& inst = ctx->h_instances[k];
     bboxes[k]        = empty[inst.shape] ? ythost::bbox{} : ythost::transform_bbox(inst.frame, roots[inst.shape]);
+  }
+  if (on_device(nshapes)) {  // an instance tree that was built on the device is refitted on the host: bring it home
+    int rc0 = ensure_host_bvh(ctx);
+    if (rc0) return rc0;
+    ytgpu::free_tree(&ctx->d_trees[nshapes]);
+    ctx->d_trees.pop_back();
+    ctx->d_tree_on_host.pop_back();
   }
   ythost::refit_bvh(b.nodes.data() + b.node_offset[nshapes], b.node_offset[nshapes + 1] - b.node_offset[nshapes],
       b.prims.data() + b.prim_offset[nshapes], bboxes);

@@ -146,10 +146,54 @@ def trace_params(**kw):
     return p
 
 
+def params_to_json(params):
+    """to_json(trace_params) — yocto_sceneio.cpp:5815-5833 (ythip_params_to_json)."""
+    lib = load_library()
+    n = lib.ythip_params_to_json(C.byref(params), None, 0)
+    if n < 0:
+        raise YthipError(lib.ythip_io_last_error().decode())
+    buf = C.create_string_buffer(n + 1)
+    lib.ythip_params_to_json(C.byref(params), buf, n + 1)
+    return buf.value.decode()
+
+
+def params_from_json(text, params=None):
+    """from_json(trace_params): keys that are absent keep the values of `params` (default: trace_params{})."""
+    lib = load_library()
+    if params is None:
+        params = CParams()
+        lib.ythip_params_default(C.byref(params))
+    b = text.encode() if isinstance(text, str) else text
+    if lib.ythip_params_from_json(b, len(b), C.byref(params)):
+        raise YthipError(lib.ythip_io_last_error().decode())
+    return params
+
+
+def load_ply(path, flip_texcoord=True):
+    """load_shape (yocto_sceneio.cpp:1017-1033) of a PLY file through ythip_ply_open / ythip_ply_read:
+    a dict of the shape's arrays (absent ones empty), converted straight from the mapped file."""
+    lib = load_library()
+    h = C.c_void_p()
+    counts = np.zeros(1, shape_dt)
+    if lib.ythip_ply_open(str(path).encode(), C.byref(h), counts.ctypes.data):
+        raise YthipError(lib.ythip_io_last_error().decode())
+    c = counts[0]
+    out = {name: np.zeros((int(c["num_" + name]), n), dt) for name, dt, n in FlatScene.POOLS[:9]}
+    ptr = lambda a: a.ctypes.data if a.size else None  # noqa: E731
+    rc = lib.ythip_ply_read(h, int(flip_texcoord), ptr(out["positions"]), ptr(out["normals"]), ptr(out["texcoords"]),
+                            ptr(out["colors"]), ptr(out["radius"]), ptr(out["points"]), ptr(out["lines"]),
+                            ptr(out["triangles"]), ptr(out["quads"]))
+    lib.ythip_ply_close(h)
+    if rc:
+        raise YthipError(lib.ythip_io_last_error().decode())
+    return out
+
+
 class CBuildInfo(C.Structure):
     _fields_ = [("device_trees", C.c_int32), ("host_trees", C.c_int32), ("fallbacks", C.c_int32),
                 ("max_depth", C.c_int32), ("device_prims", C.c_int64), ("device_ms", C.c_double),
-                ("build_ms", C.c_double), ("bake_ms", C.c_double)]
+                ("build_ms", C.c_double), ("bake_ms", C.c_double), ("host_threads", C.c_int32),
+                ("device_tlas", C.c_int32)]
 
 
 class CStats(C.Structure):
@@ -421,6 +465,13 @@ _SIGNATURES = {
     "ythip_bvh_baked_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ythip_bvh_baked_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ythip_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
+    "ythip_params_default": (None, [C.c_void_p]),
+    "ythip_params_from_json": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p]),
+    "ythip_params_to_json": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "ythip_io_last_error": (C.c_char_p, []),
+    "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "ythip_ply_read": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9),
+    "ythip_ply_close": (None, [C.c_void_p]),
     "ythip_bvh_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ythip_bvh_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
