@@ -537,6 +537,12 @@ int ythip_intersect_instance_batch(ythip_ctx* ctx, const int32_t* instances,
  * evaluated on the device for n arguments (y may be NULL for the one-argument functions).
  * Test entry: the results must equal the host's glibc bit for bit. */
 int ythip_test_libm(ythip_ctx* ctx, int fn, const float* x, const float* y, int64_t n, float* out);
+/* Parity is pinned to ONE libm: glibc 2.35's x86-64 `_fma` variants (yt_libm.h).  This asks whether
+ * the host's own libm — what a reference built on this machine renders with — agrees with the device
+ * on 2,304 probe arguments: 1 yes, 0 no (the first disagreement in ythip_last_error: bit parity with a
+ * reference run on THIS host is then not to be expected), < 0 error.  The drop-in shim calls it once
+ * per process and warns on stderr. */
+int ythip_host_libm_matches(ythip_ctx* ctx);
 /* sample_camera for the next sample of every resident pixel
  * (yocto_trace.cpp:338-358,1467-1468) WITHOUT advancing the resident rngs;
  * writes width*(rows) rays.  Test entry. */

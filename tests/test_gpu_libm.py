@@ -68,3 +68,11 @@ def test_device_ieee_division_and_sqrt():
         assert _same(ctx.test_libm("div", x, y), x / y).all()
         assert _same(ctx.test_libm("sqrtf", x), np.sqrt(x)).all()
     ctx.close()
+
+
+def test_host_libm_agreement_probe():
+    """ythip_host_libm_matches: on this image (glibc 2.35, a CPU with FMA) the host's libm IS the one the
+    device restates, so the probe must say yes; the shim prints a warning where it says no."""
+    ctx = yt.Context(0)
+    assert ctx.host_libm_matches()
+    ctx.close()

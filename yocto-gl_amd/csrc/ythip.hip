@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdarg>
 #include <chrono>
 #include <cstdio>
@@ -2184,6 +2185,61 @@ int ythip_test_libm(ythip_ctx* ctx, int fn, const float* x, const float* y, int6
   free_all(tmp);
   if (e != hipSuccess) return fail(ctx, YTHIP_ERR_HIP, "test_libm failed: %s", hipGetErrorString(e));
   return YTHIP_OK;
+}
+
+// Does the HOST's libm — the one a reference built on this machine renders with — agree with
+// what the device evaluates (yt_libm.h: glibc 2.35's x86-64 `_fma` variants)?  A host whose glibc
+// dispatches to other variants (no FMA, another release) produces other last bits in sinf / powf ...,
+// the reference on it renders other images, and the drop-in's bit parity with THAT reference is
+// gone — silently, unless somebody looks: 1 = the probes agree, 0 = they do not (message in
+// ythip_last_error), < 0 = error.  2,304 probe arguments (256 per function) over the ranges the path
+// uses; the exhaustive comparison is tests/cpp/libm_check.cpp.
+int ythip_host_libm_matches(ythip_ctx* ctx) {
+  if (!ctx) return -YTHIP_ERR_INVALID;
+  const int          N = 256;
+  std::vector<float> x(N), y(N), dev(N);
+  unsigned long long lcg = 0x9e3779b97f4a7c15ull;
+  auto               uni = [&]() {
+    lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+    return (float)((lcg >> 40) * (1.0 / 16777216.0));
+  };
+  static const char* names[] = {"sinf", "cosf", "expf", "exp2f", "logf", "atanf", "acosf", "atan2f", "powf"};
+  for (int fn = 0; fn < 9; fn++) {
+    for (int k = 0; k < N; k++) {
+      float u = uni(), v = uni();
+      switch (fn) {
+        case 0: case 1: x[k] = (u - 0.5f) * 4 * 6.2831853f; break;    // a few periods around 0
+        case 2: case 3: x[k] = (u - 0.5f) * 40; break;
+        case 4: x[k] = u * 100 + 1e-6f; break;
+        case 5: x[k] = (u - 0.5f) * 50; break;
+        case 6: x[k] = u * 2 - 1; break;
+        case 7: x[k] = (u - 0.5f) * 4, y[k] = (v - 0.5f) * 4; break;
+        default: x[k] = u * 4 + 1e-4f, y[k] = (v - 0.5f) * 12; break;
+      }
+    }
+    int rc = ythip_test_libm(ctx, fn, x.data(), fn >= 7 ? y.data() : nullptr, N, dev.data());
+    if (rc) return -rc;
+    for (int k = 0; k < N; k++) {
+      float h = 0;
+      switch (fn) {
+        case 0: h = ::sinf(x[k]); break;
+        case 1: h = ::cosf(x[k]); break;
+        case 2: h = ::expf(x[k]); break;
+        case 3: h = ::exp2f(x[k]); break;
+        case 4: h = ::logf(x[k]); break;
+        case 5: h = ::atanf(x[k]); break;
+        case 6: h = ::acosf(x[k]); break;
+        case 7: h = ::atan2f(x[k], y[k]); break;
+        default: h = ::powf(x[k], y[k]); break;
+      }
+      if (std::memcmp(&h, &dev[k], 4) != 0 && !(h != h && dev[k] != dev[k])) {
+        fail(ctx, YTHIP_OK, "host %s(%a%s) = %a, the device's restatement of glibc 2.35 gives %a: a reference built on this host "
+                            "will not be matched bit for bit", names[fn], (double)x[k], fn >= 7 ? ", ..." : "", (double)h, (double)dev[k]);
+        return 0;
+      }
+    }
+  }
+  return 1;
 }
 
 int ythip_camera_rays(ythip_ctx* ctx, const ythip_params* params, ythip_ray* rays) {

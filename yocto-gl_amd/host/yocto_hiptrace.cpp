@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
@@ -382,6 +383,12 @@ void ensure_context(residency& r) {
   auto rc = ythip_create_multi(devices.data(), (int)devices.size(), &r.multi);
   if (rc != YTHIP_OK) raise(ythip_multi_last_error(nullptr), rc);
   r.ranks = ythip_multi_size(r.multi);
+  // parity is pinned to one libm (csrc/yt_libm.h): say so once if this host's is another
+  static std::once_flag libm_once;
+  std::call_once(libm_once, [&] {
+    if (ythip_host_libm_matches(r.ctx(0)) == 0)
+      std::fprintf(stderr, "yocto::hip: %s\n", ythip_last_error(r.ctx(0)));
+  });
 }
 
 // Scene ingest: scene_data's vector-of-vectors go straight into

@@ -465,6 +465,7 @@ _SIGNATURES = {
     "ythip_bvh_baked_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ythip_bvh_baked_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ythip_set_traversal": (C.c_int, [C.c_void_p, C.c_int]),
+    "ythip_host_libm_matches": (C.c_int, [C.c_void_p]),
     "ythip_params_default": (None, [C.c_void_p]),
     "ythip_params_from_json": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p]),
     "ythip_params_to_json": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
@@ -962,6 +963,13 @@ class Context:
 
     def set_early_miss(self, enable):
         self._check(self.lib.ythip_set_early_miss(self.h, int(enable)), "set_early_miss")
+
+    def host_libm_matches(self):
+        """Does the host's libm agree with the device's restatement of glibc 2.35 (ythip_host_libm_matches)?"""
+        rc = self.lib.ythip_host_libm_matches(self.h)
+        if rc < 0:
+            self._check(-rc, "host_libm_matches")
+        return rc == 1
 
     def set_traversal(self, mode):
         """"binary" | "wide" | "auto" (default): which BVH walk the kernels use."""
