@@ -2,7 +2,7 @@
 (the Cornell box with 1M-triangle walls: deep paths, area-light pdf walks), cfg4
 (10,000 instances of a 1,024-triangle sphere) and cfg5 (800,000 hair segments,
 subsurface) — bit-exact hit records for whole frames of camera rays against the
-live compiled reference, renders within the float tolerances written below, and
+live compiled reference, renders equal to the reference's whole trace_state byte for byte, and
 size-independent properties (row shards == full frame) where no reference run
 is needed."""
 import numpy as np
