@@ -22,6 +22,8 @@
 //   * atanf, atan2f, acosf — Sun's fdlibm in float (s_atanf.c, e_atan2f.c, e_acosf.c): plain
 //     float arithmetic in source order (no ifunc variant, baseline SSE2, nothing fused).
 // The table values were read out of that libm.so.6 (they are the published ones).
+// Upstream copyright notices and licence texts (LGPL-2.1-or-later for glibc, the Sun fdlibm notice):
+// csrc/licenses/README.md.
 //
 // Checked in tests/cpp/libm_check.cpp (CPU, `-m "not gpu"`): this header compiled for the
 // host against the live glibc — every one of the 2^32 arguments of the one-argument functions,
