@@ -516,6 +516,29 @@ int  ythip_ply_read(ythip_ply* ply, int flip_texcoord, float* positions, float* 
     float* colors, float* radius, int32_t* points, int32_t* lines, int32_t* triangles, int32_t* quads);
 void ythip_ply_close(ythip_ply* ply);
 
+/* A scene FILE into the flat pools — the reference's load_scene for its builtin JSON format
+ * (load_json_scene, libs/yocto/yocto_sceneio.cpp:3618-3857: scene.json, its PLY shapes, its HDR / PNG textures)
+ * without scene_data's vector-of-vectors generation.  ythip_scene_open parses scene.json (versions 4.2 /
+ * 5.0), maps every PLY and reads every texture header, and reports all the num_* of ythip_scene in
+ * `counts`; ythip_scene_read fills caller pools of those sizes (every pointer of `pools`, writable — the
+ * pools of ythip_scene_staging, or plain memory): records with the reference's defaults and fix-ups
+ * (lookat, add_missing_camera :2119-2139, add_missing_radius :2142-2148, load_texture's `linear`),
+ * shapes converted by ythip_ply_read, textures decoded to what stbi_loadf / stbi_load(…, 4) return,
+ * shapes and textures on `threads` threads (<= 0: one per hardware thread).  The pools equal the
+ * reference loader's scene_data flattened, byte for byte.  Not read here, refused by name: subdivs,
+ * formats 4.0 / 4.1, non-PLY shapes, JPEG / EXR / TGA / BMP / .ypreset textures.
+ * ythip_load_scene = open + ythip_scene_staging + read + ythip_upload_scene_staged (`staged`, optional,
+ * receives the pools: pass it to ythip_build_bvh / ythip_build_lights).  ythip_scene_find_camera mirrors
+ * find_camera (yocto_scene.cpp:656-675); ythip_scene_name: `what` 0 camera, 1 instance, 2 environment,
+ * 3 shape, 4 texture, 5 material. */
+typedef struct ythip_scene_file ythip_scene_file;
+int         ythip_scene_open(const char* path, ythip_scene_file** file, ythip_scene* counts);
+int         ythip_scene_read(ythip_scene_file* file, const ythip_scene* pools, int threads);
+int32_t     ythip_scene_find_camera(const ythip_scene_file* file, const char* name);
+const char* ythip_scene_name(const ythip_scene_file* file, int what, int32_t index);
+void        ythip_scene_close(ythip_scene_file* file);
+int         ythip_load_scene(ythip_ctx* ctx, const char* path, int threads, ythip_scene* staged);
+
 /* Which BVH walk k_trace's extend stage and the test entries below use: 0 the
  * binary walk (one sibling pair per dependent fetch), 1 the wide walk (the four
  * grandchildren per fetch: half the fetch chain, yt_bvh.h), 2 (default) chosen by

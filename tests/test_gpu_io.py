@@ -83,3 +83,39 @@ def test_ply_files_into_the_staging_pools(name, tmp_path):
     want_state = P.gpu_render(ref, flat, params)
     ref.close()
     P.assert_identical(want_state, got, name)
+
+
+@pytest.mark.parametrize("name", ["materials", "lines_points"])
+def test_load_scene_files_to_hbm(name, tmp_path):
+    """ythip_load_scene: scene.json + PLY + PNG / HDR files -> pinned staging pools -> HBM in one call; the render
+    equals the render of the reference loader's scene uploaded the ordinary way, and the staged pools are the
+    reference loader's flattened scene."""
+    src = ry.RefScene.from_flat(P.SCENES[name]())
+    scene_file = str(tmp_path / "scene.json")
+    src.save(scene_file)
+    flat = ry.RefScene.load(scene_file).flat()
+    ctx = yt.Context(0)
+    staged = ctx.load_scene(scene_file)
+    for field in P._FIELDS:
+        assert np.ascontiguousarray(getattr(staged, field)).tobytes() == np.ascontiguousarray(getattr(flat, field)).tobytes(), field
+    ctx.make_trace_bvh(staged)
+    ctx.make_trace_lights(staged)
+    params = yt.trace_params(sampler="path", resolution=96, samples=4, batch=2)
+    got = P.gpu_render(ctx, staged, params)
+    ctx.close()
+    ref = P.gpu_context(flat)
+    want = P.gpu_render(ref, flat, params)
+    ref.close()
+    P.assert_identical(want, got, name)
+
+
+def test_load_scene_refusal_leaves_the_context_usable(tmp_path):
+    ctx = yt.Context(0)
+    with pytest.raises(yt.YthipError, match="cannot open"):
+        ctx.load_scene(str(tmp_path / "absent.json"))
+    flat = P.SCENES["cornellbox"]()
+    ctx.upload_scene(flat)
+    ctx.make_trace_bvh(flat)
+    ctx.make_trace_lights(flat)
+    P.gpu_render(ctx, flat, yt.trace_params(sampler="eyelight", resolution=32, samples=1, batch=1))
+    ctx.close()

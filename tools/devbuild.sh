@@ -11,7 +11,8 @@ mkdir -p build/dev
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/gpubuild_$name.o yocto-gl_amd/csrc/yt_gpubuild.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/multi_$name.o yocto-gl_amd/csrc/yt_multi.hip
 [ -f build/dev/order.o ] && [ build/dev/order.o -nt yocto-gl_amd/csrc/yt_order.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/order.o yocto-gl_amd/csrc/yt_order.hip
-[ -f build/dev/io.o ] && [ build/dev/io.o -nt yocto-gl_amd/csrc/yt_io.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -o build/dev/io.o yocto-gl_amd/csrc/yt_io.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/dev/libythip_$name.so build/dev/ythip_$name.o build/dev/gpubuild_$name.o build/dev/multi_$name.o build/dev/order.o build/dev/io.o -ldl
+[ -f build/dev/io.o ] && [ build/dev/io.o -nt yocto-gl_amd/csrc/yt_io.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/io.o yocto-gl_amd/csrc/yt_io.hip
+[ -f build/dev/sceneio.o ] && [ build/dev/sceneio.o -nt yocto-gl_amd/csrc/yt_sceneio.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c -o build/dev/sceneio.o yocto-gl_amd/csrc/yt_sceneio.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/dev/libythip_$name.so build/dev/ythip_$name.o build/dev/gpubuild_$name.o build/dev/multi_$name.o build/dev/order.o build/dev/io.o build/dev/sceneio.o -ldl -lz
 rm -f build/dev/ythip_$name.o build/dev/gpubuild_$name.o build/dev/multi_$name.o
 echo built build/dev/libythip_$name.so

@@ -177,6 +177,10 @@ bool label_to_enum(const char* const (&labels)[N], const std::string& s, int32_t
 
 }  // namespace
 
+namespace ytio {
+int fail(int code, const std::string& msg) { return io_fail(code, msg); }  // for yt_sceneio.hip
+}
+
 extern "C" {
 
 const char* ythip_io_last_error(void) { return g_io_error.c_str(); }

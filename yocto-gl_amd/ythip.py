@@ -189,6 +189,32 @@ def load_ply(path, flip_texcoord=True):
     return out
 
 
+def load_scene_file(path, threads=0):
+    """load_scene (yocto_sceneio.cpp:3618-3857) of a builtin-format scene through ythip_scene_open /
+    ythip_scene_read into numpy pools: a FlatScene equal to the reference loader's scene_data flattened,
+    plus the names ({"cameras": [...], ...}) and the index find_camera("") picks."""
+    lib = load_library()
+    h, counts = C.c_void_p(), CScene()
+    if lib.ythip_scene_open(str(path).encode(), C.byref(h), C.byref(counts)):
+        raise YthipError(lib.ythip_io_last_error().decode())
+    fs = FlatScene()
+    fs.cameras, fs.instances = np.zeros(counts.num_cameras, camera_dt), np.zeros(counts.num_instances, instance_dt)
+    fs.environments, fs.shapes = np.zeros(counts.num_environments, environment_dt), np.zeros(counts.num_shapes, shape_dt)
+    fs.textures, fs.materials = np.zeros(counts.num_textures, texture_dt), np.zeros(counts.num_materials, material_dt)
+    for name, dt, n in FlatScene.POOLS:
+        setattr(fs, name, np.zeros((getattr(counts, "num_" + name), n), dt))
+    pools = fs.c_struct()
+    rc = lib.ythip_scene_read(h, C.byref(pools), int(threads))
+    names = {}
+    for what, kind in enumerate(["cameras", "instances", "environments", "shapes", "textures", "materials"]):
+        names[kind] = [lib.ythip_scene_name(h, what, k).decode() for k in range(len(getattr(fs, kind)))]
+    camera = lib.ythip_scene_find_camera(h, b"")
+    lib.ythip_scene_close(h)
+    if rc:
+        raise YthipError(lib.ythip_io_last_error().decode())
+    return fs, names, camera
+
+
 class CBuildInfo(C.Structure):
     _fields_ = [("device_trees", C.c_int32), ("host_trees", C.c_int32), ("fallbacks", C.c_int32),
                 ("max_depth", C.c_int32), ("device_prims", C.c_int64), ("device_ms", C.c_double),
@@ -473,6 +499,12 @@ _SIGNATURES = {
     "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "ythip_ply_read": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9),
     "ythip_ply_close": (None, [C.c_void_p]),
+    "ythip_scene_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "ythip_scene_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "ythip_scene_find_camera": (C.c_int32, [C.c_void_p, C.c_char_p]),
+    "ythip_scene_name": (C.c_char_p, [C.c_void_p, C.c_int, C.c_int32]),
+    "ythip_scene_close": (None, [C.c_void_p]),
+    "ythip_load_scene": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]),
     "ythip_bvh_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ythip_bvh_download": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
@@ -685,6 +717,15 @@ class Context:
     def upload_scene(self, scene):
         cs = scene.c_struct()
         self._check(self.lib.ythip_upload_scene(self.h, C.byref(cs)), "upload_scene")
+
+    def load_scene(self, path, threads=0):
+        """ythip_load_scene: scene files -> pinned staging pools -> HBM; returns a FlatScene copy of
+        the staged pools for make_trace_bvh / make_trace_lights / make_trace_state."""
+        staged = CScene()
+        rc = self.lib.ythip_load_scene(self.h, str(path).encode(), int(threads), C.byref(staged))
+        if rc:
+            raise YthipError(self.lib.ythip_io_last_error().decode())
+        return FlatScene.from_c(staged)
 
     def update_cameras(self, cameras):
         """Re-upload only the cameras (interactive camera edits, apps/ytrace.cpp:189-204)."""
