@@ -10,6 +10,14 @@
  * std::runtime_error, mirroring the reference's exception behaviour
  * (libs/yocto/yocto_trace.cpp:1437,1454,1682-1690).
  *
+ * Threads: a ythip_ctx (and a ythip_multi) is used by ONE host thread at a time
+ * — its stream, its pinned transfer ring and its error string are not locked; the
+ * C++ shim serialises its calls under a mutex, as the reference's trace_start worker
+ * serialises its own (yocto_trace.cpp:1627-1656).  The one exception is
+ * ythip_cancel, which may be called from any thread while a batch runs.  Different
+ * contexts are independent.  The file readers at the end of this header keep no
+ * global state (ythip_io_last_error is per thread).
+ *
  * Each declaration cites the reference interface (file:line under
  * /root/reference) that it replaces or mirrors.
  */

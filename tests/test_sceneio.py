@@ -224,6 +224,39 @@ def test_the_same_refusals_as_the_reference_where_it_refuses_too(scene_dir):
         assert str(mine.value) == str(theirs.value)
 
 
+@needs_ref
+def test_json_corner_cases_behave_as_the_reference_json_library(scene_dir):
+    """Number classes, containers of the wrong kind, escapes, a BOM: the same pools or the same refusal."""
+    base = '{"asset":{"version":"4.2"},"shapes":[{"uri":"shapes/tri.ply"}],%s}'
+    cases = ['"cameras":[{"lens":1e400}]', '"cameras":[{"lens":-0}]', '"cameras":[{"lens":-0.0}]', '"cameras":[{"lens":12345678901234567890}]',
+             '"cameras":[{"lens":123456789012345678901234567890}]', '"cameras":[{"lens":null}]', '"cameras":null', '"cameras":{}',
+             '"cameras":{"b":{"lens":2},"a":{"lens":3}}', '"cameras":5', '"cameras":[{"lens":1,"lens":2}]',
+             '"cameras":[{"name":"\\u00e9\\ud83d\\ude00\\n"}]', '"cameras":[{"orthographic":1}]', '"cameras":[{"lens":1.5e-50}]',
+             '"cameras":[{"lens":01}]', '"cameras":[{"lens":1.}]', '"cameras":[{"lens":.5}]', '"cameras":[{"lens":+1}]', '"cameras":[{"lens":1}],',
+             '"materials":[{"type":5}]', '"materials":[{"type":null}]', '"materials":[{"color_tex":1.9}]', '"materials":[{"color_tex":-1.9}]',
+             '"materials":[{"color_tex":true}]', '"instances":[{"shape":0,"material":3000000000}]', '"instances":[{"shape":0,"lookat":[1,2,3]}]',
+             '"textures":[]', '"subdivs":[]', '"subdivs":null', '"cameras":[5]', '"cameras":[[]]', '"cameras":[null]', '"cameras":["x"]',
+             '"environments":[{"emission":[1,2]}]', '"environments":[{"emission":{"a":1}}]', '"environments":{"z":{"emission":[1,2,3]}}']
+    texts = [base % c for c in cases] + ['\ufeff' + base % '"cameras":[{"lens":2}]', base % '"cameras":[{"lens":2}]' + " x", "", "{"]
+    path = str(scene_dir / "scene.json")
+    outcomes = set()
+    for text in texts:
+        open(path, "w", encoding="utf-8").write(text)
+        try:
+            ref, theirs = ry.RefScene.load(path).flat(), None
+        except RuntimeError as e:
+            ref, theirs = None, str(e)
+        try:
+            got, mine = yt.load_scene_file(path)[0], None
+        except yt.YthipError as e:
+            got, mine = None, str(e)
+        assert mine == theirs, text
+        if ref is not None:
+            assert_same_scene(got, ref, text)
+        outcomes.add(theirs is None)
+    assert outcomes == {True, False}
+
+
 # ---------------------------------------------------------------------------------------------------
 # PNG
 # ---------------------------------------------------------------------------------------------------

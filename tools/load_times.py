@@ -15,6 +15,7 @@ import tempfile
 import time
 
 import numpy as np
+import torch  # before libythip: both must end up on the one libamdhip64 torch ships (two HIP runtimes in a process: the second sees no device)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -72,7 +73,6 @@ def main():
     print(f"pools: {pool_mb:.0f} MB, identical: {same}")
     print(f"reference load_scene            {t_ref * 1e3:9.1f} ms   (+ flatten {t_flat * 1e3:.1f} ms = {(t_ref + t_flat) * 1e3:.1f} ms)")
     print(f"ythip_scene_open + _read        {t_ours * 1e3:9.1f} ms   ({(t_ref + t_flat) / t_ours:.2f}x; one thread {t_one * 1e3:.1f} ms)")
-    import torch
     if torch.cuda.is_available():
         ctx = yt.Context(0)
         ctx.load_scene(path)  # first use: staging pools are allocated (hipHostMalloc), excluded like the reference's first malloc

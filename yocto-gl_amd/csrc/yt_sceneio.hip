@@ -24,6 +24,7 @@
 // No device code here; the file is a .hip unit only so that the one build rule covers it.
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <cmath>
@@ -91,7 +92,7 @@ struct Json {
     if (kind != Object) return nullptr;
     const Json* hit = nullptr;
     for (auto& m : members)
-      if (m.first == key) hit = &m.second;  // (a repeated key: the last one stays, as in a std::map insert-or-assign)
+      if (m.first == key) hit = &m.second;  // (a repeated key: the last value stays)
     return hit;
   }
 };
@@ -207,7 +208,7 @@ struct JsonParser {
     }
     v.kind = Json::Float;
     v.d    = std::strtod(tok.c_str(), nullptr);
-    return true;
+    return std::isfinite(v.d);  // ("number overflow" is a parse error there)
   }
   bool lit(const char* s) {
     size_t n = std::strlen(s);
@@ -287,6 +288,7 @@ struct JsonParser {
     return ok;
   }
   bool document(Json& v) {
+    if (end - p >= 3 && (unsigned char)p[0] == 0xEF && (unsigned char)p[1] == 0xBB && (unsigned char)p[2] == 0xBF) p += 3;  // UTF-8 BOM
     if (!value(v)) return false;
     ws();
     return p == end;
@@ -788,18 +790,36 @@ void parse_scene(const Json& json, ythip_scene_file& f, std::vector<std::string>
   auto identity = [](ythip_frame& fr) {
     fr = ythip_frame{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
   };
-  auto group = [&](const char* name) -> const std::vector<Json>* {
+  // `for (auto& element : json.at(name))`: the items of an array, the values of an object in file order
+  // (the reference's json_value is nlohmann::ordered_json), nothing for null; anything else is a conversion error, and
+  // so is an element that is not an object (its first get_opt throws)
+  std::vector<std::vector<const Json*>> groups;
+  auto group = [&](const char* name) -> const std::vector<const Json*>* {
     auto g = json.find(name);
     if (!g) return nullptr;
-    if (g->kind == Json::Array) return &g->items;
-    if (g->kind == Json::Null) {  // (iterating a null json is an empty range)
-      static const std::vector<Json> none;
-      return &none;
+    groups.emplace_back();
+    auto& out = groups.back();
+    if (g->kind == Json::Array) {
+      for (auto& e : g->items) out.push_back(&e);
+    } else if (g->kind == Json::Object) {
+      std::vector<std::pair<std::string, const Json*>> ordered;  // a repeated key keeps its first place and its last value
+      for (auto& m : g->members) {
+        bool seen = false;
+        for (auto& have : ordered)
+          if (have.first == m.first) have.second = &m.second, seen = true;
+        if (!seen) ordered.emplace_back(m.first, &m.second);
+      }
+      for (auto& m : ordered) out.push_back(m.second);
+    } else if (g->kind != Json::Null) {
+      throw BadValue{};
     }
-    throw BadValue{};  // (objects / scalars iterate as values there; nothing the format writes)
+    for (auto e : out)
+      if (e->kind != Json::Object) throw BadValue{};
+    return &out;
   };
   if (auto items = group("cameras"))
-    for (auto& e : *items) {
+    for (auto ep : *items) {
+      const Json& e = *ep;
       ythip_camera c{};
       identity(c.frame);
       c.orthographic = 0, c.lens = 0.050f, c.film = 0.036f, c.aspect = 1.500f, c.focus = 10000, c.aperture = 0;
@@ -819,7 +839,8 @@ void parse_scene(const Json& json, ythip_scene_file& f, std::vector<std::string>
       f.cameras.push_back(c);
     }
   if (auto items = group("textures"))
-    for (auto& e : *items) {
+    for (auto ep : *items) {
+      const Json& e = *ep;
       ythip_texture t{};
       f.texture_names.emplace_back();
       texture_uris.emplace_back();
@@ -831,7 +852,8 @@ void parse_scene(const Json& json, ythip_scene_file& f, std::vector<std::string>
       f.textures.push_back(t);
     }
   if (auto items = group("materials"))
-    for (auto& e : *items) {
+    for (auto ep : *items) {
+      const Json& e = *ep;
       ythip_material m{};
       m.type      = YTHIP_MATTE;
       m.color[0] = m.color[1] = m.color[2] = 0;
@@ -862,14 +884,16 @@ void parse_scene(const Json& json, ythip_scene_file& f, std::vector<std::string>
       f.materials.push_back(m);
     }
   if (auto items = group("shapes"))
-    for (auto& e : *items) {
+    for (auto ep : *items) {
+      const Json& e = *ep;
       f.shape_names.emplace_back();
       shape_uris.emplace_back();
       get_opt(e, "name", f.shape_names.back());
       get_opt(e, "uri", shape_uris.back());
     }
   if (auto items = group("instances"))
-    for (auto& e : *items) {
+    for (auto ep : *items) {
+      const Json& e = *ep;
       ythip_instance i{};
       identity(i.frame);
       i.shape = i.material = YTHIP_INVALIDID;
@@ -882,7 +906,8 @@ void parse_scene(const Json& json, ythip_scene_file& f, std::vector<std::string>
       f.instances.push_back(i);
     }
   if (auto items = group("environments"))
-    for (auto& e : *items) {
+    for (auto ep : *items) {
+      const Json& e = *ep;
       ythip_environment env{};
       identity(env.frame);
       env.emission_tex = YTHIP_INVALIDID;

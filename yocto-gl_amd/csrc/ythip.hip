@@ -1978,8 +1978,7 @@ int ythip_state_set_samples(ythip_ctx* ctx, int samples) {
 }
 
 namespace {
-// Raise the device-visible cancel flag from the side stream (the batch's kernel polls it
-// once per sample boundary; yocto_trace.cpp:1636-1637).
+// trace_cancel for the batch in flight (the reference's stop flag, yocto_trace.cpp:1636-1637).
 int raise_stop(ythip_ctx* ctx) {
   // the number of the batch in flight (or of the last one: then nobody is listening) into the pinned
   // host word; the kernels relay it (alloc_stop_word).  Callable from any thread, no HIP call.
@@ -1997,11 +1996,14 @@ void begin_batch(ythip_ctx* ctx) {
 namespace {
 // On by default since round 3 (YTHIP_LPT_PROBE=0 switches it off; +12 % on a single 64-spp batch of
 // Cornell-1M).  Round 2 left it off because the in-batch cancellation test then missed its 50 ms
-// bound.  That was not the split: the cancel word lived in ordinary device memory, whose lines an
-// XCD's L2 keeps until they happen to be evicted — 45-55 ms on a busy device, with or without the
-// probe; the two extra small launches only pushed an already marginal latency over the bound.
-// The word is uncached memory now (alloc_stop_word) and both launches of a split batch carry the
-// same batch number (begin_batch), so one cancel stops both.
+// bound.  That was not the split: the cancel word lived in ordinary device memory and was written by
+// a memset on a side stream — an XCD's L2 keeps such a line until it happens to be evicted, and a
+// stream-ordered write queues behind the batch's launches: 45-200 ms (profiles/r03_cancel_latency.txt),
+// the probe's two extra launches only pushed a marginal latency over the bound.  Now the host stores
+// the batch number into a pinned host word, every 64th loop iteration of a workgroup reads that word
+// over the fabric and relays it into a device word all workgroups poll (yt_kernels.h, relay_stop):
+// ~1 ms, no HIP call; both launches of a split batch carry the same batch number (begin_batch), so
+// one cancel stops both.
 // A batch whose tile costs are not known yet (first batch of a tile grid) and that is long
 // enough to care is launched as 1 + (batch - 1) samples: the first launch records what every
 // tile costs, the second is handed out most expensive tile first (yt_order.hip).  Two launches
