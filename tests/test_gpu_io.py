@@ -119,3 +119,31 @@ def test_load_scene_refusal_leaves_the_context_usable(tmp_path):
     ctx.make_trace_lights(flat)
     P.gpu_render(ctx, flat, yt.trace_params(sampler="eyelight", resolution=32, samples=1, batch=1))
     ctx.close()
+
+
+def test_staging_pools_are_reused_and_regrown(tmp_path):
+    """Three loads into one context — a small scene, a larger one (pools regrown), the small one again (pools
+    reused: the staged pointers are the larger load's) — each renders what a fresh context renders."""
+    import ctypes as C
+    files = {}
+    for name in ("cornellbox", "materials"):
+        os.mkdir(tmp_path / name)
+        files[name] = str(tmp_path / name / "scene.json")
+        ry.RefScene.from_flat(P.SCENES[name]()).save(files[name])
+    params = yt.trace_params(sampler="path", resolution=64, samples=2, batch=2)
+    ctx = yt.Context(0)
+    pointers = []
+    for name in ("cornellbox", "materials", "cornellbox"):
+        staged = yt.CScene()
+        assert ctx.lib.ythip_load_scene(ctx.h, files[name].encode(), 0, C.byref(staged)) == 0, ctx.lib.ythip_io_last_error()
+        pointers.append(staged.positions)
+        flat = yt.FlatScene.from_c(staged)
+        ctx.make_trace_bvh(flat)
+        ctx.make_trace_lights(flat)
+        got = P.gpu_render(ctx, flat, params)
+        fresh = P.gpu_context(flat)
+        want = P.gpu_render(fresh, flat, params)
+        fresh.close()
+        P.assert_identical(want, got, name)
+    assert pointers[2] == pointers[1]
+    ctx.close()

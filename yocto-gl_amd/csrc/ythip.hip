@@ -101,7 +101,8 @@ struct ythip_ctx {
   std::vector<void*>          order_allocs;             // the three buffers above: they outlive a state with the same tile grid
   int                         order_tiles_x = 0, order_tiles_y = 0;
   bool                        denoise_simple = false; // YTHIP_DENOISE_SIMPLE=1: the untiled kernel for every level (cross-check)
-  std::vector<void*>          staging_allocs;
+  std::vector<void*>          staging_allocs;             // the 17 pools of ythip_scene_staging, in its order
+  std::vector<size_t>         staging_caps;               // their capacities in bytes (pools are reused when they fit)
   ythip_scene                 staged      = {};
   bool                        have_staged = false;
   bool                        may_retry = false;  // opacity < 1 possible → bounce loop may exceed `bounces`
@@ -160,7 +161,7 @@ struct ythip_ctx {
   ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
 };
 
-static void free_staging(ythip_ctx* ctx) {
+static void drop_staging_views(ythip_ctx* ctx) {
   // host pools that view the staging memory go with it: the scene they belong to is no longer
   // resident as far as the host-side builders are concerned (a new upload must follow)
   bool viewed = false;
@@ -169,11 +170,15 @@ static void free_staging(ythip_ctx* ctx) {
   for (auto* pool : {&ctx->h_positions, &ctx->h_radius})
     if (pool->ext) pool->ext = nullptr, pool->n = 0, viewed = true;
   if (viewed) ctx->have_scene = ctx->have_bvh = ctx->have_lights = false;
+  ctx->have_staged = false;
+  ctx->staged      = {};
+}
+static void free_staging(ythip_ctx* ctx) {
+  drop_staging_views(ctx);
   for (auto p : ctx->staging_allocs)
     if (p) (void)hipHostFree(p);
   ctx->staging_allocs.clear();
-  ctx->have_staged = false;
-  ctx->staged      = {};
+  ctx->staging_caps.clear();
 }
 
 // The wide walk halves a ray's chain of dependent fetches and costs a little more
@@ -1147,15 +1152,27 @@ int ythip_upload_scene(ythip_ctx* ctx, const ythip_scene* sc) {
 int ythip_scene_staging(ythip_ctx* ctx, const ythip_scene* counts, ythip_scene* staged) {
   if (!ctx || !counts || !staged) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
-  free_staging(ctx);
+  // the pools of the previous staging are handed out again where they are large enough (a reload, the
+  // next frame of an animation: pinning 2 GB costs 0.2 s) — once nothing reads them any more
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  drop_staging_views(ctx);
+  ctx->staging_allocs.resize(17, nullptr);
+  ctx->staging_caps.resize(17, 0);
   ythip_scene v = *counts;
+  int  slot = 0;
   auto pin = [&](auto*& field, size_t count) -> int {
     using T = std::remove_const_t<std::remove_pointer_t<std::remove_reference_t<decltype(field)>>>;
-    void* p = nullptr;
-    if (hipHostMalloc(&p, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocDefault) != hipSuccess)
-      return fail(ctx, YTHIP_ERR_HIP, "pinned staging allocation of %zu bytes failed", count * sizeof(T));
-    ctx->staging_allocs.push_back(p);
-    field = (T*)p;
+    const size_t need = std::max<size_t>(count, 1) * sizeof(T);
+    const int    k    = slot++;
+    if (ctx->staging_caps[k] < need) {
+      if (ctx->staging_allocs[k]) (void)hipHostFree(ctx->staging_allocs[k]);
+      ctx->staging_allocs[k] = nullptr, ctx->staging_caps[k] = 0;
+      void* p = nullptr;
+      if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess)
+        return fail(ctx, YTHIP_ERR_HIP, "pinned staging allocation of %zu bytes failed", need);
+      ctx->staging_allocs[k] = p, ctx->staging_caps[k] = need;
+    }
+    field = (T*)ctx->staging_allocs[k];
     return YTHIP_OK;
   };
   int rc;
