@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -488,6 +490,10 @@ int parse_ply(ythip_ply& ply) {
     }
   }
   if (!done) return io_fail(YTHIP_ERR_INVALID, "cannot parse " + ply.path);
+  // an element occupies at least one byte of the file (a line, a record): a count the file cannot
+  // hold is a damaged header, refused before anything is sized by it; counts travel as int32
+  for (auto& e : ply.elems)
+    if (e.count > ply.size || e.count > 0x7fffffffull || e.props.size() > 4096) return io_fail(YTHIP_ERR_INVALID, "cannot read " + ply.path);
   if (ply.format == 0) {
     for (auto& e : ply.elems) {
       for (auto& pr : e.props) pr.ascii_values.reserve(e.count);
@@ -591,7 +597,7 @@ extern "C" {
 
 // Opens (maps) a PLY file and reports what load_shape (yocto_sceneio.cpp:1017-1033) would produce
 // from it as the num_* fields of `counts` (the *_offset fields are left at -1 / for the caller).
-int ythip_ply_open(const char* path, ythip_ply** out, ythip_shape* counts) {
+static int ply_open_impl(const char* path, ythip_ply** out, ythip_shape* counts) {
   if (!path || !out || !counts) return io_fail(YTHIP_ERR_INVALID, "null argument");
   *out   = nullptr;
   int fd = ::open(path, O_RDONLY);
@@ -604,14 +610,10 @@ int ythip_ply_open(const char* path, ythip_ply** out, ythip_shape* counts) {
   void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
   ::close(fd);
   if (m == MAP_FAILED) return io_fail(YTHIP_ERR_INVALID, std::string("cannot read ") + path);
-  auto ply  = new ythip_ply{};
+  std::unique_ptr<ythip_ply, void (*)(ythip_ply*)> ply(new ythip_ply{}, ythip_ply_close);  // (unmaps, whatever happens below)
   ply->path = path, ply->data = (const uint8_t*)m, ply->size = (size_t)st.st_size;
   int rc = parse_ply(*ply);
-  if (rc) {
-    ::munmap(m, ply->size);
-    delete ply;
-    return rc;
-  }
+  if (rc) return rc;
   ythip_shape c = {};
   c.points_offset = c.lines_offset = c.triangles_offset = c.quads_offset = -1;
   c.positions_offset = c.normals_offset = c.texcoords_offset = c.colors_offset = c.radius_offset = -1;
@@ -624,20 +626,27 @@ int ythip_ply_open(const char* path, ythip_ply** out, ythip_shape* counts) {
   if (have_all(v, {"radius"})) c.num_radius = (int)v->count;
   if (auto f = ply->find("face"))
     if (auto pr = f->find("vertex_indices"); pr && pr->is_list) {
-      if (list_has_quads(*pr)) c.num_quads = (int)fan_count(*pr, 4);
-      else c.num_triangles = (int)fan_count(*pr, 3);
+      size_t n = fan_count(*pr, list_has_quads(*pr) ? 4 : 3);
+      if (n > 0x7fffffffull) return io_fail(YTHIP_ERR_INVALID, std::string("cannot read ") + path);
+      if (list_has_quads(*pr)) c.num_quads = (int)n;
+      else c.num_triangles = (int)n;
     }
   if (auto l = ply->find("line"))
-    if (auto pr = l->find("vertex_indices"); pr && pr->is_list) c.num_lines = (int)line_count(*pr);
+    if (auto pr = l->find("vertex_indices"); pr && pr->is_list) {
+      size_t n = line_count(*pr);
+      if (n > 0x7fffffffull) return io_fail(YTHIP_ERR_INVALID, std::string("cannot read ") + path);
+      c.num_lines = (int)n;
+    }
   if (auto pt = ply->find("point"))
-    if (auto pr = pt->find("vertex_indices"); pr && pr->is_list) c.num_points = (int)list_total(*pr);
-  if (!c.num_points && !c.num_lines && !c.num_triangles && !c.num_quads) {
-    ::munmap(m, ply->size);
-    delete ply;
+    if (auto pr = pt->find("vertex_indices"); pr && pr->is_list) {
+      size_t n = list_total(*pr);
+      if (n > 0x7fffffffull) return io_fail(YTHIP_ERR_INVALID, std::string("cannot read ") + path);
+      c.num_points = (int)n;
+    }
+  if (!c.num_points && !c.num_lines && !c.num_triangles && !c.num_quads)
     return io_fail(YTHIP_ERR_INVALID, std::string("empty shape ") + path);  // load_shape's shape_error()
-  }
   *counts = c;
-  *out    = ply;
+  *out    = ply.release();
   return YTHIP_OK;
 }
 
@@ -645,7 +654,7 @@ int ythip_ply_open(const char* path, ythip_ply** out, ythip_shape* counts) {
 // by the counts ythip_ply_open reported: positions / normals [n][3], texcoords [n][2] (v flipped to
 // 1 - v when flip_texcoord), colors [n][4] (alpha 1 when the file has none), radius [n], points [n],
 // lines [n][2], triangles [n][3], quads [n][4] — the values of load_shape's shape_data.
-int ythip_ply_read(ythip_ply* ply, int flip_texcoord, float* positions, float* normals, float* texcoords, float* colors,
+static int ply_read_impl(ythip_ply* ply, int flip_texcoord, float* positions, float* normals, float* texcoords, float* colors,
     float* radius, int32_t* points, int32_t* lines, int32_t* triangles, int32_t* quads) {
   if (!ply) return io_fail(YTHIP_ERR_INVALID, "null argument");
   auto v      = ply->find("vertex");
@@ -736,6 +745,24 @@ int ythip_ply_read(ythip_ply* ply, int flip_texcoord, float* positions, float* n
         }
       }
   return YTHIP_OK;
+}
+
+// (nothing thrown inside — an allocation that fails on a damaged file, say — may cross the C boundary)
+int ythip_ply_open(const char* path, ythip_ply** out, ythip_shape* counts) {
+  try {
+    return ply_open_impl(path, out, counts);
+  } catch (const std::exception& e) {
+    if (out) *out = nullptr;
+    return io_fail(YTHIP_ERR_INVALID, std::string("cannot read ") + (path ? path : "") + " (" + e.what() + ")");
+  }
+}
+int ythip_ply_read(ythip_ply* ply, int flip_texcoord, float* positions, float* normals, float* texcoords, float* colors,
+    float* radius, int32_t* points, int32_t* lines, int32_t* triangles, int32_t* quads) {
+  try {
+    return ply_read_impl(ply, flip_texcoord, positions, normals, texcoords, colors, radius, points, lines, triangles, quads);
+  } catch (const std::exception& e) {
+    return io_fail(YTHIP_ERR_INVALID, std::string("cannot read ") + (ply ? ply->path : std::string()) + " (" + e.what() + ")");
+  }
 }
 
 void ythip_ply_close(ythip_ply* ply) {

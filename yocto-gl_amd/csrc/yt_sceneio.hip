@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <filesystem>
 #include <limits>
 #include <memory>
@@ -447,6 +448,10 @@ bool hdr_header(const uint8_t* data, size_t size, HdrInfo& info, std::string& wh
   if (std::strncmp(e, "+X ", 3)) return why = "unsupported HDR data layout", false;
   info.width = (int)std::strtol(e + 3, nullptr, 10);
   if (info.width <= 0 || info.height <= 0 || info.width > (1 << 24) || info.height > (1 << 24)) return why = "bad HDR size", false;
+  // stb's own limit (stbi__mad4sizes_valid: width * height * 4 * sizeof(float) fits an int), and what the file can
+  // hold at all: a run-length byte pair covers at most 127 samples
+  if ((double)info.width * info.height * 16.0 > 2147483647.0) return why = "HDR image is too large", false;
+  if ((double)info.width * info.height * 4.0 > 64.0 * (double)size + 1024.0) return why = "corrupt HDR: truncated", false;
   info.pixels = r.p;
   return true;
 }
@@ -555,6 +560,9 @@ bool png_parse(const uint8_t* data, size_t size, PngInfo& png, bool with_data, s
       if ((png.color == 2 || png.color == 4 || png.color == 6) && png.depth < 8) return why = "corrupt PNG: bad bit depth", false;
       if (body[10] || body[11] || png.interlace > 1) return why = "corrupt PNG: bad compression / filter / interlace method", false;
       png.channels = png.color == 3 ? 1 : (png.color & 2 ? 3 : 1) + (png.color & 4 ? 1 : 0);
+      // stb's limit (the RGBA8 result fits an int) and what a deflate stream of this file's size can hold (1032 : 1)
+      if ((double)png.width * png.height * 4.0 > 2147483647.0) return why = "PNG image is too large", false;
+      if ((double)png.width * png.height * png.channels * png.depth / 8.0 > 1032.0 * (double)size + 65536.0) return why = "corrupt PNG: not enough pixels", false;
       if (!with_data) return true;
     } else if (is("PLTE")) {
       if (len > 256 * 3 || len % 3) return why = "corrupt PNG: bad PLTE", false;
@@ -737,7 +745,13 @@ int for_each_parallel(size_t count, int threads, Fn&& fn, std::string& error) { 
       size_t k = next.fetch_add(1);
       if (k >= count) break;
       std::string why;
-      if (!fn(k, why)) {
+      bool        ok = false;
+      try {
+        ok = fn(k, why);
+      } catch (const std::exception& e) {  // (an allocation that fails on a damaged file must not end the process)
+        why = std::string("out of resources (") + e.what() + ")";
+      }
+      if (!ok) {
         errors[(size_t)t] = why;
         failed.store(1);
         break;
@@ -928,7 +942,7 @@ extern "C" {
 // load_json_scene up to (not including) the bulk data: scene.json parsed, every shape and texture
 // file opened and measured.  `counts` gets every num_* of ythip_scene (pointers null) — what to
 // size the pools with.
-int ythip_scene_open(const char* path, ythip_scene_file** out, ythip_scene* counts) {
+static int scene_open_impl(const char* path, ythip_scene_file** out, ythip_scene* counts) {
   if (!path || !out || !counts) return fail(YTHIP_ERR_INVALID, "null argument");
   *out = nullptr;
   std::string filename = path;
@@ -1061,7 +1075,7 @@ int ythip_scene_open(const char* path, ythip_scene_file** out, ythip_scene* coun
 // Fills the pools `dst` points to (every pointer of ythip_scene, writable, sized by the counts of
 // ythip_scene_open; a pool whose count is 0 may be null): records, converted shapes, decoded
 // textures.  `threads` <= 0: one per hardware thread.
-int ythip_scene_read(ythip_scene_file* f, const ythip_scene* dst, int threads) {
+static int scene_read_impl(ythip_scene_file* f, const ythip_scene* dst, int threads) {
   if (!f || !dst) return fail(YTHIP_ERR_INVALID, "null argument");
   auto& c       = f->counts;
   auto  missing = [&](const void* p, int64_t n) { return n > 0 && !p; };
@@ -1153,6 +1167,23 @@ int ythip_scene_read(ythip_scene_file* f, const ythip_scene* dst, int threads) {
     std::memcpy(W(dst->cameras), &cam, sizeof(cam));
   }
   return YTHIP_OK;
+}
+
+// (nothing thrown inside — std::filesystem, an allocation sized by a damaged file — may cross the C boundary)
+int ythip_scene_open(const char* path, ythip_scene_file** out, ythip_scene* counts) {
+  try {
+    return scene_open_impl(path, out, counts);
+  } catch (const std::exception& e) {
+    if (out) *out = nullptr;
+    return fail(YTHIP_ERR_INVALID, std::string("cannot load ") + (path ? path : "") + " (" + e.what() + ")");
+  }
+}
+int ythip_scene_read(ythip_scene_file* f, const ythip_scene* dst, int threads) {
+  try {
+    return scene_read_impl(f, dst, threads);
+  } catch (const std::exception& e) {
+    return fail(YTHIP_ERR_INVALID, std::string("cannot load ") + (f ? f->path : std::string()) + " (" + e.what() + ")");
+  }
 }
 
 int32_t ythip_scene_find_camera(const ythip_scene_file* f, const char* name) {  // find_camera, yocto_scene.cpp:656-675
