@@ -1220,6 +1220,9 @@ __global__ void __launch_bounds__(YT_BLOCK,
       }
       const long long tm3     = __builtin_readcyclecounter();
       const bool      any_run = __ballot(run) != 0;
+#ifdef YT_TIMING_OCC
+      const unsigned long long occ_walk = (unsigned long long)__popcll(__ballot(run && work > 0)), occ_run = (unsigned long long)__popcll(__ballot(run));
+#endif
       if ((tid & 63) == 0 && st.counters) {
         unsigned long long* c = st.counters + cnt_bank();
         atomicAdd(&c[9], (unsigned long long)(any_run ? tm1 - tm0 : 0));
@@ -1230,12 +1233,21 @@ __global__ void __launch_bounds__(YT_BLOCK,
         // lane utilisation of the traversal: sum of lane steps vs 64 x the longest lane
         atomicAdd(&c[6], (unsigned long long)tm_sum);
         atomicAdd(&c[7], (unsigned long long)tm_max * 64ull);
+#ifdef YT_TIMING_OCC  // instead of the shade split: how full the wavefront is (slots with a ray), weighted by the walk / by the iteration
+        atomicAdd(&c[14], occ_walk * tm_max);
+        atomicAdd(&c[15], occ_run * (unsigned long long)(tm2 - tm0));
+        atomicAdd(&c[8], 64ull * (unsigned long long)(tm2 - tm0));
+        if (false) {
+#else
         // shade split (waves whose lane 0 shaded a hit): shading point | bsdf + sampling | finish + regenerate
         if (any_run && tmG) {
+#endif
           atomicAdd(&c[14], (unsigned long long)(tmG - tm1));
           atomicAdd(&c[15], (unsigned long long)(tmS - tmG));
         }
+#ifndef YT_TIMING_OCC
         if (any_run) atomicAdd(&c[8], (unsigned long long)(tm2 - tmS));
+#endif
       }
     }
 #endif

@@ -2337,9 +2337,15 @@ int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
     std::fprintf(stderr, "[timing] wave-iterations %llu | extend %.1f%% shade %.1f%% partition+wait %.1f%% "
                          "idle-wave %.1f%% | cycles/wave-iteration %.0f\n",
         t[13], 100 * t[9] / tot, 100 * t[10] / tot, 100 * t[11] / tot, 100 * t[12] / tot, t[13] ? tot / t[13] : 0.0);
+#ifdef YT_TIMING_OCC
+    std::fprintf(stderr, "[timing] slots holding a ray in the walk (weighted by the longest lane): %.1f of 64 | lane steps per walking slot / longest lane: %.1f%%\n",
+        t[7] ? 64.0 * t[14] / t[7] : 0.0, t[14] ? 100.0 * t[6] / t[14] : 0.0);
+    std::fprintf(stderr, "[timing] slots running in an iteration (weighted by extend + shade time): %.1f of 64\n", t[8] ? 64.0 * t[15] / t[8] : 0.0);
+#else
     std::fprintf(stderr, "[timing] of all wave time: hit shading point %.1f%% | bsdf+sampling after it %.1f%% | "
                          "finish+regenerate (resolve_step) %.1f%%\n",
         100 * t[14] / tot, 100 * t[15] / tot, 100 * t[8] / tot);
+#endif
     std::fprintf(stderr, "[timing] traversal lane utilisation (sum of lane steps / 64 x longest lane): %.1f%%\n",
         t[7] ? 100.0 * t[6] / t[7] : 0.0);
   }
