@@ -129,6 +129,7 @@ def run_workload(name, device, steps, warmup, count=True):
     st = ctx.get_stats()
     ctx.set_profiling(0)
     sizes = ctx.bvh_baked_sizes()
+    pool = ctx.pixel_pool_info()
     ctx.close()
     ms = st["trace_ms"] / max(st["trace_launches"], 1)
     out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"],
@@ -140,13 +141,19 @@ def run_workload(name, device, steps, warmup, count=True):
                              ["rays", "nodes", "triangles", "quads", "lines", "points", "instances", "shades"]}
     if sizes:
         out["baked_bytes"] = sizes
+    out["pixel_pool"] = {"on": bool(pool["on"]), "decided": bool(pool["decided"]),
+                         "plain_ms_per_sample": round(pool["plain_ms_per_sample"], 5), "pool_ms_per_sample": round(pool["pool_ms_per_sample"], 5)}
     return out
 
 
 # ----------------------------------------------------------------------------
 # live counters: this script as a worker under rocprofv3 --pmc
 # ----------------------------------------------------------------------------
-WORKER_STEPS = 2  # timed launches of a counter worker (after one warm-up)
+WORKER_STEPS = 2  # timed launches of a counter worker (after the warm-up)
+# warm-up batches of the other workloads and of the counter workers: the first batch records the tile costs (launch order),
+# the second and third are the library's timed plain / pixel-pool pair (ythip_set_pixel_pool, mode 1), from the fourth
+# on the launch is the one it chose — the steady state a progressive render spends its life in
+OTHER_WARMUP = 3
 PMC_PASSES = [
     ["FETCH_SIZE", "TCC_REQ_sum", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_THREAD_CYCLES_VALU"],
@@ -312,6 +319,7 @@ def other_workloads(device, args, calib):
                  "roofline": roofline_of(run, None, None, calib)}
             if "baked_bytes" in run:
                 e["baked_bvh_bytes"] = run["baked_bytes"]
+            e["pixel_pool"] = run.get("pixel_pool")
             res.append(e)
             deferred.append((name, run, e))
         except Exception as ex:  # reported, never required
@@ -354,10 +362,10 @@ def worker_main(args):
     """`--worker NAME`: one warm-up + WORKER_STEPS launches of the workload, nothing printed; run under
     rocprofv3 --pmc by collect_counters()."""
     if args.worker_json:  # the timed run of one of the other workloads, in a process of its own
-        run = run_workload(args.worker, args.worker_device, steps=2, warmup=1)
+        run = run_workload(args.worker, args.worker_device, steps=2, warmup=OTHER_WARMUP)
         print("YTHIP_RUN " + json.dumps(run), flush=True)
         return
-    run_workload(args.worker, args.worker_device, steps=WORKER_STEPS, warmup=1, count=False)
+    run_workload(args.worker, args.worker_device, steps=WORKER_STEPS, warmup=OTHER_WARMUP, count=False)
 
 
 def run_workload_isolated(name, device, timeout=420):
@@ -529,6 +537,7 @@ def main():
         dt = time.perf_counter() - t0
         stats_time = ctx.get_stats()
         ctx.set_profiling(0)
+        pool_info = ctx.pixel_pool_info()
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         if gathering:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -575,7 +584,11 @@ def main():
                    "bvh_build": {"builder": "device" if build_info["device_trees"] else "host",
                                  "device_kernels_ms": round(build_info["device_ms"], 3),
                                  "build_ms": round(build_info["build_ms"], 3),
-                                 "bake_ms": round(build_info["bake_ms"], 3)}},
+                                 "bake_ms": round(build_info["bake_ms"], 3)},
+                   # the library's measured choice between the plain and the pixel-pool launch (ythip_set_pixel_pool)
+                   "pixel_pool": {"on": bool(pool_info["on"]), "decided": bool(pool_info["decided"]),
+                                  "plain_ms_per_sample": round(pool_info["plain_ms_per_sample"], 5),
+                                  "pool_ms_per_sample": round(pool_info["pool_ms_per_sample"], 5)}},
     }
     if gathering:  # what the collective library itself reports
         out["config"]["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}

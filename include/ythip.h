@@ -547,6 +547,21 @@ const char* ythip_scene_name(const ythip_scene_file* file, int what, int32_t ind
 void        ythip_scene_close(ythip_scene_file* file);
 int         ythip_load_scene(ythip_ctx* ctx, const char* path, int threads, ythip_scene* staged);
 
+/* The pixel pool: a batch launched as fewer workgroups than tiles (16 per CU) whose lanes, when their pixel has
+ * taken its samples, take the next pixel of a queue (tiles in launch order) instead of idling until the tile is
+ * done.  It fills the wavefronts of frames whose pixels cost very differently (BASELINE configs[4], hair: +15 %)
+ * and costs a few per cent on even frames, so by default (mode 1) the library measures per trace state: once the
+ * tile costs are known, one batch of >= 8 samples is timed plain, the next as a pool launch, and the faster per
+ * sample is kept.  Mode 0 never, 2 always (env YTHIP_PIXEL_POOL).  The reference's results either way, bit for
+ * bit: which lane traces a pixel's next sample is not observable (yocto_trace.cpp:1595-1619 is a parallel_for
+ * over pixels). */
+typedef struct ythip_pool_info {
+  int32_t mode, workgroups, decided, on;
+  float   plain_ms_per_sample, pool_ms_per_sample; /* the two timed batches, 0 until decided */
+} ythip_pool_info;
+int ythip_set_pixel_pool(ythip_ctx* ctx, int mode, int workgroups); /* workgroups <= 0: keep (default 16 per CU) */
+int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info);
+
 /* Which BVH walk k_trace's extend stage and the test entries below use: 0 the
  * binary walk (one sibling pair per dependent fetch), 1 the wide walk (the four
  * grandchildren per fetch: half the fetch chain, yt_bvh.h), 2 (default) chosen by

@@ -100,6 +100,10 @@ struct DState {
   // workgroup records the cycles its tile took for the next launch's order.  null: off.
   const int* tile_perm;
   unsigned*  tile_cost;
+  // pixel pool (opt-in, YTHIP_PIXEL_POOL=1): fewer workgroups than tiles; a lane whose pixel has taken its
+  // batch takes the next pixel of the queue (tiles in launch order, 64 entries each) instead of going idle.  null: off.
+  int* pool_next;
+  int  pool_total;  // queue length = nblocks * YT_BLOCK
 };
 YT_FN bool stop_requested(const int* stop, int gen) {
   return stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen;
@@ -309,7 +313,8 @@ struct Path {
   vec3f     weight, radiance;
   float     max_roughness;
   int       bounce, opbounce, flags, sidx;
-  int       pix;  // pixel index of the slot in the slice's trace_state arrays
+  int       pix;    // pixel index of the slot in the slice's trace_state arrays
+  int       vslot;  // the slot of the tile grid whose pixel this is (the path slot itself, unless the pixel pool dealt it)
   rng_state rng;
 };
 
@@ -789,6 +794,7 @@ struct WgState {
   float4     wgt[YT_BLOCK];    // weight.xyz, max_roughness
   float4     rad[YT_BLOCK];    // radiance.xyz, samples done in this batch (int)
   ulonglong2 rng[YT_BLOCK];    // rng_state {state, inc}
+  int        vslot[YT_BLOCK];  // Path::vslot
 };
 
 // everything but the ray, whose second record `rb` the caller already holds
@@ -797,7 +803,8 @@ YT_FN void load_path_rest(const DState& st, const WgState& W, int slot, Path& P,
   float4    w = W.wgt[l], r = W.rad[l];
   auto      g = W.rng[l];
   int       pi, pj;
-  P.pix           = slot_pixel(st, slot, pi, pj);
+  P.vslot         = W.vslot[l];
+  P.pix           = slot_pixel(st, P.vslot, pi, pj);
   P.bounce        = __float_as_int(rb.z);
   int fw          = __float_as_int(rb.w);
   P.flags         = fw & 0xff;
@@ -823,12 +830,13 @@ YT_FN void store_path(WgState& W, int slot, const Path& P) {
   W.ray_b[l] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
   W.wgt[l]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
   W.rad[l]   = {P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)};
+  W.vslot[l] = P.vslot;
 }
 
 // Head of trace_sample (yocto_trace.cpp:1464-1468): the pixel's next camera ray.
 YT_FN void start_sample(const DScene& sc, const DState& st, const KParams& kp, int slot, Path& P) {
   int i, j;
-  slot_pixel(st, slot, i, j);
+  slot_pixel(st, P.vslot, i, j);
   // sample_camera(camera, ij, size, puv = rand2f, luv = rand2f, tent): g++ draws luv first
   auto luv = rand2f(P.rng);
   auto puv = rand2f(P.rng);
@@ -940,6 +948,28 @@ YT_FN int resolve_step(const DScene& sc, const DState& st, const KParams& kp, in
     return OUT_PRIMARY;
   }
   st.rngs[P.pix] = {P.rng.state, P.rng.inc};  // the pixel's stream goes back to trace_state
+  if (st.pool_next && !stopped) {
+    // pixel pool: the lanes that are here together take the next queue entries with one atomic
+    while (true) {
+      const unsigned long long here   = __ballot(1);
+      const int                lane   = (int)(threadIdx.x & 63), leader = __ffsll((long long)here) - 1;
+      int                      base   = 0;
+      if (lane == leader) base = atomicAdd(st.pool_next, __popcll(here));
+      base        = __shfl(base, leader);
+      const int q = base + __popcll(here & ((1ull << lane) - 1ull));
+      if (q >= st.pool_total) break;
+      int tile = q / YT_BLOCK;
+      if (st.tile_perm) tile = st.tile_perm[tile];
+      const int vs = tile * YT_BLOCK + (q & (YT_BLOCK - 1));
+      int       i, j;
+      const int pix = slot_pixel(st, vs, i, j);
+      if (pix < 0) continue;  // a slot of an edge tile outside the slice
+      auto r  = st.rngs[pix];
+      P.vslot = vs, P.pix = pix, P.rng = {r.x, r.y}, P.sidx = 0;
+      start_sample(sc, st, kp, slot, P);
+      return OUT_PRIMARY;
+    }
+  }
   return OUT_DEAD;
 }
 
@@ -1042,9 +1072,19 @@ __global__ void __launch_bounds__(YT_BLOCK,
   __shared__ int s_pad[YT_LDS_PAD / 4];
   if (st.npix < 0) s_pad[threadIdx.x] = st.npix, st.image[0].x = (float)s_pad[(threadIdx.x + 1) & 63];
 #endif
-  const int lb = logical_block(st);
+  int lb = logical_block(st);
   if (lb < 0) return;
   if (stop_requested(st.stop, st.stop_gen)) return;  // cancelled before this tile started
+  int vtile = lb;  // the tile whose pixels the slots start on
+  if (st.pool_next) {  // pixel pool: the workgroup's first 64 queue entries = one tile; the path slots are the workgroup's own
+    __shared__ int s_first;
+    if (threadIdx.x == 0) s_first = atomicAdd(st.pool_next, YT_BLOCK);
+    __syncthreads();
+    if (s_first >= st.pool_total) return;
+    vtile = s_first / YT_BLOCK;
+    if (st.tile_perm) vtile = st.tile_perm[vtile];
+    lb = (int)blockIdx.x;
+  }
   if ((lb & 63) == 0 && relay_stop(st)) return;      // (one tile in 64 also asks the host's word: a batch cancelled before any workgroup ran)
   const long long t_tile0 = st.tile_cost ? (long long)__builtin_readcyclecounter() : 0;
   const int tid = threadIdx.x;
@@ -1062,14 +1102,15 @@ __global__ void __launch_bounds__(YT_BLOCK,
   int3 n;
   {
     int slot = lb * YT_BLOCK + tid, i, j;
-    int pix  = slot_pixel(st, slot, i, j);
+    int pix  = slot_pixel(st, vtile * YT_BLOCK + tid, i, j);
     if (st.only_pix >= 0 && pix != st.only_pix) pix = -1;
     if (pix >= 0) {
       Path P;
-      auto r = st.rngs[pix];
-      P.rng  = {r.x, r.y};
-      P.sidx = 0;
-      P.pix  = pix;
+      auto r  = st.rngs[pix];
+      P.rng   = {r.x, r.y};
+      P.sidx  = 0;
+      P.pix   = pix;
+      P.vslot = vtile * YT_BLOCK + tid;
       start_sample(sc, st, kp, slot, P);
       if (max_bounces <= 0 && SAMPLER != YTHIP_SAMPLER_FALSECOLOR) {
         // the reference's bounce loop never runs (yocto_trace.cpp:466, 1045, 1260): every
@@ -1333,7 +1374,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
 #else
   if (COUNT || LP != LP_NONE) flush_counters(st.counters, cnt);
 #endif
-  if (st.tile_cost && threadIdx.x == 0) {
+  if (st.tile_cost && !st.pool_next && threadIdx.x == 0) {
     const long long dt = ((long long)__builtin_readcyclecounter() - t_tile0) >> 6;  // 64-cycle units fit 32 bits
     st.tile_cost[lb]   = (unsigned)(dt < 0 ? 0 : (dt > 0xffffffffll ? 0xffffffffll : dt));
   }

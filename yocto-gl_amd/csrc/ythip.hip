@@ -98,6 +98,20 @@ struct ythip_ctx {
   bool                        have_tile_costs = false;  // d_tile_cost holds the previous whole-slice launch's costs
   int                         lpt_age = 0;              // launches since the order was last computed
   bool                        lpt_probe = true;         // YTHIP_LPT_PROBE=0: do not split the first batch of a tile grid (see enqueue_batch)
+  // pixel pool (yt_kernels.h, DState::pool_next): a launch of fewer workgroups than tiles whose lanes
+  // take the next pixel of a queue when their own has had its batch.  Fills the wavefronts of scenes whose pixels
+  // cost very differently (hair: +15 %) and costs a few per cent where they do not (an even scene), so the library
+  // measures: once the tile costs are known, one full-size batch is timed plain, the next as a pool launch, and
+  // whichever took less time per sample is kept for this state.  Results are bit-identical either way.
+  int*                        d_pool_next = nullptr;     // the queue's head
+  int                         pixel_pool  = 1;           // YTHIP_PIXEL_POOL: 0 never, 1 (default) measured choice, 2 always
+  int                         pool_blocks = 0;           // workgroups of a pool launch (YTHIP_POOL_BLOCKS; default 16 per CU)
+  int                         pool_tune   = 0;           // 0 time a plain batch next, 1 time a pool batch next, 2 waiting for both, 3 decided
+  bool                        pool_on     = false;       // the decision
+  hipEvent_t                  pool_ev[4]  = {nullptr, nullptr, nullptr, nullptr};  // plain begin / end, pool begin / end
+  double                      pool_samples[2] = {0, 0};  // samples per pixel of the two timed launches
+  float                       pool_ms[2]  = {0, 0};      // (kept for ythip_pool_info)
+  int launch_blocks() const { return st.pool_next ? std::min(st.nblocks, pool_blocks) : st.nblocks; }
   std::vector<void*>          order_allocs;             // the three buffers above: they outlive a state with the same tile grid
   int                         order_tiles_x = 0, order_tiles_y = 0;
   bool                        denoise_simple = false; // YTHIP_DENOISE_SIMPLE=1: the untiled kernel for every level (cross-check)
@@ -814,7 +828,7 @@ int upload_lights_impl(ythip_ctx* ctx) {
 
 template <int S, int LP>
 void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
-  dim3 grid(ctx->st.nblocks), block(YT_BLOCK);  // one persistent one-wave workgroup per 16x4 tile
+  dim3 grid(ctx->launch_blocks()), block(YT_BLOCK);  // one persistent one-wave workgroup per 16x4 tile
   if (count)  // the counting launch walks binary: its counts are the reference's
     hipLaunchKernelGGL((k_trace<S, LP, true, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
   else if (ctx->use_wide())
@@ -831,7 +845,7 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
       if (!count && ctx->all_matte && ctx->specialize && ctx->use_wide()) {
         // the default sampler on an all-matte scene: the variant compiled without the
         // other material lobes and the volume code (same results, fewer registers)
-        dim3 grid(ctx->st.nblocks), block(YT_BLOCK);
+        dim3 grid(ctx->launch_blocks()), block(YT_BLOCK);
         if (lp == LP_DEFER)
           hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 1>), grid, block, 0, ctx->stream,
               ctx->ds, ctx->st, kp);
@@ -841,7 +855,7 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
       } else if (!count && ctx->no_textures && ctx->specialize && ctx->use_wide()) {
         // no material references a texture (any material types, any primitive kinds): the
         // variant compiled without the texture lookups and the normal-map code
-        dim3 grid(ctx->st.nblocks), block(YT_BLOCK);
+        dim3 grid(ctx->launch_blocks()), block(YT_BLOCK);
         if (lp == LP_DEFER)
           hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 2>), grid, block, 0, ctx->stream, ctx->ds,
               ctx->st, kp);
@@ -979,6 +993,34 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   // one launch renders the whole batch: every workgroup loops over its tile
   // until its pixels have taken `batch` samples (k_trace)
   ctx->st.tile_perm = nullptr, ctx->st.tile_cost = nullptr;
+  ctx->st.pool_next = nullptr, ctx->st.pool_total = 0;
+  // pixel pool: only where there are more tiles than resident workgroups, and once the tile costs of a plain launch
+  // order the queue (the first batch / the probe launch runs plain and records them)
+  const bool pool_ok = ctx->pixel_pool && only_pix < 0 && !count && ctx->st.nblocks > ctx->pool_blocks &&
+                       (ctx->have_tile_costs || !ctx->d_tile_cost || ctx->pixel_pool >= 2);
+  bool pool = false;
+  int  timed = -1;  // 0: this launch is the timed plain batch, 1: the timed pool batch
+  if (pool_ok && ctx->pixel_pool >= 2) {
+    pool = true;
+  } else if (pool_ok) {
+    if (ctx->pool_tune == 2 && hipEventQuery(ctx->pool_ev[1]) == hipSuccess && hipEventQuery(ctx->pool_ev[3]) == hipSuccess) {
+      if (hipEventElapsedTime(&ctx->pool_ms[0], ctx->pool_ev[0], ctx->pool_ev[1]) == hipSuccess &&
+          hipEventElapsedTime(&ctx->pool_ms[1], ctx->pool_ev[2], ctx->pool_ev[3]) == hipSuccess)
+        ctx->pool_on = ctx->pool_ms[1] / ctx->pool_samples[1] < 0.97 * ctx->pool_ms[0] / ctx->pool_samples[0];
+      ctx->pool_tune = 3;
+    }
+    if (ctx->pool_tune == 3) pool = ctx->pool_on;
+    else if (params->batch >= 8 && ctx->pool_tune < 2) {  // (a batch long enough for its time to mean something)
+      for (auto& e : ctx->pool_ev)
+        if (!e) HIPCHECK(ctx, hipEventCreate(&e));
+      timed = ctx->pool_tune, pool = timed == 1;
+    }
+  }
+  if (pool) {
+    if (!ctx->d_pool_next) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_pool_next, 64));
+    HIPCHECK(ctx, hipMemsetAsync(ctx->d_pool_next, 0, 64, ctx->stream));
+    ctx->st.pool_next = ctx->d_pool_next, ctx->st.pool_total = ctx->st.nblocks * YT_BLOCK;
+  }
   const bool lpt = ctx->d_tile_cost && only_pix < 0 && !count;
   if (lpt) {
     if (ctx->have_tile_costs) {  // the previous batch's costs order this one (same pixels, same work)
@@ -989,15 +1031,20 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
       ctx->lpt_age++;
       ctx->st.tile_perm = ctx->d_tile_perm;
     }
-    ctx->st.tile_cost = ctx->d_tile_cost;
+    ctx->st.tile_cost = pool ? nullptr : ctx->d_tile_cost;  // (a pool launch has no per-tile time: the last plain launch's costs stay)
   }
   {
     EvScope ev(ctx, 0);
-    int     rc = launch_trace_any(ctx, kp, lp, count);
+    if (timed >= 0) HIPCHECK(ctx, hipEventRecord(ctx->pool_ev[2 * timed], ctx->stream));
+    int rc = launch_trace_any(ctx, kp, lp, count);
     if (rc) return rc;
+    if (timed >= 0) {
+      HIPCHECK(ctx, hipEventRecord(ctx->pool_ev[2 * timed + 1], ctx->stream));
+      ctx->pool_samples[timed] = params->batch, ctx->pool_tune = timed + 1;
+    }
   }
   HIPCHECK(ctx, hipGetLastError());
-  if (lpt) ctx->have_tile_costs = true;
+  if (lpt && !pool) ctx->have_tile_costs = true;
   if (only_pix < 0) ctx->samples += params->batch;  // yocto_trace.cpp:1614
   return YTHIP_OK;
 }
@@ -1081,6 +1128,12 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_PEEK")) ctx->peek_policy = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LPT")) ctx->lpt = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LPT_PROBE")) ctx->lpt_probe = std::atoi(e) != 0;
+  if (const char* e = std::getenv("YTHIP_PIXEL_POOL")) ctx->pixel_pool = std::atoi(e);
+  {
+    hipDeviceProp_t prop;
+    ctx->pool_blocks = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount * 16 : 4096;
+    if (const char* e = std::getenv("YTHIP_POOL_BLOCKS")) ctx->pool_blocks = std::max(1, std::atoi(e));
+  }
   if (const char* e = std::getenv("YTHIP_DENOISE_SIMPLE")) ctx->denoise_simple = std::atoi(e) != 0;
   if (hipMalloc((void**)&ctx->d_counters, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(ctx->d_counters, 0, CNT_BANKS * CNT_STRIDE * sizeof(unsigned long long)) != hipSuccess ||
@@ -1108,6 +1161,9 @@ void ythip_destroy(ythip_ctx* ctx) {
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->stop_host) (void)hipHostFree(ctx->stop_host);
   if (ctx->d_stop) (void)hipFree(ctx->d_stop);
+  if (ctx->d_pool_next) (void)hipFree(ctx->d_pool_next);
+  for (auto e : ctx->pool_ev)
+    if (e) (void)hipEventDestroy(e);
   free_staging(ctx);
   free_all(ctx->denoise_allocs);
   free_all(ctx->order_allocs);
@@ -1741,6 +1797,7 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
     }
   }
   ctx->lpt_age = 0;  // (the order is recomputed from the kept costs at the first launch)
+  ctx->pool_tune = 0, ctx->pool_on = false;  // (a new state: the pixel pool is measured again)
   return YTHIP_OK;
 }
 
@@ -2068,6 +2125,26 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volati
     // state.samples does not advance (yocto_trace.cpp:1636-1641)
     ctx->samples = samples_before;
     return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
+  }
+  return YTHIP_OK;
+}
+
+int ythip_set_pixel_pool(ythip_ctx* ctx, int mode, int workgroups) {
+  if (!ctx || mode < 0 || mode > 2) return fail(ctx, YTHIP_ERR_INVALID, "pixel pool mode must be 0, 1 or 2");
+  ctx->pixel_pool = mode, ctx->pool_tune = 0, ctx->pool_on = false;
+  if (workgroups > 0) ctx->pool_blocks = workgroups;
+  return YTHIP_OK;
+}
+int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info) {
+  if (!ctx || !info) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  *info            = {};
+  info->mode       = ctx->pixel_pool;
+  info->workgroups = ctx->pool_blocks;
+  info->decided    = ctx->pixel_pool >= 2 || ctx->pool_tune == 3;
+  info->on         = ctx->pixel_pool >= 2 || (ctx->pool_tune == 3 && ctx->pool_on);
+  if (ctx->pool_tune == 3 && ctx->pool_samples[0] > 0 && ctx->pool_samples[1] > 0) {
+    info->plain_ms_per_sample = (float)(ctx->pool_ms[0] / ctx->pool_samples[0]);
+    info->pool_ms_per_sample  = (float)(ctx->pool_ms[1] / ctx->pool_samples[1]);
   }
   return YTHIP_OK;
 }

@@ -215,6 +215,11 @@ def load_scene_file(path, threads=0):
     return fs, names, camera
 
 
+class CPoolInfo(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("workgroups", C.c_int32), ("decided", C.c_int32), ("on", C.c_int32),
+                ("plain_ms_per_sample", C.c_float), ("pool_ms_per_sample", C.c_float)]
+
+
 class CBuildInfo(C.Structure):
     _fields_ = [("device_trees", C.c_int32), ("host_trees", C.c_int32), ("fallbacks", C.c_int32),
                 ("max_depth", C.c_int32), ("device_prims", C.c_int64), ("device_ms", C.c_double),
@@ -496,6 +501,8 @@ _SIGNATURES = {
     "ythip_params_from_json": (C.c_int, [C.c_char_p, C.c_int64, C.c_void_p]),
     "ythip_params_to_json": (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     "ythip_io_last_error": (C.c_char_p, []),
+    "ythip_set_pixel_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ythip_get_pixel_pool": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "ythip_ply_read": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9),
     "ythip_ply_close": (None, [C.c_void_p]),
@@ -726,6 +733,15 @@ class Context:
         if rc:
             raise YthipError(self.lib.ythip_io_last_error().decode())
         return FlatScene.from_c(staged)
+
+    def set_pixel_pool(self, mode, workgroups=0):
+        """0 never, 1 measured choice (default), 2 always — ythip_set_pixel_pool."""
+        self._check(self.lib.ythip_set_pixel_pool(self.h, int(mode), int(workgroups)), "set_pixel_pool")
+
+    def pixel_pool_info(self):
+        info = CPoolInfo()
+        self._check(self.lib.ythip_get_pixel_pool(self.h, C.byref(info)), "get_pixel_pool")
+        return {k: getattr(info, k) for k, _ in CPoolInfo._fields_}
 
     def update_cameras(self, cameras):
         """Re-upload only the cameras (interactive camera edits, apps/ytrace.cpp:189-204)."""
