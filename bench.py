@@ -537,7 +537,7 @@ def main():
         dt = time.perf_counter() - t0
         stats_time = ctx.get_stats()
         ctx.set_profiling(0)
-        pool_info = ctx.pixel_pool_info()
+        pool_box[:] = [ctx.pixel_pool_info()]
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         if gathering:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -546,10 +546,12 @@ def main():
         return float(tmax.item()), (w, h), npix, stats_count, stats_time
 
     keep = []
+    pool_box = []  # the library's plain / pixel-pool choice of the last timed frame (ythip_set_pixel_pool)
     # the primary line: BASELINE configs[1] at N = 1, configs[2] (the same frame split N ways) at N > 1
     primary_weak = world > 1 and args.scaling == "weak" and not args.as_rank
     resolution = weak_resolution(args.resolution, world) if primary_weak else args.resolution
     dt, (w, h), npix, stats_count, stats_time = run(resolution, not args.no_roofline)
+    pool_info = pool_box[0]
 
     total_samples = (npix if args.as_rank else w * h) * args.spp * args.steps
     value = total_samples / dt / 1e6
