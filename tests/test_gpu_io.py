@@ -113,6 +113,17 @@ def test_load_scene_refusal_leaves_the_context_usable(tmp_path):
     ctx = yt.Context(0)
     with pytest.raises(yt.YthipError, match="cannot open"):
         ctx.load_scene(str(tmp_path / "absent.json"))
+    # a failure AFTER the pools were staged (a PNG whose header is fine and whose pixel data is not): nothing half-read is uploadable
+    scene_file = str(tmp_path / "scene.json")
+    ry.RefScene.from_flat(P.SCENES["materials"]()).save(scene_file)
+    png = [f for f in os.listdir(tmp_path / "textures") if f.endswith(".png")][0]
+    data = bytearray(open(tmp_path / "textures" / png, "rb").read())
+    at = data.index(b"IDAT") + 6
+    data[at:at + 8] = b"\xff" * 8
+    open(tmp_path / "textures" / png, "wb").write(bytes(data))
+    with pytest.raises(yt.YthipError, match="cannot raed"):
+        ctx.load_scene(scene_file)
+    assert ctx.lib.ythip_upload_scene_staged(ctx.h) == 0  # (what is staged now is an empty scene)
     flat = P.SCENES["cornellbox"]()
     ctx.upload_scene(flat)
     ctx.make_trace_bvh(flat)

@@ -1221,8 +1221,17 @@ int ythip_load_scene(ythip_ctx* ctx, const char* path, int threads, ythip_scene*
   int               rc = ythip_scene_open(path, &f, &counts);
   if (rc) return rc;
   rc = ythip_scene_staging(ctx, &counts, &pools);
-  if (rc == YTHIP_OK) rc = ythip_scene_read(f, &pools, threads);
-  else fail(rc, std::string("ythip_scene_staging: ") + ythip_last_error(ctx));
+  if (rc == YTHIP_OK) {
+    rc = ythip_scene_read(f, &pools, threads);
+    if (rc) {  // half-filled pools must not be uploadable: the staging is replaced by an empty one (the pinned pools are kept)
+      std::string why = ythip_io_last_error();
+      ythip_scene none{}, unused{};
+      (void)ythip_scene_staging(ctx, &none, &unused);
+      fail(rc, why);
+    }
+  } else {
+    fail(rc, std::string("ythip_scene_staging: ") + ythip_last_error(ctx));
+  }
   ythip_scene_close(f);
   if (rc) return rc;
   rc = ythip_upload_scene_staged(ctx);
