@@ -996,7 +996,8 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   ctx->st.pool_next = nullptr, ctx->st.pool_total = 0;
   // pixel pool: only where there are more tiles than resident workgroups, and once the tile costs of a plain launch
   // order the queue (the first batch / the probe launch runs plain and records them)
-  const bool pool_ok = ctx->pixel_pool && only_pix < 0 && !count && ctx->st.nblocks > ctx->pool_blocks &&
+  // (bounces <= 0: k_trace finishes such a batch in its prologue, tile by tile, without ever reaching the queue)
+  const bool pool_ok = ctx->pixel_pool && only_pix < 0 && !count && ctx->st.nblocks > ctx->pool_blocks && params->bounces > 0 &&
                        (ctx->have_tile_costs || !ctx->d_tile_cost || ctx->pixel_pool >= 2);
   bool pool = false;
   int  timed = -1;  // 0: this launch is the timed plain batch, 1: the timed pool batch
