@@ -739,7 +739,10 @@ int for_each_parallel(size_t count, int threads, Fn&& fn, std::string& error) { 
   n     = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n, 1), count));
   std::atomic<size_t> next{0};
   std::atomic<int>    failed{0};
-  std::vector<std::string> errors((size_t)n);
+  // Items are claimed in order and a claimed item always runs, so every item before a failing one has run too: the
+  // failure with the smallest index is the first one in file order whatever the threads did — the message does not
+  // depend on timing (the reference's parallel loader reports whichever failing file a thread reached first).
+  std::vector<std::pair<size_t, std::string>> errors((size_t)n, {count, std::string()});
   auto                worker = [&](int t) {
     while (!failed.load(std::memory_order_relaxed)) {
       size_t k = next.fetch_add(1);
@@ -752,7 +755,7 @@ int for_each_parallel(size_t count, int threads, Fn&& fn, std::string& error) { 
         why = std::string("out of resources (") + e.what() + ")";
       }
       if (!ok) {
-        errors[(size_t)t] = why;
+        errors[(size_t)t] = {k, why};
         failed.store(1);
         break;
       }
@@ -765,12 +768,12 @@ int for_each_parallel(size_t count, int threads, Fn&& fn, std::string& error) { 
     for (int t = 0; t < n; t++) pool.emplace_back(worker, t);
     for (auto& t : pool) t.join();
   }
-  if (failed.load())
+  if (failed.load()) {
+    size_t first = count;
     for (auto& e : errors)
-      if (!e.empty()) {
-        error = e;
-        return YTHIP_ERR_INVALID;
-      }
+      if (e.first < first) first = e.first, error = e.second;
+    return YTHIP_ERR_INVALID;
+  }
   return YTHIP_OK;
 }
 
