@@ -28,3 +28,23 @@ def test_fuzz_scenes_are_reproducible_and_always_lit():
             (a.shapes[i["shape"]]["num_triangles"] > 0 or a.shapes[i["shape"]]["num_quads"] > 0) for i in a.instances)
         assert lit, seed
     assert len(samplers) >= 6
+
+
+def test_kernel_resources_tool_parses_compiler_remarks(tmp_path):
+    """tools/kernel_resources.py on captured -Rpass-analysis=kernel-resource-usage remarks (no hipcc run)."""
+    import subprocess
+    import sys
+    tag = "[-Rpass-analysis=kernel-resource-usage]"
+    where = "yocto-gl_amd/csrc/yt_kernels.h:1049:1: remark:"
+    lines = [f"{where} Function Name: _ZN2yt7k_traceILi0ELi0ELb0ELb1ELi1EEEvNS_6DSceneENS_6DStateENS_7KParamsE {tag}",
+             " 1049 |     k_trace(DScene sc, DState st, KParams kp) {", "      | ^"]
+    for key, value in [("TotalSGPRs", 104), ("VGPRs", 128), ("AGPRs", 0), ("ScratchSize [bytes/lane]", 976), ("Dynamic Stack", "False"),
+                       ("Occupancy [waves/SIMD]", 4), ("SGPRs Spill", 157), ("VGPRs Spill", 2), ("LDS Size [bytes/block]", 10016)]:
+        lines.append(f"{where}     {key}: {value} {tag}")
+    remarks = tmp_path / "remarks.txt"
+    remarks.write_text("\n".join(lines) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), str(remarks)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    row = [l for l in r.stdout.splitlines() if l.startswith("yt::k_trace<0, 0, false, true, 1>")]
+    assert len(row) == 1 and row[0].split()[-7:] == ["128", "104", "2", "157", "976", "10016", "4"], r.stdout
