@@ -527,14 +527,14 @@ void ythip_ply_close(ythip_ply* ply);
 /* A scene FILE into the flat pools — the reference's load_scene for its builtin JSON format
  * (load_json_scene, libs/yocto/yocto_sceneio.cpp:3618-3857: scene.json, its PLY shapes, its HDR / PNG textures)
  * without scene_data's vector-of-vectors generation.  ythip_scene_open parses scene.json (versions 4.2 /
- * 5.0), maps every PLY and reads every texture header, and reports all the num_* of ythip_scene in
+ * 5.0, and 4.0 = files without asset.version, load_json_scene_version40 :3025-3373), maps every PLY and reads every texture header, and reports all the num_* of ythip_scene in
  * `counts`; ythip_scene_read fills caller pools of those sizes (every pointer of `pools`, writable — the
  * pools of ythip_scene_staging, or plain memory): records with the reference's defaults and fix-ups
  * (lookat, add_missing_camera :2119-2139, add_missing_radius :2142-2148, load_texture's `linear`),
  * shapes converted by ythip_ply_read, textures decoded to what stbi_loadf / stbi_load(…, 4) return,
  * shapes and textures on `threads` threads (<= 0: one per hardware thread).  The pools equal the
  * reference loader's scene_data flattened, byte for byte.  Not read here, refused by name: subdivs,
- * formats 4.0 / 4.1, non-PLY shapes, JPEG / EXR / TGA / BMP / .ypreset textures.
+ * format 4.1, PLY instance files, non-PLY shapes, JPEG / EXR / TGA / BMP / .ypreset textures.
  * ythip_load_scene = open + ythip_scene_staging + read + ythip_upload_scene_staged (`staged`, optional,
  * receives the pools: pass it to ythip_build_bvh / ythip_build_lights).  ythip_scene_find_camera mirrors
  * find_camera (yocto_scene.cpp:656-675); ythip_scene_name: `what` 0 camera, 1 instance, 2 environment,

@@ -94,17 +94,29 @@ def scene(tmp_path_factory):
            "instances": [{"name": f"i{k}", "shape": k, "material": 0} for k in range(4)],
            "environments": [{"name": "e", "emission": [1, 1, 1], "emission_tex": 6}]}
     json.dump(doc, open(d / "scene.json", "w"), indent=1)
-    return str(d)
+    # the same files as a format-4.0 scene (named elements, references by name) in a directory of its own
+    d40 = tmp_path_factory.mktemp("io_fuzz_scene40")
+    shutil.copytree(d / "shapes", d40 / "shapes"), shutil.copytree(d / "textures", d40 / "textures")
+    old = {"asset": {"copyright": "fuzz"},
+           "cameras": {"c": {"lookat": [0, 0, 3, 0, 0, 0, 0, 1, 0], "ortho": False}},
+           "environments": {"e": {"emission": [1, 1, 1], "emission_tex": "rle"}},
+           "materials": {"m": {"type": "metallic", "color_tex": "t0", "normal_tex": "t3", "emission_tex": "flat"}},
+           "instances": {f"i{k}": {"shape": n, "material": "m"} for k, n in enumerate(("tri", "hair", "dots", "ascii"))}}
+    json.dump(old, open(d40 / "scene.json", "w"), indent=1)
+    return str(d), str(d40)
 
 
-def test_the_fuzz_scene_loads_undamaged(scene):
+def test_the_fuzz_scenes_load_undamaged(scene):
     from parity import yt
-    flat, names, _ = yt.load_scene_file(os.path.join(scene, "scene.json"))
+    flat, names, _ = yt.load_scene_file(os.path.join(scene[0], "scene.json"))
     assert len(flat.shapes) == 4 and len(flat.textures) == 8 and flat.shapes["num_quads"][3] == 5
+    flat, names, _ = yt.load_scene_file(os.path.join(scene[1], "scene.json"))
+    assert names["shapes"] == ["tri", "hair", "dots", "ascii"] and names["textures"] == ["rle", "flat", "t0", "t3"]  # (order of first mention: emission_tex before color_tex)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_damaged_files_never_crash_the_readers(fuzzer, scene, seed):
+@pytest.mark.parametrize("seed,which", [(1, 0), (2, 0), (3, 1), (4, 1)])
+def test_damaged_files_never_crash_the_readers(fuzzer, scene, seed, which):
+    scene = scene[which]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=1", UBSAN_OPTIONS="print_stacktrace=1")
     env.pop("LD_PRELOAD", None)
     iters = os.environ.get("YT_FUZZ_ITERS", "1200")

@@ -13,8 +13,8 @@
 // The pools are, byte for byte, what the reference's loader + the flatten step produce
 // (tests/test_sceneio.py compares them with the live reference on its own test corpus).
 //
-// What is read: the builtin JSON format, versions 4.2 / 5.0 (what save_scene writes; the pre-4.2
-// readers are format archaeology and are refused by name), shapes in PLY, textures in Radiance HDR
+// What is read: the builtin JSON format, versions 4.2 / 5.0 (what save_scene writes) and 4.0 (files
+// without asset.version: named elements that refer to each other by name; 4.1 is refused by name), shapes in PLY, textures in Radiance HDR
 // (stbi_loadf's reader, stb_image.h:7080-7197 of the reference's vendored copy: RLE and flat
 // scanlines) and PNG (stbi_load's results: every colour type, bit depth, tRNS, Adam7; inflate
 // through zlib).  Anything else — subdivs, OBJ / glTF / PBRT scenes, JPEG / EXR / TGA / BMP
@@ -938,6 +938,180 @@ void parse_scene(const Json& json, ythip_scene_file& f, std::vector<std::string>
     }
 }
 
+
+// Format 4.0 (load_json_scene_version40, yocto_sceneio.cpp:3025-3373; files without asset.version): every group is an object of NAMED
+// elements; instances and materials refer to shapes, materials and textures by name; shapes and textures have no
+// entry of their own — they exist because something names them, in the order they are first named (environments,
+// then materials, then instances / objects), and their files are <dir>/shapes/<name>.ply, <dir>/textures/<name>.hdr |
+// .png (find_path, :3263-3270: the first extension that exists, else the first of the list).  Material types carry
+// their old labels ("metallic" = reflective, "volume" = volumetric); lookat frames of instances and environments are
+// NOT mirrored (inv_xz false, unlike 4.2).  "objects" with a PLY instance file and subdivs are refused by name.
+struct Refused {
+  std::string why;
+};
+void parse_scene40(const Json& json, ythip_scene_file& f, const std::string& dirname, std::vector<std::string>& shape_uris,
+    std::vector<std::string>& texture_uris) {
+  auto identity = [](ythip_frame& fr) {
+    fr = ythip_frame{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+  };
+  // `for (auto& [key, element] : json.at(name).items())`: members in file order (a repeated key keeps its first place and
+  // its last value), array items under their index; an element that is not an object fails at its first value()
+  std::vector<std::vector<std::pair<std::string, const Json*>>> groups;
+  auto group = [&](const char* name) -> const std::vector<std::pair<std::string, const Json*>>* {
+    auto g = json.find(name);
+    if (!g) return nullptr;
+    groups.emplace_back();
+    auto& out = groups.back();
+    if (g->kind == Json::Object) {
+      for (auto& m : g->members) {
+        bool seen = false;
+        for (auto& have : out)
+          if (have.first == m.first) have.second = &m.second, seen = true;
+        if (!seen) out.emplace_back(m.first, &m.second);
+      }
+    } else if (g->kind == Json::Array) {
+      for (size_t k = 0; k < g->items.size(); k++) out.emplace_back(std::to_string(k), &g->items[k]);
+    } else if (g->kind != Json::Null) {
+      throw BadValue{};  // (items() of a scalar yields the scalar, whose value() throws)
+    }
+    for (auto& e : out)
+      if (e.second->kind != Json::Object) throw BadValue{};
+    return &out;
+  };
+  auto name_of = [](const Json& e, const char* key) -> std::string {
+    std::string name;
+    get_opt(e, key, name);
+    return name;
+  };
+  auto find_path = [&](const std::string& name, const char* dir, std::initializer_list<const char*> extensions) {
+    for (auto ext : extensions) {
+      auto rel = (std::filesystem::u8path(dir) / std::filesystem::u8path(name + ext)).generic_u8string();
+      std::error_code ec;
+      if (std::filesystem::exists(std::filesystem::u8path(join(dirname, rel)), ec)) return rel;
+    }
+    return (std::filesystem::u8path(dir) / std::filesystem::u8path(name + *extensions.begin())).generic_u8string();
+  };
+  std::vector<std::string> texture_names, shape_names;  // in order of first mention
+  auto get_tex = [&](const Json& e, const char* key, int32_t& value) {
+    auto name = name_of(e, key);
+    if (name.empty()) return;
+    for (size_t k = 0; k < texture_names.size(); k++)
+      if (texture_names[k] == name) {
+        value = (int32_t)k;
+        return;
+      }
+    texture_names.push_back(name);
+    f.textures.push_back(ythip_texture{});
+    value = (int32_t)texture_names.size() - 1;
+  };
+  auto get_shp = [&](const Json& e, const char* key, int32_t& value) {
+    auto name = name_of(e, key);
+    if (name.empty()) return;
+    for (size_t k = 0; k < shape_names.size(); k++)
+      if (shape_names[k] == name) {
+        value = (int32_t)k;
+        return;
+      }
+    shape_names.push_back(name);
+    value = (int32_t)shape_names.size() - 1;
+  };
+  auto get_mat = [&](const Json& e, const char* key, int32_t& value) {
+    auto name = name_of(e, key);
+    if (name.empty()) return;
+    for (size_t k = 0; k < f.material_names.size(); k++)
+      if (f.material_names[k] == name) value = (int32_t)k;  // (a repeated name: the last one, as the map's assignment leaves it)
+    bool found = false;
+    for (auto& n : f.material_names) found = found || n == name;
+    if (!found) throw BadValue{};  // "missing key"
+  };
+  if (auto items = group("cameras"))
+    for (auto& [key, ep] : *items) {
+      const Json&  e = *ep;
+      ythip_camera c{};
+      identity(c.frame);
+      c.orthographic = 0, c.lens = 0.050f, c.film = 0.036f, c.aspect = 1.500f, c.focus = 10000, c.aperture = 0;
+      f.camera_names.push_back(key);
+      get_frame(e, "frame", c.frame);
+      get_flag(e, "orthographic", c.orthographic);
+      get_flag(e, "ortho", c.orthographic);
+      get_opt(e, "lens", c.lens);
+      get_opt(e, "aspect", c.aspect);
+      get_opt(e, "film", c.film);
+      get_opt(e, "focus", c.focus);
+      get_opt(e, "aperture", c.aperture);
+      if (get_lookat(e, c.frame)) {
+        c.focus = length(v3(c.frame.x) - v3(c.frame.y));
+        c.frame = lookat_frame(v3(c.frame.x), v3(c.frame.y), v3(c.frame.z), false);
+      }
+      f.cameras.push_back(c);
+    }
+  if (auto items = group("environments"))
+    for (auto& [key, ep] : *items) {
+      const Json&       e = *ep;
+      ythip_environment env{};
+      identity(env.frame);
+      env.emission_tex = YTHIP_INVALIDID;
+      f.environment_names.push_back(key);
+      get_frame(e, "frame", env.frame);
+      get_floats(e, "emission", env.emission);
+      get_tex(e, "emission_tex", env.emission_tex);
+      if (get_lookat(e, env.frame)) env.frame = lookat_frame(v3(env.frame.x), v3(env.frame.y), v3(env.frame.z), false);
+      f.environments.push_back(env);
+    }
+  static const char* const kTypes40[] = {"matte", "glossy", "metallic", "transparent", "refractive", "subsurface", "volume", "gltfpbr"};
+  if (auto items = group("materials"))
+    for (auto& [key, ep] : *items) {
+      const Json&    e = *ep;
+      ythip_material m{};
+      m.type = YTHIP_MATTE;
+      m.ior = 1.5f, m.trdepth = 0.01f, m.opacity = 1;
+      m.emission_tex = m.color_tex = m.roughness_tex = m.scattering_tex = m.normal_tex = YTHIP_INVALIDID;
+      f.material_names.push_back(key);
+      if (auto j = e.find("type")) {
+        m.type = YTHIP_MATTE;
+        if (j->kind == Json::String)
+          for (int k = 0; k < 8; k++)
+            if (j->s == kTypes40[k]) m.type = k;
+      }
+      get_floats(e, "emission", m.emission);
+      get_floats(e, "color", m.color);
+      get_opt(e, "metallic", m.metallic);
+      get_opt(e, "roughness", m.roughness);
+      get_opt(e, "ior", m.ior);
+      get_opt(e, "trdepth", m.trdepth);
+      get_floats(e, "scattering", m.scattering);
+      get_opt(e, "scanisotropy", m.scanisotropy);
+      get_opt(e, "opacity", m.opacity);
+      get_tex(e, "emission_tex", m.emission_tex);
+      get_tex(e, "color_tex", m.color_tex);
+      get_tex(e, "roughness_tex", m.roughness_tex);
+      get_tex(e, "scattering_tex", m.scattering_tex);
+      get_tex(e, "normal_tex", m.normal_tex);
+      f.materials.push_back(m);
+    }
+  for (const char* which : {"instances", "objects"})
+    if (auto items = group(which))
+      for (auto& [key, ep] : *items) {
+        const Json&    e = *ep;
+        ythip_instance i{};
+        identity(i.frame);
+        i.shape = i.material = YTHIP_INVALIDID;
+        f.instance_names.push_back(key);
+        get_frame(e, "frame", i.frame);
+        get_shp(e, "shape", i.shape);
+        get_mat(e, "material", i.material);
+        if (get_lookat(e, i.frame)) i.frame = lookat_frame(v3(i.frame.x), v3(i.frame.y), v3(i.frame.z), false);
+        if (which[0] == 'o' && e.find("instance") && !name_of(e, "instance").empty())
+          throw Refused{"object \"" + key + "\" is instanced from a PLY file of frames (not read here)"};
+        f.instances.push_back(i);
+      }
+  if (auto items = group("subdivs"))
+    if (!items->empty()) throw Refused{"the scene has subdivs (tesselation is not on this path)"};
+  f.texture_names = texture_names, f.shape_names = shape_names;
+  for (auto& n : shape_names) shape_uris.push_back(find_path(n, "shapes", {".ply", ".obj"}));
+  for (auto& n : texture_names) texture_uris.push_back(find_path(n, "textures", {".hdr", ".exr", ".png", ".jpg"}));
+}
+
 }  // namespace
 
 extern "C" {
@@ -957,27 +1131,31 @@ static int scene_open_impl(const char* path, ythip_scene_file** out, ythip_scene
   Json       json;
   JsonParser parser{(const char*)text.data.data(), (const char*)text.data.data() + text.data.size()};
   if (!parser.document(json)) return fail(YTHIP_ERR_INVALID, "cannot parse " + filename);
-  // version gate (yocto_sceneio.cpp:3625-3654)
+  // version gate (yocto_sceneio.cpp:3625-3654): no asset.version = format 4.0 (read below); "4.1", a third layout that
+  // no file of the reference's corpus uses, is refused by name
   auto        asset   = json.find("asset");
   const Json* version = asset ? asset->find("version") : nullptr;
-  if (!version) return fail(YTHIP_ERR_INVALID, "cannot load " + filename + ": a scene without asset.version is format 4.0, not read here");
-  if (version->kind != Json::String || (version->s != "4.2" && version->s != "5.0")) {
-    if (version->kind == Json::String && version->s == "4.1")
-      return fail(YTHIP_ERR_INVALID, "cannot load " + filename + ": format 4.1 is not read here");
+  const bool  old     = !version;
+  if (version && version->kind == Json::String && version->s == "4.1")
+    return fail(YTHIP_ERR_INVALID, "cannot load " + filename + ": format 4.1 is not read here");
+  if (!old && (version->kind != Json::String || (version->s != "4.2" && version->s != "5.0")))
     return fail(YTHIP_ERR_INVALID, "cannot parse " + filename);
-  }
-  if (auto s = json.find("subdivs"); s && s->kind == Json::Array && !s->items.empty())
-    return fail(YTHIP_ERR_INVALID, "cannot load " + filename + ": the scene has subdivs (tesselation is not on this path)");
+  if (!old)
+    if (auto s = json.find("subdivs"); s && (s->kind == Json::Array ? !s->items.empty() : s->kind == Json::Object && !s->members.empty()))
+      return fail(YTHIP_ERR_INVALID, "cannot load " + filename + ": the scene has subdivs (tesselation is not on this path)");
   auto f  = std::make_unique<ythip_scene_file>();
   f->path = filename;
+  auto dirname = std::filesystem::u8path(filename).parent_path().generic_u8string();
   std::vector<std::string> shape_uris, texture_uris;
   try {
-    get_opt(*asset, "copyright", f->copyright);
-    parse_scene(json, *f, shape_uris, texture_uris);
+    if (asset) get_opt(*asset, "copyright", f->copyright);
+    if (old) parse_scene40(json, *f, dirname, shape_uris, texture_uris);
+    else parse_scene(json, *f, shape_uris, texture_uris);
   } catch (const BadValue&) {
     return fail(YTHIP_ERR_INVALID, "cannot parse " + filename);
+  } catch (const Refused& r) {
+    return fail(YTHIP_ERR_INVALID, "cannot load " + filename + ": " + r.why);
   }
-  auto dirname = std::filesystem::u8path(filename).parent_path().generic_u8string();
   auto dependent = [&](const std::string& why) { return fail(YTHIP_ERR_INVALID, "cannot load " + filename + " since " + why); };
 
   // shapes: map and measure (load_shape's format switch, yocto_sceneio.cpp:1008-1016: PLY only here)
