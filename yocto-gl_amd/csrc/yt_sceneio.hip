@@ -14,12 +14,13 @@
 // (tests/test_sceneio.py compares them with the live reference on its own test corpus).
 //
 // What is read: the builtin JSON format, versions 4.2 / 5.0 (what save_scene writes) and 4.0 (files
-// without asset.version: named elements that refer to each other by name; 4.1 is refused by name), shapes in PLY, textures in Radiance HDR
-// (stbi_loadf's reader, stb_image.h:7080-7197 of the reference's vendored copy: RLE and flat
-// scanlines) and PNG (stbi_load's results: every colour type, bit depth, tRNS, Adam7; inflate
-// through zlib).  Anything else — subdivs, OBJ / glTF / PBRT scenes, JPEG / EXR / TGA / BMP
-// textures, .ypreset — fails loudly by name: those stay with the reference's loader, whose
-// scene_data goes through ythip_upload_scene as before.
+// without asset.version: named elements that refer to each other by name), shapes in PLY, textures
+// in Radiance HDR (stbi_loadf's reader, stb_image.h:7080-7197 of the reference's vendored copy: RLE
+// and flat scanlines) and PNG (stbi_load's results: every colour type, bit depth, tRNS, Adam7;
+// inflate through zlib).  Anything else — subdivs (tesselate_subdivs is scene processing, re-used
+// from the reference: SURVEY.md §2), format 4.1, PLY instance files, OBJ / glTF / PBRT scenes,
+// JPEG / EXR / TGA / BMP textures, .ypreset — fails loudly by name: those stay with the
+// reference's loader, whose scene_data goes through ythip_upload_scene as before.
 //
 // No device code here; the file is a .hip unit only so that the one build rule covers it.
 #include <zlib.h>
