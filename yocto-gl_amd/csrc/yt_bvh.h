@@ -952,3 +952,16 @@ YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, b
 }
 
 }  // namespace yt
+
+#ifdef YT_COOP_LEAF  // experiment (yt_coop.h): line leaves tested by the whole wavefront
+#include "yt_coop.h"
+namespace yt {
+// the scene walk of k_trace's extend stage for ALL lanes of the wavefront (`active`: this lane has a ray)
+template <bool TRI>
+YT_FN Hit traverse_coop_any(const DScene& sc, const ray3f& wray, bool active, Stack& st, Counters& cnt) {
+  Hit h = traverse_coop<TRI>(sc, wray, active, st, cnt);
+  if (active && h.instance == HIT_ABORT) h = traverse<false, false, TRI>(sc, wray, -1, false, st, cnt);
+  return h;
+}
+}  // namespace yt
+#endif

@@ -1165,6 +1165,19 @@ __global__ void __launch_bounds__(YT_BLOCK,
     const long long tm0 = __builtin_readcyclecounter();
     long long       tm1 = tm0, tm2 = tm0, tmS = tm0, tmG = 0;
 #endif
+#ifdef YT_COOP_LEAF  // experiment (yt_coop.h): the extend stage with every lane of the wavefront inside the walk
+    constexpr bool COOP = WIDE && !COUNT && !MATTE && !PHASED_SCENE;
+    Hit            coop_isec = {-1, -1, 0, 0, 0, false};
+    if constexpr (COOP) {
+      const int    l  = (run ? slot : (int)threadIdx.x) & (YT_BLOCK - 1);
+      const float4 ra = W.ray_a[l], rb = W.ray_b[l];
+      const bool   walk = run && !(MIS && (__float_as_int(rb.w) & PF_SKIPEXTEND));
+      ray3f          ray = make_ray({ra.x, ra.y, ra.z}, {ra.w, rb.x, rb.y});
+      const unsigned s0  = cnt.steps;
+      coop_isec          = traverse_coop_any<MATTE>(sc, ray, walk, stack, cnt);
+      if (walk) work = cnt.steps - s0 + 1;
+    }
+#endif
     if (run) {
       Path   P;
       float4 ra = W.ray_a[slot & (YT_BLOCK - 1)], rb = W.ray_b[slot & (YT_BLOCK - 1)];
@@ -1177,10 +1190,17 @@ __global__ void __launch_bounds__(YT_BLOCK,
         int    inst = __float_as_int(ha.w);
         P.isec      = {inst, st.nhit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
       } else {
-        ray3f          ray = make_ray(P.o, P.d);
-        const unsigned s0  = cnt.steps;
-        P.isec             = traverse_any<COUNT, WIDE, MATTE, PHASED_SCENE>(sc, ray, -1, false, stack, cnt);
-        work               = cnt.steps - s0 + 1;
+#ifdef YT_COOP_LEAF
+        if constexpr (COOP) {
+          P.isec = coop_isec;
+        } else
+#endif
+        {
+          ray3f          ray = make_ray(P.o, P.d);
+          const unsigned s0  = cnt.steps;
+          P.isec             = traverse_any<COUNT, WIDE, MATTE, PHASED_SCENE>(sc, ray, -1, false, stack, cnt);
+          work               = cnt.steps - s0 + 1;
+        }
       }
 #ifdef YT_TIMING
       tm1 = __builtin_readcyclecounter();
