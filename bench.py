@@ -75,9 +75,18 @@ def _workloads():
                       make=lambda: ysc.cornell_1m_scene(ysc.load_scene(CORNELL)), resolution=1024, spp=64),
         "configs3": dict(label="BASELINE configs[3]: 10,000 instances x 1,024-triangle sphere + constant env",
                          make=ysc.instanced_scene, resolution=1920, spp=256),
-        "configs4": dict(label="BASELINE configs[4]: 100,000 hair strands (800,000 line segments) + subsurface "
-                               "material on a sphere + constant env",
-                         make=ysc.hair_scene_synthetic, resolution=1280, spp=64),
+        "configs4": dict(label="BASELINE configs[4]: make_hair(make_sphere(32, 1), {8, 100000}, {0.2, 0.2}, {0.002, 0.001}) "
+                               "— 800,000 line segments, the reference's own strand roots (tests/golden/hair_roots.npz) — "
+                               "subsurface material on the sphere + constant env",
+                         make=ysc.hair_scene, resolution=1280, spp=64),
+        # the GENERAL kernel class (k_trace<..., 0>: every lobe, textures, normal maps, all primitive kinds): two scenes of the
+        # reference's own test corpus, from the committed fixtures (parity: tests/test_reference_scenes.py)
+        "materials1": dict(label="reference corpus tests/_version43/materials1 (13 materials: glossy / reflective / transparent / "
+                                 "refractive / subsurface ..., textured floor, environment map): the general kernel class",
+                           make=lambda: ysc.load_corpus_scene("materials1"), resolution=1280, spp=64),
+        "features1": dict(label="reference corpus tests/_version43/features1 (textures, normal map, area light, environment "
+                                "map): the general kernel class",
+                          make=lambda: ysc.load_corpus_scene("features1"), resolution=1280, spp=64),
         "cornell9m": dict(label="cache-exceeding scene: Cornell box with 8,987,066 triangles "
                                 "(1.3 GB of baked BVH + leaf data, > the 256 MB Infinity Cache)",
                           make=lambda: ysc.cornell_1m_scene(ysc.load_scene(CORNELL), n=948), resolution=1024,
@@ -100,9 +109,10 @@ def progress(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def run_workload(name, device, steps, warmup, count=True):
+def run_workload(name, device, steps, warmup, count=True, fastmath=0):
     """One workload through the C ABI: optional counting launch, warm-up, `steps` timed
-    launches (hipEvents on the launch stream).  Returns a dict."""
+    launches (hipEvents on the launch stream).  Returns a dict.  fastmath: ythip_params::fastmath (the
+    tolerance mode: same integrators / rng streams / traversal, fast shading arithmetic — DESIGN.md §4b)."""
     import ythip as yt
     w = _workloads()[name]
     progress(f"workload {name}: scene")
@@ -111,7 +121,7 @@ def run_workload(name, device, steps, warmup, count=True):
     ctx = open_context(device, flat)
     progress(f"workload {name}: launches")
     p = yt.trace_params(sampler="path", resolution=w["resolution"], bounces=8, clamp=10.0,
-                        samples=1 << 30, batch=w["spp"])
+                        samples=1 << 30, batch=w["spp"], fastmath=int(fastmath))
     width, height = ctx.make_trace_state(flat, p)
     cnt = None
     if count:
@@ -130,9 +140,10 @@ def run_workload(name, device, steps, warmup, count=True):
     ctx.set_profiling(0)
     sizes = ctx.bvh_baked_sizes()
     pool = ctx.pixel_pool_info()
+    ran_fast = ctx.last_launch_fastmath()
     ctx.close()
     ms = st["trace_ms"] / max(st["trace_launches"], 1)
-    out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"],
+    out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"], "fastmath": bool(ran_fast),
            "ms_per_launch": ms, "launches": st["trace_launches"], "samples_per_launch": width * height * w["spp"]}
     if cnt is not None:
         nsamp = max(cnt["samples"], 1)
@@ -168,12 +179,12 @@ def rocprof_path():
     return None
 
 
-def collect_counters(name, device, timeout=240):
-    progress(f"counters {name}: rocprofv3 --pmc passes of a worker process")
-    return _collect_counters(name, device, timeout)
+def collect_counters(name, device, timeout=240, fastmath=0):
+    progress(f"counters {name}{' (tolerance mode)' if fastmath else ''}: rocprofv3 --pmc passes of a worker process")
+    return _collect_counters(name, device, timeout, fastmath)
 
 
-def _collect_counters(name, device, timeout=240):
+def _collect_counters(name, device, timeout=240, fastmath=0):
     """Per-launch counter means of the workload's k_trace launches, from separate
     rocprofv3 --pmc passes of `bench.py --worker name` (counters only: never combined with
     tracing).  Returns (dict counter -> per-launch mean, kernel name) or (None, reason)."""
@@ -185,7 +196,7 @@ def _collect_counters(name, device, timeout=240):
         out = tempfile.mkdtemp(prefix="ythip_pmc_", dir="/tmp")
         cmd = [prof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--",
                                             sys.executable, os.path.abspath(__file__), "--worker", name,
-                                            "--worker-device", str(device)]
+                                            "--worker-device", str(device)] + (["--worker-fastmath"] if fastmath else [])
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
@@ -198,7 +209,7 @@ def _collect_counters(name, device, timeout=240):
         for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                if not k.startswith("yt::k_trace"):
+                if not (k.startswith("yt::k_trace") or k.startswith("yt_fast::k_trace")):  # (yt_fast: the tolerance-mode unit)
                     continue
                 kernel = k
                 d = per.setdefault(row["Counter_Name"], {})
@@ -308,11 +319,18 @@ def other_workloads(device, args, calib):
     tests/test_gpu_baseline_configs.py): 1 counting launch + 1 warm-up + 2 timed launches
     each, then the live counter passes -> fractions of the roofs that can bind."""
     res, deferred = [], []
-    for name in ["cfg2b", "configs3", "configs4", "cornell9m"]:
+    # every workload bit-exact (the reference's bytes), then the BASELINE workloads once more in the tolerance mode
+    # (ythip_params::fastmath: statistically equal images, tests/test_gpu_fastmath.py) — what bit-exactness costs
+    todo = [(n, 0) for n in ["cfg2b", "configs3", "configs4", "cornell9m", "materials1", "features1"]] + \
+           [(n, 1) for n in ["configs1", "cfg2b", "configs3", "configs4", "cornell9m", "materials1"]]
+    for name, fast in todo:
         try:
-            run = run_workload_isolated(name, device)
+            run = run_workload_isolated(name, device, fastmath=fast)
             e = {"workload": f"{run['label']}, {run['width']}x{run['height']}x{run['spp']}spp, "
                              f"sampler=path bounces=8 clamp=10",
+                 "name": name,
+                 "mode": "tolerance (ythip_params::fastmath = 1): statistically equal image, exact hit records" if run.get("fastmath")
+                         else "bit-exact (the reference's trace_state, byte for byte)",
                  "value": round(run["samples_per_launch"] / run["ms_per_launch"] / 1e3, 3), "unit": "Msamples/s",
                  "ms_per_step": round(run["ms_per_launch"], 3), "steps": run["launches"],
                  "bytes_per_sample": round(run["bytes_per_sample"], 1), "per_sample": run["per_sample"],
@@ -323,7 +341,12 @@ def other_workloads(device, args, calib):
             res.append(e)
             deferred.append((name, run, e))
         except Exception as ex:  # reported, never required
-            res.append({"workload": name, "error": str(ex)[:300]})
+            res.append({"workload": name, "name": name, "fastmath": bool(fast), "error": str(ex)[:300]})
+    # what the tolerance mode buys, per workload
+    exact = {e["name"]: e["value"] for e in res if "value" in e and e["mode"].startswith("bit-exact")}
+    for e in res:
+        if "value" in e and e["mode"].startswith("tolerance") and e["name"] in exact:
+            e["speedup_over_bit_exact"] = round(e["value"] / exact[e["name"]], 3)
     return res, deferred
 
 
@@ -333,7 +356,7 @@ def fill_counters(deferred, device, calib):
     nothing it does (or suffers) can touch the timed numbers already taken."""
     for name, run, entry in deferred:
         try:
-            counters, kernel = collect_counters(name, device)
+            counters, kernel = collect_counters(name, device, fastmath=1 if run.get("fastmath") else 0)
             roof = roofline_of(run, counters, kernel if counters else entry["roofline"].get("kernel"), calib)
             if counters is None:
                 roof["note"] = kernel
@@ -362,20 +385,21 @@ def worker_main(args):
     """`--worker NAME`: one warm-up + WORKER_STEPS launches of the workload, nothing printed; run under
     rocprofv3 --pmc by collect_counters()."""
     if args.worker_json:  # the timed run of one of the other workloads, in a process of its own
-        run = run_workload(args.worker, args.worker_device, steps=2, warmup=OTHER_WARMUP)
+        run = run_workload(args.worker, args.worker_device, steps=2, warmup=OTHER_WARMUP, fastmath=args.worker_fastmath)
         print("YTHIP_RUN " + json.dumps(run), flush=True)
         return
-    run_workload(args.worker, args.worker_device, steps=WORKER_STEPS, warmup=OTHER_WARMUP, count=False)
+    run_workload(args.worker, args.worker_device, steps=WORKER_STEPS, warmup=OTHER_WARMUP, count=False, fastmath=args.worker_fastmath)
 
 
-def run_workload_isolated(name, device, timeout=420):
+def run_workload_isolated(name, device, timeout=420, fastmath=0):
     """run_workload(name) in a worker process: a failure there (a device fault kills the process
     it happens in) costs that entry, not the line."""
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", name, "--worker-device", str(device),
-                        "--worker-json"], capture_output=True, text=True, timeout=timeout, env=env)
+                        "--worker-json"] + (["--worker-fastmath"] if fastmath else []), capture_output=True, text=True,
+                       timeout=timeout, env=env)
     for line in r.stdout.splitlines():
         if line.startswith("YTHIP_RUN "):
             return json.loads(line[len("YTHIP_RUN "):])
@@ -413,6 +437,7 @@ def main():
     ap.add_argument("--worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--worker-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--worker-json", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--worker-fastmath", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.worker:
         return worker_main(args)

@@ -184,13 +184,22 @@ enum {
   YTHIP_FC_MATERIAL, YTHIP_FC_ELEMENT, YTHIP_FC_HIGHLIGHT
 };
 
-/* trace_params — libs/yocto/yocto_trace.h:95-113 (same fields, bools as int32) */
+/* trace_params — libs/yocto/yocto_trace.h:95-113 (same fields, bools as int32) + one field of this library:
+ *   fastmath  0 (default): every float of trace_state is the reference's, bit for bit.
+ *             1: the TOLERANCE mode — the same integrators, rng streams and traversal (hit records stay
+ *             bit-exact for a given ray), but shading / sampling / camera arithmetic on the GPU's fast
+ *             forms (reciprocals for divisions, hardware sin / cos / exp / log / sqrt, fused multiply-adds).
+ *             The image agrees with the reference's statistically (mean within 0.5 %, 8x8-block error
+ *             below the reference's own seed-to-seed spread: tests/test_gpu_fastmath.py), not bit for bit.
+ *             Scenes the wide walk cannot serve (tiny or very deep trees) and the debug samplers
+ *             (diagram, falsecolor) render with the exact kernels either way. */
 typedef struct ythip_params {
   int32_t  camera, resolution, sampler, falsecolor, samples, bounces;
   float    clamp;
   int32_t  nocaustics, envhidden, tentfilter;
   uint64_t seed;
   int32_t  embreebvh, highqualitybvh, noparallel, pratio, denoise, batch;
+  int32_t  fastmath;
 } ythip_params;
 
 /* scene_intersection — libs/yocto/yocto_bvh.h:96-102 (24 B) */
@@ -561,6 +570,10 @@ typedef struct ythip_pool_info {
 } ythip_pool_info;
 int ythip_set_pixel_pool(ythip_ctx* ctx, int mode, int workgroups); /* workgroups <= 0: keep (default 16 per CU) */
 int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info);
+
+/* 1 when the last trace_samples / trace_sample launch of this context ran the tolerance-mode kernels
+ * (ythip_params::fastmath was set AND such a kernel exists for the sampler and the resident scene), else 0. */
+int ythip_last_launch_fastmath(ythip_ctx* ctx);
 
 /* Which BVH walk k_trace's extend stage and the test entries below use: 0 the
  * binary walk (one sibling pair per dependent fetch), 1 the wide walk (the four

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <stdexcept>
 #include <thread>
 
@@ -486,6 +487,87 @@ int main() {
     EXPECT(same_bytes(cpu.image, gpu.image), "render after invalidate() differs");
   }
 
+  // 5b. an in-place edit of ONE vertex of a large shape — outside the 256-element strided sample the shim used to
+  //     stamp large arrays with (such an edit rendered the old data, silently).  The reference reads
+  //     its arguments fresh on every call (yocto_trace.cpp:1595-1619): the edited vertex must be what both render.
+  {
+    auto sc  = scene;
+    auto grid = make_recty({40, 40}, {1, 1});  // the Cornell box's floor as 1,600 quads over 1,681 vertices
+    auto& floor = sc.shapes[0];
+    floor.positions = grid.positions, floor.quads = grid.quads, floor.triangles.clear();
+    floor.normals.clear(), floor.texcoords.clear();  // (geometric normals: a moved vertex shows in eyelight shading)
+    auto params       = trace_params{};
+    params.sampler    = trace_sampler_type::eyelight;
+    params.resolution = 96;
+    params.samples    = 6;
+    params.batch      = 2;
+    auto bvh    = make_trace_bvh(sc, params);
+    auto lights = make_trace_lights(sc, params);
+    auto cpu = make_trace_state(sc, params), gpu = make_trace_state(sc, params), control = make_trace_state(sc, params);
+    for (auto k = 0; k < 3; k++) trace_samples(control, sc, bvh, lights, params);  // the unedited scene, for comparison
+    trace_samples(cpu, sc, bvh, lights, params);
+    hip::trace_samples(gpu, sc, bvh, lights, params);
+    EXPECT(same_bytes(cpu.image, gpu.image), "grid-floor scene differs before the edit");
+    // a vertex no strided sample of 256 elements looks at, in the middle of the floor
+    const size_t n = floor.positions.size();
+    auto sampled   = [&](size_t v) {
+      for (size_t k = 0; k < 256; k++)
+        if ((size_t)((unsigned __int128)k * (n - 1) / 255) == v) return true;
+      return false;
+    };
+    size_t v = 20 * 41 + 17;
+    while (sampled(v)) v++;
+    floor.positions[v].y += 0.04f;  // a bump (stays inside its leaves' boxes? no matter: both back-ends keep the old boxes)
+    for (auto k = 0; k < 2; k++) {
+      trace_samples(cpu, sc, bvh, lights, params);
+      hip::trace_samples(gpu, sc, bvh, lights, params);
+    }
+    EXPECT(!same_bytes(cpu.image, control.image), "the edit is invisible: the test does not test anything");
+    EXPECT(same_bytes(cpu.image, gpu.image) && same_bytes(cpu.albedo, gpu.albedo) && same_bytes(cpu.normal, gpu.normal) &&
+               same_bytes(cpu.hits, gpu.hits) && same_bytes(cpu.rngs, gpu.rngs),
+        "in-place edit of one vertex (#%zu of %zu, not in the old 256-element sample) not seen", v, n);
+    // the opt-in sampled stamp: the same kind of edit needs invalidate(), as documented
+    hip::set_residency_check(hip::residency_sampled);
+    auto cpu2 = make_trace_state(sc, params), gpu2 = make_trace_state(sc, params);
+    trace_samples(cpu2, sc, bvh, lights, params);
+    hip::trace_samples(gpu2, sc, bvh, lights, params);
+    EXPECT(same_bytes(cpu2.image, gpu2.image), "sampled residency check: first batch differs");
+    floor.positions[v].y -= 0.08f;
+    hip::invalidate();
+    trace_samples(cpu2, sc, bvh, lights, params);
+    hip::trace_samples(gpu2, sc, bvh, lights, params);
+    EXPECT(same_bytes(cpu2.image, gpu2.image) && same_bytes(cpu2.rngs, gpu2.rngs), "sampled residency check + invalidate() differs");
+    hip::set_residency_check(hip::residency_full);
+    EXPECT(hip::get_residency_check() == hip::residency_full, "residency mode did not switch back");
+    // what the full hash costs per call (a 1M-triangle scene's arrays are ~100 MB)
+    {
+      auto big = scene_data{};
+      big.cameras = scene.cameras, big.materials = scene.materials;
+      auto sh = make_recty({1000, 500}, {10, 10});
+      sh.triangles = quads_to_triangles(sh.quads), sh.quads.clear();
+      big.shapes.push_back(sh);
+      big.instances.push_back({identity3x4f, 0, 0});
+      big.environments.push_back({identity3x4f, {1, 1, 1}, invalidid});
+      auto p2 = params;
+      p2.resolution = 64, p2.samples = 1 << 20, p2.batch = 1;
+      auto b2 = hip::make_trace_bvh(big, p2);
+      auto l2 = hip::make_trace_lights(big, p2);
+      auto s2 = hip::make_trace_state(big, p2);
+      hip::trace_samples_resident(s2, big, b2, l2, p2);
+      double ms[2] = {0, 0};
+      for (int mode = 0; mode < 2; mode++) {
+        hip::set_residency_check(mode ? hip::residency_sampled : hip::residency_full);
+        hip::trace_samples_resident(s2, big, b2, l2, p2);
+        auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 20; k++) hip::trace_samples_resident(s2, big, b2, l2, p2);
+        ms[mode] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 20;
+      }
+      hip::set_residency_check(hip::residency_full);
+      std::printf("1M-triangle scene, 64x36x1spp calls: %.3f ms per call with the full-content stamp, %.3f ms with the sampled one\n",
+          ms[0], ms[1]);
+    }
+  }
+
   // 6. two states interleaved with trace_samples_resident: the device copy of the first must
   //    survive the second taking the device (it is stashed, not lost)
   {
@@ -542,6 +624,17 @@ int main() {
     EXPECT(ms < bound, "trace_cancel took %.1f ms", ms);
     EXPECT(!context.done && state.samples == 0, "cancelled batch: done %d samples %d", (int)context.done.load(), state.samples);
     std::printf("trace_cancel of a 1280x1280x4096spp batch returned in %.1f ms\n", ms);
+    // a cancel of ANOTHER context leaves this one's batch alone (the relay word was global)
+    {
+      auto other = make_trace_context(params);
+      hip::trace_start(context, state, scene, bvh, lights, params);
+      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      hip::trace_cancel(other);  // never started: nothing to stop
+      EXPECT(context.worker.wait_for(std::chrono::milliseconds(100)) == std::future_status::timeout,
+          "cancelling an idle context ended another context's batch");
+      hip::trace_cancel(context);
+      EXPECT(!context.done && state.samples == 0, "second cancelled batch: done %d samples %d", (int)context.done.load(), state.samples);
+    }
     // the back-end keeps working after a cancel
     params.sampler = trace_sampler_type::eyelight, params.resolution = 64, params.samples = 2, params.batch = 2;
     auto cpu = make_trace_state(scene, params), gpu = make_trace_state(scene, params);

@@ -187,13 +187,7 @@ def ref_scene_names():
 def load_ref_scene(name):
     """A scene of the reference's test corpus as the reference's own loader read it
     (flat POD layout; arrays stored by content hash)."""
-    import json
-    with open(os.path.join(REF_SCENE_DIR, name + ".json")) as f:
-        manifest = json.load(f)
-    sc = yt.FlatScene()
-    for field, key in manifest.items():
-        setattr(sc, field, np.load(os.path.join(REF_SCENE_DIR, "blobs", key + ".npz"))["a"])
-    return sc
+    return ysc.load_corpus_scene(name, REF_SCENE_DIR)
 
 
 SCENES = {

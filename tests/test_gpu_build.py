@@ -283,13 +283,27 @@ def test_device_instance_tree_renders_refits_and_downloads():
     hctx.make_trace_bvh(flat)
     want = hctx.intersect_batch(rays)
     assert P.hits_equal(want, got)
-    # moving instances: update_scene_bvh brings the device-built instance tree home and refits it there
+    # moving instances: the device-built instance tree is refitted on the device (kind 0 of k_refit) and stays there;
+    # 3,658 frames travel as two compact arrays + one scatter kernel
     ids = np.arange(0, len(flat.instances), 7, dtype=np.int32)
     frames = flat.instances["frame"][ids].copy()
     frames[:, 10] += f32(0.05)
     for c in (ctx, hctx):
         c.update_instance_frames(ids, frames)
         c.update_bvh(updated_instances=ids)
+    assert ctx.bvh_build_info()["device_tlas"] == 1 and hctx.bvh_build_info()["device_tlas"] == 0
+    a, b = ctx.download_bvh(), hctx.download_bvh()
+    assert a.nodes.tobytes() == b.nodes.tobytes() and a.primitives.tobytes() == b.primitives.tobytes()
+    assert P.hits_equal(hctx.intersect_batch(rays), ctx.intersect_batch(rays))
+    # a second edit: the tree is still on the device, an instance named twice keeps its last frame (no scatter then)
+    ids2 = np.concatenate([ids[:100], ids[:3]]).astype(np.int32)
+    frames2 = flat.instances["frame"][ids2].copy()
+    frames2[:, 9] -= f32(0.02)
+    frames2[100:, 9] -= f32(0.03)
+    for c in (ctx, hctx):
+        c.update_instance_frames(ids2, frames2)
+        c.update_bvh(updated_instances=ids2)
+    assert ctx.bvh_build_info()["device_tlas"] == 1
     a, b = ctx.download_bvh(), hctx.download_bvh()
     assert a.nodes.tobytes() == b.nodes.tobytes() and a.primitives.tobytes() == b.primitives.tobytes()
     assert P.hits_equal(hctx.intersect_batch(rays), ctx.intersect_batch(rays))

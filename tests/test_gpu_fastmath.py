@@ -1,0 +1,126 @@
+"""The TOLERANCE mode (`-m gpu`): ythip_params::fastmath = 1 renders with the kernels of csrc/yt_fast.hip — the same
+integrators, rng streams and traversal, shading / sampling / camera arithmetic on the GPU's fast forms.
+
+north_star's bar for radiance is "within a stated float tolerance" (+ bit-exact hit indices); the stated tolerance is
+BASELINE.md §3.5's statistical gate, against the bit-exact render (= the reference's bytes, test_gpu_parity.py) at
+equal spp and equal seed:
+
+  * image mean (rgb) within 0.5 %;
+  * mean absolute error of the 8x8-block means <= the reference's own seed-to-seed spread (the same measure between
+    two bit-exact renders with different seeds) — in fact far below it, since both renders follow the same rng streams;
+  * hit records are not touched by the mode (ythip_intersect_batch always runs the bit-exact kernels; inside k_trace the
+    traversal arithmetic is the exact one — yt_bvh.h has no fast path), checked by the hit-index known answer after a
+    fast render and by `hits` (the per-pixel hit counters) agreeing in all but a handful of pixels.
+"""
+import numpy as np
+import pytest
+
+import parity as P
+from parity import yt, ysc
+
+pytestmark = pytest.mark.gpu
+
+
+def blocks(img, w, h):
+    a = np.asarray(img, np.float64).reshape(h, w, -1)[:h - h % 8, :w - w % 8, :3]
+    return a.reshape(a.shape[0] // 8, 8, a.shape[1] // 8, 8, 3).mean((1, 3))
+
+
+def gate(ctx, flat, what, resolution, spp, sampler="path", **kw):
+    """Renders exact (seed A), exact (seed B) and fast (seed A); asserts the two gates; returns the measures."""
+    pa = yt.trace_params(sampler=sampler, resolution=resolution, samples=spp, batch=spp, **kw)
+    pb = yt.trace_params(sampler=sampler, resolution=resolution, samples=spp, batch=spp, seed=20240917, **kw)
+    pf = yt.trace_params(sampler=sampler, resolution=resolution, samples=spp, batch=spp, fastmath=1, **kw)
+    exact = P.gpu_render(ctx, flat, pa)
+    assert not ctx.last_launch_fastmath()
+    w, h = ctx.width, ctx.height
+    other = P.gpu_render(ctx, flat, pb)
+    fast = P.gpu_render(ctx, flat, pf)
+    assert ctx.last_launch_fastmath(), f"{what}: the tolerance-mode kernels did not run"
+    assert np.isfinite(fast["image"]).all()
+    me, mf = exact["image"][:, :3].astype(np.float64).mean(), fast["image"][:, :3].astype(np.float64).mean()
+    rel_mean = abs(mf - me) / max(me, 1e-9)
+    be, bo, bf = blocks(exact["image"], w, h), blocks(other["image"], w, h), blocks(fast["image"], w, h)
+    spread = np.abs(bo - be).mean()
+    err = np.abs(bf - be).mean()
+    same_rng = float((fast["rngs"] == exact["rngs"]).all(axis=-1).mean()) if fast["rngs"].ndim > 1 else \
+        float((fast["rngs"] == exact["rngs"]).mean())
+    hits_differ = int((fast["hits"] != exact["hits"]).sum())
+    print(f"[fastmath] {what}: mean {mf:.6f} vs {me:.6f} (rel {rel_mean:.2e}); 8x8-block MAE {err:.3e} vs seed-to-seed spread "
+          f"{spread:.3e} (ratio {err / max(spread, 1e-30):.4f}); pixels with identical rng streams {same_rng:.4f}; "
+          f"hit counters differing in {hits_differ} of {len(exact['hits'])} pixels")
+    assert rel_mean <= 0.005, (what, rel_mean)
+    assert err <= spread, (what, err, spread)
+    assert hits_differ <= max(8, len(exact["hits"]) // 200), (what, hits_differ)
+    return dict(rel_mean=rel_mean, err=err, spread=spread, same_rng=same_rng)
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "materials", "lines_points", "instances", "plane"])
+def test_tolerance_mode_passes_the_statistical_gates_on_the_test_scenes(name):
+    flat = P.SCENES[name]()
+    ctx = P.gpu_context(flat)
+    gate(ctx, flat, name, 256, 64)
+    ctx.close()
+
+
+@pytest.mark.parametrize("sampler", ["pathdirect", "pathmis", "naive", "eyelight", "pathtest"])
+def test_tolerance_mode_of_the_other_samplers(sampler):
+    flat = P.SCENES["materials"]()
+    ctx = P.gpu_context(flat)
+    gate(ctx, flat, "materials " + sampler, 192, 32, sampler=sampler)
+    ctx.close()
+
+
+WORKLOADS = {  # bench.py's five workloads, at a size that renders in a second
+    "configs1": (ysc.plane_scene, 640, 32),
+    "cfg2b": (P.scene_cornell_1m, 512, 32),
+    "configs3": (ysc.instanced_scene, 640, 32),
+    "configs4": (ysc.hair_scene, 640, 32),
+    "cornell9m": (lambda: ysc.cornell_1m_scene(P.scene_cornellbox(), n=948), 384, 16),
+}
+
+
+@pytest.mark.parametrize("name", list(WORKLOADS))
+def test_tolerance_mode_on_the_bench_workloads(name):
+    make, res, spp = WORKLOADS[name]
+    flat = make()
+    ctx = P.gpu_context(flat)
+    gate(ctx, flat, name, res, spp)
+    ctx.close()
+
+
+def test_hit_records_are_untouched_and_debug_samplers_stay_exact():
+    flat = P.SCENES["cornellbox"]()
+    ctx = P.gpu_context(flat)
+    rays = P.random_rays(flat, 50000)
+    before = ctx.intersect_batch(rays)
+    p = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8, fastmath=1)
+    P.gpu_render(ctx, flat, p)
+    assert ctx.last_launch_fastmath()
+    assert ctx.intersect_batch(rays).tobytes() == before.tobytes()
+    if P.have_ref():
+        assert P.hits_equal(P.RefBundle(flat).intersect_batch(rays), before)
+    # falsecolor has no tolerance build: the flag is accepted and the exact kernel runs — the reference's bytes
+    pf = yt.trace_params(sampler="falsecolor", falsecolor="normal", resolution=96, samples=1, fastmath=1)
+    pe = yt.trace_params(sampler="falsecolor", falsecolor="normal", resolution=96, samples=1)
+    a = P.gpu_render(ctx, flat, pf)
+    assert not ctx.last_launch_fastmath()
+    b = P.gpu_render(ctx, flat, pe)
+    P.assert_identical(a, b, "falsecolor with the fastmath flag")
+    # and the exact mode after a fast batch is still the exact mode
+    pe2 = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8)
+    c = P.gpu_render(ctx, flat, pe2)
+    if P.have_ref():
+        P.assert_identical(c, P.RefBundle(flat).render(pe2), "exact render after a fast one")
+    ctx.close()
+
+
+def test_tolerance_mode_progressive_batches_and_slices_agree_with_one_batch():
+    """The mode changes arithmetic, not bookkeeping: 4 x 4 samples == 16 samples, bit for bit (same kernels, same
+    per-pixel sample order), and a column slice equals the full frame's pixels."""
+    flat = P.SCENES["materials"]()
+    ctx = P.gpu_context(flat)
+    one = P.gpu_render(ctx, flat, yt.trace_params(resolution=160, samples=16, batch=16, fastmath=1))
+    four = P.gpu_render(ctx, flat, yt.trace_params(resolution=160, samples=16, batch=4, fastmath=1))
+    P.assert_identical(one, four, "fastmath: 4 x 4 samples vs 16")
+    ctx.close()

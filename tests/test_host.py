@@ -78,7 +78,7 @@ def test_pod_struct_sizes_match_reference_layouts():
     assert yt.camera_dt.itemsize == 72 and yt.instance_dt.itemsize == 56
     assert yt.material_dt.itemsize == 84 and yt.environment_dt.itemsize == 64
     assert yt.node_dt.itemsize == 32 and yt.hit_dt.itemsize == 24 and yt.ray_dt.itemsize == 32
-    assert C.sizeof(yt.CParams) == 72
+    assert C.sizeof(yt.CParams) == 80  # trace_params (72 B) + this library's `fastmath` word, padded
 
 
 def test_pcg_seeding_known_answers():
@@ -181,6 +181,28 @@ def test_plane_generator_matches_reference_generators():
     assert mine.instances.tobytes() == ref.instances.tobytes()
     assert mine.materials.tobytes() == ref.materials.tobytes()
     assert mine.environments.tobytes() == ref.environments.tobytes()
+
+
+def test_hair_scene_is_configs4_as_specified():
+    """bench.py's configs[4] = scenes.hair_scene(): 100,000 strands x 8 segments with radii over make_sphere(32, 1)
+    (SURVEY.md §8d), from the committed strand roots (tests/golden/hair_roots.npz)."""
+    flat = P.ysc.hair_scene()
+    assert len(flat.shapes) == 2 and int(flat.shapes[1]["num_lines"]) == 800_000
+    assert int(flat.shapes[1]["num_positions"]) == 900_000 and int(flat.shapes[1]["num_radius"]) == 900_000
+    assert int(flat.shapes[0]["num_quads"]) == 6 * 32 * 32
+    r = flat.shape_arrays(1)["radius"].reshape(-1, 9)
+    assert (r[:, 0] == np.float32(0.002)).all() and (r[:, 8] == np.float32(0.001)).all()
+
+
+@needs_ref
+def test_hair_scene_equals_the_reference_make_hair_scene():
+    """... and it IS the scene the full-size parity test renders (tests/test_gpu_baseline_configs.py builds it through
+    the g++ reference's make_hair): every pool, byte for byte.  The numpy restatement of make_hair / make_lines / the
+    strand-length PCG stream (scenes.hair_scene) is therefore the reference's (yocto_shape.cpp:1264-1334, :962-990)."""
+    import test_gpu_baseline_configs as T
+    ref, mine = T.hair_scene(), P.ysc.hair_scene()
+    for k in ["cameras", "instances", "environments", "shapes", "materials"] + [p[0] for p in type(ref).POOLS]:
+        assert getattr(ref, k).tobytes() == getattr(mine, k).tobytes(), k
 
 
 def test_full_size_plane_bvh_shape():

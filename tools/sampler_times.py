@@ -14,10 +14,8 @@ if SCENE == "plane":
     flat = ysc.plane_scene()
 elif SCENE == "cfg4":  # BASELINE configs[3]: 10,000 instances of a 1,024-triangle sphere
     flat = ysc.instanced_scene()
-elif SCENE == "cfg5":  # BASELINE configs[4]: 800,000 hair segments (geometry from the compiled reference)
-    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import test_gpu_baseline_configs as T
-    flat = T.hair_scene()
+elif SCENE == "cfg5":  # BASELINE configs[4]: 800,000 hair segments (the reference's make_hair scene: scenes.hair_scene)
+    flat = ysc.hair_scene()
 elif SCENE == "cornell1m":  # cfg2b: the Cornell box with 1M-triangle walls
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import parity as P
@@ -34,8 +32,9 @@ if os.environ.get('TRAVERSAL'):
     ctx.set_traversal(os.environ['TRAVERSAL'])
 spp = int(os.environ.get('SPP', '64'))
 RES = int(os.environ.get('RES', '1280'))
+FAST = int(os.environ.get("FASTMATH", "0"))  # 1: the tolerance mode (params.fastmath)
 for sampler in (os.environ.get("SAMPLERS") or "falsecolor,eyelight,naive,pathtest,path").split(","):
-    p = yt.trace_params(sampler=sampler, resolution=RES, samples=1 << 30, batch=spp)
+    p = yt.trace_params(sampler=sampler, resolution=RES, samples=1 << 30, batch=spp, fastmath=FAST)
     ctx.make_trace_state(flat, p)
     ctx.trace_samples(p)
     ctx.set_profiling(1); ctx.reset_stats()

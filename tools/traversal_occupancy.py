@@ -15,8 +15,7 @@ if SCENE == "cornell1m":
 elif SCENE == "cfg4":
     flat = ysc.instanced_scene()
 elif SCENE == "cfg5":
-    import test_gpu_baseline_configs as T
-    flat = T.hair_scene()
+    flat = ysc.hair_scene()
 else:
     flat = ysc.plane_scene()
 n = int(os.environ.get("N", "4000000"))

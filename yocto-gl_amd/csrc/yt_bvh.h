@@ -224,7 +224,7 @@ YT_FN PrimHit intersect_line(vec3f o, vec3f dd, float tmin, float tmax, vec3f p0
   auto d2  = dot(prl, prl);
   auto r   = r0 * (1 - s) + r1 * s;
   if (d2 > r * r) return {0, 0, flt_max, false};
-  return {s, sqrt_(d2) / r, t, true};
+  return {s, sqrt_ieee_(d2) / r, t, true};
 }
 // intersect_point — yocto_geometry.h:697-713
 YT_FN PrimHit intersect_point(vec3f o, vec3f d, float tmin, float tmax, vec3f p, float r) {
@@ -416,11 +416,15 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   // root, whose bbox travels in the instance record.  Returns the root's ref
   // when the walk goes on, REF_NONE (level state untouched) when the shape BVH
   // is empty (yocto_bvh.cpp:466) or the root is culled.
-  auto enter = [&](int inst) -> int {
-    const float4* ti = reinterpret_cast<const float4*>(sc.tinst + inst);
+  // `rec`: the instance's traversal record — sc.tinst + inst, or the copy of it in TLAS-leaf order (sc.tinst_leaf + k,
+  // whose pad word carries the instance id: one dependent fetch less per TLAS-leaf entry than tlas_prims -> tinst).
+  // `tested`: the root-box test has been made when the TLAS leaf was expanded (pretest below).
+  auto enter = [&](const DInstanceT* rec, int inst, bool tested = false) -> int {
+    const float4* ti = reinterpret_cast<const float4*>(rec);
     float4        m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
     int4          m5 = reinterpret_cast<const int4*>(ti)[5];
     int           root = __float_as_int(m4.z);
+    if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
     vec3f   io   = transform_point(inv, wo);
@@ -433,9 +437,11 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       }
     }
     if (COUNT) cnt.nodes++;
-    float t0;
-    bool  ok = slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
-    if (!ok) return REF_NONE;
+    if (!tested) {
+      float t0;
+      bool  ok = slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
+      if (!ok) return REF_NONE;
+    }
     o = io, d = id, dinv = idin;
     tame = ray_is_tame(o, dinv, tmin);
     sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
@@ -446,6 +452,43 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     push(REF_EXIT, 0);
     return root;
   };
+  // entry `k` of the TLAS-leaf order (a continuation entry's code >> 1)
+  auto enter_leaf_entry = [&](int k, bool tested) -> int {
+#ifdef YT_TINST_LEAF
+    return enter(sc.tinst_leaf + k, -1, tested);
+#else
+    const int inst = sc.tlas_prims[k];
+    return enter(sc.tinst + inst, inst, tested);
+#endif
+  };
+  // YT_PRETEST (wide walk): the tmax-INDEPENDENT half of an instance's root-box test — transform_ray + intersect_bbox's
+  // interval (yocto_bvh.cpp:619-628 with :470-477) — made for all (up to 4) instances of a TLAS leaf when the leaf is
+  // expanded: their records are independent fetches (one round trip instead of one per instance), and an instance whose
+  // root box the ray misses whatever tmax is never becomes an entry at all.  What passes is pushed with its t0 and gets the
+  // tmax-dependent half, t0 <= tmax * k, when it is popped — in the reference's order, after the earlier instances of the
+  // leaf have shrunk tmax: the same decision on the same floats as testing at entry time (header, and slab()).
+  // Returns false for "cannot enter whatever tmax is"; an irregular instance-level ray passes (enter() then aborts).
+  auto pretest = [&](int k, float& t0) -> bool {
+#ifdef YT_TINST_LEAF
+    const float4* ti = reinterpret_cast<const float4*>(sc.tinst_leaf + k);
+#else
+    const float4* ti = reinterpret_cast<const float4*>(sc.tinst + sc.tlas_prims[k]);
+#endif
+    float4 m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
+    t0 = 0;
+    if (__float_as_int(m4.z) == REF_NONE) return false;
+    frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
+    vec3f   io   = transform_point(inv, wo);
+    vec3f   id   = transform_vector(inv, wd);
+    vec3f   idin = {1 / id.x, 1 / id.y, 1 / id.z};
+    if (!ray_is_tame(io, idin, tmin)) return true;
+    return slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0);
+  };
+#if defined(YT_PRETEST)
+  constexpr bool PRETEST = WIDE;
+#else
+  constexpr bool PRETEST = false;
+#endif
 
   // back to the TLAS level: restore the world ray.  Returns true when the
   // find_any early-out of intersect_scene_bvh fires (yocto_bvh.cpp:613: checked
@@ -459,7 +502,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   int cur = REF_NONE;  // node to process next, REF_NONE = pop one
   if (only_instance >= 0) {
     cur_last = true;
-    cur      = enter(only_instance);
+    cur      = enter(sc.tinst + only_instance, only_instance);
     if (WIDE && abort) return Hit{HIT_ABORT, -1, 0, 0, 0, false};
     if (cur_inst < 0) return best;
   } else {
@@ -500,7 +543,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         }
         StackEntry e = pop();
         cur          = e.ref;
-        if (e.ref < REF_INST && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;  // culled at pop time
+        // culled at pop time (with PRETEST the instance entries carry their root box's t0 too)
+        if ((PRETEST ? e.ref != REF_EXIT : e.ref < REF_INST) && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;
 #ifdef YT_TIGHT_POP
         // a culled entry costs this lane a pop, not a whole lock-step iteration of the loop
         while (cur == REF_NONE && sp > 0) {
@@ -633,7 +677,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       int code = cur - REF_INST;
       cur_last = (code & 1) != 0;
       if (COUNT) cnt.instances++;  // TLAS leaf entry (yocto_bvh.cpp:600-604)
-      cur = enter(sc.tlas_prims[code >> 1]);
+      cur = enter_leaf_entry(code >> 1, PRETEST);
       if (WIDE && abort) {
         best = Hit{HIT_ABORT, -1, 0, 0, 0, false};
         done = true;
@@ -645,6 +689,20 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     if (cur_inst < 0) {
       // TLAS leaf: instances are walked in order, each to completion
       // (yocto_bvh.cpp:600-609) → continuation entries in reverse, first one now.
+      if constexpr (PRETEST) {
+        // ... after the tmax-independent half of each instance's root-box test (pretest above): the survivors in
+        // reverse, each with its t0; the next pop applies the tmax-dependent half to the first of them
+        float tk[4];
+        bool  pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) pk[k] = k < num && pretest(first + k, tk[k]);
+        for (int k = num - 1; k >= 4; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);  // (never: leaves hold <= 4)
+#pragma unroll
+        for (int k = 3; k >= 0; k--)
+          if (pk[k]) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), tk[k]);
+        cur = REF_NONE;
+        continue;
+      }
       for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
       cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
       continue;
@@ -755,11 +813,12 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
   int             sp  = 0;
   StackEntry      spill[YT_SPILL];
   YT_STACK_OPS(YT_LDS_DEPTH, YT_SPILL)
-  auto enter = [&](int inst) -> int {
-    const float4* ti = reinterpret_cast<const float4*>(sc.tinst + inst);
+  auto enter = [&](const DInstanceT* rec, int inst) -> int {  // (rec / inst as in traverse())
+    const float4* ti = reinterpret_cast<const float4*>(rec);
     float4        m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
     int4          m5 = reinterpret_cast<const int4*>(ti)[5];
     int           root = __float_as_int(m4.z);
+    if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
     vec3f   io   = transform_point(inv, wo);
@@ -788,7 +847,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
   };
   int cur = REF_NONE;
   if (only_instance >= 0) {
-    cur = enter(only_instance);
+    cur = enter(sc.tinst + only_instance, only_instance);
     if (best.instance == HIT_ABORT) return best;
     if (cur_inst < 0) return best;
   } else {
@@ -921,7 +980,14 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
         }
       }
     } else {
-      if (wantE) cur = enter(sc.tlas_prims[(cur - REF_INST) >> 1]);
+      if (wantE) {
+#ifdef YT_TINST_LEAF
+        cur = enter(sc.tinst_leaf + ((cur - REF_INST) >> 1), -1);
+#else
+        const int inst = sc.tlas_prims[(cur - REF_INST) >> 1];
+        cur            = enter(sc.tinst + inst, inst);
+#endif
+      }
     }
   }
   return best;
@@ -953,7 +1019,7 @@ YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, b
 
 }  // namespace yt
 
-#ifdef YT_COOP_LEAF  // experiment (yt_coop.h): line leaves tested by the whole wavefront
+#if defined(YT_COOP_LEAF) || defined(YT_COOP_TLAS)  // yt_coop.h: line leaves / TLAS-leaf root-box tests by the whole wavefront
 #include "yt_coop.h"
 namespace yt {
 // the scene walk of k_trace's extend stage for ALL lanes of the wavefront (`active`: this lane has a ray)

@@ -1,7 +1,5 @@
-// yt_coop.h — EXPERIMENT, compiled only with -DYT_COOP_LEAF (tools/devbuild.sh NAME -DYT_COOP_LEAF); not part of
-// the shipped library.  Written at the end of round 3 after the GPU budget had ended: it compiles, it has NOT run.
-// DESIGN.md §7e has the reasoning; first thing to test (tools/ab_libs.sh digests must equal the shipped build's)
-// and measure next round.
+// yt_coop.h — the wide walk with wavefront-cooperative sections, compiled with -DYT_COOP_LEAF (line leaves) and / or
+// -DYT_COOP_TLAS (the root-box tests of a TLAS leaf's instances).  DESIGN.md §6 (round 4) has the measurements.
 //
 // Line leaves tested by the whole wavefront.  On the hair (BASELINE configs[4]) the leaf phase is 60-70 % of a walk's
 // cycles and runs with 6-20 of the 64 lanes holding a leaf, each testing its <= 4 segments one after the other
@@ -78,11 +76,23 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
   StackEntry      spill[SPILL_LEVELS];
   YT_STACK_OPS(LDS_LEVELS, SPILL_LEVELS)
 
-  auto enter = [&](int inst) -> int {
-    const float4* ti = reinterpret_cast<const float4*>(sc.tinst + inst);
+#ifdef YT_COOP_TLAS
+  constexpr bool TESTED = true;  // instance entries have had the tmax-independent half of their root-box test (section 3b)
+#else
+  constexpr bool TESTED = false;
+#endif
+  auto enter = [&](int k) -> int {  // k: index in TLAS-leaf order
+#ifdef YT_TINST_LEAF
+    const float4* ti   = reinterpret_cast<const float4*>(sc.tinst_leaf + k);
+    int           inst = -1;
+#else
+    int           inst = sc.tlas_prims[k];
+    const float4* ti   = reinterpret_cast<const float4*>(sc.tinst + inst);
+#endif
     float4        m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
     int4          m5 = reinterpret_cast<const int4*>(ti)[5];
     int           root = __float_as_int(m4.z);
+    if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
     vec3f   io   = transform_point(inv, wo);
@@ -92,9 +102,11 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
       abort = true;
       return REF_NONE;
     }
-    float t0;
-    bool  ok = slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
-    if (!ok) return REF_NONE;
+    if (!TESTED) {
+      float t0;
+      bool  ok = slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
+      if (!ok) return REF_NONE;
+    }
     o = io, d = id, dinv = idin;
     sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
     cur_inst = inst;
@@ -102,6 +114,24 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
     leafbias = m5.x;
     push(REF_EXIT, 0);
     return root;
+  };
+  // the tmax-independent half of the root-box test of entry k of the TLAS-leaf order for the WORLD ray (ro, rd, rtmin)
+  // — of any lane: section 3b runs it for other lanes' rays (traverse()'s `pretest`, same arithmetic)
+  auto pretest = [&](vec3f ro, vec3f rd, float rtmin, int k, float& t0) -> bool {
+#ifdef YT_TINST_LEAF
+    const float4* ti = reinterpret_cast<const float4*>(sc.tinst_leaf + k);
+#else
+    const float4* ti = reinterpret_cast<const float4*>(sc.tinst + sc.tlas_prims[k]);
+#endif
+    float4 m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
+    t0 = 0;
+    if (__float_as_int(m4.z) == REF_NONE) return false;
+    frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
+    vec3f   io   = transform_point(inv, ro);
+    vec3f   id   = transform_vector(inv, rd);
+    vec3f   idin = {1 / id.x, 1 / id.y, 1 / id.z};
+    if (!ray_is_tame(io, idin, rtmin)) return true;  // (enter() aborts the walk when this entry is reached)
+    return slab<false>(io, idin, rtmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0);
   };
   auto exit_instance = [&]() {
     o = wo, d = wd, dinv = wdinv, sign = wsign;
@@ -126,6 +156,8 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
   while (__ballot(!done) != 0ull) {
     bool own = false;  // this lane reached a line leaf in this iteration
     int  lnum = 0, lbase = 0;
+    bool town = false;  // this lane reached a TLAS leaf in this iteration (YT_COOP_TLAS)
+    int  tnum = 0, tfirst = 0;
     if (!done) {
       // ---- (1) descend: until this lane holds a leaf / instance entry ----------
       while (true) {
@@ -136,7 +168,8 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
           }
           StackEntry e = pop();
           cur          = e.ref;
-          if (e.ref < REF_INST && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;  // culled at pop time
+          // culled at pop time (instance entries carry their root box's t0 when TESTED)
+          if ((TESTED ? e.ref != REF_EXIT : e.ref < REF_INST) && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;
           if (cur == REF_NONE) continue;
         }
         if ((unsigned)cur >= (unsigned)REF_INST) break;  // BLAS leaf or instance entry → phase 2
@@ -184,14 +217,27 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
             exit_instance();
           } else {
             int code = cur - REF_INST;
-            cur      = enter(sc.tlas_prims[code >> 1]);
+            cur      = enter(code >> 1);
             if (abort) best = Hit{HIT_ABORT, -1, 0, 0, 0, false}, done = true;
           }
         } else {
           const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
           if (cur_inst < 0) {
+#ifdef YT_COOP_TLAS
+            // the instances' root boxes are tested by the whole wavefront in section 3b; the survivors become entries there
+            if (num <= 4) {
+              town = true, tnum = num, tfirst = first;
+            } else {  // (never: leaves hold <= 4)
+              for (int k = num - 1; k >= 0; k--) {
+                float t0;
+                if (pretest(wo, wd, tmin, first + k, t0)) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), t0);
+              }
+            }
+            cur = REF_NONE;
+#else
             for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
             cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
+#endif
           } else {
             cur = REF_NONE;
             cnt.steps++;
@@ -217,7 +263,11 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
             } else if (kind == KIND_LINES) {
               // (leaves of more than four segments do not exist — bvh_max_prims = 4, yocto_bvh.cpp:54 — but the
               //  record could carry 7: those would be tested here, per lane)
+#ifdef YT_COOP_LEAF
               if (num <= 4) {
+#else
+              if (false) {
+#endif
                 own = true, lnum = num, lbase = leafbias + first * 3;
               } else {
                 const float4* L = sc.leafdata + (leafbias + first * 3);
@@ -239,6 +289,40 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
         }
       }
     }
+#ifdef YT_COOP_TLAS
+    // ---- (3b) TLAS leaves: (ray, instance) pairs over the wavefront, converged ---------------------
+    // Worker lane w takes owner rank w / 4 and instance w mod 4 of that owner's leaf, pulls the owner's WORLD ray and
+    // makes the tmax-independent half of the instance's root-box test (transform_ray + the slab interval: 64 lanes of
+    // record fetches in flight instead of one per owner and round); the owners take their (up to four) verdicts back
+    // and push the survivors in reverse order with their t0 — each gets the tmax-dependent half when it is popped, in
+    // the reference's order (yocto_bvh.cpp:600-609), after the earlier instances of the leaf have shrunk tmax.
+    const unsigned long long towners = __ballot(town);
+    if (towners != 0ull) {
+      const int nown   = __popcll(towners);
+      const int myrank = __popcll(towners & ((1ull << lane) - 1ull));  // (meaningful where `town`)
+      for (int q = 0; q < nown; q += 16) {  // (wave-uniform trip count)
+        const int  i    = q + (lane >> 2), k = lane & 3;
+        const bool have = i < nown;
+        const int  ol   = have ? nth_set_bit(towners, i) : lane;
+        const int   n_ = __shfl(tnum, ol), f_ = __shfl(tfirst, ol);
+        const float ox = __shfl(wo.x, ol), oy = __shfl(wo.y, ol), oz = __shfl(wo.z, ol);
+        const float dx = __shfl(wd.x, ol), dy = __shfl(wd.y, ol), dz = __shfl(wd.z, ol);
+        const float tn = __shfl(tmin, ol);
+        float t0   = 0;
+        int   pass = 0;
+        if (have && k < n_) pass = pretest({ox, oy, oz}, {dx, dy, dz}, tn, f_ + k, t0) ? 1 : 0;
+        const bool mine = town && myrank >= q && myrank < q + 16;
+        const int  w0   = ((myrank - q) & 15) * 4;
+#pragma unroll
+        for (int kk = 3; kk >= 0; kk--) {
+          const int   src = (w0 + kk) & 63;
+          const int   pk  = __shfl(pass, src);
+          const float tk  = __shfl(t0, src);
+          if (mine && kk < tnum && pk) push(REF_INST + (((tfirst + kk) << 1) | (kk == tnum - 1 ? 1 : 0)), tk);
+        }
+      }
+    }
+#endif
     // ---- (3) line leaves: every lane of the wavefront, converged ---------------------------------
     const unsigned long long owners = __ballot(own);
     if (owners != 0ull) {

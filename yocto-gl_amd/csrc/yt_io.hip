@@ -257,6 +257,7 @@ int ythip_params_from_json(const char* text, int64_t length, ythip_params* p) {
     else if (key == "highqualitybvh") { if (!as_bool(p->highqualitybvh)) return bad("a boolean"); }
     else if (key == "noparallel") { if (!as_bool(p->noparallel)) return bad("a boolean"); }
     else if (key == "denoise") { if (!as_bool(p->denoise)) return bad("a boolean"); }
+    else if (key == "fastmath") { if (!as_bool(p->fastmath)) return bad("a boolean"); }  // (this library's key; the reference ignores it)
     c.ws();
     if (c.p < c.end && *c.p == ',') {
       c.p++;
@@ -296,7 +297,8 @@ int64_t ythip_params_to_json(const ythip_params* p, char* buffer, int64_t capaci
   s += std::string("  \"noparallel\": ") + b(p->noparallel) + ",\n";
   s += "  \"pratio\": " + std::to_string(p->pratio) + ",\n";
   s += std::string("  \"denoise\": ") + b(p->denoise) + ",\n";
-  s += "  \"batch\": " + std::to_string(p->batch) + "\n}\n";
+  // (the tolerance switch is this library's: written only when it is on, so that a default file is the reference's)
+  s += "  \"batch\": " + std::to_string(p->batch) + (p->fastmath ? std::string(",\n  \"fastmath\": true") : std::string()) + "\n}\n";
   if (buffer && capacity > 0) {
     int64_t n = std::min<int64_t>((int64_t)s.size(), capacity - 1);
     std::memcpy(buffer, s.data(), (size_t)n);

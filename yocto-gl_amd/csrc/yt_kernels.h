@@ -35,6 +35,9 @@
 #include "yt_bvh.h"
 #include "yt_shading.h"
 
+#ifdef YT_FAST  // tolerance mode: multiply-adds written in this file may fuse (the traversal's, in yt_bvh.h, never do)
+#pragma clang fp contract(fast)
+#endif
 namespace yt {
 
 // Path flags (low byte) | opbounce << 8
@@ -243,7 +246,7 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
     if (environment.emission_tex != YTHIP_INVALIDID) {
       const auto& tex = sc.textures[environment.emission_tex];
       auto        idx = sample_discrete(sc.cdf + light.cdf_offset, light.cdf_count, rel);
-      auto        uv  = vec2f{((idx % tex.width) + 0.5f) / tex.width, ((idx / tex.width) + 0.5f) / tex.height};
+      auto        uv  = vec2f{div_((idx % tex.width) + 0.5f, (float)tex.width), div_((idx / tex.width) + 0.5f, (float)tex.height)};
       float sx, cx, sy, cy;
       ytm::sincosf(uv.x * 2 * pif, &sx, &cx);
       ytm::sincosf(uv.y * pif, &sy, &cy);
@@ -277,7 +280,7 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
           auto e         = load_element(sc, sh, isec.element);
           auto lposition = eval_position(sc, frame, sh, e, {isec.u, isec.v});
           auto lnormal   = eval_element_normal(sc, frame, sh, e);
-          lpdf += distance_squared(lposition, position) / (fabs_(dot(lnormal, direction)) * area);
+          lpdf += div_(distance_squared(lposition, position), fabs_(dot(lnormal, direction)) * area);
           next_position = lposition + direction * 1e-3f;
         }
         pdf += lpdf;
@@ -287,14 +290,14 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
       if (environment.emission_tex != YTHIP_INVALIDID) {
         const auto& tex      = sc.textures[environment.emission_tex];
         auto        wl       = transform_direction(ldframe(sc.env_inv + 12 * light.environment), direction);
-        auto        texcoord = vec2f{ytm::atan2f(wl.z, wl.x) / (2 * pif), ytm::acosf(clamp_(wl.y, -1.0f, 1.0f)) / pif};
+        auto        texcoord = vec2f{div_(ytm::atan2f(wl.z, wl.x), 2 * pif), div_(ytm::acosf(clamp_(wl.y, -1.0f, 1.0f)), pif)};
         if (texcoord.x < 0) texcoord.x += 1;
         auto i     = clamp_((int)(texcoord.x * tex.width), 0, tex.width - 1);
         auto j     = clamp_((int)(texcoord.y * tex.height), 0, tex.height - 1);
         auto cdf   = sc.cdf + light.cdf_offset;
-        auto prob  = sample_discrete_pdf(cdf, j * tex.width + i) / cdf[light.cdf_count - 1];
-        auto angle = (2 * pif / tex.width) * (pif / tex.height) * ytm::sinf(pif * (j + 0.5f) / tex.height);
-        pdf += prob / angle;
+        auto prob  = div_(sample_discrete_pdf(cdf, j * tex.width + i), cdf[light.cdf_count - 1]);
+        auto angle = div_(2 * pif, (float)tex.width) * div_(pif, (float)tex.height) * ytm::sinf(div_(pif * (j + 0.5f), (float)tex.height));
+        pdf += div_(prob, angle);
       } else {
         pdf += 1 / (4 * pif);
       }
@@ -350,7 +353,7 @@ YT_FN void store_volume(const DState& s, int slot, const material_point& m) {
 // the same lerp and weight trace_sample's tail uses, instead of being parked in
 // per-slot arrays until the sample ends (saves 72 B of state traffic per sample).
 YT_FN void set_first_hit(const DState& s, const Path& P, vec3f albedo, vec3f normal) {
-  auto weight = 1.0f / (s.sample_base + P.sidx + 1);
+  auto weight = rcp_((float)(s.sample_base + P.sidx + 1));
   auto alb    = lerp_(ld3(s.albedo, P.pix), albedo, weight);
   auto nrm    = lerp_(ld3(s.normal, P.pix), normal, weight);
 #ifdef YT_EXP_LASTSTORE  // ceiling experiment: accumulator stores only in the batch's last sample — WRONG results
@@ -378,7 +381,7 @@ YT_FN int step_tail(Path& P) {
   if (P.bounce > 3) {
     auto rr_prob = min_((float)0.99, max_(P.weight));
     if (rand1f(P.rng) >= rr_prob) return STEP_END;
-    P.weight *= 1 / rr_prob;
+    P.weight *= rcp_(rr_prob);
   }
   return STEP_NEXT;
 }
@@ -858,8 +861,8 @@ YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Pa
   vec3f radiance = P.radiance;
   bool  hit      = (P.flags & PF_HIT) != 0;
   if (!isfinite_(radiance)) radiance = {0, 0, 0};
-  if (max_(radiance) > kp.clamp) radiance = radiance * (kp.clamp / max_(radiance));
-  auto      weight = 1.0f / (sample + 1);
+  if (max_(radiance) > kp.clamp) radiance = radiance * div_(kp.clamp, max_(radiance));
+  auto      weight = rcp_((float)(sample + 1));
   const int pix    = P.pix;
   float4    im     = st.image[pix];
   vec4f     image  = {im.x, im.y, im.z, im.w};
@@ -1076,12 +1079,13 @@ __global__ void __launch_bounds__(YT_BLOCK,
   if (lb < 0) return;
   if (stop_requested(st.stop, st.stop_gen)) return;  // cancelled before this tile started
   int vtile = lb;  // the tile whose pixels the slots start on
-  if (st.pool_next) {  // pixel pool: the workgroup's first 64 queue entries = one tile; the path slots are the workgroup's own
-    __shared__ int s_first;
-    if (threadIdx.x == 0) s_first = atomicAdd(st.pool_next, YT_BLOCK);
-    __syncthreads();
-    if (s_first >= st.pool_total) return;
-    vtile = s_first / YT_BLOCK;
+  if (st.pool_next) {
+    // pixel pool: the workgroup's first 64 queue entries = one tile, assigned STATICALLY — workgroup b starts on entries
+    // [64 b, 64 b + 64) and the queue's head starts at 64 x the number of workgroups (enqueue_samples).  (the
+    // first tile used to come from the same counter the refills advance by arbitrary lane counts, so a workgroup whose
+    // prologue ran after somebody's refill could start on an unaligned entry and render another workgroup's pixels.)
+    if ((int)blockIdx.x * YT_BLOCK >= st.pool_total) return;
+    vtile = (int)blockIdx.x;
     if (st.tile_perm) vtile = st.tile_perm[vtile];
     lb = (int)blockIdx.x;
   }
@@ -1165,8 +1169,12 @@ __global__ void __launch_bounds__(YT_BLOCK,
     const long long tm0 = __builtin_readcyclecounter();
     long long       tm1 = tm0, tm2 = tm0, tmS = tm0, tmG = 0;
 #endif
-#ifdef YT_COOP_LEAF  // experiment (yt_coop.h): the extend stage with every lane of the wavefront inside the walk
-    constexpr bool COOP = WIDE && !COUNT && !MATTE && !PHASED_SCENE;
+#if defined(YT_COOP_LEAF) || defined(YT_COOP_TLAS)  // yt_coop.h: the extend stage with every lane of the wavefront inside the walk
+#ifdef YT_COOP_TLAS
+    constexpr bool COOP = WIDE && !COUNT && !PHASED_SCENE;
+#else
+    constexpr bool COOP = WIDE && !COUNT && !MATTE && !PHASED_SCENE;  // (line leaves only exist outside the all-triangle class)
+#endif
     Hit            coop_isec = {-1, -1, 0, 0, 0, false};
     if constexpr (COOP) {
       const int    l  = (run ? slot : (int)threadIdx.x) & (YT_BLOCK - 1);
@@ -1190,7 +1198,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
         int    inst = __float_as_int(ha.w);
         P.isec      = {inst, st.nhit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
       } else {
-#ifdef YT_COOP_LEAF
+#if defined(YT_COOP_LEAF) || defined(YT_COOP_TLAS)
         if constexpr (COOP) {
           P.isec = coop_isec;
         } else
@@ -1354,10 +1362,10 @@ __global__ void __launch_bounds__(YT_BLOCK,
                 const float  bsdf_pdf  = a.w;
                 const float  light_pdf = sample_lights_pdf<2, COUNT>(sc, P.o, inc, &stack, &cnt);
                 auto         heur      = [](float this_pdf, float other_pdf) {
-                  return (this_pdf * this_pdf) / (this_pdf * this_pdf + other_pdf * other_pdf);
+                  return div_(this_pdf * this_pdf, this_pdf * this_pdf + other_pdf * other_pdf);
                 };
-                const float mis_weight = pass == 0 ? heur(light_pdf, bsdf_pdf) / light_pdf
-                                                   : heur(bsdf_pdf, light_pdf) / bsdf_pdf;
+                const float mis_weight = pass == 0 ? div_(heur(light_pdf, bsdf_pdf), light_pdf)
+                                                   : div_(heur(bsdf_pdf, light_pdf), bsdf_pdf);
                 if (bsdfcos != vec3f{0, 0, 0} && mis_weight != 0) {
                   ray3f nray  = make_ray(P.o, inc);
                   Hit   nisec = traverse_any<COUNT, WIDE>(sc, nray, -1, false, stack, cnt);
@@ -1476,3 +1484,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_camera_rays(DScene sc, DState st, 
 }
 
 }  // namespace yt
+#ifdef YT_FAST
+#pragma clang fp contract(off)
+#endif
+

@@ -25,7 +25,11 @@ static inline float __uint_as_float(unsigned u) {
 }
 #endif
 
+#ifdef YT_FAST  // the tolerance mode's translation unit (yt_fast.hip): hardware transcendentals, reciprocals instead of divisions
+#include "yt_fastmath.h"
+#else
 #include "yt_libm.h"  // the reference platform's libm (glibc 2.35), restated: ytm::sinf ... ytm::powf
+#endif
 
 namespace yt {
 
@@ -61,7 +65,20 @@ YT_FN int   min_(int a, int b) { return (a < b) ? a : b; }
 YT_FN int   max_(int a, int b) { return (a > b) ? a : b; }
 YT_FN int   clamp_(int a, int lo, int hi) { return min_(max_(a, lo), hi); }
 YT_FN bool  isfinite_(float a) { return __builtin_isfinite(a); }
-YT_FN float sqrt_(float a) { return __builtin_sqrtf(a); }  // IEEE (v_sqrt + fixup)
+YT_FN float sqrt_ieee_(float a) { return __builtin_sqrtf(a); }  // IEEE (v_sqrt + fixup): the traversal's, in every mode
+// Shading / sampling arithmetic goes through div_ / sqrt_ (and the vector operator/, normalize): the reference's IEEE
+// operations in the bit-exact build; in the tolerance mode (-DYT_FAST) v_rcp / v_sqrt / v_rsq_f32, about 1 ulp each.
+// The TRAVERSAL (yt_bvh.h, misses_scene_root) spells its divisions `/` and its root sqrt_ieee_: identical in both.
+#ifdef YT_FAST
+YT_FN float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }
+YT_FN float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+YT_FN float sqrt_(float a) { return __builtin_amdgcn_sqrtf(a); }
+YT_FN float rsqrt_(float a) { return __builtin_amdgcn_rsqf(a); }
+#else
+YT_FN float rcp_(float a) { return 1 / a; }
+YT_FN float div_(float a, float b) { return a / b; }
+YT_FN float sqrt_(float a) { return __builtin_sqrtf(a); }
+#endif
 YT_FN float lerp_(float a, float b, float u) { return a * (1 - u) + b * u; }
 
 // vec2 -----------------------------------------------------------------------
@@ -83,9 +100,19 @@ YT_FN vec3f operator-(float a, vec3f b) { return {a - b.x, a - b.y, a - b.z}; }
 YT_FN vec3f operator*(vec3f a, vec3f b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 YT_FN vec3f operator*(vec3f a, float b) { return {a.x * b, a.y * b, a.z * b}; }
 YT_FN vec3f operator*(float a, vec3f b) { return {a * b.x, a * b.y, a * b.z}; }
+// (vector division is shading arithmetic: the traversal only ever divides scalars)
+#ifdef YT_FAST
+YT_FN vec3f operator/(vec3f a, vec3f b) { return {a.x * rcp_(b.x), a.y * rcp_(b.y), a.z * rcp_(b.z)}; }
+YT_FN vec3f operator/(vec3f a, float b) {
+  const float r = rcp_(b);
+  return {a.x * r, a.y * r, a.z * r};
+}
+YT_FN vec3f operator/(float a, vec3f b) { return {a * rcp_(b.x), a * rcp_(b.y), a * rcp_(b.z)}; }
+#else
 YT_FN vec3f operator/(vec3f a, vec3f b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
 YT_FN vec3f operator/(vec3f a, float b) { return {a.x / b, a.y / b, a.z / b}; }
 YT_FN vec3f operator/(float a, vec3f b) { return {a / b.x, a / b.y, a / b.z}; }
+#endif
 YT_FN vec3f& operator+=(vec3f& a, vec3f b) { return a = a + b; }
 YT_FN vec3f& operator*=(vec3f& a, vec3f b) { return a = a * b; }
 YT_FN vec3f& operator*=(vec3f& a, float b) { return a = a * b; }
@@ -96,8 +123,13 @@ YT_FN vec3f cross(vec3f a, vec3f b) {                                           
 }
 YT_FN float length(vec3f a) { return sqrt_(dot(a, a)); }
 YT_FN vec3f normalize(vec3f a) {  // :1314
+#ifdef YT_FAST
+  auto l2 = dot(a, a);
+  return (l2 != 0) ? a * rsqrt_(l2) : a;
+#else
   auto l = length(a);
   return (l != 0) ? a / l : a;
+#endif
 }
 YT_FN float distance_squared(vec3f a, vec3f b) { return dot(a - b, a - b); }
 YT_FN vec3f orthonormalize(vec3f a, vec3f b) { return normalize(a - b * dot(a, b)); }  // :1332
@@ -118,7 +150,7 @@ YT_FN vec3f lerp_(vec3f a, vec3f b, float u) { return a * (1 - u) + b * u; }  //
 YT_FN float max_(vec3f a) { return max_(max_(a.x, a.y), a.z); }               // :1369
 YT_FN float min_(vec3f a) { return min_(min_(a.x, a.y), a.z); }
 YT_FN float sum(vec3f a) { return a.x + a.y + a.z; }
-YT_FN float mean(vec3f a) { return sum(a) / 3; }
+YT_FN float mean(vec3f a) { return div_(sum(a), 3); }
 YT_FN vec3f abs_(vec3f a) { return {fabs_(a.x), fabs_(a.y), fabs_(a.z)}; }
 YT_FN vec3f sqrt_(vec3f a) { return {sqrt_(a.x), sqrt_(a.y), sqrt_(a.z)}; }
 YT_FN vec3f exp_(vec3f a) { return {ytm::expf(a.x), ytm::expf(a.y), ytm::expf(a.z)}; }
@@ -141,7 +173,7 @@ YT_FN mat3f transpose(const mat3f& a) {
 YT_FN mat3f basis_fromz(vec3f v) {
   auto z    = normalize(v);
   auto sign = copysignf(1.0f, z.z);
-  auto a    = -1.0f / (sign + z.z);
+  auto a    = div_(-1.0f, sign + z.z);
   auto b    = z.x * z.y * a;
   auto x    = vec3f{1.0f + sign * z.x * z.x * a, sign * b, -sign * z.x};
   auto y    = vec3f{b, sign + z.y * z.y * a, -z.y};
@@ -165,7 +197,7 @@ YT_FN vec3f transform_direction(const mat3f& a, vec3f b) { return normalize(a * 
 YT_FN mat3f inverse(const mat3f& a) {
   auto det = dot(a.x, cross(a.y, a.z));
   auto adj = transpose(mat3f{cross(a.y, a.z), cross(a.z, a.x), cross(a.x, a.y)});
-  auto s   = 1 / det;
+  auto s   = rcp_(det);
   return {adj.x * s, adj.y * s, adj.z * s};
 }
 // transform_normal(frame, n, non_rigid = true): normalize(transpose(inverse(rot)) * n)
@@ -212,6 +244,9 @@ YT_FN vec3f rand3f(rng_state& rng) {
   return {x, y, z};
 }
 
+#ifdef YT_FAST  // tolerance mode: the samplers below may fuse their multiply-adds (vector helpers above: never — the traversal uses them)
+#pragma clang fp contract(fast)
+#endif
 // ---------------------------------------------------------------------------
 // Monte Carlo sampling — libs/yocto/yocto_sampling.h:252-398
 // ---------------------------------------------------------------------------
@@ -234,7 +269,7 @@ YT_FN vec3f sample_hemisphere_cos(vec3f normal, vec2f ruv) {  // :297
 }
 YT_FN float sample_hemisphere_cos_pdf(vec3f normal, vec3f direction) {  // :304
   auto cosw = dot(normal, direction);
-  return (cosw <= 0) ? 0 : cosw / pif;
+  return (cosw <= 0) ? 0 : div_(cosw, pif);
 }
 YT_FN vec2f sample_disk(vec2f ruv) {  // :339
   auto r   = sqrt_(ruv.y);
@@ -249,7 +284,7 @@ YT_FN vec2f sample_triangle(vec2f ruv) {  // :354
 YT_FN int sample_uniform(int size, float r) {  // :371
   return clamp_((int)(r * size), 0, size - 1);
 }
-YT_FN float sample_uniform_pdf(int size) { return (float)1 / (float)size; }
+YT_FN float sample_uniform_pdf(int size) { return div_((float)1, (float)size); }
 // sample_discrete — :388-393 (std::upper_bound = first element > r)
 YT_FN int sample_discrete(const float* cdf, int n, float r) {
   auto last = cdf[n - 1];
@@ -271,5 +306,9 @@ YT_FN float sample_discrete_pdf(const float* cdf, int idx) {  // :395
   if (idx == 0) return cdf[0];
   return cdf[idx] - cdf[idx - 1];
 }
+
+#ifdef YT_FAST
+#pragma clang fp contract(off)
+#endif
 
 }  // namespace yt

@@ -7,6 +7,9 @@
 #include "yt_material.h"
 #include "yt_math.h"
 
+#ifdef YT_FAST  // tolerance mode: multiply-adds written in this file may fuse (the traversal's, in yt_bvh.h, never do)
+#pragma clang fp contract(fast)
+#endif
 namespace yt {
 
 // element kinds, in the reference's two dispatch orders
@@ -34,7 +37,8 @@ struct DInstanceT {
   int   kind;       // kind_bvh of the shape
   int   leaf_bias;  // float4 index: leafdata of global primitive p starts at leaf_bias + p * stride
   int   shape;
-  int   pad_[2];
+  int   instance;   // tinst_leaf only: the instance this copy belongs to
+  int   pad_;
 };
 static_assert(sizeof(DInstanceT) == 96, "DInstanceT is fetched as 6 float4");
 
@@ -70,6 +74,7 @@ struct DScene {
   const float4*     leafdata;   // pre-gathered leaf primitives in leaf order
   const int*        tlas_prims; // instance ids in TLAS leaf order
   const DInstanceT* tinst;      // per instance
+  const DInstanceT* tinst_leaf; // the same records gathered in TLAS-leaf order (tinst[tlas_prims[k]], with .instance set)
   int               tlas_ref;   // ref of the TLAS root, REF_NONE if empty
   vec3f             tlas_bmin, tlas_bmax;
   // lights
@@ -99,22 +104,22 @@ YT_FN ray3f make_ray(vec3f o, vec3f d) { return {o, d, ray_eps, flt_max}; }
 // eval_camera — yocto_scene.cpp:66-101
 // ---------------------------------------------------------------------------
 YT_FN ray3f eval_camera(const ythip_camera& camera, vec2f image_uv, vec2f lens_uv) {
-  auto film = camera.aspect >= 1 ? vec2f{camera.film, camera.film / camera.aspect}
+  auto film = camera.aspect >= 1 ? vec2f{camera.film, div_(camera.film, camera.aspect)}
                                  : vec2f{camera.film * camera.aspect, camera.film};
   auto frame = ldframe(camera.frame);
   if (!camera.orthographic) {
     auto q  = vec3f{film.x * (0.5f - image_uv.x), film.y * (image_uv.y - 0.5f), camera.lens};
     auto dc = -normalize(q);
-    auto e  = vec3f{lens_uv.x * camera.aperture / 2, lens_uv.y * camera.aperture / 2, 0};
+    auto e  = vec3f{div_(lens_uv.x * camera.aperture, 2), div_(lens_uv.y * camera.aperture, 2), 0};
     auto p  = dc * camera.focus / fabs_(dc.z);
     auto d  = normalize(p - e);
     return make_ray(transform_point(frame, e), transform_direction(frame, d));
   } else {
-    auto scale = 1 / camera.lens;
+    auto scale = rcp_(camera.lens);
     auto q     = vec3f{film.x * (0.5f - image_uv.x) * scale,
         film.y * (image_uv.y - 0.5f) * scale, camera.lens};
     auto e     = vec3f{-q.x, -q.y, 0} +
-             vec3f{lens_uv.x * camera.aperture / 2, lens_uv.y * camera.aperture / 2, 0};
+             vec3f{div_(lens_uv.x * camera.aperture, 2), div_(lens_uv.y * camera.aperture, 2), 0};
     auto p = vec3f{-q.x, -q.y, -camera.focus};
     auto d = normalize(p - e);
     return make_ray(transform_point(frame, e), transform_direction(frame, d));
@@ -125,7 +130,7 @@ YT_FN ray3f eval_camera(const ythip_camera& camera, vec2f image_uv, vec2f lens_u
 YT_FN ray3f sample_camera(const ythip_camera& camera, int i, int j, int width, int height,
     vec2f puv, vec2f luv, bool tent) {
   if (!tent) {
-    auto uv = vec2f{(i + puv.x) / width, (j + puv.y) / height};
+    auto uv = vec2f{div_(i + puv.x, (float)width), div_(j + puv.y, (float)height)};
     return eval_camera(camera, uv, sample_disk(luv));
   } else {
     const auto width_ = 2.0f;
@@ -133,7 +138,7 @@ YT_FN ray3f sample_camera(const ythip_camera& camera, int i, int j, int width, i
     auto       fuv    = vec2f{puv.x < 0.5f ? sqrt_(2 * puv.x) - 1 : 1 - sqrt_(2 - 2 * puv.x),
                      puv.y < 0.5f ? sqrt_(2 * puv.y) - 1 : 1 - sqrt_(2 - 2 * puv.y)};
     fuv = {width_ * fuv.x + offset, width_ * fuv.y + offset};
-    auto uv = vec2f{(i + fuv.x) / width, (j + fuv.y) / height};
+    auto uv = vec2f{div_(i + fuv.x, (float)width), div_(j + fuv.y, (float)height)};
     return eval_camera(camera, uv, sample_disk(luv));
   }
 }
@@ -142,8 +147,8 @@ YT_FN ray3f sample_camera(const ythip_camera& camera, int i, int j, int width, i
 // textures — yocto_scene.cpp:111-178, yocto_color.h:223-249
 // ---------------------------------------------------------------------------
 YT_FN float srgb_to_rgb(float srgb) {  // yocto_color.h:235 (double-typed threshold)
-  return ((double)srgb <= 0.04045) ? srgb / 12.92f
-                                   : ytm::powf((srgb + 0.055f) / (1.0f + 0.055f), 2.4f);
+  return ((double)srgb <= 0.04045) ? div_(srgb, 12.92f)
+                                   : ytm::powf(div_(srgb + 0.055f, 1.0f + 0.055f), 2.4f);
 }
 YT_FN vec3f srgb_to_rgb(vec3f c) { return {srgb_to_rgb(c.x), srgb_to_rgb(c.y), srgb_to_rgb(c.z)}; }
 YT_FN vec4f lookup_texture(const DScene& sc, const ythip_texture& t, int i, int j, bool as_linear) {
@@ -154,7 +159,7 @@ YT_FN vec4f lookup_texture(const DScene& sc, const ythip_texture& t, int i, int 
     color  = {v.x, v.y, v.z, v.w};
   } else {
     auto b = reinterpret_cast<const uchar4*>(sc.pixelsb)[idx];
-    color  = {b.x / 255.0f, b.y / 255.0f, b.z / 255.0f, b.w / 255.0f};
+    color  = {div_((float)b.x, 255.0f), div_((float)b.y, 255.0f), div_((float)b.z, 255.0f), div_((float)b.w, 255.0f)};
   }
   if (as_linear && !t.linear) {
     return {srgb_to_rgb(color.x), srgb_to_rgb(color.y), srgb_to_rgb(color.z), color.w};
@@ -469,7 +474,7 @@ YT_FN vec3f eval_environment(const DScene& sc, int env, vec3f direction) {
   }
   auto inv      = ldframe(sc.env_inv + 12 * env);
   auto wl       = transform_direction(inv, direction);
-  auto texcoord = vec2f{ytm::atan2f(wl.z, wl.x) / (2 * pif), ytm::acosf(clamp_(wl.y, -1.0f, 1.0f)) / pif};
+  auto texcoord = vec2f{div_(ytm::atan2f(wl.z, wl.x), 2 * pif), div_(ytm::acosf(clamp_(wl.y, -1.0f, 1.0f)), pif)};
   if (texcoord.x < 0) texcoord.x += 1;
   return emission * xyz(eval_texture(sc, environment.emission_tex, texcoord, false));
 }
@@ -480,3 +485,7 @@ YT_FN vec3f eval_environment(const DScene& sc, vec3f direction) {
 }
 
 }  // namespace yt
+#ifdef YT_FAST
+#pragma clang fp contract(off)
+#endif
+

@@ -33,6 +33,9 @@
 #include "../../include/ythip.h"  // material types
 #include "yt_material.h"
 
+#ifdef YT_FAST  // tolerance mode: multiply-adds written in this file may fuse (the traversal's, in yt_bvh.h, never do)
+#pragma clang fp contract(fast)
+#endif
 namespace yt {
 
 // f = eval_bsdfcos, pdf = sample_bsdfcos_pdf of one (outgoing, incoming) pair
@@ -49,14 +52,14 @@ YT_FN float dielectric_fresnel(float eta, float c) {
   auto cosw  = fabs_(c);
   auto sin2  = 1 - cosw * cosw;
   auto eta2  = eta * eta;
-  auto cos2t = 1 - sin2 / eta2;
+  auto cos2t = 1 - div_(sin2, eta2);
   if (cos2t < 0) return 1;  // total internal reflection
   auto t0 = sqrt_(cos2t);
   auto t1 = eta * t0;
   auto t2 = eta * cosw;
-  auto rs = (cosw - t1) / (cosw + t1);
-  auto rp = (t0 - t2) / (t0 + t2);
-  return (rs * rs + rp * rp) / 2;
+  auto rs = div_(cosw - t1, cosw + t1);
+  auto rp = div_(t0 - t2, t0 + t2);
+  return div_(rs * rs + rp * rp, 2);
 }
 // fresnel_schlick(specular, normal, dir) with c = dot(normal, dir) — :308-315
 YT_FN vec3f schlick_fresnel(vec3f specular, float c) {
@@ -95,21 +98,21 @@ YT_FN float ggx_d(float roughness, float nh) {
   if (nh <= 0) return 0;
   auto roughness2 = roughness * roughness;
   auto cosine2    = nh * nh;
-  return roughness2 / (pif * (cosine2 * roughness2 + 1 - cosine2) * (cosine2 * roughness2 + 1 - cosine2));
+  return div_(roughness2, pif * (cosine2 * roughness2 + 1 - cosine2) * (cosine2 * roughness2 + 1 - cosine2));
 }
 // microfacet_shadowing1 with nd = dot(normal, dir), hd = dot(halfway, dir) — :427-447
 YT_FN float ggx_g1(float roughness, float nd, float hd) {
   if (nd * hd <= 0) return 0;
   auto roughness2 = roughness * roughness;
   auto cosine2    = nd * nd;
-  return 2 * fabs_(nd) / (fabs_(nd) + sqrt_(cosine2 - roughness2 * cosine2 + roughness2));
+  return div_(2 * fabs_(nd), fabs_(nd) + sqrt_(cosine2 - roughness2 * cosine2 + roughness2));
 }
 // sample_microfacet_pdf given D and nh — :474-479
 YT_FN float ggx_pdf(float d, float nh) { return nh < 0 ? 0 : d * nh; }
 // sample_microfacet (ggx) — :458-471
 YT_FN vec3f sample_microfacet(float roughness, vec3f normal, vec2f rn) {
   auto  phi   = 2 * pif * rn.x;
-  auto  theta = ytm::atanf(roughness * sqrt_(rn.y / (1 - rn.y)));
+  auto  theta = ytm::atanf(roughness * sqrt_(div_(rn.y, 1 - rn.y)));
   float sp, cp, st, ct;
   ytm::sincosf(phi, &sp, &cp);
   ytm::sincosf(theta, &st, &ct);
@@ -158,7 +161,7 @@ YT_FN LobeEval lobe_glossy(vec3f color, float ior, float roughness, vec3f n, vec
   auto ui = dot(up, i), uo = dot(up, o);
   LobeEval r;
   r.f   = color * (1 - f1) / pif * fabs_(ui) + vec3f{1, 1, 1} * fh * s.d * s.g / (4 * uo * ui) * fabs_(ui);
-  r.pdf = f1 * ggx_pdf(s.d, s.nh) / (4 * fabs_(dot(o, halfway))) + (1 - f1) * sample_hemisphere_cos_pdf(up, i);
+  r.pdf = div_(f1 * ggx_pdf(s.d, s.nh), 4 * fabs_(dot(o, halfway))) + (1 - f1) * sample_hemisphere_cos_pdf(up, i);
   return r;
 }
 // reflective (rough, colour-parametrised conductor) — eval :620-630, pdf :641-650
@@ -172,7 +175,7 @@ YT_FN LobeEval lobe_reflective(vec3f color, float roughness, vec3f n, vec3f o, v
   auto ui      = dot(up, i);
   LobeEval r;
   r.f   = fh * s.d * s.g / (4 * dot(up, o) * ui) * fabs_(ui);
-  r.pdf = ggx_pdf(s.d, s.nh) / (4 * fabs_(dot(o, halfway)));
+  r.pdf = div_(ggx_pdf(s.d, s.nh), 4 * fabs_(dot(o, halfway)));
   return r;
 }
 // gltfpbr — eval :739-752, pdf :776-789.  Shared: reflectivity, F1 (the pdf's weight is mean(F1)).
@@ -188,7 +191,7 @@ YT_FN LobeEval lobe_gltfpbr(vec3f color, float ior, float roughness, float metal
   auto ui = dot(up, i), w = mean(f1);
   LobeEval r;
   r.f   = color * (1 - metallic) * (1 - f1) / pif * fabs_(ui) + fh * s.d * s.g / (4 * dot(up, o) * ui) * fabs_(ui);
-  r.pdf = w * ggx_pdf(s.d, s.nh) / (4 * fabs_(dot(o, halfway))) + (1 - w) * sample_hemisphere_cos_pdf(up, i);
+  r.pdf = div_(w * ggx_pdf(s.d, s.nh), 4 * fabs_(dot(o, halfway))) + (1 - w) * sample_hemisphere_cos_pdf(up, i);
   return r;
 }
 // transparent (thin rough dielectric) — eval :792-812, pdf :833-846.  Transmission is evaluated on
@@ -203,7 +206,7 @@ YT_FN LobeEval lobe_transparent(vec3f color, float ior, float roughness, vec3f n
     auto s       = specular_terms(roughness, up, halfway, o, i);
     auto ui      = dot(up, i);
     r.f          = vec3f{1, 1, 1} * fh * s.d * s.g / (4 * dot(up, o) * ui) * fabs_(ui);
-    r.pdf        = fh * ggx_pdf(s.d, s.nh) / (4 * fabs_(dot(o, halfway)));
+    r.pdf        = div_(fh * ggx_pdf(s.d, s.nh), 4 * fabs_(dot(o, halfway)));
   } else {
     auto reflected = reflect(-i, up);
     auto halfway   = normalize(reflected + o);
@@ -212,7 +215,7 @@ YT_FN LobeEval lobe_transparent(vec3f color, float ior, float roughness, vec3f n
     auto ur        = dot(up, reflected);
     r.f            = color * (1 - fh) * s.d * s.g / (4 * dot(up, o) * ur) * (fabs_(ur));
     auto d         = (1 - fh) * ggx_pdf(s.d, s.nh);
-    r.pdf          = d / (4 * fabs_(dot(o, halfway)));
+    r.pdf          = div_(d, 4 * fabs_(dot(o, halfway)));
   }
   return r;
 }
@@ -221,7 +224,7 @@ YT_FN LobeEval lobe_refractive(vec3f color, float ior, float roughness, vec3f n,
   auto no       = dot(n, o);
   auto entering = no >= 0;
   auto up       = entering ? n : -n;
-  auto rel_ior  = entering ? ior : (1 / ior);
+  auto rel_ior  = entering ? ior : rcp_(ior);
   auto ni       = dot(n, i);
   LobeEval r;
   if (ni * no >= 0) {
@@ -229,7 +232,7 @@ YT_FN LobeEval lobe_refractive(vec3f color, float ior, float roughness, vec3f n,
     auto fh      = dielectric_fresnel(rel_ior, dot(halfway, o));
     auto s       = specular_terms(roughness, up, halfway, o, i);
     r.f          = vec3f{1, 1, 1} * fh * s.d * s.g / fabs_(4 * no * ni) * fabs_(ni);
-    r.pdf        = fh * ggx_pdf(s.d, s.nh) / (4 * fabs_(dot(o, halfway)));
+    r.pdf        = div_(fh * ggx_pdf(s.d, s.nh), 4 * fabs_(dot(o, halfway)));
   } else {
     auto halfway = -normalize(rel_ior * i + o) * (entering ? 1.0f : -1.0f);
     auto fh      = dielectric_fresnel(rel_ior, dot(halfway, o));
@@ -237,9 +240,9 @@ YT_FN LobeEval lobe_refractive(vec3f color, float ior, float roughness, vec3f n,
     // [Walter 2007] equations 21 (f) and 17 (pdf); the eval writes its dots (vector, halfway) /
     // (vector, normal), the pdf (halfway, vector): dot is commutative term by term
     auto oh = dot(o, halfway), ih = dot(i, halfway);
-    r.f     = vec3f{1, 1, 1} * fabs_((oh * ih) / (dot(o, n) * dot(i, n))) * (1 - fh) * s.d * s.g /
+    r.f     = vec3f{1, 1, 1} * fabs_(div_(oh * ih, dot(o, n) * dot(i, n))) * (1 - fh) * s.d * s.g /
           sqr_(rel_ior * dot(halfway, i) + dot(halfway, o)) * fabs_(ni);
-    r.pdf = (1 - fh) * ggx_pdf(s.d, s.nh) * fabs_(dot(halfway, i)) / sqr_(rel_ior * dot(halfway, i) + dot(halfway, o));
+    r.pdf = div_((1 - fh) * ggx_pdf(s.d, s.nh) * fabs_(dot(halfway, i)), sqr_(rel_ior * dot(halfway, i) + dot(halfway, o)));
   }
   return r;
 }
@@ -303,8 +306,8 @@ YT_FN vec3f sample_lobe(const material_point& m, vec3f n, vec3f o, float rnl, ve
       auto entering = no >= 0;
       auto up       = entering ? n : -n;
       auto halfway  = sample_microfacet(m.roughness, up, rn);
-      if (rnl < dielectric_fresnel(entering ? m.ior : (1 / m.ior), dot(halfway, o))) return reflect_in_hemisphere(up, o, halfway);
-      auto incoming = refract(o, halfway, entering ? (1 / m.ior) : m.ior);
+      if (rnl < dielectric_fresnel(entering ? m.ior : rcp_(m.ior), dot(halfway, o))) return reflect_in_hemisphere(up, o, halfway);
+      auto incoming = refract(o, halfway, entering ? rcp_(m.ior) : m.ior);
       return same_hemisphere(up, o, incoming) ? vec3f{0, 0, 0} : incoming;
     }
     default: return {0, 0, 0};
@@ -325,7 +328,7 @@ YT_FN DeltaDielectric delta_refractive_terms(float ior, vec3f n, vec3f o, vec3f 
   auto no       = dot(n, o);
   auto entering = no >= 0;
   auto up       = entering ? n : -n;
-  auto rel_ior  = entering ? ior : (1 / ior);
+  auto rel_ior  = entering ? ior : rcp_(ior);
   return {dielectric_fresnel(rel_ior, dot(up, o)), rel_ior, dot(n, i) * no >= 0};
 }
 YT_FN vec3f eval_delta(const material_point& m, vec3f n, vec3f o, vec3f i) {
@@ -346,7 +349,7 @@ YT_FN vec3f eval_delta(const material_point& m, vec3f n, vec3f o, vec3f i) {
     case YTHIP_REFRACTIVE: {
       if ((double)fabs_(m.ior - 1) < 1e-3) return dot(n, i) * dot(n, o) <= 0 ? vec3f{1, 1, 1} : vec3f{0, 0, 0};
       auto t = delta_refractive_terms(m.ior, n, o, i);
-      return t.same_side ? vec3f{1, 1, 1} * t.fresnel : vec3f{1, 1, 1} * (1 / (t.rel_ior * t.rel_ior)) * (1 - t.fresnel);
+      return t.same_side ? vec3f{1, 1, 1} * t.fresnel : vec3f{1, 1, 1} * rcp_(t.rel_ior * t.rel_ior) * (1 - t.fresnel);
     }
     case YTHIP_VOLUMETRIC: return dot(n, i) * dot(n, o) >= 0 ? vec3f{0, 0, 0} : vec3f{1, 1, 1};  // passthrough
     default: return {0, 0, 0};
@@ -383,8 +386,8 @@ YT_FN vec3f sample_delta(const material_point& m, vec3f n, vec3f o, float rnl) {
       if ((double)fabs_(m.ior - 1) < 1e-3) return -o;
       auto entering = dot(n, o) >= 0;
       auto up       = entering ? n : -n;
-      auto rel_ior  = entering ? m.ior : (1 / m.ior);
-      return rnl < dielectric_fresnel(rel_ior, dot(up, o)) ? reflect(o, up) : refract(o, up, 1 / rel_ior);
+      auto rel_ior  = entering ? m.ior : rcp_(m.ior);
+      return rnl < dielectric_fresnel(rel_ior, dot(up, o)) ? reflect(o, up) : refract(o, up, rcp_(rel_ior));
     }
     case YTHIP_VOLUMETRIC: return -o;  // sample_passthrough
     default: return {0, 0, 0};
@@ -403,25 +406,25 @@ YT_FN vec3f eval_transmittance(vec3f density, float distance) { return exp_(-den
 YT_FN float sample_transmittance(vec3f density, float max_distance, float rl, float rd) {
   auto channel  = clamp_((int)(rl * 3), 0, 2);
   auto dch      = at(density, channel);
-  auto distance = (dch == 0) ? flt_max : -ytm::logf(1 - rd) / dch;
+  auto distance = (dch == 0) ? flt_max : div_(-ytm::logf(1 - rd), dch);
   return min_(distance, max_distance);
 }
 YT_FN float sample_transmittance_pdf(vec3f density, float distance, float max_distance) {
-  return distance < max_distance ? sum(density * exp_(-density * distance)) / 3 : sum(exp_(-density * max_distance)) / 3;
+  return distance < max_distance ? div_(sum(density * exp_(-density * distance)), 3) : div_(sum(exp_(-density * max_distance)), 3);
 }
 // Henyey-Greenstein
 YT_FN float eval_phasefunction(float anisotropy, vec3f outgoing, vec3f incoming) {
   auto cosine = -dot(outgoing, incoming);
   auto denom  = 1 + anisotropy * anisotropy - 2 * anisotropy * cosine;
-  return (1 - anisotropy * anisotropy) / (4 * pif * denom * sqrt_(denom));
+  return div_(1 - anisotropy * anisotropy, 4 * pif * denom * sqrt_(denom));
 }
 YT_FN vec3f sample_phasefunction(float anisotropy, vec3f outgoing, vec2f rn) {
   auto cos_theta = 0.0f;
   if (fabs_(anisotropy) < 1e-3f) {
     cos_theta = 1 - 2 * rn.y;
   } else {
-    auto square = (1 - anisotropy * anisotropy) / (1 + anisotropy - 2 * anisotropy * rn.y);
-    cos_theta   = (1 + anisotropy * anisotropy - square * square) / (2 * anisotropy);
+    auto square = div_(1 - anisotropy * anisotropy, 1 + anisotropy - 2 * anisotropy * rn.y);
+    cos_theta   = div_(1 + anisotropy * anisotropy - square * square, 2 * anisotropy);
   }
   auto  sin_theta = sqrt_(max_(0.0f, 1 - cos_theta * cos_theta));
   float sp, cp;
@@ -448,3 +451,7 @@ YT_FN vec3f sample_scattering(const volume_point& v, vec3f outgoing, float rnl, 
 }
 
 }  // namespace yt
+#ifdef YT_FAST
+#pragma clang fp contract(off)
+#endif
+

@@ -32,6 +32,12 @@ struct Bounce {
   hipEvent_t ev[N]   = {nullptr, nullptr, nullptr, nullptr};
   bool       busy[N] = {false, false, false, false};
   int        next    = 0;
+  // small uploads share a chunk (one 48-byte copy used to cost a whole 4-MiB slot and, from the fifth call
+  // on, an event wait): `cur` is the chunk being filled, `fill` its used bytes; its event is recorded when it is closed
+  static constexpr size_t SMALL = 256u << 10;
+  int         cur        = -1;
+  size_t      fill       = 0;
+  hipStream_t cur_stream = nullptr;
 
   hipError_t init() {
     if (buf[0]) return hipSuccess;
@@ -51,7 +57,15 @@ struct Bounce {
       if (buf[k]) (void)hipHostFree(buf[k]);
       ev[k] = nullptr, buf[k] = nullptr, busy[k] = false;
     }
-    next = 0;
+    next = 0, cur = -1, fill = 0;
+  }
+  // the shared chunk of the small uploads is complete: from now on it is busy until its last copy has run
+  hipError_t close_small() {
+    if (cur < 0) return hipSuccess;
+    hipError_t e = hipEventRecord(ev[cur], cur_stream);
+    busy[cur]    = e == hipSuccess;
+    cur = -1, fill = 0;
+    return e;
   }
   // host memory the device can address as it is: pinned by the caller or by this library
   static bool pinned(const void* p) {
@@ -77,8 +91,23 @@ struct Bounce {
   // (then it must stay valid until `s` has been synchronised, as with any asynchronous copy).
   hipError_t h2d(hipStream_t s, void* dst, const void* src, size_t bytes) {
     if (!bytes) return hipSuccess;
+    if (bytes <= SMALL) {  // (no pointer query either: copying a few KB costs less than asking)
+      hipError_t e = init();
+      if (e != hipSuccess) return e;
+      const size_t need = (bytes + 255) & ~(size_t)255;
+      if (cur >= 0 && (fill + need > CHUNK || cur_stream != s) && (e = close_small()) != hipSuccess) return e;
+      if (cur < 0) {
+        if ((e = acquire(&cur)) != hipSuccess) return cur = -1, e;
+        fill = 0, cur_stream = s;
+      }
+      std::memcpy((char*)buf[cur] + fill, src, bytes);
+      e = hipMemcpyAsync(dst, (char*)buf[cur] + fill, bytes, hipMemcpyHostToDevice, s);
+      fill += need;
+      return e;
+    }
     if (pinned(src)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
     hipError_t e = init();
+    if (e == hipSuccess) e = close_small();
     for (size_t off = 0; off < bytes && e == hipSuccess; off += CHUNK) {
       const size_t n = bytes - off < CHUNK ? bytes - off : CHUNK;
       int          k;
@@ -99,6 +128,7 @@ struct Bounce {
       return e == hipSuccess ? hipStreamSynchronize(s) : e;
     }
     hipError_t e = init();
+    if (e == hipSuccess) e = close_small();
     if (e != hipSuccess) return e;
     // the DMA of chunk c + 1 .. c + N - 1 runs while chunk c is copied out of its bounce buffer
     struct Pending {

@@ -173,7 +173,11 @@ struct ythip_ctx {
   int*               stop_host     = nullptr;  // pinned host word ythip_cancel stores the batch number into ...
   const int*         stop_host_dev = nullptr;  // ... and its device address (the kernels relay it into d_stop)
   ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
+  bool               last_launch_fast = false;  // the last k_trace launch ran the tolerance-mode kernels (yt_fast.hip)
 };
+
+// yt_fast.hip: the tolerance-mode kernels (same source, -DYT_FAST, own namespace); 0 = launched, 1 = no such kernel
+extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds, const void* st, const void* kp, int lp, int cls);
 
 static void drop_staging_views(ythip_ctx* ctx) {
   // host pools that view the staging memory go with it: the scene they belong to is no longer
@@ -282,6 +286,22 @@ KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
 // h_bvh is filled lazily by ensure_host_bvh()).  Host trees are baked here and
 // uploaded slice by slice, device trees are baked by kernels; both produce the
 // same bytes (tests/test_gpu_build.py).
+__global__ void __launch_bounds__(YT_BLOCK) k_gather_tinst(const DInstanceT* tinst, const int* tlas_prims, int n, int ninst,
+    DInstanceT* out) {
+  const int k = (int)(blockIdx.x * YT_BLOCK + threadIdx.x);
+  if (k >= n) return;
+  const int inst = tlas_prims[k];
+  if (inst < 0 || inst >= ninst) {  // (an uploaded tree with a bad instance id: an empty record, never entered)
+    DInstanceT e = {};
+    e.root_ref = REF_NONE, e.instance = -1;
+    out[k]     = e;
+    return;
+  }
+  DInstanceT r = tinst[inst];
+  r.instance   = inst;
+  out[k]       = r;
+}
+
 int bake_bvh(ythip_ctx* ctx) {
   auto& b        = ctx->h_bvh;
   int   nshapes  = (int)ctx->h_shapes.size();
@@ -621,6 +641,16 @@ int bake_bvh(ythip_ctx* ctx) {
                   (size_t)(b.prim_offset[nshapes + 1] - b.prim_offset[nshapes]))))
     return rc;
   if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tinst, tinst.data(), tinst.size()))) return rc;
+  {  // the records once more, in TLAS-leaf order: entering the k-th instance of a leaf is then ONE dependent fetch
+    const int64_t ntl = b.prim_offset[nshapes + 1] - b.prim_offset[nshapes];
+    DInstanceT*   d_tl = nullptr;
+    if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_tl, (size_t)ntl))) return rc;
+    if (ntl > 0)
+      hipLaunchKernelGGL(k_gather_tinst, dim3(grid_for(ntl)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds.tinst, ctx->ds.tlas_prims,
+          (int)ntl, (int)tinst.size(), d_tl);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->ds.tinst_leaf = d_tl;
+  }
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   ctx->have_bvh = true;
   return YTHIP_OK;
@@ -670,6 +700,10 @@ int build_bvh_mixed(ythip_ctx* ctx, const ythip_scene& sc, bool highquality, boo
   std::vector<ythost::tree> host_trees(nshapes);
   std::vector<char>         on_host(nshapes, 0);
   for (int k = 0; k < nshapes; k++) on_host[k] = !(use_device && prims_of(sc.shapes[k]) >= ctx->device_build_min_prims);
+  // what the worker threads may touch: the shapes that were host shapes BEFORE the threads started.  (they
+  // used to test on_host[], which this thread edits when a device build falls back — a worker could then build and
+  // assign the same host_trees[k] concurrently.)  Fallbacks belong to this thread alone.
+  const std::vector<char> worker_shapes = on_host;
   std::atomic<int>         next_shape{0};
   std::vector<std::thread> workers;
   {
@@ -680,7 +714,7 @@ int build_bvh_mixed(ythip_ctx* ctx, const ythip_scene& sc, bool highquality, boo
     if (const char* e = std::getenv("YTHIP_BUILD_THREADS")) want = (unsigned)std::max(0, std::atoi(e));
     auto work = [&]() {
       for (int k; (k = next_shape.fetch_add(1)) < nshapes;)
-        if (on_host[k]) host_trees[k] = ythost::make_shape_bvh(sc, sc.shapes[k], highquality);
+        if (worker_shapes[k]) host_trees[k] = ythost::make_shape_bvh(sc, sc.shapes[k], highquality);
     };
     for (unsigned t = 0; t < want; t++) workers.emplace_back(work);
     ctx->build_info.host_threads = (int)want;
@@ -839,7 +873,16 @@ void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
 
 // lp: LP_NONE / LP_DEFER for path & pathtest (area lights absent / present);
 // pathdirect & pathmis always trace inline; the rest never need a light pdf.
-int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count) {
+// fast: ythip_params::fastmath — the tolerance-mode kernels of yt_fast.hip where they exist (wide walk, real samplers).
+int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count, bool fast = false) {
+  if (fast && !count && ctx->use_wide()) {
+    const int cls = kp.sampler == YTHIP_SAMPLER_PATH && ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : 0) : 0;
+    if (ythip_fast_launch(ctx->stream, ctx->launch_blocks(), &ctx->ds, &ctx->st, &kp, lp, cls) == 0) {
+      ctx->last_launch_fast = true;
+      return YTHIP_OK;
+    }
+  }
+  ctx->last_launch_fast = false;
   switch (kp.sampler) {
     case YTHIP_SAMPLER_PATH:
       if (!count && ctx->all_matte && ctx->specialize && ctx->use_wide()) {
@@ -1019,8 +1062,9 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   }
   if (pool) {
     if (!ctx->d_pool_next) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_pool_next, 64));
-    HIPCHECK(ctx, hipMemsetAsync(ctx->d_pool_next, 0, 64, ctx->stream));
     ctx->st.pool_next = ctx->d_pool_next, ctx->st.pool_total = ctx->st.nblocks * YT_BLOCK;
+    // the queue's head starts behind the statically assigned first tiles (workgroup b owns entries [64 b, 64 b + 64): k_trace)
+    HIPCHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_pool_next, ctx->launch_blocks() * YT_BLOCK, 16, ctx->stream));
   }
   const bool lpt = ctx->d_tile_cost && only_pix < 0 && !count;
   if (lpt) {
@@ -1037,7 +1081,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   {
     EvScope ev(ctx, 0);
     if (timed >= 0) HIPCHECK(ctx, hipEventRecord(ctx->pool_ev[2 * timed], ctx->stream));
-    int rc = launch_trace_any(ctx, kp, lp, count);
+    int rc = launch_trace_any(ctx, kp, lp, count, params->fastmath != 0);
     if (rc) return rc;
     if (timed >= 0) {
       HIPCHECK(ctx, hipEventRecord(ctx->pool_ev[2 * timed + 1], ctx->stream));
@@ -1450,6 +1494,15 @@ int ythip_update_shape_vertices(ythip_ctx* ctx, int32_t shape, const float* posi
   return YTHIP_OK;
 }
 
+namespace {
+// many edited frames travel as two compact arrays and are put in place by the device (one copy per 48-byte
+// frame was one bounce slot, one event and one DMA descriptor each)
+__global__ void __launch_bounds__(64) k_scatter_frames(ythip_instance* instances, const int32_t* ids, const ythip_frame* frames, int n) {
+  const int k = (int)(blockIdx.x * 64 + threadIdx.x);
+  if (k < n) instances[ids[k]].frame = frames[k];
+}
+}  // namespace
+
 int ythip_update_instance_frames(ythip_ctx* ctx, const int32_t* instances, int32_t num, const ythip_frame* frames) {
   if (!ctx || (num > 0 && (!instances || !frames))) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
@@ -1457,10 +1510,31 @@ int ythip_update_instance_frames(ythip_ctx* ctx, const int32_t* instances, int32
     if (instances[k] < 0 || instances[k] >= (int)ctx->h_instances.size())
       return fail(ctx, YTHIP_ERR_INVALID, "instance %d out of range [0,%d)", instances[k], (int)ctx->h_instances.size());
   HIPCHECK(ctx, hipSetDevice(ctx->device));
-  for (int k = 0; k < num; k++) {
-    ctx->h_instances[instances[k]].frame = frames[k];
-    HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)&ctx->ds.instances[instances[k]].frame, &frames[k], sizeof(ythip_frame)));
+  bool scatter = num >= 64;
+  if (scatter) {  // (an instance named twice keeps its LAST frame, as a loop of assignments would: those go one by one)
+    std::vector<char> seen(ctx->h_instances.size(), 0);
+    for (int k = 0; k < num && scatter; k++) scatter = !seen[instances[k]], seen[instances[k]] = 1;
   }
+  for (int k = 0; k < num; k++) ctx->h_instances[instances[k]].frame = frames[k];
+  if (scatter) {
+    std::vector<void*> tmp;
+    const int32_t*     d_ids    = nullptr;
+    const ythip_frame* d_frames = nullptr;
+    int                rc;
+    if ((rc = dupload(ctx, tmp, &d_ids, instances, (size_t)num)) || (rc = dupload(ctx, tmp, &d_frames, frames, (size_t)num))) {
+      free_all(tmp);
+      return rc;
+    }
+    hipLaunchKernelGGL(k_scatter_frames, dim3((num + 63) / 64), dim3(64), 0, ctx->stream, (ythip_instance*)ctx->ds.instances,
+        d_ids, d_frames, (int)num);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    free_all(tmp);
+    HIPCHECK(ctx, e);
+    return YTHIP_OK;
+  }
+  for (int k = 0; k < num; k++)
+    HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)&ctx->ds.instances[instances[k]].frame, &frames[k], sizeof(ythip_frame)));
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
   return YTHIP_OK;
 }
@@ -1530,15 +1604,27 @@ int ythip_update_bvh(ythip_ctx* ctx, const int32_t* updated_instances, int32_t n
     const auto& inst = ctx->h_instances[k];
     bboxes[k]        = empty[inst.shape] ? ythost::bbox{} : ythost::transform_bbox(inst.frame, roots[inst.shape]);
   }
-  if (on_device(nshapes)) {  // an instance tree that was built on the device is refitted on the host: bring it home
-    int rc0 = ensure_host_bvh(ctx);
-    if (rc0) return rc0;
-    ytgpu::free_tree(&ctx->d_trees[nshapes]);
-    ctx->d_trees.pop_back();
-    ctx->d_tree_on_host.pop_back();
+  if (on_device(nshapes)) {
+    // an instance tree that was built on the device is refitted there too (kind 0: the instances' boxes are the
+    // primitives) and stays there.  (it used to be brought home through ensure_host_bvh — which downloads EVERY
+    // device-resident shape tree — refitted on the host and dropped from the device for good.)
+    static_assert(sizeof(ythost::bbox) == 6 * sizeof(float), "bbox is {min, max}");
+    float* d_boxes = nullptr;
+    HIPCHECK(ctx, hipMalloc((void**)&d_boxes, bboxes.size() * sizeof(ythost::bbox)));
+    hipError_t  e = ctx->xfer.h2d(ctx->stream, d_boxes, bboxes.data(), bboxes.size() * sizeof(ythost::bbox));
+    std::string err;
+    int brc = e == hipSuccess ? ytgpu::refit_shape_tree(ctx->stream, ctx->d_trees[nshapes], 0, nullptr, d_boxes, nullptr, &err)
+                              : ytgpu::BUILD_ERROR;
+    (void)hipFree(d_boxes);
+    if (brc != ytgpu::BUILD_OK)
+      return fail(ctx, YTHIP_ERR_HIP, "device instance-tree refit failed: %s", e != hipSuccess ? hipGetErrorString(e) : err.c_str());
+    ctx->d_tree_on_host[nshapes] = 0;  // the host copy of the instance tree is stale now
+    ctx->build_info.device_tlas  = 1;
+    ctx->build_info.device_ms += ctx->d_trees[nshapes].build_ms;
+  } else {
+    ythost::refit_bvh(b.nodes.data() + b.node_offset[nshapes], b.node_offset[nshapes + 1] - b.node_offset[nshapes],
+        b.prims.data() + b.prim_offset[nshapes], bboxes);
   }
-  ythost::refit_bvh(b.nodes.data() + b.node_offset[nshapes], b.node_offset[nshapes + 1] - b.node_offset[nshapes],
-      b.prims.data() + b.prim_offset[nshapes], bboxes);
   ctx->build_info.build_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   auto t_bake = std::chrono::steady_clock::now();
@@ -2149,6 +2235,8 @@ int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info) {
   }
   return YTHIP_OK;
 }
+
+int ythip_last_launch_fastmath(ythip_ctx* ctx) { return ctx && ctx->last_launch_fast ? 1 : 0; }
 
 int ythip_cancel(ythip_ctx* ctx) {
   if (!ctx) return YTHIP_ERR_INVALID;

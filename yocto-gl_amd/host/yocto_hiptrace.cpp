@@ -10,19 +10,26 @@
 //
 #include "yocto_hiptrace.h"
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <future>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ythip.h"
+#include "yt_stamp.h"
 
 namespace yocto::hip {
 
@@ -184,8 +191,18 @@ void flatten(const trace_lights& l, flat_lights& f) {
   f.view = {(int)f.lights.size(), f.lights.data(), (int64_t)f.cdf.size(), f.cdf.data()};
 }
 
+// the tolerance mode (ythip_params::fastmath) is not a field of the reference's trace_params: a process-wide switch
+std::atomic<bool>& fast_math() {
+  static std::atomic<bool> on{[] {
+    auto e = std::getenv("YOCTO_HIP_FASTMATH");
+    return e && std::atoi(e) != 0;
+  }()};
+  return on;
+}
+
 ythip_params flat(const trace_params& p) {
   ythip_params q   = {};
+  q.fastmath       = fast_math().load() ? 1 : 0;
   q.camera         = p.camera;
   q.resolution     = p.resolution;
   q.sampler        = (int)p.sampler;
@@ -209,37 +226,21 @@ ythip_params flat(const trace_params& p) {
 // ---------------------------------------------------------------------------
 // residency cache
 // ---------------------------------------------------------------------------
-// The reference reads scene / bvh / lights fresh on every trace_samples call; the device
-// mirrors must notice edits.  A stamp = the object's identity + a CONTENT hash:
+// The reference reads scene / bvh / lights fresh on every trace_samples call
+// (yocto_trace.cpp:1595-1619: they are arguments); the device mirrors must notice edits.  A
+// stamp = the object's identity + a CONTENT hash:
 //   * small pools (cameras, materials, environments, instances): hashed in full on every
 //     call — a material edited in place by the GUI is seen, and only that pool is re-sent;
 //   * large arrays (vertices, elements, texture pixels, bvh nodes, light cdfs): their size,
-//     their storage address and a strided sample of 256 elements each (what a refit, a
-//     re-tesselation or a texture reload changes); an edit that keeps all of these can be
-//     announced with hip::invalidate().
-using hash_t = uint64_t;
-hash_t fnv(const void* data, size_t bytes, hash_t h = 1469598103934665603ull) {
-  auto p = (const unsigned char*)data;
-  for (size_t k = 0; k < bytes; k++) h = (h ^ p[k]) * 1099511628211ull;
-  return h;
-}
-template <typename T>
-hash_t fnv_all(const std::vector<T>& v, hash_t h) {
-  auto n = v.size();
-  h      = fnv(&n, sizeof(n), h);
-  return v.empty() ? h : fnv(v.data(), v.size() * sizeof(T), h);
-}
-template <typename T>
-hash_t fnv_sampled(const std::vector<T>& v, hash_t h) {
-  auto n = v.size();
-  auto a = (uintptr_t)v.data();
-  h      = fnv(&n, sizeof(n), h);
-  h      = fnv(&a, sizeof(a), h);
-  if (n == 0) return h;
-  if (n <= 256) return fnv(v.data(), n * sizeof(T), h);
-  for (size_t k = 0; k < 256; k++) h = fnv(&v[(size_t)((unsigned __int128)k * (n - 1) / 255)], sizeof(T), h);
-  return h;
-}
+//     their storage address and — by default — a 64-bit hash of EVERY byte, computed in 1-MiB
+//     pieces on a pool of host threads (memory-bound: ~1 ms per 100 MB on a server host).  An
+//     in-place edit of one vertex or one texel is therefore seen like any other, as in the
+//     reference.  (Until round 3 the large arrays were hashed through a 256-element strided
+//     sample: an edit that missed the sample rendered the old data, silently.)
+//     hip::set_residency_check(residency_sampled) / YOCTO_HIP_RESIDENCY=sampled brings the
+//     sample back for loops that call trace_samples thousands of times a second on a large
+//     scene and promise to announce such edits with hip::invalidate().
+using namespace stamp;  // yt_stamp.h: hash_t, fnv, array_hasher, residency_mode
 
 struct scene_stamp {
   const void* who = nullptr;
@@ -258,17 +259,18 @@ scene_stamp stamp_of(const scene_data& s) {
   // instances: frames feed the instance tree and the traversal records, so they belong to the layout
   static_assert(sizeof(instance_data) == 56, "instance_data layout");
   h = fnv_all(s.instances, h);
+  array_hasher big;
   for (auto& sh : s.shapes) {
-    h = fnv_sampled(sh.points, h), h = fnv_sampled(sh.lines, h), h = fnv_sampled(sh.triangles, h);
-    h = fnv_sampled(sh.quads, h), h = fnv_sampled(sh.positions, h), h = fnv_sampled(sh.normals, h);
-    h = fnv_sampled(sh.texcoords, h), h = fnv_sampled(sh.colors, h), h = fnv_sampled(sh.radius, h);
+    big.add(sh.points), big.add(sh.lines), big.add(sh.triangles), big.add(sh.quads), big.add(sh.positions);
+    big.add(sh.normals), big.add(sh.texcoords), big.add(sh.colors), big.add(sh.radius);
   }
   for (auto& t : s.textures) {
     int f[] = {t.width, t.height, t.linear, t.nearest, t.clamp};
     h       = fnv(f, sizeof(f), h);
-    h = fnv_sampled(t.pixelsf, h), h = fnv_sampled(t.pixelsb, h);
+    big.add(t.pixelsf), big.add(t.pixelsb);
   }
-  st.layout = h;
+  auto hb   = big.finish();
+  st.layout = fnv(&hb, sizeof(hb), h);
   hash_t c  = 1469598103934665603ull;
   for (auto& cam : s.cameras) {
     auto f = flat(cam);
@@ -287,19 +289,23 @@ scene_stamp stamp_of(const scene_data& s) {
 // (a trace_bvh is identified by its node storage, not by the object's address: it is
 // returned by value from make_trace_bvh and moved into the caller's variable)
 hash_t stamp_of(const trace_bvh& b) {
-  hash_t h = fnv_sampled(b.bvh.bvh.nodes, 1469598103934665603ull);
-  h        = fnv_sampled(b.bvh.bvh.primitives, h);
-  for (auto& s : b.bvh.shapes) h = fnv_sampled(s.bvh.nodes, h), h = fnv_sampled(s.bvh.primitives, h);
+  array_hasher big;
+  big.add(b.bvh.bvh.nodes), big.add(b.bvh.bvh.primitives);
+  for (auto& s : b.bvh.shapes) big.add(s.bvh.nodes), big.add(s.bvh.primitives);
+  hash_t h = big.finish();
   return h ? h : 1;
 }
 hash_t stamp_of(const trace_lights& l) {
-  auto   a = (uintptr_t)&l;
-  hash_t h = fnv(&a, sizeof(a));
+  auto         a = (uintptr_t)&l;
+  hash_t       h = fnv(&a, sizeof(a));
+  array_hasher big;
   for (auto& x : l.lights) {
     int ids[] = {x.instance, x.environment};
     h         = fnv(ids, sizeof(ids), h);
-    h         = fnv_sampled(x.elements_cdf, h);
+    big.add(x.elements_cdf);
   }
+  auto hb = big.finish();
+  h       = fnv(&hb, sizeof(hb), h);
   return h ? h : 1;
 }
 
@@ -327,15 +333,24 @@ struct residency {
   std::vector<shadow_state> shadows;
   ythip_scene  staged      = {};       // rank 0's pinned staging pools (the flat scene, filled in place)
   bool         have_staged = false;
-  // trace_cancel's relay: the worker of trace_start hands this word to the library as the batch's
-  // `stop` flag (libythip polls it every 50 us while the batch runs and cancels the batch by its
-  // number); trace_cancel only stores to it — it touches nothing else of this struct, so it needs
-  // no lock and cannot race with ensure_context() / release()
-  std::atomic<int32_t> cancel{0};
-  static_assert(sizeof(std::atomic<int32_t>) == sizeof(int32_t) && std::atomic<int32_t>::is_always_lock_free,
-      "the relay word is read by libythip as a plain volatile int32_t");
   ythip_ctx*   ctx(int r = 0) { return ythip_multi_ctx(multi, r); }
 };
+// trace_cancel's relay words, one per trace_context (one global word made a cancel of context A end a batch
+// of context B too, and trace_start's reset could erase a cancel meant for a batch still in flight).  trace_start makes
+// a fresh word for its context and its worker hands that word to the library as the batch's `stop` flag (libythip
+// polls it while the batch runs and cancels the batch by its number); trace_cancel raises the word of ITS context and
+// nothing else.  A word lives as long as somebody holds it (the worker, the table).
+using cancel_word = std::atomic<int32_t>;
+static_assert(sizeof(cancel_word) == sizeof(int32_t) && cancel_word::is_always_lock_free,
+    "the relay word is read by libythip as a plain volatile int32_t");
+struct cancel_table {
+  std::mutex                                                             mutex;
+  std::unordered_map<const trace_context*, std::shared_ptr<cancel_word>> words;
+};
+cancel_table& cancel_words() {
+  static cancel_table t;
+  return t;
+}
 residency& cache() {
   static residency r;
   return r;
@@ -627,7 +642,7 @@ void ensure_state(residency& r, trace_state& state, const scene_data& scene, con
 }
 
 void trace_impl(trace_state& state, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights,
-    const trace_params& params, bool download, const std::atomic<bool>* stop = nullptr) {
+    const trace_params& params, bool download, const std::atomic<bool>* stop = nullptr, const cancel_word* relay = nullptr) {
   if (state.samples >= params.samples) return;  // yocto_trace.cpp:1598
   if (params.embreebvh) throw std::invalid_argument("yocto::hip::trace_samples: embreebvh has no device mirror");
   auto& r = cache();
@@ -635,7 +650,7 @@ void trace_impl(trace_state& state, const scene_data& scene, const trace_bvh& bv
   ensure_state(r, state, scene, bvh, lights);
   if (stop && stop->load()) return;  // cancelled during the uploads: nothing is launched
   auto p  = flat(params);
-  auto rc = ythip_multi_trace_samples(r.multi, &p, stop ? reinterpret_cast<const volatile int32_t*>(&r.cancel) : nullptr);
+  auto rc = ythip_multi_trace_samples(r.multi, &p, relay ? reinterpret_cast<const volatile int32_t*>(relay) : nullptr);
   if (rc != YTHIP_OK && rc != YTHIP_ERR_CANCELLED) mcheck(r, rc);
   if (rc == YTHIP_ERR_CANCELLED || (stop && stop->load())) {
     // cancelled while the batch ran (trace_cancel raised the device flags): as in the
@@ -743,6 +758,16 @@ void invalidate() {
   r.scene    = {};
   r.bvh = r.lights = 0;
 }
+void set_fast_math(bool on) { fast_math().store(on); }
+bool get_fast_math() { return fast_math().load(); }
+void set_residency_check(residency_check mode) {
+  auto& r    = cache();
+  auto  lock = std::lock_guard{r.mutex};
+  residency_mode().store(mode == residency_sampled ? 1 : 0);
+  r.scene = {};  // stamps taken one way do not compare with stamps taken the other way
+  r.bvh = r.lights = 0;
+}
+residency_check get_residency_check() { return residency_mode().load() == 1 ? residency_sampled : residency_full; }
 
 // make_trace_state — yocto_trace.cpp:1495-1520, through libythip's own builders (the image-size
 // rule ythip_state_size, the serial master stream ythip_make_rngs): the same code the
@@ -1112,10 +1137,15 @@ void trace_start(trace_context& context, trace_state& state, const scene_data& s
   if (state.samples >= params.samples) return;
   context.stop   = false;
   context.done   = false;
-  cache().cancel.store(0);
-  context.worker = std::async(std::launch::async, [&]() {
+  auto word      = std::make_shared<cancel_word>(0);
+  {
+    auto& t    = cancel_words();
+    auto  lock = std::lock_guard{t.mutex};
+    t.words[&context] = word;  // (replaces the word of an earlier batch of this context: that batch has been joined)
+  }
+  context.worker = std::async(std::launch::async, [&, word]() {
     if (context.stop) return;
-    trace_impl(state, scene, bvh, lights, params, false, &context.stop);  // includes the denoise hand-off
+    trace_impl(state, scene, bvh, lights, params, false, &context.stop, word.get());  // includes the denoise hand-off
     if (context.stop) return;
     context.done = true;
   });
@@ -1126,7 +1156,13 @@ void trace_start(trace_context& context, trace_state& state, const scene_data& s
 // about one sample's time instead of running to its end.
 void trace_cancel(trace_context& context) {
   context.stop = true;
-  cache().cancel.store(1);  // the library relays it to the batch in flight (residency::cancel)
+  std::shared_ptr<cancel_word> word;
+  {
+    auto& t    = cancel_words();
+    auto  lock = std::lock_guard{t.mutex};
+    if (auto it = t.words.find(&context); it != t.words.end()) word = it->second, t.words.erase(it);
+  }
+  if (word) word->store(1);  // the library relays it to this context's batch in flight, and to no other
   if (context.worker.valid()) context.worker.get();
 }
 // trace_preview — yocto_trace.cpp:1660-1676

@@ -42,14 +42,31 @@ bool hip_supported();
 // framebuffer gather (libythip's ythip_multi).
 int hip_device_count();
 
+// Arithmetic mode of the accelerated calls.  Default (false): every float of `state` is the CPU
+// tracer's, bit for bit.  true (or YOCTO_HIP_FASTMATH=1 in the environment): libythip's tolerance
+// mode — same integrators, same rng streams, same hit records for a given ray, but shading /
+// sampling / camera arithmetic on the GPU's fast forms (reciprocals, hardware sin / cos / exp /
+// log / sqrt, fused multiply-adds; include/ythip.h: ythip_params::fastmath).  The image then agrees
+// with the CPU tracer's statistically (mean within 0.5 %, block error below the tracer's own
+// seed-to-seed spread), not bit for bit; trace_params has no such field, hence a switch.
+void set_fast_math(bool on);
+bool get_fast_math();
+
 // The device mirrors follow in-place edits of the scene the way the reference does (it
 // reads everything fresh on every call): cameras, materials, environments and instances
-// are compared by content on every call, large arrays (vertices, elements, texture
-// pixels, bvh nodes, light cdfs) by size, storage address and a 256-element content
-// sample.  An edit that escapes the sample (a few vertices moved without
-// update_trace_bvh, a few texels repainted) is announced with invalidate(): the next
-// call uploads scene, bvh and lights again.
-void invalidate();
+// are compared by content on every call, and so are the large arrays (vertices, elements,
+// texture pixels, bvh nodes, light cdfs) — size, storage address and a 64-bit hash of every
+// byte, computed on a pool of host threads (about 1 ms per 100 MB).  One moved vertex or one
+// repainted texel is seen and re-sent like any other edit.
+//   residency_sampled (or YOCTO_HIP_RESIDENCY=sampled in the environment) replaces the full
+// hash of the large arrays by a 256-element strided sample each — for loops that call
+// trace_samples thousands of times a second on a large scene.  Under it an edit that
+// misses the sample (a few vertices moved without update_trace_bvh, a few texels repainted)
+// MUST be announced with invalidate(): the next call then uploads scene, bvh and lights again.
+enum residency_check { residency_full = 0, residency_sampled = 1 };
+void            set_residency_check(residency_check mode);
+residency_check get_residency_check();
+void            invalidate();
 
 // Scene ingest goes straight from scene_data into libythip's pinned staging pools
 // (ythip_scene_staging: one copy of the geometry instead of three, DMA upload).  This test

@@ -164,6 +164,23 @@ def load_scene(path):
     return sc
 
 
+def load_corpus_scene(name, root=None):
+    """A scene of the reference's own test corpus (tests/_version43: features1, materials1-4, ...) from the committed
+    fixtures tests/golden/scenes/<name>.json + blobs/ — the flat pools the reference's load_scene + tesselate_subdivs
+    produced, stored by content hash (tests/golden/make_scene_fixtures.py).  Textured, mixed-material scenes: what the
+    general kernel class renders."""
+    import json
+    import os
+    if root is None:
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes")
+    with open(os.path.join(root, name + ".json")) as f:
+        manifest = json.load(f)
+    sc = FlatScene()
+    for field, key in manifest.items():
+        setattr(sc, field, np.load(os.path.join(root, "blobs", key + ".npz"))["a"])
+    return sc
+
+
 def cornell_1m_scene(base, n=316):
     """cfg2b (the north star's "1M-triangle Cornell-box-style scene"):
     the reference's Cornell box `base` (make_cornellbox, yocto_scene.cpp:970-1075, as
@@ -194,32 +211,67 @@ def cornell_1m_scene(base, n=316):
     return sc
 
 
-def hair_scene_synthetic(strands=100000, steps=8, length=0.2, radius=(0.002, 0.001), seed=7):
-    """BASELINE configs[4] for bench.py: `strands` straight hairs of `steps`
-    segments grown along the normals of a unit sphere (what make_hair(make_sphere(32, 1),
-    {8, 100000}, {0.2, 0.2}, {0.002, 0.001}) builds, yocto_shape.cpp:1264-1334, without
-    noise / clumping) — 800,000 line segments, 900,000 vertices with radii — over a matte
-    base sphere, subsurface hair material, constant environment, the camera of the parity
-    tests.  The strand roots are seeded numpy draws, not the reference's sample_shape
-    stream (whose geometry is compiler-dependent): the parity
-    tests (tests/test_gpu_baseline_configs.py) use the reference's own arrays, this
-    generator keeps bench.py free of anything under oracle/."""
-    rng = np.random.default_rng(seed)
+def _pcg32_floats(seed, seq, n):
+    """rand1f(rng) x n of make_rng(seed, seq) — yocto_sampling.h:187-232 (PCG32, integer-exact)."""
+    M = (1 << 64) - 1
+    inc = ((seq << 1) | 1) & M
+    state = 0
+
+    def advance():
+        nonlocal state
+        old = state
+        state = (old * 6364136223846793005 + inc) & M
+        xs = (((old >> 18) ^ old) >> 27) & 0xffffffff
+        rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xffffffff
+
+    advance()
+    state = (state + seed) & M
+    advance()
+    bits = np.fromiter(((advance() >> 9) | 0x3f800000 for _ in range(n)), np.uint32, n)
+    return bits.view(np.float32) - f32(1)
+
+
+HAIR_ROOTS = None  # tests/golden/hair_roots.npz (set by the first call)
+
+
+def hair_scene(roots_file=None, steps=8, length=(0.2, 0.2), radius=(0.002, 0.001), seed=7):
+    """BASELINE configs[4] exactly: make_hair(make_sphere(32, 1), {8, 100000}, {0.2, 0.2},
+    {0.002, 0.001}) — 800,000 line segments on 900,000 vertices with radii — over its base sphere, subsurface hair
+    material, matte base, constant environment, the camera of the parity tests.  The strand roots / normals are the
+    g++ reference's sample_shape output (the one compiler-dependent part, stored in tests/golden/hair_roots.npz by
+    tests/golden/make_hair_fixture.py); the rest of make_hair (yocto_shape.cpp:1279-1305 with noise = clump = 0) is
+    restated here in float32 with the reference's operation order and checked against the reference's arrays byte for
+    byte (tests/test_host.py), so bench.py renders the scene the parity tests render without touching oracle/."""
+    import os
+    global HAIR_ROOTS
+    if roots_file is None:
+        roots_file = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "hair_roots.npz")
+    if HAIR_ROOTS is None or HAIR_ROOTS[0] != roots_file:
+        z = np.load(roots_file)
+        HAIR_ROOTS = (roots_file, z["roots"].astype(f32), z["normals"].astype(f32),
+                      {k[5:]: z[k] for k in z.files if k.startswith("base_")})  # make_sphere(32, 1) as the reference built it
+    bpos, bnorm = HAIR_ROOTS[1], HAIR_ROOTS[2]
+    base = HAIR_ROOTS[3]
+    strands = len(bpos)
     sc = FlatScene()
     sc.add_camera(lookat_frame((0, 0.5, 3.2), (0, 0, 0)), lens=0.035, film=0.036, aspect=16 / 9,
-                  focus=float(np.sqrt(0.25 + 3.2 * 3.2)), aperture=0.0)
-    base = triangulated(make_uvsphere((64, 32), 1.0))
+                  focus=float(np.sqrt(f32(0.5 * 0.5 + 3.2 * 3.2), dtype=f32)), aperture=0.0)
     s_base = add_shape(sc, base)
-    z = rng.uniform(-1, 1, strands)
-    phi = rng.uniform(0, 2 * np.pi, strands)
-    rxy = np.sqrt(1 - z * z)
-    nrm = np.stack([rxy * np.cos(phi), z, rxy * np.sin(phi)], -1).astype(f32)
-    u = (np.arange(steps + 1, dtype=f32) / f32(steps))
-    pos = (nrm[:, None, :] * (f32(1) + u[None, :, None] * f32(length))).reshape(-1, 3).astype(f32)
+    # blen = lerp(len.x, len.y, rand1f(rng)) with rng = make_rng(seed, 3)
+    r = _pcg32_floats(seed, 3, strands)
+    blen = (f32(length[0]) * (f32(1) - r) + f32(length[1]) * r).astype(f32)
+    # make_lines(steps, ...): u = i / steps.x per vertex of a strand; positions = bpos + bnorm * u * blen
+    u = (np.arange(steps + 1, dtype=f32) / f32(steps)).astype(f32)
+    pos = (bpos[:, None, :] + (bnorm[:, None, :] * u[None, :, None]) * blen[:, None, None]).astype(f32).reshape(-1, 3)
+    nrm = np.repeat(bnorm, steps + 1, 0)
     rad = np.tile((f32(radius[0]) * (f32(1) - u) + f32(radius[1]) * u).astype(f32), strands)
+    v = (np.arange(steps + 1, dtype=f32) / f32(steps))  # make_lines texcoords: {i / steps.x, j / steps.y}
+    w = (np.arange(strands, dtype=f32) / f32(strands - 1)) if strands > 1 else np.zeros(1, f32)
+    tex = np.stack([np.tile(v, strands), np.repeat(w, steps + 1)], -1).astype(f32)
     k = (np.arange(strands, dtype=np.int32) * (steps + 1))[:, None] + np.arange(steps, dtype=np.int32)[None, :]
     lines = np.stack([k, k + 1], -1).reshape(-1, 2).astype(np.int32)
-    s_hair = sc.add_shape(pos, lines=lines, normals=np.repeat(nrm, steps + 1, 0), radius=rad)
+    s_hair = sc.add_shape(pos, lines=lines, normals=nrm, texcoords=tex, radius=rad)
     m_base = sc.add_material(type="matte", color=(0.7, 0.7, 0.7))
     m_hair = sc.add_material(type="subsurface", color=(0.8, 0.6, 0.4), roughness=0.3, scattering=(0.5, 0.5, 0.5))
     sc.add_instance(s_base, m_base)

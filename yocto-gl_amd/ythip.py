@@ -124,7 +124,7 @@ class CParams(C.Structure):
                 ("seed", C.c_uint64), ("embreebvh", C.c_int32),
                 ("highqualitybvh", C.c_int32), ("noparallel", C.c_int32),
                 ("pratio", C.c_int32), ("denoise", C.c_int32),
-                ("batch", C.c_int32)]
+                ("batch", C.c_int32), ("fastmath", C.c_int32)]
 
 
 TRACE_DEFAULT_SEED = 961748941
@@ -134,7 +134,7 @@ def trace_params(**kw):
     p = CParams(camera=0, resolution=1280, sampler=0, falsecolor=7, samples=512,
                 bounces=8, clamp=10.0, nocaustics=0, envhidden=0, tentfilter=0,
                 seed=TRACE_DEFAULT_SEED, embreebvh=0, highqualitybvh=0,
-                noparallel=0, pratio=8, denoise=0, batch=1)
+                noparallel=0, pratio=8, denoise=0, batch=1, fastmath=0)
     for k, v in kw.items():
         if k == "sampler" and isinstance(v, str):
             v = SAMPLERS.index(v)
@@ -503,6 +503,7 @@ _SIGNATURES = {
     "ythip_io_last_error": (C.c_char_p, []),
     "ythip_set_pixel_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ythip_get_pixel_pool": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_last_launch_fastmath": (C.c_int, [C.c_void_p]),
     "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "ythip_ply_read": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9),
     "ythip_ply_close": (None, [C.c_void_p]),
@@ -742,6 +743,10 @@ class Context:
         info = CPoolInfo()
         self._check(self.lib.ythip_get_pixel_pool(self.h, C.byref(info)), "get_pixel_pool")
         return {k: getattr(info, k) for k, _ in CPoolInfo._fields_}
+
+    def last_launch_fastmath(self):
+        """True when the last trace launch ran the tolerance-mode kernels (params.fastmath, yt_fast.hip)."""
+        return bool(self.lib.ythip_last_launch_fastmath(self.h))
 
     def update_cameras(self, cameras):
         """Re-upload only the cameras (interactive camera edits, apps/ytrace.cpp:189-204)."""
