@@ -184,7 +184,7 @@ def collect_counters(name, device, timeout=240, fastmath=0):
     return _collect_counters(name, device, timeout, fastmath)
 
 
-def _collect_counters(name, device, timeout=240, fastmath=0):
+def _collect_counters(name, device, timeout=240, fastmath=0, passes=None):
     """Per-launch counter means of the workload's k_trace launches, from separate
     rocprofv3 --pmc passes of `bench.py --worker name` (counters only: never combined with
     tracing).  Returns (dict counter -> per-launch mean, kernel name) or (None, reason)."""
@@ -192,7 +192,7 @@ def _collect_counters(name, device, timeout=240, fastmath=0):
     if prof is None:
         return None, "rocprofv3 not found"
     vals, kernel = {}, None
-    for counters in PMC_PASSES:
+    for counters in (passes or PMC_PASSES):
         out = tempfile.mkdtemp(prefix="ythip_pmc_", dir="/tmp")
         cmd = [prof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--",
                                             sys.executable, os.path.abspath(__file__), "--worker", name,
@@ -523,7 +523,22 @@ def main():
                              always=args.rehearse_gather) if gathering else None
         snapshot = torch.empty_like(image) if comm is not None else None
 
+        # N > 1: where a step's time goes on THIS rank — events on the kernel stream around the rank's slice (k_trace) and
+        # around the framebuffer gather, summed over the timed steps, so that a run explains its own scaling efficiency
+        # (a slow rank: slice_ms; an expensive collective: gather_ms; waiting for the slowest rank shows up as gather time
+        # of the fast ranks)
+        ev = [] if gathering and comm is None else None
+
         def step():
+            if ev is not None and timing[0]:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record(stream)
+                ctx.trace_samples_async(p)
+                e1.record(stream)
+                gather.frame(image)
+                e2.record(stream)
+                ev.append((e0, e1, e2))
+                return
             ctx.trace_samples_async(p)
             if not gathering:
                 return
@@ -555,11 +570,21 @@ def main():
         ctx.set_profiling(1 if want_roofline else 0)  # hipEvents around the k_trace launches
         ctx.reset_stats()
         fence()
+        timing[0] = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         dt = time.perf_counter() - t0
+        timing[0] = False
+        if ev:
+            mine = torch.tensor([sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev),
+                                 sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)],
+                                device=dev if backend == "nccl" else "cpu", dtype=torch.float64)  # (gloo gathers host tensors)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rank_times[:] = [{"slice_ms": [round(float(t[0]), 4) for t in every],
+                              "gather_ms": [round(float(t[1]), 4) for t in every]}]
         stats_time = ctx.get_stats()
         ctx.set_profiling(0)
         pool_box[:] = [ctx.pixel_pool_info()]
@@ -571,6 +596,8 @@ def main():
         return float(tmax.item()), (w, h), npix, stats_count, stats_time
 
     keep = []
+    timing = [False]  # inside the timed region
+    rank_times = []   # N > 1: per-rank {slice_ms, gather_ms} of the last timed frame (means over its steps)
     pool_box = []  # the library's plain / pixel-pool choice of the last timed frame (ythip_set_pixel_pool)
     # the primary line: BASELINE configs[1] at N = 1, configs[2] (the same frame split N ways) at N > 1
     primary_weak = world > 1 and args.scaling == "weak" and not args.as_rank
@@ -619,6 +646,8 @@ def main():
     }
     if gathering:  # what the collective library itself reports
         out["config"]["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+        if rank_times:  # per rank: ms per step in its slice's kernel / in the gather that follows it (stream events)
+            out["config"]["per_rank"] = rank_times[0]
     calib = valu_calibration()
     deferred_counters = []  # (workload, timed run, entry whose "roofline" gets the live counters), filled last
     if rank == 0 and stats_count is not None and stats_time["trace_launches"] > 0:
@@ -651,8 +680,10 @@ def main():
         # same K steps between the same fences.  Reported, never required: a failure here
         # (identical on every rank) must not cost the primary line.
         try:
+            rank_times[:] = []
             dt2, (w2, h2), npix2, _, _ = run(weak_resolution(args.resolution, world), False)
             out["weak_scaling"] = {
+                **({"per_rank": rank_times[0]} if rank_times else {}),
                 "value": round(w2 * h2 * args.spp * args.steps / dt2 / 1e6, 3), "unit": "Msamples/s",
                 "ms_per_step": round(dt2 / args.steps * 1e3, 3), "scaling": "weak",
                 "resolution": [w2, h2], "spp": args.spp, "pixels_per_rank": npix2,

@@ -91,7 +91,12 @@ def test_two_rank_launch_rehearsed_with_gloo():
     assert (w, h) == (320, 180) and j["config"]["pixels_per_rank"] == w * h // 2  # the SAME frame, split
     assert "configs[2]" in j["config"]["workload"] and j["config"]["sharding"] == "columns/2"
     assert j["config"]["collective"] == {"backend": "gloo", "ranks": 2}
+    # a run explains its own efficiency: per rank, ms per step in its slice's kernel and in the gather that follows
+    pr = j["config"]["per_rank"]
+    assert len(pr["slice_ms"]) == 2 and len(pr["gather_ms"]) == 2 and all(t > 0 for t in pr["slice_ms"] + pr["gather_ms"])
+    assert max(a + b for a, b in zip(pr["slice_ms"], pr["gather_ms"])) <= j["ms_per_step"] * 1.5 + 1.0
     assert abs(j["value"] - w * h * 4 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
     s = j["weak_scaling"]
     assert s["resolution"] == [448, 252] and s["pixels_per_rank"] == 448 * 252 // 2 and s["value"] > 0  # weak_resolution(320, 2)
+    assert len(s["per_rank"]["slice_ms"]) == 2
     assert "cpu_baseline" not in j and "other_configs" not in j  # rank 0 at N=1 only

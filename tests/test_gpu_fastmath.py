@@ -99,7 +99,8 @@ def test_hit_records_are_untouched_and_debug_samplers_stay_exact():
     assert ctx.last_launch_fastmath()
     assert ctx.intersect_batch(rays).tobytes() == before.tobytes()
     if P.have_ref():
-        assert P.hits_equal(P.RefBundle(flat).intersect_batch(rays), before)
+        rb = P.RefBundle(flat)
+        assert P.hits_equal(P.ry.intersect_batch(rb.bvh, rb.scene, rays), before)
     # falsecolor has no tolerance build: the flag is accepted and the exact kernel runs — the reference's bytes
     pf = yt.trace_params(sampler="falsecolor", falsecolor="normal", resolution=96, samples=1, fastmath=1)
     pe = yt.trace_params(sampler="falsecolor", falsecolor="normal", resolution=96, samples=1)

@@ -47,7 +47,7 @@ YT_FN int nth_set_bit(unsigned long long m, int n) {
 // The wide walk of the scene for EVERY lane of the wavefront (`active` false: the lane has no ray and only helps).
 // Must be called with all 64 lanes of the wavefront converged.  Returns what traverse<false, true, TRI> returns for
 // the active lanes (HIT_ABORT for rays the wide walk declines), an empty hit for the others.
-template <bool TRI, int LDSD = YT_LDS_DEPTH>
+template <int TRI, int LDSD = YT_LDS_DEPTH>
 YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack& st, Counters& cnt) {
   constexpr int LDS_LEVELS = LDSD, SPILL_LEVELS = 128 - LDSD;
   constexpr bool COUNT = false;  // (YT_STACK_OPS's statistics hook)
@@ -77,11 +77,11 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
   YT_STACK_OPS(LDS_LEVELS, SPILL_LEVELS)
 
 #ifdef YT_COOP_TLAS
-  constexpr bool TESTED = true;  // instance entries have had the tmax-independent half of their root-box test (section 3b)
+  constexpr bool TESTED = true;  // instance entries carry a t0 and the "tested" bit (section 3b); single-instance leaves enter untested
 #else
   constexpr bool TESTED = false;
 #endif
-  auto enter = [&](int k) -> int {  // k: index in TLAS-leaf order
+  auto enter = [&](int k, bool tested) -> int {  // k: index in TLAS-leaf order
 #ifdef YT_TINST_LEAF
     const float4* ti   = reinterpret_cast<const float4*>(sc.tinst_leaf + k);
     int           inst = -1;
@@ -102,7 +102,7 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
       abort = true;
       return REF_NONE;
     }
-    if (!TESTED) {
+    if (!tested) {
       float t0;
       bool  ok = slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0) && t0 <= tmaxk;
       if (!ok) return REF_NONE;
@@ -110,7 +110,8 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
     o = io, d = id, dinv = idin;
     sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
     cur_inst = inst;
-    kind     = TRI ? KIND_TRIANGLES : __float_as_int(m4.w);
+    kind     = TRI == 1 ? KIND_TRIANGLES : __float_as_int(m4.w);
+    if (TRI == 2 && kind != KIND_TRIANGLES) kind = KIND_QUADS;
     leafbias = m5.x;
     push(REF_EXIT, 0);
     return root;
@@ -217,7 +218,7 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
             exit_instance();
           } else {
             int code = cur - REF_INST;
-            cur      = enter(code >> 1);
+            cur      = enter(code >> 1, TESTED && (code & 1) != 0);
             if (abort) best = Hit{HIT_ABORT, -1, 0, 0, 0, false}, done = true;
           }
         } else {
@@ -225,15 +226,19 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
           if (cur_inst < 0) {
 #ifdef YT_COOP_TLAS
             // the instances' root boxes are tested by the whole wavefront in section 3b; the survivors become entries there
-            if (num <= 4) {
+            // (a leaf of ONE instance gains nothing from testing ahead — one dependent fetch either way — and would waste
+            //  three of its four worker lanes: it is entered as before, untested)
+            cur = REF_NONE;
+            if (num == 1) {
+              cur = REF_INST + (first << 1);
+            } else if (num <= 4) {
               town = true, tnum = num, tfirst = first;
             } else {  // (never: leaves hold <= 4)
               for (int k = num - 1; k >= 0; k--) {
                 float t0;
-                if (pretest(wo, wd, tmin, first + k, t0)) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), t0);
+                if (pretest(wo, wd, tmin, first + k, t0)) push(REF_INST + (((first + k) << 1) | 1), t0);
               }
             }
-            cur = REF_NONE;
 #else
             for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
             cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
@@ -241,7 +246,7 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
           } else {
             cur = REF_NONE;
             cnt.steps++;
-            if (kind == KIND_TRIANGLES) {
+            if (TRI == 1 || kind == KIND_TRIANGLES) {
               const float4* L = sc.leafdata + (leafbias + first * 3);
               for (int k0 = 0; k0 < num; k0 += 2) {
                 float4 a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
@@ -253,14 +258,14 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
                   if (h.hit) accept(__float_as_int(c1.y), h);
                 }
               }
-            } else if (kind == KIND_QUADS) {
+            } else if (TRI != 1 && kind == KIND_QUADS) {
               const float4* L = sc.leafdata + (leafbias + first * 4);
               for (int k = 0; k < num; k++) {
                 float4 a = L[4 * k], b = L[4 * k + 1], c = L[4 * k + 2], e4 = L[4 * k + 3];
                 auto   h = intersect_quad(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, {c.y, c.z, c.w});
                 if (h.hit) accept(__float_as_int(e4.x), h);
               }
-            } else if (kind == KIND_LINES) {
+            } else if (TRI == 0 && kind == KIND_LINES) {
               // (leaves of more than four segments do not exist — bvh_max_prims = 4, yocto_bvh.cpp:54 — but the
               //  record could carry 7: those would be tested here, per lane)
 #ifdef YT_COOP_LEAF
@@ -277,7 +282,7 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
                   if (h.hit) accept(__float_as_int(c.x), h);
                 }
               }
-            } else if (kind == KIND_POINTS) {
+            } else if (TRI == 0 && kind == KIND_POINTS) {
               const float4* L = sc.leafdata + (leafbias + first * 2);
               for (int k = 0; k < num; k++) {
                 float4 a = L[2 * k], b = L[2 * k + 1];
@@ -318,7 +323,7 @@ YT_FN Hit traverse_coop(const DScene& sc, const ray3f& wray, bool active, Stack&
           const int   src = (w0 + kk) & 63;
           const int   pk  = __shfl(pass, src);
           const float tk  = __shfl(t0, src);
-          if (mine && kk < tnum && pk) push(REF_INST + (((tfirst + kk) << 1) | (kk == tnum - 1 ? 1 : 0)), tk);
+          if (mine && kk < tnum && pk) push(REF_INST + (((tfirst + kk) << 1) | 1), tk);
         }
       }
     }

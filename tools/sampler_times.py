@@ -22,6 +22,8 @@ elif SCENE == "cornell1m":  # cfg2b: the Cornell box with 1M-triangle walls
     flat = P.scene_cornell_1m()
 elif SCENE == "cornell9m":  # bench.py's cache-exceeding scene: 8,987,066 wall triangles
     flat = ysc.cornell_1m_scene(ysc.load_scene(os.path.join(ROOT, "tests", "golden", "cornellbox.npz")), n=948)
+elif SCENE.startswith("corpus:"):  # a scene of the reference's own test corpus (tests/golden/scenes): corpus:materials1 ...
+    flat = ysc.load_corpus_scene(SCENE[7:])
 else:
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import parity as P
@@ -30,6 +32,8 @@ ctx = yt.Context(0)
 ctx.upload_scene(flat); ctx.make_trace_bvh(flat, bool(int(os.environ.get('HQ', '0')))); ctx.make_trace_lights(flat)  # HQ=1: highqualitybvh (split_sah)
 if os.environ.get('TRAVERSAL'):
     ctx.set_traversal(os.environ['TRAVERSAL'])
+if os.environ.get('SPECIALIZE'):  # 0: the general kernel class whatever the scene is (ythip_set_specialization)
+    ctx.set_specialization(int(os.environ['SPECIALIZE']))
 spp = int(os.environ.get('SPP', '64'))
 RES = int(os.environ.get('RES', '1280'))
 FAST = int(os.environ.get("FASTMATH", "0"))  # 1: the tolerance mode (params.fastmath)

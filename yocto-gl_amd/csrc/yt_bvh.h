@@ -373,7 +373,9 @@ constexpr int HIT_ABORT = -2;  // Hit::instance of a wide walk that met an irreg
 
 // LDSD: stack entries per lane kept in the LDS column of `st` (the rest, up to the
 // reference's 128, in scratch).  0 = a walk that leaves the LDS stack alone.
-template <bool COUNT, bool WIDE = false, bool TRI = false, int LDSD = YT_LDS_DEPTH>
+// TRI: what is known about the scene's shapes — 0 nothing, 1 every shape is a triangle mesh, 2 triangle and quad meshes only
+// (checked at upload; tells the compiler which intersectors can be reached, the arithmetic of the live ones is the same)
+template <bool COUNT, bool WIDE = false, int TRI = 0, int LDSD = YT_LDS_DEPTH>
 YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt) {
   constexpr int LDS_LEVELS = LDSD, SPILL_LEVELS = 128 - LDSD;
@@ -446,7 +448,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     tame = ray_is_tame(o, dinv, tmin);
     sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
     cur_inst = inst;
-    kind     = TRI ? KIND_TRIANGLES : __float_as_int(m4.w);  // TRI: every shape of the scene is a triangle mesh
+    kind     = TRI == 1 ? KIND_TRIANGLES : __float_as_int(m4.w);  // TRI 1: every shape of the scene is a triangle mesh
+    if (TRI == 2 && kind != KIND_TRIANGLES) kind = KIND_QUADS;       // TRI 2: ... or a quad mesh
     leafbias = m5.x;
     blas_hit = false;
     push(REF_EXIT, 0);
@@ -454,14 +457,14 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   };
   // entry `k` of the TLAS-leaf order (a continuation entry's code >> 1)
   auto enter_leaf_entry = [&](int k, bool tested) -> int {
-#ifdef YT_TINST_LEAF
+#ifndef YT_NO_TINST_LEAF
     return enter(sc.tinst_leaf + k, -1, tested);
-#else
+#else  // development builds: the two dependent fetches of rounds 1-3 (tlas_prims -> tinst)
     const int inst = sc.tlas_prims[k];
     return enter(sc.tinst + inst, inst, tested);
 #endif
   };
-  // YT_PRETEST (wide walk): the tmax-INDEPENDENT half of an instance's root-box test — transform_ray + intersect_bbox's
+  // PRETEST (the wide walk; round 4, +4 ... +10 % on scenes with instances, profiles/r04_traversal.txt): the tmax-INDEPENDENT half of an instance's root-box test — transform_ray + intersect_bbox's
   // interval (yocto_bvh.cpp:619-628 with :470-477) — made for all (up to 4) instances of a TLAS leaf when the leaf is
   // expanded: their records are independent fetches (one round trip instead of one per instance), and an instance whose
   // root box the ray misses whatever tmax is never becomes an entry at all.  What passes is pushed with its t0 and gets the
@@ -469,7 +472,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   // leaf have shrunk tmax: the same decision on the same floats as testing at entry time (header, and slab()).
   // Returns false for "cannot enter whatever tmax is"; an irregular instance-level ray passes (enter() then aborts).
   auto pretest = [&](int k, float& t0) -> bool {
-#ifdef YT_TINST_LEAF
+#ifndef YT_NO_TINST_LEAF
     const float4* ti = reinterpret_cast<const float4*>(sc.tinst_leaf + k);
 #else
     const float4* ti = reinterpret_cast<const float4*>(sc.tinst + sc.tlas_prims[k]);
@@ -484,9 +487,12 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     if (!ray_is_tame(io, idin, tmin)) return true;
     return slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0);
   };
-#if defined(YT_PRETEST)
+#if !defined(YT_NO_PRETEST) && defined(YT_EARLY_BOOKKEEPING)
+#error "YT_EARLY_BOOKKEEPING pushes instance entries whose bit 0 is the `last` flag; the pretest reads it as `tested`"
+#endif
+#if !defined(YT_NO_PRETEST)
   constexpr bool PRETEST = WIDE;
-#else
+#else  // development builds: every instance's root box tested when its entry is popped, as in rounds 1-3
   constexpr bool PRETEST = false;
 #endif
 
@@ -677,7 +683,9 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       int code = cur - REF_INST;
       cur_last = (code & 1) != 0;
       if (COUNT) cnt.instances++;  // TLAS leaf entry (yocto_bvh.cpp:600-604)
-      cur = enter_leaf_entry(code >> 1, PRETEST);
+      // (PRETEST: bit 0 of the code says "root box already tested" — the `last` flag it carries otherwise only matters to
+      //  find_any queries, which the wide walk never serves)
+      cur = enter_leaf_entry(code >> 1, PRETEST && cur_last);
       if (WIDE && abort) {
         best = Hit{HIT_ABORT, -1, 0, 0, 0, false};
         done = true;
@@ -691,15 +699,21 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       // (yocto_bvh.cpp:600-609) → continuation entries in reverse, first one now.
       if constexpr (PRETEST) {
         // ... after the tmax-independent half of each instance's root-box test (pretest above): the survivors in
-        // reverse, each with its t0; the next pop applies the tmax-dependent half to the first of them
+        // reverse, each with its t0 and the "tested" bit; the next pop applies the tmax-dependent half to the first of
+        // them.  A leaf of ONE instance gains nothing from testing ahead (one dependent fetch either way): it is
+        // entered as before, untested.
+        if (num == 1) {
+          cur = REF_INST + (first << 1);
+          continue;
+        }
         float tk[4];
         bool  pk[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) pk[k] = k < num && pretest(first + k, tk[k]);
-        for (int k = num - 1; k >= 4; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);  // (never: leaves hold <= 4)
+        for (int k = num - 1; k >= 4; k--) push(REF_INST + ((first + k) << 1), 0);  // (never: leaves hold <= 4) untested
 #pragma unroll
         for (int k = 3; k >= 0; k--)
-          if (pk[k]) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), tk[k]);
+          if (pk[k]) push(REF_INST + (((first + k) << 1) | 1), tk[k]);
         cur = REF_NONE;
         continue;
       }
@@ -710,7 +724,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     cur = REF_NONE;
     cnt.steps++;
     // BLAS leaf — yocto_bvh.cpp:505-545
-    if (kind == KIND_TRIANGLES) {
+    if (TRI == 1 || kind == KIND_TRIANGLES) {
       const float4* L = sc.leafdata + (leafbias + first * 3);
       // two triangles per round trip (the pool is padded, over-reads are ignored)
       for (int k0 = 0; k0 < num; k0 += 2) {
@@ -737,7 +751,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           if (h.hit) accept(__float_as_int(c1.y), h);
         }
       }
-    } else if (kind == KIND_QUADS) {
+    } else if (TRI != 1 && kind == KIND_QUADS) {
       const float4* L = sc.leafdata + (leafbias + first * 4);
       for (int k = 0; k < num; k++) {
         YT_WP(7, __popcll(__ballot(1)));
@@ -747,7 +761,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         auto h = intersect_quad(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, {c.y, c.z, c.w});
         if (h.hit) accept(__float_as_int(e4.x), h);
       }
-    } else if (kind == KIND_LINES) {
+    } else if (TRI == 0 && kind == KIND_LINES) {
       const float4* L = sc.leafdata + (leafbias + first * 3);
       for (int k = 0; k < num; k++) {
         YT_WP(7, __popcll(__ballot(1)));
@@ -757,7 +771,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         auto h = intersect_line(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
         if (h.hit) accept(__float_as_int(c.x), h);
       }
-    } else if (kind == KIND_POINTS) {
+    } else if (TRI == 0 && kind == KIND_POINTS) {
       const float4* L = sc.leafdata + (leafbias + first * 2);
       for (int k = 0; k < num; k++) {
         YT_WP(7, __popcll(__ballot(1)));
@@ -796,7 +810,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
 // expansion) in a short private loop and then runs the ONE step kind most lanes are waiting
 // for.  Same nodes, same order, same tests per ray as traverse<false, true, TRI> — only the
 // interleaving between lanes differs — so the hit records are identical (tested).
-template <bool TRI>
+template <int TRI>
 YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance, Stack& st, Counters& cnt) {
   Hit best = {-1, -1, 0, 0, 0, false};
   const vec3f wo = wray.o, wd = wray.d;
@@ -835,7 +849,8 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
     o = io, d = id, dinv = idin;
     sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
     cur_inst = inst;
-    kind     = TRI ? KIND_TRIANGLES : __float_as_int(m4.w);
+    kind     = TRI == 1 ? KIND_TRIANGLES : __float_as_int(m4.w);
+    if (TRI == 2 && kind != KIND_TRIANGLES) kind = KIND_QUADS;
     leafbias = m5.x;
     push(REF_EXIT, 0);
     return root;
@@ -944,7 +959,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
         const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
         cur = REF_NONE;
         cnt.steps++;
-        if (TRI || kind == KIND_TRIANGLES) {
+        if (TRI == 1 || kind == KIND_TRIANGLES) {
           const float4* L = sc.leafdata + (leafbias + first * 3);
           for (int k0 = 0; k0 < num; k0 += 2) {
             float4 a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
@@ -956,21 +971,21 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
               if (h.hit) accept(__float_as_int(c1.y), h);
             }
           }
-        } else if (kind == KIND_QUADS) {
+        } else if (TRI != 1 && kind == KIND_QUADS) {
           const float4* L = sc.leafdata + (leafbias + first * 4);
           for (int k = 0; k < num; k++) {
             float4 a = L[4 * k], b = L[4 * k + 1], c = L[4 * k + 2], e4 = L[4 * k + 3];
             auto h = intersect_quad(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, {c.y, c.z, c.w});
             if (h.hit) accept(__float_as_int(e4.x), h);
           }
-        } else if (kind == KIND_LINES) {
+        } else if (TRI == 0 && kind == KIND_LINES) {
           const float4* L = sc.leafdata + (leafbias + first * 3);
           for (int k = 0; k < num; k++) {
             float4 a = L[3 * k], b = L[3 * k + 1], c = L[3 * k + 2];
             auto h = intersect_line(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
             if (h.hit) accept(__float_as_int(c.x), h);
           }
-        } else if (kind == KIND_POINTS) {
+        } else if (TRI == 0 && kind == KIND_POINTS) {
           const float4* L = sc.leafdata + (leafbias + first * 2);
           for (int k = 0; k < num; k++) {
             float4 a = L[2 * k], b = L[2 * k + 1];
@@ -981,7 +996,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
       }
     } else {
       if (wantE) {
-#ifdef YT_TINST_LEAF
+#ifndef YT_NO_TINST_LEAF
         cur = enter(sc.tinst_leaf + ((cur - REF_INST) >> 1), -1);
 #else
         const int inst = sc.tlas_prims[(cur - REF_INST) >> 1];
@@ -1000,7 +1015,7 @@ constexpr bool PHASED_DEFAULT = true;
 #else
 constexpr bool PHASED_DEFAULT = false;
 #endif
-template <bool COUNT, bool WIDE, bool TRI = false, bool PHASED = PHASED_DEFAULT>
+template <bool COUNT, bool WIDE, int TRI = 0, bool PHASED = PHASED_DEFAULT>
 YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt) {
   if constexpr (WIDE && !COUNT) {
@@ -1018,16 +1033,3 @@ YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, b
 }
 
 }  // namespace yt
-
-#if defined(YT_COOP_LEAF) || defined(YT_COOP_TLAS)  // yt_coop.h: line leaves / TLAS-leaf root-box tests by the whole wavefront
-#include "yt_coop.h"
-namespace yt {
-// the scene walk of k_trace's extend stage for ALL lanes of the wavefront (`active`: this lane has a ray)
-template <bool TRI>
-YT_FN Hit traverse_coop_any(const DScene& sc, const ray3f& wray, bool active, Stack& st, Counters& cnt) {
-  Hit h = traverse_coop<TRI>(sc, wray, active, st, cnt);
-  if (active && h.instance == HIT_ABORT) h = traverse<false, false, TRI>(sc, wray, -1, false, st, cnt);
-  return h;
-}
-}  // namespace yt
-#endif

@@ -45,7 +45,7 @@ void launch(hipStream_t stream, int blocks, const DScene& ds, const DState& st, 
 // The dispatch of the tolerance mode: the wide-walk kernels only (a scene the wide walk cannot serve — trees of fewer
 // than 64 primitives, trees too deep for its stack — renders with the bit-exact kernels: returns 1, nothing launched).
 // `ds` / `st` / `kp` point at the caller's yt::DScene / yt::DState / yt::KParams: the same structs under this unit's
-// namespace.  cls: the scene class of the path sampler (0 general, 1 all matte triangles, 2 no textures).
+// namespace.  cls: the scene class of the path sampler (0 general, 1 all matte triangles, 2 no textures, 3 opaque textured).
 extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds_, const void* st_, const void* kp_, int lp, int cls) {
   const DScene&  ds = *static_cast<const DScene*>(ds_);
   const DState&  st = *static_cast<const DState*>(st_);
@@ -56,6 +56,7 @@ extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds_, cons
     case YTHIP_SAMPLER_PATH:
       if (cls == 1) defer ? launch<YTHIP_SAMPLER_PATH, LP_DEFER, 1>(s, blocks, ds, st, kp) : launch<YTHIP_SAMPLER_PATH, LP_NONE, 1>(s, blocks, ds, st, kp);
       else if (cls == 2) defer ? launch<YTHIP_SAMPLER_PATH, LP_DEFER, 2>(s, blocks, ds, st, kp) : launch<YTHIP_SAMPLER_PATH, LP_NONE, 2>(s, blocks, ds, st, kp);
+      else if (cls == 3) defer ? launch<YTHIP_SAMPLER_PATH, LP_DEFER, 3>(s, blocks, ds, st, kp) : launch<YTHIP_SAMPLER_PATH, LP_NONE, 3>(s, blocks, ds, st, kp);
       else defer ? launch<YTHIP_SAMPLER_PATH, LP_DEFER>(s, blocks, ds, st, kp) : launch<YTHIP_SAMPLER_PATH, LP_NONE>(s, blocks, ds, st, kp);
       return 0;
     case YTHIP_SAMPLER_PATHTEST:

@@ -214,14 +214,15 @@ struct Surface {
   elem4                 e;
   vec2f                 uv;
 };
-// TRI: the caller knows that every shape of the scene is a triangle mesh
-template <bool TRI = false>
+// TRI: what the caller knows about the scene's shapes (as traverse(): 1 triangle meshes only, 2 triangle and quad meshes only)
+template <int TRI = 0>
 YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv) {
   const auto& inst = sc.instances[instance];
   Surface     s;
   s.frame = ldframe(inst.frame);
   s.shc   = sc.shapes[inst.shape];
-  if (TRI) s.shc.kind_eval = KIND_TRIANGLES;
+  if (TRI == 1) s.shc.kind_eval = KIND_TRIANGLES;
+  if (TRI == 2 && s.shc.kind_eval != KIND_TRIANGLES) s.shc.kind_eval = KIND_QUADS;
   s.mat   = &sc.materials[inst.material];
   s.e     = load_element(sc, s.shc, element);
   s.uv    = uv;
@@ -260,7 +261,7 @@ YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel,
 
 // sample_lights_pdf — yocto_trace.cpp:391-443.  WALK: 0 = no instance lights in
 // the scene (no traversal code at all), 2 = the instance walks inline (the walk stage of k_trace).
-template <int WALK, bool COUNT = true>
+template <int WALK, bool COUNT = true, int TRI = 0>
 YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt) {
   auto pdf = 0.0f;
   for (int l = 0; l < sc.num_lights; l++) {
@@ -275,7 +276,7 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
         auto        area          = sc.cdf[light.cdf_offset + light.cdf_count - 1];
         for (auto bounce = 0; bounce < 100; bounce++) {
           ray3f ray  = make_ray(next_position, direction);
-          Hit   isec = traverse<COUNT>(sc, ray, light.instance, false, *st, *cnt);  // (counts only in the counting launch)
+          Hit   isec = traverse<COUNT, false, TRI>(sc, ray, light.instance, false, *st, *cnt);  // (counts only in the counting launch)
           if (!isec.hit) break;
           auto e         = load_element(sc, sh, isec.element);
           auto lposition = eval_position(sc, frame, sh, e, {isec.u, isec.v});
@@ -393,16 +394,20 @@ YT_FN int step_tail(Path& P) {
 // CLS: what is known about the resident scene (checked at upload; the assignments below only
 // tell the compiler, the arithmetic on the live path is the same): 0 nothing; 1 "simple scene" —
 // every material matte and untextured, every shape a triangle mesh; 2 no material references
-// a texture (any material types, any shapes: the hair scene of configs[4]).
+// a texture (any material types, any shapes: the hair scene of configs[4]); 3 "opaque textured" —
+// every material matte, glossy or reflective (nothing transmits: no volumes), textures only in the
+// color and normal slots, triangle and quad meshes only: the scenes of the reference's own test
+// corpus (materials1 / materials3 / shapes1 / instances1 / arealights1 / environments1).
 template <int SAMPLER, int LP, int CLS = 0>
 YT_FN int step_path(ShadeEnv& E, Path& P) {
-  constexpr bool MATTE = CLS == 1, NOTEX = CLS >= 1;
+  constexpr bool MATTE = CLS == 1, NOTEX = CLS == 1 || CLS == 2, OPAQUE = CLS == 3;
+  constexpr int  PRIMS = MATTE ? 1 : (OPAQUE ? 2 : 0);
   const auto& sc = E.sc;
   const auto& kp = E.kp;
   constexpr bool DIRECT  = SAMPLER == YTHIP_SAMPLER_PATHDIRECT;
   constexpr bool MIS     = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   constexpr bool TEST    = SAMPLER == YTHIP_SAMPLER_PATHTEST;
-  constexpr bool VOLUMES = !TEST && !MATTE;
+  constexpr bool VOLUMES = !TEST && !MATTE && !OPAQUE;
   static_assert(!(DIRECT || MIS) || LP == LP_DEFER, "the NEE samplers run their walks in the walk stage");
   const bool next_emission = !(P.flags & PF_NOEMIT);
 
@@ -430,10 +435,10 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
   if (!in_volume) {
     // prepare shading point
     auto outgoing = -P.d;
-    auto s        = load_surface<MATTE>(sc, isec.instance, isec.element, {isec.u, isec.v});
+    auto s        = load_surface<PRIMS>(sc, isec.instance, isec.element, {isec.u, isec.v});
     auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
     auto normal   = eval_shading_normal<NOTEX>(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
-    auto material = eval_material<NOTEX>(sc, s.shc, *s.mat, s.e, s.uv);
+    auto material = eval_material<NOTEX, OPAQUE>(sc, s.shc, *s.mat, s.e, s.uv);
     count_shade(E.st);
 #ifdef YT_TIMING
     asm volatile("" ::"v"(position.x), "v"(normal.x), "v"(material.color.x), "v"(material.roughness));
@@ -569,7 +574,7 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     // update volume stack
     if (VOLUMES && is_volumetric(*s.mat) && dot(normal, outgoing) * dot(normal, incoming) < 0) {
       if (!(P.flags & PF_VOLUME)) {
-        auto vmat = eval_material<NOTEX>(sc, s.shc, *s.mat, s.e, s.uv);
+        auto vmat = eval_material<NOTEX, OPAQUE>(sc, s.shc, *s.mat, s.e, s.uv);
         store_volume(E.st, E.slot, vmat);
         P.flags |= PF_VOLUME;
       } else {
@@ -1051,6 +1056,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
     (CLS == 0 && !COUNT ? YT_WAVES_PER_EU_GENERAL : YT_WAVES_PER_EU))
     k_trace(DScene sc, DState st, KParams kp) {
   constexpr bool MATTE = CLS == 1;
+  constexpr int  PRIMS = MATTE ? 1 : (CLS == 3 ? 2 : 0);  // what the walks know about the shapes (yt_bvh.h: TRI)
   // majority-phase scene walk (yt_bvh.h::traverse_phased) for the kernels where it wins:
   // simple scenes with area lights (closed rooms: every ray hits, bounce rays as long as
   // camera rays).  Measured, DESIGN.md §6.
@@ -1169,23 +1175,6 @@ __global__ void __launch_bounds__(YT_BLOCK,
     const long long tm0 = __builtin_readcyclecounter();
     long long       tm1 = tm0, tm2 = tm0, tmS = tm0, tmG = 0;
 #endif
-#if defined(YT_COOP_LEAF) || defined(YT_COOP_TLAS)  // yt_coop.h: the extend stage with every lane of the wavefront inside the walk
-#ifdef YT_COOP_TLAS
-    constexpr bool COOP = WIDE && !COUNT && !PHASED_SCENE;
-#else
-    constexpr bool COOP = WIDE && !COUNT && !MATTE && !PHASED_SCENE;  // (line leaves only exist outside the all-triangle class)
-#endif
-    Hit            coop_isec = {-1, -1, 0, 0, 0, false};
-    if constexpr (COOP) {
-      const int    l  = (run ? slot : (int)threadIdx.x) & (YT_BLOCK - 1);
-      const float4 ra = W.ray_a[l], rb = W.ray_b[l];
-      const bool   walk = run && !(MIS && (__float_as_int(rb.w) & PF_SKIPEXTEND));
-      ray3f          ray = make_ray({ra.x, ra.y, ra.z}, {ra.w, rb.x, rb.y});
-      const unsigned s0  = cnt.steps;
-      coop_isec          = traverse_coop_any<MATTE>(sc, ray, walk, stack, cnt);
-      if (walk) work = cnt.steps - s0 + 1;
-    }
-#endif
     if (run) {
       Path   P;
       float4 ra = W.ray_a[slot & (YT_BLOCK - 1)], rb = W.ray_b[slot & (YT_BLOCK - 1)];
@@ -1198,17 +1187,10 @@ __global__ void __launch_bounds__(YT_BLOCK,
         int    inst = __float_as_int(ha.w);
         P.isec      = {inst, st.nhit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
       } else {
-#if defined(YT_COOP_LEAF) || defined(YT_COOP_TLAS)
-        if constexpr (COOP) {
-          P.isec = coop_isec;
-        } else
-#endif
-        {
-          ray3f          ray = make_ray(P.o, P.d);
-          const unsigned s0  = cnt.steps;
-          P.isec             = traverse_any<COUNT, WIDE, MATTE, PHASED_SCENE>(sc, ray, -1, false, stack, cnt);
-          work               = cnt.steps - s0 + 1;
-        }
+        ray3f          ray = make_ray(P.o, P.d);
+        const unsigned s0  = cnt.steps;
+        P.isec             = traverse_any<COUNT, WIDE, PRIMS, PHASED_SCENE>(sc, ray, -1, false, stack, cnt);
+        work               = cnt.steps - s0 + 1;
       }
 #ifdef YT_TIMING
       tm1 = __builtin_readcyclecounter();
@@ -1385,7 +1367,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
           if (nee != 2) {
             float4 pd = st.pend[slot];
             // weight *= f / (0.5 * pdf_a + 0.5 * sample_lights_pdf(position, incoming))
-            auto lpdf = sample_lights_pdf<2, COUNT>(sc, P.o, P.d, &stack, &cnt);
+            auto lpdf = sample_lights_pdf<2, COUNT, PRIMS>(sc, P.o, P.d, &stack, &cnt);
             P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
             step = step_tail(P);
           }

@@ -405,12 +405,18 @@ YT_FN vec3f eval_shading_normal(const DScene& sc, const frame3f& frame, const DS
 // ---------------------------------------------------------------------------
 // (struct material_point: yt_material.h)
 
-// NOTEX: the caller knows that no material of the scene references a texture
-template <bool NOTEX = false>
+// What the caller knows about the resident scene (checked at upload; same arithmetic on the live path):
+// NOTEX: no material references a texture.  OPAQUE: the "opaque textured" class — every material is matte, glossy or
+// reflective (no transmission: no density) and the only texture slots in use are color_tex and normal_tex.
+template <bool NOTEX = false, bool OPAQUE = false>
 YT_FN material_point eval_material(const DScene& sc, const DShape& sh, const ythip_material& material_,
     elem4 e, vec2f uv) {
   ythip_material material = material_;
   if (NOTEX) material.emission_tex = material.color_tex = material.roughness_tex = material.scattering_tex = -1;
+  if (OPAQUE) {
+    material.emission_tex = material.roughness_tex = material.scattering_tex = -1;
+    if ((unsigned)material.type > (unsigned)YTHIP_REFLECTIVE) material.type = YTHIP_MATTE;  // (never: tells the compiler)
+  }
   // texcoords are only read by texture lookups: skip the three gathers for untextured materials
   const bool textured = (material.emission_tex & material.color_tex & material.roughness_tex &
                             material.scattering_tex) != YTHIP_INVALIDID;
@@ -437,8 +443,8 @@ YT_FN material_point eval_material(const DScene& sc, const DShape& sh, const yth
   point.scanisotropy = material.scanisotropy;
   point.trdepth      = material.trdepth;
 
-  if (material.type == YTHIP_REFRACTIVE || material.type == YTHIP_VOLUMETRIC ||
-      material.type == YTHIP_SUBSURFACE) {
+  if (!OPAQUE && (material.type == YTHIP_REFRACTIVE || material.type == YTHIP_VOLUMETRIC ||
+                     material.type == YTHIP_SUBSURFACE)) {
     point.density = -log_(clamp_(point.color, 0.0001f, 1.0f)) / point.trdepth;
   } else {
     point.density = {0, 0, 0};
@@ -446,7 +452,7 @@ YT_FN material_point eval_material(const DScene& sc, const DShape& sh, const yth
 
   if (point.type == YTHIP_MATTE || point.type == YTHIP_GLTFPBR || point.type == YTHIP_GLOSSY) {
     point.roughness = clamp_(point.roughness, min_roughness, 1.0f);
-  } else if (material.type == YTHIP_VOLUMETRIC) {
+  } else if (!OPAQUE && material.type == YTHIP_VOLUMETRIC) {
     point.roughness = 0;
   } else {
     if (point.roughness < min_roughness) point.roughness = 0;

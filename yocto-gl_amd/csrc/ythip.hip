@@ -123,6 +123,7 @@ struct ythip_ctx {
   bool                        has_volumes = false;
   bool                        all_matte   = false;  // "simple scene": matte untextured materials, triangle meshes only
   bool                        no_textures = false;  // no material references a texture
+  bool                        opaque_textured = false;  // matte / glossy / reflective only, color + normal textures only, triangles + quads only
   int                         specialize  = 1;
   int                         num_cameras = 0;
 
@@ -875,8 +876,12 @@ void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
 // pathdirect & pathmis always trace inline; the rest never need a light pdf.
 // fast: ythip_params::fastmath — the tolerance-mode kernels of yt_fast.hip where they exist (wide walk, real samplers).
 int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count, bool fast = false) {
-  if (fast && !count && ctx->use_wide()) {
-    const int cls = kp.sampler == YTHIP_SAMPLER_PATH && ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : 0) : 0;
+  // (the tolerance-mode unit has the wide-walk kernels only: they serve every tree the wide walk's stack bound admits —
+  //  use_wide()'s preference for the binary walk on scenes of tiny trees is a matter of speed, not of results)
+  if (fast && !count && ctx->wide_stack_ok && ctx->traversal_mode != 0) {
+    const int cls = kp.sampler == YTHIP_SAMPLER_PATH && ctx->specialize
+                        ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0)
+                        : 0;
     if (ythip_fast_launch(ctx->stream, ctx->launch_blocks(), &ctx->ds, &ctx->st, &kp, lp, cls) == 0) {
       ctx->last_launch_fast = true;
       return YTHIP_OK;
@@ -904,6 +909,17 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count, bool
               ctx->st, kp);
         else
           hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 2>), grid, block, 0, ctx->stream, ctx->ds,
+              ctx->st, kp);
+      } else if (!count && ctx->opaque_textured && ctx->specialize && ctx->use_wide()) {
+        // the "opaque textured" class (matte / glossy / reflective materials, textures in the color and normal slots only,
+        // triangle and quad meshes — the scenes of the reference's own corpus): no transmission lobes, no volume code,
+        // two texture evaluators instead of five, no line / point intersectors
+        dim3 grid(ctx->launch_blocks()), block(YT_BLOCK);
+        if (lp == LP_DEFER)
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 3>), grid, block, 0, ctx->stream, ctx->ds,
+              ctx->st, kp);
+        else
+          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 3>), grid, block, 0, ctx->stream, ctx->ds,
               ctx->st, kp);
       } else if (lp == LP_DEFER)
         launch_trace<YTHIP_SAMPLER_PATH, LP_DEFER>(ctx, kp, count);
@@ -1113,6 +1129,15 @@ void classify_scene(ythip_ctx* ctx, const ythip_material* materials, int num_mat
     const auto& m = materials[k];
     if ((m.emission_tex & m.color_tex & m.roughness_tex & m.scattering_tex & m.normal_tex) != YTHIP_INVALIDID) ctx->no_textures = false;
   }
+  ctx->opaque_textured = num_materials > 0;
+  for (int k = 0; k < num_materials; k++) {
+    const auto& m = materials[k];
+    if ((m.type != YTHIP_MATTE && m.type != YTHIP_GLOSSY && m.type != YTHIP_REFLECTIVE) ||
+        (m.emission_tex & m.roughness_tex & m.scattering_tex) != YTHIP_INVALIDID)
+      ctx->opaque_textured = false;
+  }
+  for (auto& sh : ctx->h_shapes)
+    if (sh.num_points || sh.num_lines) ctx->opaque_textured = false;
   ctx->may_retry = false;
   for (int k = 0; k < num_materials; k++)
     if (materials[k].opacity < 1 || materials[k].color_tex != YTHIP_INVALIDID) ctx->may_retry = true;
