@@ -51,15 +51,24 @@ def test_default_line_carries_the_contract():
     if "error" not in b:
         assert b["kind"] == "reference" and b["unit"] == "Msamples/s" and b["cores"] >= 1 and b["value"] > 0
         assert j["value"] > b["value"]
-    # cfg2b, configs[3], configs[4] (hair) and the cache-exceeding Cornell box, each with its own fractions
-    assert isinstance(j.get("other_configs"), list) and len(j["other_configs"]) == 4
+    # cfg2b, configs[3], configs[4] (hair), the cache-exceeding Cornell box and two scenes of the reference's corpus (the
+    # general kernel class) bit-exact, then the BASELINE workloads in the tolerance mode — each with its own fractions
+    assert isinstance(j.get("other_configs"), list)
+    exact = [o for o in j["other_configs"] if o.get("mode", "").startswith("bit-exact")]
+    fast = [o for o in j["other_configs"] if o.get("mode", "").startswith("tolerance")]
+    assert [o["name"] for o in exact] == ["cfg2b", "configs3", "configs4", "cornell9m", "materials1", "features1"]
+    assert [o["name"] for o in fast] == ["configs1", "cfg2b", "configs3", "configs4", "cornell9m", "materials1"]
     for o in j["other_configs"]:
         assert "error" not in o, o
         assert o["value"] > 0 and o["unit"] == "Msamples/s"
         f = o["roofline"]["fractions"]
         assert set(f) == {"hbm", "l2", "valu"} and all(0 < x <= 1 for x in f.values()), (o["workload"], f)
-    assert "800,000 line segments" in j["other_configs"][2]["workload"]
-    big = j["other_configs"][3]
+    assert all(o["roofline"]["kernel"].startswith("yt::k_trace") for o in exact)
+    assert all(o["roofline"]["kernel"].startswith("yt_fast::k_trace") for o in fast)  # the tolerance-mode unit really ran
+    assert all(0.9 < o["speedup_over_bit_exact"] < 2 for o in fast)
+    assert "800,000 line segments" in exact[2]["workload"]
+    assert exact[4]["roofline"]["kernel"].endswith("3>") and exact[5]["roofline"]["kernel"].endswith("0>")  # opaque-textured / general class
+    big = exact[3]
     assert big["baked_bvh_bytes"] > 400e6  # larger than the 256 MB Infinity Cache
 
 

@@ -30,7 +30,6 @@
 #define YT_FAST 1
 #define yt yt_fast
 #define ytm ytm_fast
-#define YT_DEV_NO_TEST_KERNELS 1
 #include "yt_kernels.h"
 
 using namespace yt_fast;

@@ -1413,6 +1413,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_IB_WAVES) k_intersect_batch(DScen
   if (COUNT) flush_counters(counters, cnt);
 }
 
+#ifdef YT_MISC_KERNELS  // the plain (non-template) kernels below are compiled by ONE unit: ythip.hip defines this
 // ---------------------------------------------------------------------------
 // Display path: tonemap(trace_state.image) on the device, so
 // a viewer downloads 4 B/pixel instead of 16 — yocto_color.h:322-364 (tonemap,
@@ -1464,6 +1465,7 @@ __global__ void __launch_bounds__(YT_BLOCK) k_camera_rays(DScene sc, DState st, 
   auto ray = sample_camera(sc.cameras[kp.camera], i, j, st.width, st.height, puv, luv, kp.tentfilter != 0);
   rays[slot] = {{ray.o.x, ray.o.y, ray.o.z}, {ray.d.x, ray.d.y, ray.d.z}, ray.tmin, ray.tmax};
 }
+#endif  // YT_MISC_KERNELS
 
 }  // namespace yt
 #ifdef YT_FAST

@@ -8,843 +8,18 @@
 // contraction on baseline x86-64; -fno-slp-vectorize is REQUIRED too: with ROCm 7.2's SLP
 // vectorizer one k_trace instantiation is miscompiled and all of them are 5-40 % slower —
 // __graft_entry__.py, profiles/r03_slp_vectorizer.txt).
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdarg>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <string>
-#include <limits>
-#include <mutex>
-#include <thread>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/ythip.h"
-#include "yt_build.h"
-#include "yt_xfer.h"
-#include "yt_gpubuild.h"
-#include "yt_kernels.h"
-#include "yt_denoise.h"
+#define YT_MISC_KERNELS 1  // k_tonemap / k_guide_image / k_camera_rays of yt_kernels.h are compiled in this unit only
+#include "yt_ctx.h"
+#include "yt_denoise.h"  // (plain kernels: this unit only)
+#include "yt_launch.h"
 #include "yt_order.h"
 
-using namespace yt;
-
 namespace {
-
 thread_local std::string g_error;
-
-struct DevBuf {
-  void*  p = nullptr;
-  size_t n = 0;
-};
-
 }  // namespace
-
-// A host-side pool of the flat scene layout: either a copy the context owns, or a view of
-// the pinned staging pool the loader filled directly (ythip_scene_staging).
-template <typename T>
-struct HostPool {
-  std::vector<T> own;
-  T*             ext = nullptr;
-  size_t         n   = 0;
-  T*             data() { return ext ? ext : own.data(); }
-  const T*       data() const { return ext ? ext : own.data(); }
-  size_t         size() const { return ext ? n : own.size(); }
-  bool           empty() const { return size() == 0; }
-  T&             operator[](size_t i) { return data()[i]; }
-  const T&       operator[](size_t i) const { return data()[i]; }
-  void           assign(const T* a, const T* b) {
-    ext = nullptr, n = 0;
-    own.assign(a, b);
-  }
-  void adopt(T* p, size_t count) {
-    std::vector<T>().swap(own);
-    ext = p, n = count;
-  }
-};
-
-struct ythip_ctx {
-  int         device     = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream     = nullptr;
-  std::string err;
-
-  std::vector<void*> scene_allocs, bvh_allocs, light_allocs, state_allocs;
-
-  // host copies kept for BVH baking / light building
-  std::vector<ythip_shape>    h_shapes;
-  std::vector<ythip_instance> h_instances;
-  HostPool<int32_t>           h_points, h_lines, h_triangles, h_quads;
-  HostPool<float>             h_positions, h_radius;
-  // scene ingest straight into the flat layout: pinned pools the
-  // loader fills in place; they become the context's host copies and the DMA source
-  // on-device denoiser (yt_denoise.h): working images for a w x h frame, result in dn_out
-  std::vector<void*>          denoise_allocs;
-  float4 *                    dn_a = nullptr, *dn_b = nullptr, *dn_gn = nullptr, *dn_ga = nullptr, *dn_out = nullptr;
-  size_t                      dn_pixels    = 0;
-  bool                        have_denoised = false;  // dn_out holds the filtered image of the resident state
-  // longest-tile-first launch order (yt_order.hip): 0 off, 1 on (YTHIP_LPT)
-  int                         lpt = 1;
-  unsigned*                   d_tile_cost = nullptr;
-  int*                        d_tile_perm = nullptr;
-  void*                       d_sort_temp = nullptr;
-  size_t                      sort_temp_bytes = 0;
-  bool                        have_tile_costs = false;  // d_tile_cost holds the previous whole-slice launch's costs
-  int                         lpt_age = 0;              // launches since the order was last computed
-  bool                        lpt_probe = true;         // YTHIP_LPT_PROBE=0: do not split the first batch of a tile grid (see enqueue_batch)
-  // pixel pool (yt_kernels.h, DState::pool_next): a launch of fewer workgroups than tiles whose lanes
-  // take the next pixel of a queue when their own has had its batch.  Fills the wavefronts of scenes whose pixels
-  // cost very differently (hair: +15 %) and costs a few per cent where they do not (an even scene), so the library
-  // measures: once the tile costs are known, one full-size batch is timed plain, the next as a pool launch, and
-  // whichever took less time per sample is kept for this state.  Results are bit-identical either way.
-  int*                        d_pool_next = nullptr;     // the queue's head
-  int                         pixel_pool  = 1;           // YTHIP_PIXEL_POOL: 0 never, 1 (default) measured choice, 2 always
-  int                         pool_blocks = 0;           // workgroups of a pool launch (YTHIP_POOL_BLOCKS; default 16 per CU)
-  int                         pool_tune   = 0;           // 0 time a plain batch next, 1 time a pool batch next, 2 waiting for both, 3 decided
-  bool                        pool_on     = false;       // the decision
-  hipEvent_t                  pool_ev[4]  = {nullptr, nullptr, nullptr, nullptr};  // plain begin / end, pool begin / end
-  double                      pool_samples[2] = {0, 0};  // samples per pixel of the two timed launches
-  float                       pool_ms[2]  = {0, 0};      // (kept for ythip_pool_info)
-  int launch_blocks() const { return st.pool_next ? std::min(st.nblocks, pool_blocks) : st.nblocks; }
-  std::vector<void*>          order_allocs;             // the three buffers above: they outlive a state with the same tile grid
-  int                         order_tiles_x = 0, order_tiles_y = 0;
-  bool                        denoise_simple = false; // YTHIP_DENOISE_SIMPLE=1: the untiled kernel for every level (cross-check)
-  std::vector<void*>          staging_allocs;             // the 17 pools of ythip_scene_staging, in its order
-  std::vector<size_t>         staging_caps;               // their capacities in bytes (pools are reused when they fit)
-  ythip_scene                 staged      = {};
-  bool                        have_staged = false;
-  bool                        may_retry = false;  // opacity < 1 possible → bounce loop may exceed `bounces`
-  bool                        has_volumes = false;
-  bool                        all_matte   = false;  // "simple scene": matte untextured materials, triangle meshes only
-  bool                        no_textures = false;  // no material references a texture
-  bool                        opaque_textured = false;  // matte / glossy / reflective only, color + normal textures only, triangles + quads only
-  int                         specialize  = 1;
-  int                         num_cameras = 0;
-
-  ythost::flat_bvh    h_bvh;     // as uploaded/built (reference layout) for download
-  // shapes whose tree was built on the device (yt_gpubuild.hip); their slice of
-  // h_bvh is downloaded on demand (ensure_host_bvh)
-  std::vector<ytgpu::DeviceTree> d_trees;
-  std::vector<char>              d_tree_on_host;
-  int64_t                        device_build_min_prims = 16384;
-  int                            bvh_builder            = 1;  // 0 host only, 1 device for large shapes
-  int                            hold_policy            = 1;
-  int                            peek_policy            = 1;
-  // which walk k_trace / the test entries use: 0 binary, 1 wide, 2 (default) by the
-  // work at hand — see use_wide()
-  int     traversal_mode = 2;
-  int64_t largest_tree   = 0;  // primitives of the largest tree of the resident BVH
-  bool    wide_stack_ok  = true;  // the wide walk's worst-case stack depth fits the 128 entries (bake_bvh)
-  bool    use_wide() const;
-  ythip_build_info               build_info             = {};
-  int64_t                        num_pairs = 0, num_leaf4 = 0;
-  ythost::flat_lights h_lights;
-
-  DScene ds = {};
-  DState st = {};
-  bool   have_scene = false, have_bvh = false, have_lights = false, have_state = false;
-  bool   state_bound = false;
-  int    samples     = 0;
-
-  // measurement
-  int                                          prof_mode = 0;
-  unsigned long long*                          d_counters = nullptr;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-  std::vector<std::pair<int, int>>             ev_used;  // (pool index, kind 0 extend / 1 shade)
-  size_t                                       ev_next = 0;
-  ythip_stats                                  stats   = {};
-  float4 *nee_a = nullptr, *nee_b = nullptr, *nee_c = nullptr, *nee_d = nullptr, *nee_e = nullptr;  // deferred NEE (per slot)
-  float4*                                      nhit_a   = nullptr;
-  int*                                         nhit_e   = nullptr;
-
-  int*               d_stop        = nullptr;  // device-visible cancel word polled by the kernels
-  hipEvent_t         done_event    = nullptr;
-  // Cancellation by generation: every batch gets a number, the kernels stop when the
-  // word at d_stop EQUALS their batch's number, ythip_cancel writes the number of the batch in
-  // flight.  Nothing ever has to lower the flag, so a cancel that races with the next enqueue can
-  // neither be lost into it nor leak into it (the boolean of round 2 could end up raised with
-  // nobody left to lower it: every later tile then exited at once while `samples` kept advancing).
-  std::atomic<int>   stop_gen{0};
-  int*               stop_host     = nullptr;  // pinned host word ythip_cancel stores the batch number into ...
-  const int*         stop_host_dev = nullptr;  // ... and its device address (the kernels relay it into d_stop)
-  ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
-  bool               last_launch_fast = false;  // the last k_trace launch ran the tolerance-mode kernels (yt_fast.hip)
-};
-
-// yt_fast.hip: the tolerance-mode kernels (same source, -DYT_FAST, own namespace); 0 = launched, 1 = no such kernel
-extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds, const void* st, const void* kp, int lp, int cls);
-
-static void drop_staging_views(ythip_ctx* ctx) {
-  // host pools that view the staging memory go with it: the scene they belong to is no longer
-  // resident as far as the host-side builders are concerned (a new upload must follow)
-  bool viewed = false;
-  for (auto* pool : {&ctx->h_points, &ctx->h_lines, &ctx->h_triangles, &ctx->h_quads})
-    if (pool->ext) pool->ext = nullptr, pool->n = 0, viewed = true;
-  for (auto* pool : {&ctx->h_positions, &ctx->h_radius})
-    if (pool->ext) pool->ext = nullptr, pool->n = 0, viewed = true;
-  if (viewed) ctx->have_scene = ctx->have_bvh = ctx->have_lights = false;
-  ctx->have_staged = false;
-  ctx->staged      = {};
-}
-static void free_staging(ythip_ctx* ctx) {
-  drop_staging_views(ctx);
-  for (auto p : ctx->staging_allocs)
-    if (p) (void)hipHostFree(p);
-  ctx->staging_allocs.clear();
-  ctx->staging_caps.clear();
-}
-
-// The wide walk halves a ray's chain of dependent fetches and costs a little more
-// arithmetic per level.  It pays when the waves have the machine to themselves
-// (small slices: one GPU of eight, previews) and on large trees; on scenes made of
-// tiny trees the 4-slot records are mostly empty.  Measured in DESIGN.md §6.
-bool ythip_ctx::use_wide() const {
-  if (!wide_stack_ok) return false;  // trees too deep for the wide walk's pushes (bake_bvh): the binary walk
-  if (traversal_mode != 2) return traversal_mode == 1;
-  return largest_tree >= 64;
-}
+std::string& ythip_thread_error() { return g_error; }
 
 namespace {
-
-int fail(ythip_ctx* ctx, int code, const char* fmt, ...) {
-  char    buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  if (ctx) ctx->err = buf;
-  g_error = buf;
-  return code;
-}
-
-#define HIPCHECK(ctx, call)                                                                        \
-  do {                                                                                             \
-    hipError_t e_ = (call);                                                                        \
-    if (e_ != hipSuccess)                                                                          \
-      return fail(ctx, YTHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
-          __LINE__);                                                                               \
-  } while (0)
-
-void free_all(std::vector<void*>& v) {
-  for (auto p : v)
-    if (p) (void)hipFree(p);
-  v.clear();
-}
-
-template <typename T>
-int dalloc(ythip_ctx* ctx, std::vector<void*>& pool, T** out, size_t count) {
-  *out = nullptr;
-  if (count == 0) count = 1;  // keep pointers valid
-  void* p = nullptr;
-  HIPCHECK(ctx, hipMalloc(&p, count * sizeof(T)));
-  pool.push_back(p);
-  *out = (T*)p;
-  return YTHIP_OK;
-}
-template <typename T>
-int dupload(ythip_ctx* ctx, std::vector<void*>& pool, const T** out, const T* src, size_t count) {
-  T*  d  = nullptr;
-  int rc = dalloc(ctx, pool, &d, count);
-  if (rc) return rc;
-  if (count && src) HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, d, src, count * sizeof(T)));
-  *out = d;
-  return YTHIP_OK;
-}
-
-int grid_for(long long n) { return (int)((n + YT_BLOCK - 1) / YT_BLOCK); }
-
-KParams to_kparams(const ythip_ctx* ctx, const ythip_params* p) {
-  KParams k;
-  k.camera     = p->camera;
-  k.sampler    = p->sampler;
-  k.falsecolor = p->falsecolor;
-  k.bounces    = p->bounces;
-  k.clamp      = p->clamp;
-  k.nocaustics = p->nocaustics;
-  k.envhidden  = p->envhidden;
-  k.tentfilter = p->tentfilter;
-  k.has_env    = ctx->ds.num_environments > 0;
-  k.hold       = ctx->hold_policy;
-  k.peek       = ctx->peek_policy;
-  return k;
-}
-
-// Bake the reference-layout trees into the device layout of yt_bvh.h:
-//   * pairs:    one 64-B record per internal node holding BOTH children
-//               {bbox, ref} (+ the parent's split axis) — the two nodes the
-//               reference pops one after the other arrive in one fetch
-//   * leafdata: primitives pre-gathered in leaf order (ids come from
-//               `primitives[]`, so hit indices are unaffected)
-//   * tinst:    per-instance inverse frame + BLAS root {bbox, ref}
-// Trees live either on the host (ctx->h_bvh: uploaded, or built by yt_build.h)
-// or on the device (ctx->d_trees[s], built by yt_gpubuild.hip; their slice of
-// h_bvh is filled lazily by ensure_host_bvh()).  Host trees are baked here and
-// uploaded slice by slice, device trees are baked by kernels; both produce the
-// same bytes (tests/test_gpu_build.py).
-__global__ void __launch_bounds__(YT_BLOCK) k_gather_tinst(const DInstanceT* tinst, const int* tlas_prims, int n, int ninst,
-    DInstanceT* out) {
-  const int k = (int)(blockIdx.x * YT_BLOCK + threadIdx.x);
-  if (k >= n) return;
-  const int inst = tlas_prims[k];
-  if (inst < 0 || inst >= ninst) {  // (an uploaded tree with a bad instance id: an empty record, never entered)
-    DInstanceT e = {};
-    e.root_ref = REF_NONE, e.instance = -1;
-    out[k]     = e;
-    return;
-  }
-  DInstanceT r = tinst[inst];
-  r.instance   = inst;
-  out[k]       = r;
-}
-
-int bake_bvh(ythip_ctx* ctx) {
-  auto& b        = ctx->h_bvh;
-  int   nshapes  = (int)ctx->h_shapes.size();
-  int   ntrees   = (int)b.node_offset.size() - 1;
-  if (ntrees != nshapes + 1)
-    return fail(ctx, YTHIP_ERR_INVALID, "bvh has %d trees, scene has %d shapes (+1 expected)", ntrees, nshapes);
-  free_all(ctx->bvh_allocs);
-  auto on_device = [&](int t) { return t < (int)ctx->d_trees.size() && ctx->d_trees[t].nodes != nullptr; };
-
-  const auto&          nodes = b.nodes;
-  std::vector<int64_t> leaf_base(nshapes, 0);
-  std::vector<int>     strides(nshapes, 0);
-  int64_t              nleaf4 = 0;
-  for (int s = 0; s < nshapes; s++) {
-    leaf_base[s] = nleaf4;
-    int kind     = ythost::kind_bvh(ctx->h_shapes[s]);
-    strides[s]   = kind == KIND_TRIANGLES ? 3 : (kind == KIND_QUADS ? 4 : (kind == KIND_LINES ? 3 : 2));
-    nleaf4 += (b.prim_offset[s + 1] - b.prim_offset[s]) * strides[s];
-  }
-  if (nleaf4 > 0x7fffff00ll || (int64_t)nodes.size() > 0x7fffffffll || b.prim_offset[ntrees] > 0x0fffffffll)
-    return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit device references");
-  // sibling-pair ids: one per internal node, in node order, all trees
-  std::vector<int64_t> pair_base(ntrees + 1, 0);
-  for (int t = 0; t < ntrees; t++) {
-    int64_t n = 0;
-    if (on_device(t)) {
-      n = (ctx->d_trees[t].num_nodes - 1) / 2;  // strictly binary tree
-    } else {
-      for (int64_t k = b.node_offset[t]; k < b.node_offset[t + 1]; k++) n += nodes[k].internal ? 1 : 0;
-    }
-    pair_base[t + 1] = pair_base[t] + n;
-  }
-  const int64_t npairs = pair_base[ntrees];
-  if (npairs >= (int64_t)REF_INST) return fail(ctx, YTHIP_ERR_INVALID, "bvh too large for 32-bit device references");
-
-  const int LEAF_PAD = 8;  // the triangle loop fetches two primitives per round trip
-  float4 *  d_pairs = nullptr, *d_leaf = nullptr, *d_quads = nullptr;
-  int       rc;
-  if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_pairs, (size_t)npairs * 4 + 4))) return rc;
-  if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_quads, (size_t)npairs * 8 + 8))) return rc;
-  if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_leaf, (size_t)nleaf4 + LEAF_PAD))) return rc;
-  HIPCHECK(ctx, hipMemsetAsync(d_pairs + 4 * npairs, 0, 4 * sizeof(float4), ctx->stream));
-  HIPCHECK(ctx, hipMemsetAsync(d_leaf + nleaf4, 0, LEAF_PAD * sizeof(float4), ctx->stream));
-
-  struct Root {
-    float bmin[3], bmax[3];
-    int   ref;
-  };
-  std::vector<Root>                roots(ntrees, Root{{0, 0, 0}, {0, 0, 0}, REF_NONE});
-  std::vector<std::vector<float4>> staging;  // host-baked slices (YTHIP_HOST_BAKE=1)
-  bool                             bad_leaf = false;
-  // host-resident trees are baked by the device, all in one go (yt_gpubuild.hip: bake_host_trees)
-  const bool host_bake = [] { const char* e = std::getenv("YTHIP_HOST_BAKE"); return e && std::atoi(e) != 0; }();
-  struct Run {
-    int64_t node_begin, node_end, prim_begin, prim_end, cnode, cprim;
-  };
-  std::vector<ytgpu::HostTreeDesc> table;
-  std::vector<Run>                 runs;
-  int64_t                          compact_nodes = 0, compact_prims = 0;
-
-  for (int t = 0; t < ntrees; t++) {
-    const bool    blas  = t < nshapes;
-    const int64_t nn    = b.node_offset[t + 1] - b.node_offset[t];
-    const int64_t np    = b.prim_offset[t + 1] - b.prim_offset[t];
-    if (on_device(t) && !blas) {  // the instance tree, built on the device: pairs + quads, no leaf data
-      float       root7[7];
-      std::string err;
-      if (ytgpu::bake_shape_tree(ctx->stream, ctx->d_trees[t], 0, nullptr, nullptr, nullptr, pair_base[t], 0, 0, d_pairs,
-              d_quads, d_leaf, root7, &err) != ytgpu::BUILD_OK)
-        return fail(ctx, YTHIP_ERR_HIP, "device instance-tree bake failed: %s", err.c_str());
-      for (int c = 0; c < 3; c++) roots[t].bmin[c] = root7[c], roots[t].bmax[c] = root7[3 + c];
-      std::memcpy(&roots[t].ref, &root7[6], 4);
-      continue;
-    }
-    if (on_device(t)) {
-      const auto& sh   = ctx->h_shapes[t];
-      int         kind = ythost::kind_bvh(sh);
-      const int*  el   = kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
-                         : kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
-                         : kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
-                                                : ctx->ds.points + sh.points_offset;
-      float       root7[7];
-      std::string err;
-      if (ytgpu::bake_shape_tree(ctx->stream, ctx->d_trees[t], kind, el, ctx->ds.positions + 3 * sh.positions_offset,
-              sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, pair_base[t],
-              b.prim_offset[t], leaf_base[t], d_pairs, d_quads, d_leaf, root7, &err) != ytgpu::BUILD_OK)
-        return fail(ctx, YTHIP_ERR_HIP, "device bvh bake failed: %s", err.c_str());
-      for (int c = 0; c < 3; c++) roots[t].bmin[c] = root7[c], roots[t].bmax[c] = root7[3 + c];
-      std::memcpy(&roots[t].ref, &root7[6], 4);
-      continue;
-    }
-    // ---- a host-resident tree (yt_build.h, or uploaded by the caller) ---------------------
-    if (!host_bake) {
-      // baked on the device together with every other host tree (ytgpu::bake_host_trees): here only
-      // its descriptor, its place in the compact upload and its root
-      ytgpu::HostTreeDesc d = {};
-      d.node_off      = compact_nodes;
-      d.prim_off      = compact_prims;
-      d.pair_base     = pair_base[t];
-      d.ref_prim_base = blas ? b.prim_offset[t] : 0;
-      d.leaf_base     = blas ? leaf_base[t] : 0;
-      d.kind          = 0;
-      if (blas) {
-        const auto& sh = ctx->h_shapes[t];
-        d.kind         = ythost::kind_bvh(sh);
-        d.elems        = d.kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
-                         : d.kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
-                         : d.kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
-                         : d.kind == KIND_POINTS  ? ctx->ds.points + sh.points_offset
-                                                  : nullptr;
-        d.positions    = ctx->ds.positions + 3 * sh.positions_offset;
-        d.radius       = sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr;
-        if (d.kind == KIND_NONE) d.kind = 0;  // (an element-less shape: a one-node tree with an empty leaf)
-      }
-      table.push_back(d);
-      if (!runs.empty() && runs.back().node_end == b.node_offset[t] && runs.back().prim_end == b.prim_offset[t])
-        runs.back().node_end = b.node_offset[t + 1], runs.back().prim_end = b.prim_offset[t + 1];
-      else
-        runs.push_back({b.node_offset[t], b.node_offset[t + 1], b.prim_offset[t], b.prim_offset[t + 1], compact_nodes, compact_prims});
-      compact_nodes += nn, compact_prims += np;
-      for (int64_t k = b.node_offset[t]; k < b.node_offset[t + 1]; k++)
-        if (!nodes[k].internal && (nodes[k].num < 0 || nodes[k].num > 7)) bad_leaf = true;
-      if (nn > 0) {
-        const auto& root = nodes[b.node_offset[t]];
-        roots[t].ref     = root.internal ? (int32_t)pair_base[t]
-                                         : (int32_t)(0x80000000u | ((uint32_t)(root.num & 7) << 28) |
-                                                     (uint32_t)((blas ? b.prim_offset[t] : 0) + root.start));
-        for (int c = 0; c < 3; c++) roots[t].bmin[c] = root.bbox_min[c], roots[t].bmax[c] = root.bbox_max[c];
-      }
-      continue;
-    }
-    // ---- YTHIP_HOST_BAKE=1: the same records assembled on the host (the cross-check of the kernels) ----
-    if (blas && np > 0) {
-      const auto&  sh     = ctx->h_shapes[t];
-      int          kind   = ythost::kind_bvh(sh);
-      int          stride = strides[t];
-      const float* P      = ctx->h_positions.data() + 3 * sh.positions_offset;
-      const float* R      = sh.radius_offset >= 0 ? ctx->h_radius.data() + sh.radius_offset : nullptr;
-      auto         pos    = [&](int v) { return float3{P[3 * v], P[3 * v + 1], P[3 * v + 2]}; };
-      staging.emplace_back((size_t)np * stride, float4{0, 0, 0, 0});
-      auto& leaf = staging.back();
-      for (int64_t k = 0; k < np; k++) {
-        int     id = b.prims[b.prim_offset[t] + k];
-        float4* L  = leaf.data() + k * stride;
-        if (kind == KIND_TRIANGLES) {
-          const int* tr = ctx->h_triangles.data() + 3 * (sh.triangles_offset + id);
-          auto       p0 = pos(tr[0]), p1 = pos(tr[1]), p2 = pos(tr[2]);
-          L[0] = {p0.x, p0.y, p0.z, p1.x};
-          L[1] = {p1.y, p1.z, p2.x, p2.y};
-          L[2] = {p2.z, __builtin_bit_cast(float, id), 0, 0};
-        } else if (kind == KIND_QUADS) {
-          const int* q  = ctx->h_quads.data() + 4 * (sh.quads_offset + id);
-          auto       p0 = pos(q[0]), p1 = pos(q[1]), p2 = pos(q[2]), p3 = pos(q[3]);
-          L[0] = {p0.x, p0.y, p0.z, p1.x};
-          L[1] = {p1.y, p1.z, p2.x, p2.y};
-          L[2] = {p2.z, p3.x, p3.y, p3.z};
-          L[3] = {__builtin_bit_cast(float, id), 0, 0, 0};
-        } else if (kind == KIND_LINES) {
-          const int* l  = ctx->h_lines.data() + 2 * (sh.lines_offset + id);
-          auto       p0 = pos(l[0]), p1 = pos(l[1]);
-          L[0] = {p0.x, p0.y, p0.z, p1.x};
-          L[1] = {p1.y, p1.z, R ? R[l[0]] : 0.0f, R ? R[l[1]] : 0.0f};
-          L[2] = {__builtin_bit_cast(float, id), 0, 0, 0};
-        } else if (kind == KIND_POINTS) {
-          int  v = ctx->h_points[sh.points_offset + id];
-          auto p = pos(v);
-          L[0]   = {p.x, p.y, p.z, R ? R[v] : 0.0f};
-          L[1]   = {__builtin_bit_cast(float, id), 0, 0, 0};
-        }
-      }
-      HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, d_leaf + leaf_base[t], leaf.data(), leaf.size() * sizeof(float4)));
-    }
-    // pair ids of this tree, in node order
-    std::vector<int32_t> pair_id((size_t)nn, -1);
-    int64_t              next = pair_base[t];
-    for (int64_t n = 0; n < nn; n++)
-      if (nodes[b.node_offset[t] + n].internal) pair_id[n] = (int32_t)next++;
-    auto ref_of = [&](int64_t ln) -> int32_t {  // ln: tree-local node index
-      const auto& node = nodes[b.node_offset[t] + ln];
-      if (node.internal) return pair_id[ln];
-      if (node.num < 0 || node.num > 7) bad_leaf = true;
-      // BLAS leaves address leaf data by global primitive index, TLAS leaves index tlas_prims
-      int64_t first = (blas ? b.prim_offset[t] : 0) + node.start;
-      return (int32_t)(0x80000000u | ((uint32_t)(node.num & 7) << 28) | (uint32_t)first);
-    };
-    const int64_t np_t = pair_base[t + 1] - pair_base[t];
-    if (np_t > 0) {
-      staging.emplace_back((size_t)np_t * 4, float4{0, 0, 0, 0});
-      auto& pairs = staging.back();
-      for (int64_t n = 0; n < nn; n++) {
-        const auto& node = nodes[b.node_offset[t] + n];
-        if (!node.internal) continue;
-        float4* P = pairs.data() + 4 * (size_t)(pair_id[n] - pair_base[t]);
-        for (int c = 0; c < 2; c++) {
-          int64_t     lc = node.start + c;
-          const auto& ch = nodes[b.node_offset[t] + lc];
-          P[2 * c]       = {ch.bbox_min[0], ch.bbox_min[1], ch.bbox_max[0], ch.bbox_max[1]};
-          P[2 * c + 1]   = {ch.bbox_min[2], ch.bbox_max[2], __builtin_bit_cast(float, ref_of(lc)),
-                __builtin_bit_cast(float, (int32_t)node.axis)};
-        }
-      }
-      HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, d_pairs + 4 * pair_base[t], pairs.data(), pairs.size() * sizeof(float4)));
-      // grandchildren ("quad") records of the wide walk, same ids: slots 0,1 = children
-      // of child 0 (or child 0 itself when it is a leaf, slot 1 empty), slots 2,3
-      // likewise for child 1
-      staging.emplace_back((size_t)np_t * 8, float4{0, 0, 0, 0});
-      auto& quads = staging.back();
-      for (int64_t n = 0; n < nn; n++) {
-        const auto& node = nodes[b.node_offset[t] + n];
-        if (!node.internal) continue;
-        float4* Qr   = quads.data() + 8 * (size_t)(pair_id[n] - pair_base[t]);
-        int     axes = node.axis & 3;
-        for (int h = 0; h < 2; h++) {
-          int64_t     lc = node.start + h;
-          const auto& ch = nodes[b.node_offset[t] + lc];
-          int64_t     slot_node[2] = {lc, -1};
-          if (ch.internal) {
-            slot_node[0] = ch.start, slot_node[1] = ch.start + 1;
-            axes |= (ch.axis & 3) << (2 + 2 * h);
-          }
-          for (int k = 0; k < 2; k++) {
-            float4* S = Qr + 2 * (2 * h + k);
-            if (slot_node[k] < 0) {
-              S[0] = {0, 0, 0, 0};
-              S[1] = {0, 0, __builtin_bit_cast(float, (int32_t)REF_NONE), 0};
-              continue;
-            }
-            const auto& g = nodes[b.node_offset[t] + slot_node[k]];
-            S[0]          = {g.bbox_min[0], g.bbox_min[1], g.bbox_max[0], g.bbox_max[1]};
-            S[1]          = {g.bbox_min[2], g.bbox_max[2], __builtin_bit_cast(float, ref_of(slot_node[k])), 0};
-          }
-        }
-        Qr[1].w = __builtin_bit_cast(float, (int32_t)axes);
-      }
-      HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, d_quads + 8 * pair_base[t], quads.data(), quads.size() * sizeof(float4)));
-    }
-    if (nn > 0) {
-      const auto& root = nodes[b.node_offset[t]];
-      roots[t].ref     = ref_of(0);
-      for (int c = 0; c < 3; c++) roots[t].bmin[c] = root.bbox_min[c], roots[t].bmax[c] = root.bbox_max[c];
-    }
-  }
-  if (!table.empty()) {
-    // one compact upload of the host trees' nodes and primitives (run by run: host trees that sit next
-    // to each other in h_bvh travel together), the descriptor table, one set of launches for all of them
-    ythip_bvh_node*      d_nodes_c = nullptr;
-    int32_t*             d_prims_c = nullptr;
-    ytgpu::HostTreeDesc* d_table   = nullptr;
-    std::vector<void*>   tmp;
-    if ((rc = dalloc(ctx, tmp, &d_nodes_c, (size_t)compact_nodes)) || (rc = dalloc(ctx, tmp, &d_prims_c, (size_t)compact_prims)) ||
-        (rc = dalloc(ctx, tmp, &d_table, table.size()))) {
-      free_all(tmp);
-      return rc;
-    }
-    hipError_t e = ctx->xfer.h2d(ctx->stream, d_table, table.data(), table.size() * sizeof(ytgpu::HostTreeDesc));
-    for (auto& r : runs) {
-      if (e == hipSuccess && r.node_end > r.node_begin)
-        e = ctx->xfer.h2d(ctx->stream, d_nodes_c + r.cnode, b.nodes.data() + r.node_begin,
-            (size_t)(r.node_end - r.node_begin) * sizeof(ythip_bvh_node));
-      if (e == hipSuccess && r.prim_end > r.prim_begin)
-        e = ctx->xfer.h2d(ctx->stream, d_prims_c + r.cprim, b.prims.data() + r.prim_begin,
-            (size_t)(r.prim_end - r.prim_begin) * sizeof(int32_t));
-    }
-    std::string err;
-    int brc = e == hipSuccess ? ytgpu::bake_host_trees(ctx->stream, d_nodes_c, compact_nodes, d_prims_c, compact_prims, d_table,
-                                    (int)table.size(), d_pairs, d_quads, d_leaf, &err)
-                              : ytgpu::BUILD_ERROR;
-    free_all(tmp);
-    if (brc != ytgpu::BUILD_OK)
-      return fail(ctx, YTHIP_ERR_HIP, "bvh bake failed: %s", e != hipSuccess ? hipGetErrorString(e) : err.c_str());
-  }
-  // One 128-entry stack serves the TLAS walk, the TLAS-leaf continuation entries, the exit
-  // marker and the BLAS walk (yt_bvh.h), where the reference has 128 entries PER LEVEL
-  // (yocto_bvh.cpp:470, 560): refuse trees so deep that the shared stack could overflow
-  // where the reference's would not (a DFS holds at most one pending sibling per level;
-  // + 3 continuation entries of a 4-instance TLAS leaf + the exit marker).
-  {
-    auto depth_of = [&](int t) -> int {
-      if (on_device(t)) return ctx->d_trees[t].depth;
-      const int64_t nn = b.node_offset[t + 1] - b.node_offset[t];
-      if (nn <= 0) return 0;
-      int                                  best = 0;
-      std::vector<std::pair<int64_t, int>> todo = {{0, 1}};
-      while (!todo.empty()) {
-        auto [n, dpt] = todo.back();
-        todo.pop_back();
-        best = std::max(best, dpt);
-        const auto& node = nodes[b.node_offset[t] + n];
-        if (node.internal) todo.push_back({node.start, dpt + 1}), todo.push_back({node.start + 1, dpt + 1});
-      }
-      return best;
-    };
-    int deepest_blas = 0;
-    for (int t = 0; t < nshapes; t++) deepest_blas = std::max(deepest_blas, depth_of(t));
-    const int tlas_depth = depth_of(nshapes);
-    if (tlas_depth + deepest_blas + 5 > 128)
-      return fail(ctx, YTHIP_ERR_INVALID,
-          "bvh too deep for the shared traversal stack: instance tree %d levels + deepest shape tree %d levels + 5 > 128",
-          tlas_depth, deepest_blas);
-    // The wide walk advances two levels per step and can leave up to THREE pending siblings per
-    // step: 3 * ceil(depth / 2) entries per tree.  Trees between that bound and the
-    // binary one are walked binary — the reference renders them, so they are not refused.
-    auto wide_need      = [](int depth) { return 3 * ((depth + 1) / 2); };
-    ctx->wide_stack_ok = wide_need(tlas_depth) + wide_need(deepest_blas) + 5 <= 128;
-  }
-  // per-instance traversal records
-  std::vector<DInstanceT> tinst(ctx->h_instances.size());
-  for (size_t k = 0; k < tinst.size(); k++) {
-    const auto& inst = ctx->h_instances[k];
-    auto&       ti   = tinst[k];
-    ti               = DInstanceT{};
-    ythost::inverse_frame_nonrigid(inst.frame, ti.inv);
-    int s       = inst.shape;
-    ti.root_ref = roots[s].ref;
-    for (int c = 0; c < 3; c++) ti.root_bmin[c] = roots[s].bmin[c], ti.root_bmax[c] = roots[s].bmax[c];
-    ti.kind      = ythost::kind_bvh(ctx->h_shapes[s]);
-    ti.leaf_bias = (int)(leaf_base[s] - b.prim_offset[s] * strides[s]);
-    ti.shape     = s;
-  }
-  ctx->ds.tlas_ref  = roots[nshapes].ref;
-  ctx->ds.tlas_bmin = {roots[nshapes].bmin[0], roots[nshapes].bmin[1], roots[nshapes].bmin[2]};
-  ctx->ds.tlas_bmax = {roots[nshapes].bmax[0], roots[nshapes].bmax[1], roots[nshapes].bmax[2]};
-  if (bad_leaf) return fail(ctx, YTHIP_ERR_INVALID, "bvh leaf with more than 7 primitives (reference builds <= 4)");
-  ctx->ds.pairs    = d_pairs;
-  ctx->ds.wide     = d_quads;
-  ctx->ds.leafdata = d_leaf;
-  ctx->largest_tree = 0;
-  for (int t = 0; t < ntrees; t++) {
-    const int64_t np = b.prim_offset[t + 1] - b.prim_offset[t];
-    if (np > ctx->largest_tree) ctx->largest_tree = np;
-  }
-  ctx->num_pairs   = npairs;
-  ctx->num_leaf4   = nleaf4;
-  if (on_device(nshapes)) {
-    ctx->ds.tlas_prims = ctx->d_trees[nshapes].prims;  // (owned by the device tree, which outlives the bake)
-  } else if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tlas_prims, b.prims.data() + b.prim_offset[nshapes],
-                  (size_t)(b.prim_offset[nshapes + 1] - b.prim_offset[nshapes]))))
-    return rc;
-  if ((rc = dupload(ctx, ctx->bvh_allocs, &ctx->ds.tinst, tinst.data(), tinst.size()))) return rc;
-  {  // the records once more, in TLAS-leaf order: entering the k-th instance of a leaf is then ONE dependent fetch
-    const int64_t ntl = b.prim_offset[nshapes + 1] - b.prim_offset[nshapes];
-    DInstanceT*   d_tl = nullptr;
-    if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_tl, (size_t)ntl))) return rc;
-    if (ntl > 0)
-      hipLaunchKernelGGL(k_gather_tinst, dim3(grid_for(ntl)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds.tinst, ctx->ds.tlas_prims,
-          (int)ntl, (int)tinst.size(), d_tl);
-    HIPCHECK(ctx, hipGetLastError());
-    ctx->ds.tinst_leaf = d_tl;
-  }
-  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
-  ctx->have_bvh = true;
-  return YTHIP_OK;
-}
-
-void free_device_trees(ythip_ctx* ctx) {
-  for (auto& t : ctx->d_trees) ytgpu::free_tree(&t);
-  ctx->d_trees.clear();
-}
-
-// Fill the slices of ctx->h_bvh that belong to device-built trees (download).
-int ensure_host_bvh(ythip_ctx* ctx) {
-  auto& b = ctx->h_bvh;
-  for (size_t t = 0; t < ctx->d_trees.size(); t++) {
-    auto& dt = ctx->d_trees[t];
-    if (!dt.nodes || ctx->d_tree_on_host[t]) continue;
-    HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, b.nodes.data() + b.node_offset[t], dt.nodes, (size_t)dt.num_nodes * sizeof(ythip_bvh_node)));
-    HIPCHECK(ctx, ctx->xfer.d2h(ctx->stream, b.prims.data() + b.prim_offset[t], dt.prims, (size_t)dt.num_prims * sizeof(int32_t)));
-    ctx->d_tree_on_host[t] = 1;
-  }
-  return YTHIP_OK;
-}
-
-// make_scene_bvh (yocto_bvh.cpp:364-396) with the large shapes built on the
-// device (yt_gpubuild.hip) and everything else — small shapes, the instance
-// tree — by the host builder of yt_build.h.  Same trees either way.
-int build_bvh_mixed(ythip_ctx* ctx, const ythip_scene& sc, bool highquality, bool use_device) {
-  auto t_start = std::chrono::steady_clock::now();
-  free_device_trees(ctx);
-  auto& out = ctx->h_bvh;
-  out       = ythost::flat_bvh{};
-  ctx->build_info = {};
-  int  nshapes = sc.num_shapes;
-  ctx->d_trees.assign(nshapes, ytgpu::DeviceTree{});
-  ctx->d_tree_on_host.assign(nshapes, 0);
-  auto roots = std::vector<ythost::bbox>(nshapes);
-  auto empty = std::vector<char>(nshapes, 1);
-  auto prims_of = [&](const ythip_shape& sh) -> int64_t {
-    int kind = ythost::kind_bvh(sh);
-    return kind == KIND_POINTS ? sh.num_points : kind == KIND_LINES ? sh.num_lines
-           : kind == KIND_TRIANGLES ? sh.num_triangles : kind == KIND_QUADS ? sh.num_quads : 0;
-  };
-  // Shapes below the device threshold are built by a pool of host threads, as the reference does
-  // (make_scene_bvh's parallel_for over the shapes: yocto_bvh.cpp:369-378), WHILE this thread
-  // drives the device builds of the large ones.  Every tree is independent; they are concatenated
-  // in shape order afterwards, so the flat layout does not depend on who finished first.
-  std::vector<ythost::tree> host_trees(nshapes);
-  std::vector<char>         on_host(nshapes, 0);
-  for (int k = 0; k < nshapes; k++) on_host[k] = !(use_device && prims_of(sc.shapes[k]) >= ctx->device_build_min_prims);
-  // what the worker threads may touch: the shapes that were host shapes BEFORE the threads started.  (they
-  // used to test on_host[], which this thread edits when a device build falls back — a worker could then build and
-  // assign the same host_trees[k] concurrently.)  Fallbacks belong to this thread alone.
-  const std::vector<char> worker_shapes = on_host;
-  std::atomic<int>         next_shape{0};
-  std::vector<std::thread> workers;
-  {
-    int64_t host_count = 0, host_prims = 0;
-    for (int k = 0; k < nshapes; k++)
-      if (on_host[k]) host_count++, host_prims += prims_of(sc.shapes[k]);
-    unsigned want = host_prims > 50000 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), (unsigned)host_count) : 0;
-    if (const char* e = std::getenv("YTHIP_BUILD_THREADS")) want = (unsigned)std::max(0, std::atoi(e));
-    auto work = [&]() {
-      for (int k; (k = next_shape.fetch_add(1)) < nshapes;)
-        if (worker_shapes[k]) host_trees[k] = ythost::make_shape_bvh(sc, sc.shapes[k], highquality);
-    };
-    for (unsigned t = 0; t < want; t++) workers.emplace_back(work);
-    ctx->build_info.host_threads = (int)want;
-    // (no pool: the host shapes are built below, on this thread, after the device ones)
-  }
-  auto join_workers = [&]() {
-    for (auto& w : workers) w.join();
-    workers.clear();
-  };
-  // the device builds (they synchronise once per tree level: the host threads run meanwhile)
-  for (int k = 0; k < nshapes; k++) {
-    if (on_host[k]) continue;
-    const auto& sh    = sc.shapes[k];
-    int         kind  = ythost::kind_bvh(sh);
-    int64_t     nprim = prims_of(sh);
-    const int*  el    = kind == KIND_TRIANGLES ? ctx->ds.triangles + 3 * sh.triangles_offset
-                        : kind == KIND_QUADS   ? ctx->ds.quads + 4 * sh.quads_offset
-                        : kind == KIND_LINES   ? ctx->ds.lines + 2 * sh.lines_offset
-                                               : ctx->ds.points + sh.points_offset;
-    std::string err;
-    int rc = ytgpu::build_shape_tree(ctx->stream, kind, el, ctx->ds.positions + 3 * sh.positions_offset,
-        sh.radius_offset >= 0 && sh.num_radius ? ctx->ds.radius + sh.radius_offset : nullptr, nprim, highquality,
-        &ctx->d_trees[k], &err);
-    if (rc == ytgpu::BUILD_ERROR) {
-      join_workers();
-      return fail(ctx, YTHIP_ERR_HIP, "device bvh build failed: %s", err.c_str());
-    }
-    if (rc == ytgpu::BUILD_OK) {
-      auto& dt = ctx->d_trees[k];
-      ythip_bvh_node root;
-      if (auto e = ctx->xfer.d2h(ctx->stream, &root, dt.nodes, sizeof(root)); e != hipSuccess) {
-        join_workers();
-        return fail(ctx, YTHIP_ERR_HIP, "device bvh root readback failed: %s", hipGetErrorString(e));
-      }
-      roots[k].min = {root.bbox_min[0], root.bbox_min[1], root.bbox_min[2]};
-      roots[k].max = {root.bbox_max[0], root.bbox_max[1], root.bbox_max[2]};
-      empty[k]     = 0;
-      ctx->build_info.device_trees += 1;
-      ctx->build_info.device_prims += nprim;
-      ctx->build_info.device_ms += dt.build_ms;
-      ctx->build_info.max_depth = std::max(ctx->build_info.max_depth, dt.depth);
-    } else {  // (signed-zero tie: only the serial builder knows the answer)
-      ctx->build_info.fallbacks += 1;
-      host_trees[k] = ythost::make_shape_bvh(sc, sh, highquality);
-      on_host[k]    = 2;
-    }
-  }
-  if (workers.empty()) {
-    for (int k = 0; k < nshapes; k++)
-      if (on_host[k] == 1) host_trees[k] = ythost::make_shape_bvh(sc, sc.shapes[k], highquality);
-  }
-  join_workers();
-  // concatenate in shape order
-  for (int k = 0; k < nshapes; k++) {
-    out.node_offset.push_back((int64_t)out.nodes.size());
-    out.prim_offset.push_back((int64_t)out.prims.size());
-    if (!on_host[k]) {  // device tree: its slice is filled by ensure_host_bvh() on demand
-      auto& dt = ctx->d_trees[k];
-      out.nodes.resize(out.nodes.size() + (size_t)dt.num_nodes);
-      out.prims.resize(out.prims.size() + (size_t)dt.num_prims);
-      continue;
-    }
-    auto& t = host_trees[k];
-    if (!t.nodes.empty()) {
-      empty[k]     = 0;
-      auto& n      = t.nodes[0];
-      roots[k].min = {n.bbox_min[0], n.bbox_min[1], n.bbox_min[2]};
-      roots[k].max = {n.bbox_max[0], n.bbox_max[1], n.bbox_max[2]};
-    }
-    out.nodes.insert(out.nodes.end(), t.nodes.begin(), t.nodes.end());
-    out.prims.insert(out.prims.end(), t.prims.begin(), t.prims.end());
-    ythost::tree().nodes.swap(t.nodes);
-    ctx->build_info.host_trees += 1;
-  }
-  // the instance tree — yocto_bvh.cpp:381-393: make_bvh over the instances' world bounds.  With
-  // many instances it is built on the device like a large shape (kind 0: the boxes are the
-  // primitives); instances of empty shapes carry the invalid box, which stays with the host builder.
-  auto bboxes    = std::vector<ythost::bbox>(sc.num_instances);
-  bool any_empty = false;
-  for (auto k = 0; k < sc.num_instances; k++) {
-    auto& inst = sc.instances[k];
-    any_empty |= empty[inst.shape] != 0;
-    bboxes[k] = empty[inst.shape] ? ythost::bbox{} : ythost::transform_bbox(inst.frame, roots[inst.shape]);
-  }
-  out.node_offset.push_back((int64_t)out.nodes.size());
-  out.prim_offset.push_back((int64_t)out.prims.size());
-  bool tlas_on_device = false;
-  if (use_device && !any_empty && sc.num_instances >= ctx->device_build_min_prims) {
-    static_assert(sizeof(ythost::bbox) == 6 * sizeof(float), "bbox is {min, max}");
-    float* d_boxes = nullptr;
-    HIPCHECK(ctx, hipMalloc((void**)&d_boxes, bboxes.size() * sizeof(ythost::bbox)));
-    auto e = ctx->xfer.h2d(ctx->stream, d_boxes, bboxes.data(), bboxes.size() * sizeof(ythost::bbox));
-    std::string err;
-    ctx->d_trees.push_back(ytgpu::DeviceTree{});
-    ctx->d_tree_on_host.push_back(0);
-    int rc = e == hipSuccess ? ytgpu::build_shape_tree(ctx->stream, 0, nullptr, d_boxes, nullptr, sc.num_instances,
-                                   highquality, &ctx->d_trees[nshapes], &err)
-                             : ytgpu::BUILD_ERROR;
-    (void)hipFree(d_boxes);
-    if (rc == ytgpu::BUILD_ERROR) return fail(ctx, YTHIP_ERR_HIP, "device instance-tree build failed: %s", err.c_str());
-    if (rc == ytgpu::BUILD_OK) {
-      auto& dt = ctx->d_trees[nshapes];
-      out.nodes.resize(out.nodes.size() + (size_t)dt.num_nodes);  // filled by ensure_host_bvh()
-      out.prims.resize(out.prims.size() + (size_t)dt.num_prims);
-      ctx->build_info.device_ms += dt.build_ms;
-      ctx->build_info.device_tlas = 1;
-      ctx->build_info.max_depth   = std::max(ctx->build_info.max_depth, dt.depth);
-      tlas_on_device              = true;
-    } else {
-      ctx->build_info.fallbacks += 1;
-      ctx->d_trees.pop_back();
-      ctx->d_tree_on_host.pop_back();
-    }
-  }
-  if (!tlas_on_device) {
-    auto tlas = ythost::make_bvh(bboxes, highquality);
-    out.nodes.insert(out.nodes.end(), tlas.nodes.begin(), tlas.nodes.end());
-    out.prims.insert(out.prims.end(), tlas.prims.begin(), tlas.prims.end());
-  }
-  out.node_offset.push_back((int64_t)out.nodes.size());
-  out.prim_offset.push_back((int64_t)out.prims.size());
-  ctx->build_info.build_ms =
-      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-  auto t_bake = std::chrono::steady_clock::now();
-  int  rc     = bake_bvh(ctx);
-  ctx->build_info.bake_ms =
-      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bake).count();
-  return rc;
-}
 
 int upload_lights_impl(ythip_ctx* ctx) {
   free_all(ctx->light_allocs);
@@ -860,95 +35,39 @@ int upload_lights_impl(ythip_ctx* ctx) {
   ctx->have_lights = true;
   return YTHIP_OK;
 }
-
-template <int S, int LP>
-void launch_trace(ythip_ctx* ctx, const KParams& kp, bool count) {
-  dim3 grid(ctx->launch_blocks()), block(YT_BLOCK);  // one persistent one-wave workgroup per 16x4 tile
-  if (count)  // the counting launch walks binary: its counts are the reference's
-    hipLaunchKernelGGL((k_trace<S, LP, true, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
-  else if (ctx->use_wide())
-    hipLaunchKernelGGL((k_trace<S, LP, false, true>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
-  else
-    hipLaunchKernelGGL((k_trace<S, LP, false, false>), grid, block, 0, ctx->stream, ctx->ds, ctx->st, kp);
-}
-
 // lp: LP_NONE / LP_DEFER for path & pathtest (area lights absent / present);
 // pathdirect & pathmis always trace inline; the rest never need a light pdf.
 // fast: ythip_params::fastmath — the tolerance-mode kernels of yt_fast.hip where they exist (wide walk, real samplers).
+// The kernels themselves are compiled in the yt_trace_*.hip units (yt_launch.h), by sampler family.
 int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count, bool fast = false) {
+  // the scene class of the default sampler (yt_kernels.h: step_path's CLS)
+  const int cls = kp.sampler == YTHIP_SAMPLER_PATH && ctx->specialize
+                      ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0)
+                      : 0;
   // (the tolerance-mode unit has the wide-walk kernels only: they serve every tree the wide walk's stack bound admits —
   //  use_wide()'s preference for the binary walk on scenes of tiny trees is a matter of speed, not of results)
   if (fast && !count && ctx->wide_stack_ok && ctx->traversal_mode != 0) {
-    const int cls = kp.sampler == YTHIP_SAMPLER_PATH && ctx->specialize
-                        ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0)
-                        : 0;
     if (ythip_fast_launch(ctx->stream, ctx->launch_blocks(), &ctx->ds, &ctx->st, &kp, lp, cls) == 0) {
       ctx->last_launch_fast = true;
       return YTHIP_OK;
     }
   }
   ctx->last_launch_fast = false;
+  ytl::Launch l = {ctx->stream, ctx->launch_blocks(), &ctx->ds, &ctx->st, &kp, count, ctx->use_wide(), lp, cls};
+  int rc = 1;
   switch (kp.sampler) {
     case YTHIP_SAMPLER_PATH:
-      if (!count && ctx->all_matte && ctx->specialize && ctx->use_wide()) {
-        // the default sampler on an all-matte scene: the variant compiled without the
-        // other material lobes and the volume code (same results, fewer registers)
-        dim3 grid(ctx->launch_blocks()), block(YT_BLOCK);
-        if (lp == LP_DEFER)
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 1>), grid, block, 0, ctx->stream,
-              ctx->ds, ctx->st, kp);
-        else
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 1>), grid, block, 0, ctx->stream,
-              ctx->ds, ctx->st, kp);
-      } else if (!count && ctx->no_textures && ctx->specialize && ctx->use_wide()) {
-        // no material references a texture (any material types, any primitive kinds): the
-        // variant compiled without the texture lookups and the normal-map code
-        dim3 grid(ctx->launch_blocks()), block(YT_BLOCK);
-        if (lp == LP_DEFER)
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 2>), grid, block, 0, ctx->stream, ctx->ds,
-              ctx->st, kp);
-        else
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 2>), grid, block, 0, ctx->stream, ctx->ds,
-              ctx->st, kp);
-      } else if (!count && ctx->opaque_textured && ctx->specialize && ctx->use_wide()) {
-        // the "opaque textured" class (matte / glossy / reflective materials, textures in the color and normal slots only,
-        // triangle and quad meshes — the scenes of the reference's own corpus): no transmission lobes, no volume code,
-        // two texture evaluators instead of five, no line / point intersectors
-        dim3 grid(ctx->launch_blocks()), block(YT_BLOCK);
-        if (lp == LP_DEFER)
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_DEFER, false, true, 3>), grid, block, 0, ctx->stream, ctx->ds,
-              ctx->st, kp);
-        else
-          hipLaunchKernelGGL((k_trace<YTHIP_SAMPLER_PATH, LP_NONE, false, true, 3>), grid, block, 0, ctx->stream, ctx->ds,
-              ctx->st, kp);
-      } else if (lp == LP_DEFER)
-        launch_trace<YTHIP_SAMPLER_PATH, LP_DEFER>(ctx, kp, count);
-      else
-        launch_trace<YTHIP_SAMPLER_PATH, LP_NONE>(ctx, kp, count);
-      break;
-    case YTHIP_SAMPLER_PATHTEST:
-      if (lp == LP_DEFER)
-        launch_trace<YTHIP_SAMPLER_PATHTEST, LP_DEFER>(ctx, kp, count);
-      else
-        launch_trace<YTHIP_SAMPLER_PATHTEST, LP_NONE>(ctx, kp, count);
-      break;
-#if !defined(YT_DEV_ONLY_PATH) || defined(YT_DEV_NEE)  // development builds: compile the path / pathtest / naive kernels only (10x faster; -DYT_DEV_NEE adds these two)
+    case YTHIP_SAMPLER_PATHTEST: rc = ytl::launch_path(l); break;
     case YTHIP_SAMPLER_PATHDIRECT:
-      launch_trace<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER>(ctx, kp, count);
-      break;
-    case YTHIP_SAMPLER_PATHMIS:
-      launch_trace<YTHIP_SAMPLER_PATHMIS, LP_DEFER>(ctx, kp, count);
-      break;
-#endif
-    case YTHIP_SAMPLER_NAIVE: launch_trace<YTHIP_SAMPLER_NAIVE, LP_NONE>(ctx, kp, count); break;
-#ifndef YT_DEV_ONLY_PATH
-    case YTHIP_SAMPLER_EYELIGHT: launch_trace<YTHIP_SAMPLER_EYELIGHT, LP_NONE>(ctx, kp, count); break;
-    case YTHIP_SAMPLER_DIAGRAM: launch_trace<YTHIP_SAMPLER_DIAGRAM, LP_NONE>(ctx, kp, count); break;
-    case YTHIP_SAMPLER_FURNACE: launch_trace<YTHIP_SAMPLER_FURNACE, LP_NONE>(ctx, kp, count); break;
-    case YTHIP_SAMPLER_FALSECOLOR: launch_trace<YTHIP_SAMPLER_FALSECOLOR, LP_NONE>(ctx, kp, count); break;
-#endif
-    default: return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
+    case YTHIP_SAMPLER_PATHMIS: rc = ytl::launch_nee(l); break;
+    case YTHIP_SAMPLER_NAIVE:
+    case YTHIP_SAMPLER_EYELIGHT:
+    case YTHIP_SAMPLER_DIAGRAM:
+    case YTHIP_SAMPLER_FURNACE:
+    case YTHIP_SAMPLER_FALSECOLOR: rc = ytl::launch_misc(l); break;
+    default: break;
   }
+  if (rc) return fail(ctx, YTHIP_ERR_SAMPLER, "sampler unknown");
   return YTHIP_OK;
 }
 
