@@ -45,6 +45,7 @@ import glob
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -168,7 +169,11 @@ OTHER_WARMUP = 3
 PMC_PASSES = [
     ["FETCH_SIZE", "TCC_REQ_sum", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_THREAD_CYCLES_VALU"],
+    # the vector-memory address path (round 4: the co-bound the first two passes could not name): cycles the texture
+    # addressers (one per CU) are busy, wave-level load instructions, L1 tag lookups; its own cycle count
+    ["TA_TA_BUSY_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "GRBM_GUI_ACTIVE"],
 ]
+N_CU = 256  # MI355X: 8 XCDs x 32 CUs (MI355X_MICROARCH.md); one texture addresser (TA) per CU
 VALU_CYCLES = 2.0  # MI355X_MICROARCH.md (CU): a wave64 VALU instruction occupies a 32-lane SIMD for 2 cycles
 
 
@@ -200,11 +205,21 @@ def _collect_counters(name, device, timeout=240, fastmath=0, passes=None):
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
+        # (its own process group: on a timeout the profiler AND the worker under it go — a worker left behind would keep
+        #  the device busy under every later measurement)
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                start_new_session=True)
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            so, se = proc.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.communicate()
             shutil.rmtree(out, ignore_errors=True)
-            return None, f"rocprofv3 pass timed out after {timeout} s"
+            return None, f"rocprofv3 pass {' '.join(counters)} timed out after {timeout} s"
+        r = subprocess.CompletedProcess(cmd, proc.returncode, so, se)
         per = {}  # counter -> dispatch -> value (rows of one dispatch, e.g. per XCD, are summed)
         for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
@@ -217,13 +232,16 @@ def _collect_counters(name, device, timeout=240, fastmath=0, passes=None):
         shutil.rmtree(out, ignore_errors=True)
         if not per:
             return None, f"rocprofv3 pass produced no counters (rc {r.returncode}): {r.stderr[-200:]}"
+        ta_pass = "TA_TA_BUSY_sum" in counters
         for c, d in per.items():
+            if ta_pass and c == "GRBM_GUI_ACTIVE":
+                c = "GRBM_GUI_ACTIVE_ta_pass"  # (the TA share is taken against the cycles of ITS pass)
             # the worker's last WORKER_STEPS dispatches are its timed, full-size launches (what comes
             # before is the warm-up — with YTHIP_LPT_PROBE=1 a 1 + (batch - 1) pair of launches).
             # GRBM_GUI_ACTIVE is a wall-clock cycle count of the dispatch window: anything else the
             # device does meanwhile inflates it, so the quietest launch is the measurement
             last = [d[k] for k in sorted(d, key=int)[-WORKER_STEPS:]]
-            vals[c] = min(last) if c == "GRBM_GUI_ACTIVE" else sum(last) / len(last)
+            vals[c] = min(last) if c.startswith("GRBM_GUI_ACTIVE") else sum(last) / len(last)
     return vals, kernel
 
 
@@ -264,6 +282,16 @@ def roofline_of(run, counters, kernel, calib):
         roof["valu_cycles_per_instruction"] = VALU_CYCLES
         roof["shader_clock_GHz"] = round(cyc / sec / 1e9, 3)
         fr["valu"] = counters["SQ_INSTS_VALU"] * VALU_CYCLES / (N_SIMD * cyc)
+    if counters.get("TA_TA_BUSY_sum") and counters.get("GRBM_GUI_ACTIVE_ta_pass"):
+        # the vector-memory address path: busy cycles of the 256 texture addressers over 256 x the launch's shader cycles.
+        # A wave-level 16-B-per-lane load keeps its CU's TA busy for ~16-20 cycles however many of its lanes are active,
+        # so divergent loads waste this pipe exactly as they waste VALU lanes.
+        cyc_ta = counters["GRBM_GUI_ACTIVE_ta_pass"] / 8.0
+        fr["ta"] = counters["TA_TA_BUSY_sum"] / (N_CU * cyc_ta)
+        if counters.get("TA_FLAT_READ_WAVEFRONTS_sum"):
+            roof["ta_cycles_per_wave_load"] = round(counters["TA_TA_BUSY_sum"] / counters["TA_FLAT_READ_WAVEFRONTS_sum"], 2)
+            if counters.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                roof["l1_lookups_per_wave_load"] = round(counters["TCP_TOTAL_CACHE_ACCESSES_sum"] / counters["TA_FLAT_READ_WAVEFRONTS_sum"], 2)
     if counters.get("SQ_THREAD_CYCLES_VALU") and counters.get("SQ_ACTIVE_INST_VALU"):
         roof["lane_utilisation"] = round(counters["SQ_THREAD_CYCLES_VALU"] / (64.0 * counters["SQ_ACTIVE_INST_VALU"]), 4)
     if counters.get("SQ_WAIT_ANY") and counters.get("SQ_WAVE_CYCLES"):
@@ -278,6 +306,9 @@ def roofline_of(run, counters, kernel, calib):
             roof.update(achieved=roof["hbm_GBps"], peak=HBM_PEAK_GBS, unit="GB/s")
         elif b == "l2":
             roof.update(achieved=roof["l2_GBps"], peak=L2_PEAK_GBS, unit="GB/s")
+        elif b == "ta":
+            ach = counters["TA_TA_BUSY_sum"] / sec / 1e9
+            roof.update(achieved=round(ach, 1), peak=round(ach / fr["ta"], 1), unit="G texture-addresser busy cycles/s (256 TAs)")
         else:
             ach = counters["SQ_INSTS_VALU"] / sec / 1e9
             roof.update(achieved=round(ach, 1), peak=round(ach / fr["valu"], 1), unit="G wave-instructions/s")

@@ -36,7 +36,7 @@ def test_default_line_carries_the_contract():
     r = j["roofline"]
     # fractions of the roofs that can bind, from live counters of this workload: all <= 1, the
     # largest is the bound
-    assert r["bound"] in ("hbm", "l2", "valu") and set(r["fractions"]) == {"hbm", "l2", "valu"}
+    assert r["bound"] in ("hbm", "l2", "valu", "ta") and set(r["fractions"]) == {"hbm", "l2", "valu", "ta"}
     assert all(0 < f <= 1 for f in r["fractions"].values()), r["fractions"]
     assert r["frac"] == max(r["fractions"].values()) and r["fractions"][r["bound"]] == r["frac"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
@@ -62,7 +62,7 @@ def test_default_line_carries_the_contract():
         assert "error" not in o, o
         assert o["value"] > 0 and o["unit"] == "Msamples/s"
         f = o["roofline"]["fractions"]
-        assert set(f) == {"hbm", "l2", "valu"} and all(0 < x <= 1 for x in f.values()), (o["workload"], f)
+        assert set(f) == {"hbm", "l2", "valu", "ta"} and all(0 < x <= 1 for x in f.values()), (o["workload"], f)
     assert all(o["roofline"]["kernel"].startswith("yt::k_trace") for o in exact)
     assert all(o["roofline"]["kernel"].startswith("yt_fast::k_trace") for o in fast)  # the tolerance-mode unit really ran
     assert all(0.9 < o["speedup_over_bit_exact"] < 2 for o in fast)

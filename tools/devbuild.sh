@@ -12,20 +12,20 @@ HIPCC=/opt/rocm/bin/hipcc
 FLAGS="--offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -ffp-contract=off -fPIC"
 C=yocto-gl_amd/csrc
 newest_header=$(ls -t $C/*.h include/ythip.h | head -1)
-for u in yt_gpubuild yt_multi yt_order yt_io yt_sceneio yt_fast yt_bake; do
+for u in yt_gpubuild yt_multi yt_order yt_io yt_sceneio yt_fast; do
   o=build/dev/$u.o
   if [ ! -f $o ] || [ $C/$u.hip -nt $o ] || [ $newest_header -nt $o ]; then
     ( flock 9; if [ ! -f $o ] || [ $C/$u.hip -nt $o ] || [ $newest_header -nt $o ]; then $HIPCC $FLAGS -c -o $o.tmp.$$ $C/$u.hip && mv $o.tmp.$$ $o; fi ) 9> build/dev/.lock.$u &
   fi
 done
 pids=""
-for u in ythip yt_trace_path yt_trace_nee yt_trace_misc; do
+for u in ythip yt_bake yt_trace_path yt_trace_nee yt_trace_misc; do
   $HIPCC $FLAGS -DYT_DEV_ONLY_PATH "$@" -c -o build/dev/${u}_$name.o $C/$u.hip & pids="$pids $!"
 done
 for p in $pids; do wait $p; done
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o build/dev/libythip_$name.so build/dev/ythip_$name.o build/dev/yt_trace_path_$name.o \
-  build/dev/yt_trace_nee_$name.o build/dev/yt_trace_misc_$name.o build/dev/yt_bake.o build/dev/yt_gpubuild.o build/dev/yt_multi.o \
+  build/dev/yt_trace_nee_$name.o build/dev/yt_trace_misc_$name.o build/dev/yt_bake_$name.o build/dev/yt_gpubuild.o build/dev/yt_multi.o \
   build/dev/yt_order.o build/dev/yt_io.o build/dev/yt_sceneio.o build/dev/yt_fast.o -ldl -lz
-rm -f build/dev/ythip_$name.o build/dev/yt_trace_*_$name.o
+rm -f build/dev/ythip_$name.o build/dev/yt_trace_*_$name.o build/dev/yt_bake_$name.o
 echo built build/dev/libythip_$name.so

@@ -21,7 +21,8 @@ for a in sys.argv[2:]:
         cur.append(a)
 if cur:
     passes.append(cur)
-vals, kernel = bench._collect_counters(name, 0, 600, 1 if fast == "fast" else 0, passes)
+# (every pass under its own short timeout: a counter set the profiler cannot schedule has been seen to hang, not fail)
+vals, kernel = bench._collect_counters(name, 0, int(os.environ.get("PMC_TIMEOUT", "90")), 1 if fast == "fast" else 0, passes)
 if vals is None:
     sys.exit(f"{name}: {kernel}")
 print(f"{sys.argv[1]}  kernel {kernel}")

@@ -31,6 +31,35 @@ __global__ void __launch_bounds__(YT_BLOCK) k_gather_tinst(const DInstanceT* tin
   out[k]       = r;
 }
 
+#ifdef YT_WIDE8
+// Great-grandchildren ("oct") records from the baked pair and quad records, one thread per internal node: for each of
+// the quad record's four slots g — a grandchild — its two children out of g's pair record (or g itself + an empty slot
+// when g is a leaf; two empty slots when g is empty), and the axes of the seven nodes involved.
+__global__ void __launch_bounds__(YT_BLOCK) k_bake_oct(const float4* pairs, const float4* quads, long long n, float4* oct) {
+  const long long k = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  const float4* Q    = quads + 8 * k;
+  float4*       O    = oct + 16 * k;
+  int           axes = __float_as_int(Q[1].w) & 63;
+  const float4  none0 = {0, 0, 0, 0}, none1 = {0, 0, __int_as_float(REF_NONE), 0};
+  for (int g = 0; g < 4; g++) {
+    const float4 s0 = Q[2 * g], s1 = Q[2 * g + 1];
+    const int    ref = __float_as_int(s1.z);
+    float4*      D   = O + 4 * g;
+    if (ref >= 0 && ref < REF_INST) {  // internal: its two children
+      const float4* P = pairs + 4 * (long long)ref;
+      D[0] = P[0], D[1] = {P[1].x, P[1].y, P[1].z, 0}, D[2] = P[2], D[3] = {P[3].x, P[3].y, P[3].z, 0};
+      axes |= (__float_as_int(P[1].w) & 3) << (6 + 2 * g);
+    } else if (ref == REF_NONE) {
+      D[0] = none0, D[1] = none1, D[2] = none0, D[3] = none1;
+    } else {  // a leaf: itself, then nothing
+      D[0] = s0, D[1] = {s1.x, s1.y, s1.z, 0}, D[2] = none0, D[3] = none1;
+    }
+  }
+  O[1].w = __int_as_float(axes);
+}
+#endif
+
 int bake_bvh(ythip_ctx* ctx) {
   auto& b        = ctx->h_bvh;
   int   nshapes  = (int)ctx->h_shapes.size();
@@ -333,7 +362,11 @@ int bake_bvh(ythip_ctx* ctx) {
     // The wide walk advances two levels per step and can leave up to THREE pending siblings per
     // step: 3 * ceil(depth / 2) entries per tree.  Trees between that bound and the
     // binary one are walked binary — the reference renders them, so they are not refused.
+#ifdef YT_WIDE8  // (three levels per step, up to seven pending siblings per step)
+    auto wide_need      = [](int depth) { return 7 * ((depth + 2) / 3); };
+#else
     auto wide_need      = [](int depth) { return 3 * ((depth + 1) / 2); };
+#endif
     ctx->wide_stack_ok = wide_need(tlas_depth) + wide_need(deepest_blas) + 5 <= 128;
   }
   // per-instance traversal records
@@ -380,6 +413,16 @@ int bake_bvh(ythip_ctx* ctx) {
     HIPCHECK(ctx, hipGetLastError());
     ctx->ds.tinst_leaf = d_tl;
   }
+#ifdef YT_WIDE8
+  {
+    float4* d_oct = nullptr;
+    if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_oct, (size_t)npairs * 16 + 16))) return rc;
+    if (npairs > 0)
+      hipLaunchKernelGGL(k_bake_oct, dim3(grid_for(npairs)), dim3(YT_BLOCK), 0, ctx->stream, d_pairs, d_quads, (long long)npairs, d_oct);
+    HIPCHECK(ctx, hipGetLastError());
+    ctx->ds.oct = d_oct;
+  }
+#endif
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   ctx->have_bvh = true;
   return YTHIP_OK;

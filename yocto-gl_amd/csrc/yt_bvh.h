@@ -324,6 +324,37 @@ YT_FN bool slab_rec(vec3f o, vec3f dinv, float tmin, float4 r0, float4 r1, float
 #endif
 }
 
+// Wavefront-uniform reads through the SCALAR cache (round 4).  The vector-memory address path is this kernel's co-bound
+// (profiles/r04_traversal.txt §5: a wave-level 16-B-per-lane load keeps the CU's texture addresser busy ~16-20 cycles
+// however many lanes are active).  When every lane that executes a load asks for the SAME record — camera rays of a tile
+// in the upper levels of their walks, every ray entering the one instance of a scene, every light-pdf walk of one light —
+// the record can come through s_load instead: the baked traversal data never changes during a launch, so it may be read
+// through the constant address space.  wave_uniform(x, u): u = x of the first active lane; true when all active lanes agree.
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const v4f_ cv4f;
+YT_FN bool wave_uniform(int x, int& u) {
+  u = __builtin_amdgcn_readfirstlane(x);
+  return __ballot(x != u) == 0ull;
+}
+YT_FN float4 ldc4(const void* p, int k) {  // float4 #k at the (uniform) address p, by scalar load
+  const v4f_ v = ((cv4f*)p)[k];
+  return float4{v.x, v.y, v.z, v.w};
+}
+// the 96-B traversal record #idx of `base` (sc.tinst or sc.tinst_leaf)
+YT_FN void load_instance_record(const DInstanceT* base, int idx, float4& m0, float4& m1, float4& m2, float4& m3, float4& m4, int4& m5) {
+  int u;
+  if (SCALAR_LOADS && wave_uniform(idx, u)) {
+    const DInstanceT* r = base + u;
+    m0 = ldc4(r, 0), m1 = ldc4(r, 1), m2 = ldc4(r, 2), m3 = ldc4(r, 3), m4 = ldc4(r, 4);
+    const float4 t = ldc4(r, 5);
+    m5 = {__float_as_int(t.x), __float_as_int(t.y), __float_as_int(t.z), __float_as_int(t.w)};
+    return;
+  }
+  const float4* ti = reinterpret_cast<const float4*>(base + idx);
+  m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
+  m5 = reinterpret_cast<const int4*>(ti)[5];
+}
+
 // Software prefetch (YT_PREFETCH): gfx950 has no prefetch instruction, but a load that lands in
 // LDS (global_load_lds_dword: M0 = LDS byte offset, destination M0 + 4 * lane) needs no VGPR and
 // nobody has to wait for it; the line it touches is then in the L2 (and the CU's vector L1) when the
@@ -421,11 +452,11 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   // `rec`: the instance's traversal record — sc.tinst + inst, or the copy of it in TLAS-leaf order (sc.tinst_leaf + k,
   // whose pad word carries the instance id: one dependent fetch less per TLAS-leaf entry than tlas_prims -> tinst).
   // `tested`: the root-box test has been made when the TLAS leaf was expanded (pretest below).
-  auto enter = [&](const DInstanceT* rec, int inst, bool tested = false) -> int {
-    const float4* ti = reinterpret_cast<const float4*>(rec);
-    float4        m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
-    int4          m5 = reinterpret_cast<const int4*>(ti)[5];
-    int           root = __float_as_int(m4.z);
+  auto enter = [&](const DInstanceT* base, int idx, int inst, bool tested = false) -> int {
+    float4 m0, m1, m2, m3, m4;
+    int4   m5;
+    load_instance_record(base, idx, m0, m1, m2, m3, m4, m5);
+    int root = __float_as_int(m4.z);
     if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
@@ -458,10 +489,10 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   // entry `k` of the TLAS-leaf order (a continuation entry's code >> 1)
   auto enter_leaf_entry = [&](int k, bool tested) -> int {
 #ifndef YT_NO_TINST_LEAF
-    return enter(sc.tinst_leaf + k, -1, tested);
+    return enter(sc.tinst_leaf, k, -1, tested);
 #else  // development builds: the two dependent fetches of rounds 1-3 (tlas_prims -> tinst)
     const int inst = sc.tlas_prims[k];
-    return enter(sc.tinst + inst, inst, tested);
+    return enter(sc.tinst, inst, inst, tested);
 #endif
   };
   // PRETEST (the wide walk; round 4, +4 ... +10 % on scenes with instances, profiles/r04_traversal.txt): the tmax-INDEPENDENT half of an instance's root-box test — transform_ray + intersect_bbox's
@@ -472,12 +503,13 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   // leaf have shrunk tmax: the same decision on the same floats as testing at entry time (header, and slab()).
   // Returns false for "cannot enter whatever tmax is"; an irregular instance-level ray passes (enter() then aborts).
   auto pretest = [&](int k, float& t0) -> bool {
+    float4 m0, m1, m2, m3, m4;
+    int4   m5;
 #ifndef YT_NO_TINST_LEAF
-    const float4* ti = reinterpret_cast<const float4*>(sc.tinst_leaf + k);
+    load_instance_record(sc.tinst_leaf, k, m0, m1, m2, m3, m4, m5);
 #else
-    const float4* ti = reinterpret_cast<const float4*>(sc.tinst + sc.tlas_prims[k]);
+    load_instance_record(sc.tinst, sc.tlas_prims[k], m0, m1, m2, m3, m4, m5);
 #endif
-    float4 m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
     t0 = 0;
     if (__float_as_int(m4.z) == REF_NONE) return false;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
@@ -508,7 +540,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   int cur = REF_NONE;  // node to process next, REF_NONE = pop one
   if (only_instance >= 0) {
     cur_last = true;
-    cur      = enter(sc.tinst + only_instance, only_instance);
+    cur      = enter(sc.tinst, only_instance, only_instance);
     if (WIDE && abort) return Hit{HIT_ABORT, -1, 0, 0, 0, false};
     if (cur_inst < 0) return best;
   } else {
@@ -583,57 +615,143 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
 #endif
         break;  // BLAS leaf or instance entry → phase 2
       }
+#ifdef YT_WIDE8  // experiment: THREE levels per dependent fetch — 256-B records of a node's eight great-grandchildren
+      if constexpr (WIDE) {
+        // The record (yt_bake.hip: k_bake_oct) is two quad-shaped halves: half h = the (up to) four grandchildren-of-child-h,
+        // i.e. for each of child h's two children g its two children (or g itself + an empty slot when g is a leaf).  The
+        // half the reference visits SECOND goes first here — everything of it that passes is pushed, last visited first —
+        // then the near half, whose first survivor becomes `cur`: one pending entry carried through both, exactly the
+        // quad step's push logic twice.  Same visit order (ray_dsign of the node, of the child, of the grandchild), same
+        // pop-time test per slot, skipped ancestor tests implied as for the quad records (a box contains its descendants').
+        const float4* Op   = sc.oct + 16 * (int64_t)cur;
+        const int     axes = __float_as_int(Op[1].w);  // node | child0 << 2 | child1 << 4 | grandchildren 0..3 << 6, 8, 10, 12
+        const bool    ns   = ((sign >> (axes & 3)) & 1) != 0;  // ray_dsign[node.axis]: child 1's half is visited first
+        cnt.steps++;
+        int   pr = REF_NONE;
+        float pt = 0;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+          const int     h  = pass == 0 ? (ns ? 0 : 1) : (ns ? 1 : 0);  // pass 0: the half visited second
+          const float4* Qp = Op + 8 * h;
+          float4        a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
+          float ta, tb, tc, td;
+          bool  fa = slab_rec(o, dinv, tmin, a0, a1, ta);
+          bool  fb = slab_rec(o, dinv, tmin, b0, b1, tb);
+          bool  fc = slab_rec(o, dinv, tmin, c0, c1, tc);
+          bool  fd = slab_rec(o, dinv, tmin, d0, d1, td);
+          int ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
+          int rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;
+          int rc = (fc && tc <= tmaxk) ? __float_as_int(c1.z) : REF_NONE;
+          int rd = (fd && td <= tmaxk) ? __float_as_int(d1.z) : REF_NONE;
+          // a, b = children of grandchild 2h (or itself); c, d = of grandchild 2h + 1
+          const bool hs = ((sign >> ((axes >> (2 + 2 * h)) & 3)) & 1) != 0;   // child h's axis: its child 1 first
+          const bool ls = ((sign >> ((axes >> (6 + 4 * h)) & 3)) & 1) != 0;   // grandchild 2h's axis
+          const bool rs = ((sign >> ((axes >> (8 + 4 * h)) & 3)) & 1) != 0;   // grandchild 2h + 1's axis
+          int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
+          float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
+          int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
+          float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
+          if (v3r != REF_NONE) {
+            if (pr != REF_NONE) push(pr, pt);
+            pr = v3r, pt = v3t;
+          }
+          if (v2r != REF_NONE) {
+            if (pr != REF_NONE) push(pr, pt);
+            pr = v2r, pt = v2t;
+          }
+          if (v1r != REF_NONE) {
+            if (pr != REF_NONE) push(pr, pt);
+            pr = v1r, pt = v1t;
+          }
+          if (v0r != REF_NONE) {
+            if (pr != REF_NONE) push(pr, pt);
+            pr = v0r, pt = v0t;
+          }
+        }
+        cur = pr;
+        continue;
+      }
+#endif
       if constexpr (WIDE) {
         // internal node, two levels at once: its grandchildren in the order the
         // reference's walk reaches them, each pushed with its own pop-time test
-        const float4* Qp = sc.wide + 8 * (int64_t)cur;
-        float4        a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
         cnt.steps++;
-        float ta, tb, tc, td;
-        // per slot {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axes}, like the pair records
-        bool  fa = slab_rec(o, dinv, tmin, a0, a1, ta);
-        bool  fb = slab_rec(o, dinv, tmin, b0, b1, tb);
-        bool  fc = slab_rec(o, dinv, tmin, c0, c1, tc);
-        bool  fd = slab_rec(o, dinv, tmin, d0, d1, td);
-        // slots: a, b = children of child 0 (or child 0 itself, then b is empty); c, d likewise for child 1
-        int ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
-        int rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;
-        int rc = (fc && tc <= tmaxk) ? __float_as_int(c1.z) : REF_NONE;
-        int rd = (fd && td <= tmaxk) ? __float_as_int(d1.z) : REF_NONE;
-        const int  axes = __float_as_int(a1.w);  // node axis | child 0's axis << 2 | child 1's axis << 4
-        const bool hs = ((sign >> (axes & 3)) & 1) != 0, ls = ((sign >> ((axes >> 2) & 3)) & 1) != 0,
-                   rs = ((sign >> ((axes >> 4) & 3)) & 1) != 0;
-        // within each half: ray_dsign[child.axis] → its child 1 first (yocto_bvh.cpp:498-504)
-        int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
-        float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
-        // the halves: ray_dsign[node.axis] → child 1's half first
-        int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
-        float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
-        // last to first: whatever passed is pushed, the nearest one becomes `cur`
-        int   pr = REF_NONE;
-        float pt = 0;
-        YT_PF_DECL
-        if (v3r != REF_NONE) pr = v3r, pt = v3t;
-        if (v2r != REF_NONE) {
-          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
-          pr = v2r, pt = v2t;
+        // (the step on a record given by value: the wavefront-uniform form below hands it scalar registers)
+        auto wide_step = [&](const float4 a0, const float4 a1, const float4 b0, const float4 b1, const float4 c0, const float4 c1,
+                             const float4 d0, const float4 d1) __attribute__((always_inline)) {
+          float ta, tb, tc, td;
+          // per slot {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axes}, like the pair records
+          bool  fa = slab_rec(o, dinv, tmin, a0, a1, ta);
+          bool  fb = slab_rec(o, dinv, tmin, b0, b1, tb);
+          bool  fc = slab_rec(o, dinv, tmin, c0, c1, tc);
+          bool  fd = slab_rec(o, dinv, tmin, d0, d1, td);
+          // slots: a, b = children of child 0 (or child 0 itself, then b is empty); c, d likewise for child 1
+          int ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
+          int rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;
+          int rc = (fc && tc <= tmaxk) ? __float_as_int(c1.z) : REF_NONE;
+          int rd = (fd && td <= tmaxk) ? __float_as_int(d1.z) : REF_NONE;
+          const int  axes = __float_as_int(a1.w);  // node axis | child 0's axis << 2 | child 1's axis << 4
+          const bool hs = ((sign >> (axes & 3)) & 1) != 0, ls = ((sign >> ((axes >> 2) & 3)) & 1) != 0,
+                     rs = ((sign >> ((axes >> 4) & 3)) & 1) != 0;
+          // within each half: ray_dsign[child.axis] → its child 1 first (yocto_bvh.cpp:498-504)
+          int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
+          float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
+          // the halves: ray_dsign[node.axis] → child 1's half first
+          int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
+          float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
+          // last to first: whatever passed is pushed, the nearest one becomes `cur`
+          int   pr = REF_NONE;
+          float pt = 0;
+          YT_PF_DECL
+          if (v3r != REF_NONE) pr = v3r, pt = v3t;
+          if (v2r != REF_NONE) {
+            if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+            pr = v2r, pt = v2t;
+          }
+          if (v1r != REF_NONE) {
+            if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+            pr = v1r, pt = v1t;
+          }
+          if (v0r != REF_NONE) {
+            if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+            pr = v0r, pt = v0t;
+          }
+          YT_PF_ISSUE
+          cur = pr;
+        };
+        // Wavefront-uniform steps through the scalar cache (wave_uniform / ldc4 above): when every lane that takes a node
+        // step now is at the SAME node the record is fetched once, into scalar registers — no work for the vector-memory
+        // address path — and the slab tests take the box as scalar operands.  Same arithmetic: configs[1] +8.4 %, the
+        // rest +0 ... +3 %, bit-identical (profiles/r04_traversal.txt §7).
+        if (int ucur; SCALAR_LOADS && wave_uniform(cur, ucur)) {
+          const float4* Qs = sc.wide + 8 * (int64_t)ucur;
+          wide_step(ldc4(Qs, 0), ldc4(Qs, 1), ldc4(Qs, 2), ldc4(Qs, 3), ldc4(Qs, 4), ldc4(Qs, 5), ldc4(Qs, 6), ldc4(Qs, 7));
+          continue;
         }
-        if (v1r != REF_NONE) {
-          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
-          pr = v1r, pt = v1t;
+#ifdef YT_HALF_STEP  // experiment (profiles/r04_traversal.txt §6: slower): the record in two halves of 64 B
+        {
+          const float4* Qp = sc.wide + 8 * (int64_t)cur;
+          float4 c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
+          asm volatile("" : "+v"(c0.x), "+v"(c1.x), "+v"(d0.x), "+v"(d1.x) : : "memory");  // (the second half is fetched after the first has arrived)
+          float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3];
+          wide_step(a0, a1, b0, b1, c0, c1, d0, d1);
+          continue;
         }
-        if (v0r != REF_NONE) {
-          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
-          pr = v0r, pt = v0t;
-        }
-        YT_PF_ISSUE
-        cur = pr;
+#endif
+        const float4* Qp = sc.wide + 8 * (int64_t)cur;
+        wide_step(Qp[0], Qp[1], Qp[2], Qp[3], Qp[4], Qp[5], Qp[6], Qp[7]);
         continue;
       }
       // internal node: its two children in the reference's visit order
       // (near-first along the split axis — yocto_bvh.cpp:498-504, 592-598)
-      const float4* P  = pairs + 4 * (int64_t)cur;
-      float4        q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3];
+      float4 q0, q1, q2, q3;
+      if (int ucur; SCALAR_LOADS && wave_uniform(cur, ucur)) {  // (as the wide step: one scalar fetch for the whole wavefront)
+        const float4* P = pairs + 4 * (int64_t)ucur;
+        q0 = ldc4(P, 0), q1 = ldc4(P, 1), q2 = ldc4(P, 2), q3 = ldc4(P, 3);
+      } else {
+        const float4* P = pairs + 4 * (int64_t)cur;
+        q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3];
+      }
       if (COUNT) cnt.nodes += 2;
       cnt.steps++;
       float t0a, t0b;
@@ -739,8 +857,15 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         float4 a0 = ntl(&L[3 * k0]), b0 = ntl(&L[3 * k0 + 1]), c0 = ntl(&L[3 * k0 + 2]);
         float4 a1 = ntl(&L[3 * k0 + 3]), b1 = ntl(&L[3 * k0 + 4]), c1 = ntl(&L[3 * k0 + 5]);
 #else
-        float4 a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
-        float4 a1 = L[3 * k0 + 3], b1 = L[3 * k0 + 4], c1 = L[3 * k0 + 5];
+        float4 a0, b0, c0, a1, b1, c1;
+        // (a walk of ONE instance — sample_lights_pdf's, every lane at the same light — usually has every lane in the same leaf)
+        if (int uoff; SCALAR_LOADS && only_instance >= 0 && wave_uniform(leafbias + first * 3, uoff)) {
+          const float4* Lu = sc.leafdata + (uoff + 3 * k0);
+          a0 = ldc4(Lu, 0), b0 = ldc4(Lu, 1), c0 = ldc4(Lu, 2), a1 = ldc4(Lu, 3), b1 = ldc4(Lu, 4), c1 = ldc4(Lu, 5);
+        } else {
+          a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
+          a1 = L[3 * k0 + 3], b1 = L[3 * k0 + 4], c1 = L[3 * k0 + 5];
+        }
 #endif
         if (COUNT) cnt.triangles++;
         auto h = intersect_triangle(o, d, tmin, tmax, {a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x});
@@ -827,11 +952,11 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
   int             sp  = 0;
   StackEntry      spill[YT_SPILL];
   YT_STACK_OPS(YT_LDS_DEPTH, YT_SPILL)
-  auto enter = [&](const DInstanceT* rec, int inst) -> int {  // (rec / inst as in traverse())
-    const float4* ti = reinterpret_cast<const float4*>(rec);
-    float4        m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
-    int4          m5 = reinterpret_cast<const int4*>(ti)[5];
-    int           root = __float_as_int(m4.z);
+  auto enter = [&](const DInstanceT* base, int idx, int inst) -> int {  // (as in traverse())
+    float4 m0, m1, m2, m3, m4;
+    int4   m5;
+    load_instance_record(base, idx, m0, m1, m2, m3, m4, m5);
+    int root = __float_as_int(m4.z);
     if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
@@ -862,7 +987,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
   };
   int cur = REF_NONE;
   if (only_instance >= 0) {
-    cur = enter(sc.tinst + only_instance, only_instance);
+    cur = enter(sc.tinst, only_instance, only_instance);
     if (best.instance == HIT_ABORT) return best;
     if (cur_inst < 0) return best;
   } else {
@@ -997,10 +1122,10 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
     } else {
       if (wantE) {
 #ifndef YT_NO_TINST_LEAF
-        cur = enter(sc.tinst_leaf + ((cur - REF_INST) >> 1), -1);
+        cur = enter(sc.tinst_leaf, (cur - REF_INST) >> 1, -1);
 #else
         const int inst = sc.tlas_prims[(cur - REF_INST) >> 1];
-        cur            = enter(sc.tinst + inst, inst);
+        cur            = enter(sc.tinst, inst, inst);
 #endif
       }
     }

@@ -208,22 +208,30 @@ YT_FN void count_lanes(unsigned long long* c, int idx) {
 // shading-point helpers
 // ---------------------------------------------------------------------------
 struct Surface {
-  frame3f               frame;
-  DShape                shc;
-  const ythip_material* mat;
-  elem4                 e;
-  vec2f                 uv;
+  frame3f        frame;
+  DShape         shc;
+  ythip_material mat;  // (by value: what is not used is never loaded — everything is inlined)
+  elem4          e;
+  vec2f          uv;
 };
+
 // TRI: what the caller knows about the scene's shapes (as traverse(): 1 triangle meshes only, 2 triangle and quad meshes only)
 template <int TRI = 0>
 YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv) {
-  const auto& inst = sc.instances[instance];
-  Surface     s;
+  // The instance, shape and material records through the scalar cache whenever the lanes that shade together agree on
+  // them (wave_uniform, yt_bvh.h): one instance per scene, or thousands of instances of one shape with one material, are
+  // the common cases, and three records are 14 + 12 + 21 dwords per lane of vector loads otherwise.
+  Surface        s;
+  ythip_instance inst;
+  if (int u; SCALAR_LOADS && wave_uniform(instance, u)) inst = ldc_record(sc.instances + u);
+  else inst = sc.instances[instance];
   s.frame = ldframe(inst.frame);
-  s.shc   = sc.shapes[inst.shape];
+  if (int u; SCALAR_LOADS && wave_uniform(inst.shape, u)) s.shc = ldc_record(sc.shapes + u);
+  else s.shc = sc.shapes[inst.shape];
   if (TRI == 1) s.shc.kind_eval = KIND_TRIANGLES;
   if (TRI == 2 && s.shc.kind_eval != KIND_TRIANGLES) s.shc.kind_eval = KIND_QUADS;
-  s.mat   = &sc.materials[inst.material];
+  if (int u; SCALAR_LOADS && wave_uniform(inst.material, u)) s.mat = ldc_record(sc.materials + u);
+  else s.mat = sc.materials[inst.material];
   s.e     = load_element(sc, s.shc, element);
   s.uv    = uv;
   return s;
@@ -265,11 +273,12 @@ template <int WALK, bool COUNT = true, int TRI = 0>
 YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction, Stack* st, Counters* cnt) {
   auto pdf = 0.0f;
   for (int l = 0; l < sc.num_lights; l++) {
-    const auto& light = sc.lights[l];
+    const auto light = SCALAR_LOADS ? ldc_record(sc.lights + l) : sc.lights[l];  // (l is wave-uniform: one scalar fetch)
     if (light.instance != YTHIP_INVALIDID) {
       if constexpr (WALK != 0) {
-        const auto& inst          = sc.instances[light.instance];
-        const auto& sh            = sc.shapes[inst.shape];
+        // (the light is the same for every lane: its instance and shape records through the scalar cache)
+        const auto inst           = SCALAR_LOADS ? ldc_record(sc.instances + light.instance) : sc.instances[light.instance];
+        const auto sh             = SCALAR_LOADS ? ldc_record(sc.shapes + inst.shape) : sc.shapes[inst.shape];
         auto        frame         = ldframe(inst.frame);
         auto        lpdf          = 0.0f;
         auto        next_position = position;
@@ -287,7 +296,7 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
         pdf += lpdf;
       }
     } else if (light.environment != YTHIP_INVALIDID) {
-      const auto& environment = sc.environments[light.environment];
+      const auto environment = SCALAR_LOADS ? ldc_record(sc.environments + light.environment) : sc.environments[light.environment];
       if (environment.emission_tex != YTHIP_INVALIDID) {
         const auto& tex      = sc.textures[environment.emission_tex];
         auto        wl       = transform_direction(ldframe(sc.env_inv + 12 * light.environment), direction);
@@ -370,8 +379,8 @@ YT_FN void count_shade(const DState& s) { count_lanes(s.counters, CNT_SHADES); }
 YT_FN vec3f nee_emission(const DScene& sc, const Hit& isec, vec3f incoming) {
   if (!isec.hit) return eval_environment(sc, incoming);
   auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
-  auto material = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, s.shc, *s.mat, s.e, s.uv, -incoming);
+  auto material = eval_material(sc, s.shc, s.mat, s.e, s.uv);
+  auto normal   = eval_shading_normal(sc, s.frame, s.shc, s.mat, s.e, s.uv, -incoming);
   return eval_emission(material, normal, -incoming);
 }
 
@@ -437,8 +446,8 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     auto outgoing = -P.d;
     auto s        = load_surface<PRIMS>(sc, isec.instance, isec.element, {isec.u, isec.v});
     auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
-    auto normal   = eval_shading_normal<NOTEX>(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
-    auto material = eval_material<NOTEX, OPAQUE>(sc, s.shc, *s.mat, s.e, s.uv);
+    auto normal   = eval_shading_normal<NOTEX>(sc, s.frame, s.shc, s.mat, s.e, s.uv, outgoing);
+    auto material = eval_material<NOTEX, OPAQUE>(sc, s.shc, s.mat, s.e, s.uv);
     count_shade(E.st);
 #ifdef YT_TIMING
     asm volatile("" ::"v"(position.x), "v"(normal.x), "v"(material.color.x), "v"(material.roughness));
@@ -572,9 +581,9 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
     }
 
     // update volume stack
-    if (VOLUMES && is_volumetric(*s.mat) && dot(normal, outgoing) * dot(normal, incoming) < 0) {
+    if (VOLUMES && is_volumetric(s.mat) && dot(normal, outgoing) * dot(normal, incoming) < 0) {
       if (!(P.flags & PF_VOLUME)) {
-        auto vmat = eval_material<NOTEX, OPAQUE>(sc, s.shc, *s.mat, s.e, s.uv);
+        auto vmat = eval_material<NOTEX, OPAQUE>(sc, s.shc, s.mat, s.e, s.uv);
         store_volume(E.st, E.slot, vmat);
         P.flags |= PF_VOLUME;
       } else {
@@ -639,8 +648,8 @@ YT_FN int step_naive(ShadeEnv& E, Path& P) {
   // furnace uses eval_position (instance transform always); naive eval_shading_position
   auto position = FURNACE ? eval_position(sc, s.frame, s.shc, s.e, s.uv)
                           : eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
-  auto material = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
+  auto normal   = eval_shading_normal(sc, s.frame, s.shc, s.mat, s.e, s.uv, outgoing);
+  auto material = eval_material(sc, s.shc, s.mat, s.e, s.uv);
   count_shade(E.st);
 
   if (material.opacity < 1 && rand1f(P.rng) >= material.opacity) {
@@ -701,8 +710,8 @@ YT_FN int step_eyelight(ShadeEnv& E, Path& P) {
   auto outgoing = -P.d;
   auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
   auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
-  auto material = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
+  auto normal   = eval_shading_normal(sc, s.frame, s.shc, s.mat, s.e, s.uv, outgoing);
+  auto material = eval_material(sc, s.shc, s.mat, s.e, s.uv);
   count_shade(E.st);
 
   if (material.opacity < 1 && rand1f(P.rng) >= material.opacity) {
@@ -747,10 +756,10 @@ YT_FN int step_falsecolor(ShadeEnv& E, Path& P) {
   auto outgoing = -P.d;
   auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
   auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, s.shc, *s.mat, s.e, s.uv, outgoing);
+  auto normal   = eval_shading_normal(sc, s.frame, s.shc, s.mat, s.e, s.uv, outgoing);
   auto gnormal  = eval_element_normal(sc, s.frame, s.shc, s.e);
   auto texcoord = eval_texcoord(sc, s.shc, s.e, s.uv);
-  auto material = eval_material(sc, s.shc, *s.mat, s.e, s.uv);
+  auto material = eval_material(sc, s.shc, s.mat, s.e, s.uv);
   auto delta    = is_delta(material) ? 1.0f : 0.0f;
   count_shade(E.st);
   const auto& inst = sc.instances[isec.instance];
@@ -848,7 +857,9 @@ YT_FN void start_sample(const DScene& sc, const DState& st, const KParams& kp, i
   // sample_camera(camera, ij, size, puv = rand2f, luv = rand2f, tent): g++ draws luv first
   auto luv = rand2f(P.rng);
   auto puv = rand2f(P.rng);
-  auto ray = sample_camera(sc.cameras[kp.camera], i, j, st.width, st.height, puv, luv, kp.tentfilter != 0);
+  // (the camera record is the same for every lane: through the scalar cache)
+  const auto camera = SCALAR_LOADS ? ldc_record(sc.cameras + kp.camera) : sc.cameras[kp.camera];
+  auto ray = sample_camera(camera, i, j, st.width, st.height, puv, luv, kp.tentfilter != 0);
   P.o = ray.o, P.d = ray.d;
   P.weight        = {1, 1, 1};
   P.radiance      = {0, 0, 0};

@@ -71,6 +71,7 @@ struct DScene {
   // bvh
   const float4*     pairs;      // sibling-pair records (4 float4 each), all trees
   const float4*     wide;       // grandchildren ("quad") records (8 float4 each), same ids as `pairs`
+  const float4*     oct;        // -DYT_WIDE8 builds: great-grandchildren records (16 float4 each), same ids; null otherwise
   const float4*     leafdata;   // pre-gathered leaf primitives in leaf order
   const int*        tlas_prims; // instance ids in TLAS leaf order
   const DInstanceT* tinst;      // per instance
@@ -82,6 +83,26 @@ struct DScene {
   const float*  cdf;
   int           num_lights;
 };
+
+// Scalar-cache reads of records every lane asks for alike (round 4; the rationale is at wave_uniform in yt_bvh.h).
+#ifndef YT_NO_SCALAR_LOADS
+constexpr bool SCALAR_LOADS = true;
+#else  // development builds: every record through the vector memory path, as in rounds 1-3
+constexpr bool SCALAR_LOADS = false;
+#endif
+// a POD record through the scalar cache, dword by dword (the compiler merges the loads): `p` wave-uniform, immutable data
+template <typename T>
+YT_FN T ldc_record(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword records");
+  typedef __attribute__((address_space(4))) const int cint;
+  int   w[sizeof(T) / 4];
+  cint* q = (cint*)p;
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(T) / 4); k++) w[k] = q[k];
+  T v;
+  __builtin_memcpy(&v, w, sizeof(T));
+  return v;
+}
 
 YT_FN vec3f ld3(const float* p, int i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
 YT_FN vec2f ld2(const float* p, int i) { return {p[2 * i], p[2 * i + 1]}; }
@@ -472,8 +493,8 @@ YT_FN bool is_volumetric(const ythip_material& m) {  // yocto_scene.cpp:258-262
 // eval_environment — yocto_scene.cpp:596-613
 // ---------------------------------------------------------------------------
 YT_FN vec3f eval_environment(const DScene& sc, int env, vec3f direction) {
-  const auto& environment = sc.environments[env];
-  auto        emission = vec3f{environment.emission[0], environment.emission[1], environment.emission[2]};
+  const auto environment = SCALAR_LOADS ? ldc_record(sc.environments + env) : sc.environments[env];  // (env is wave-uniform)
+  auto       emission = vec3f{environment.emission[0], environment.emission[1], environment.emission[2]};
   if (environment.emission_tex == YTHIP_INVALIDID) {
     // eval_texture(invalidid) = {1,1,1,1}: the lat-long lookup does not influence the result
     return emission * vec3f{1, 1, 1};
