@@ -215,6 +215,33 @@ def test_multi_device_api_equals_one_context(nranks):
     assert mode == ("none (one rank)" if nranks == 1 else "device copies") and ranks == 0
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_multi_device_gather_equals_the_process_per_gpu_gather(nranks):
+    """The two multi-GPU launch models assemble the same frame: `ythip_multi` (one process, its
+    own gather — here the device-copy branch: RCCL refuses a communicator that names a device twice) against what
+    `bench.py --gpus N` does — one plain context per rank on its striped slice of the frame, the slices put in place
+    by sharding.FrameGather's permutation (the one the gloo tests of tests/test_sharding.py exercise)."""
+    from sharding import shard_frame
+    flat = P.SCENES["materials"]()
+    params = yt.trace_params(sampler="path", resolution=272, samples=4, batch=4)  # 17 tile columns: uneven stripes
+    st, img, samples, mode, _ = _multi_render(flat, params, [0] * nranks)
+    assert mode == "device copies"
+    w, h = yt.state_size(flat.cameras[0], params.resolution)
+    rngs = yt.make_rngs(params.seed, w * h)
+    frame = np.zeros((w * h, 4), np.float32)
+    covered = np.zeros(w * h, bool)
+    for r in range(nranks):
+        shard = shard_frame(w, h, nranks, r, "columns")
+        ctx = P.gpu_context(flat)
+        ctx.make_trace_state(flat, params, rows=shard.rows, cols=shard.cols, rngs=rngs)
+        ctx.trace_samples(params)
+        frame[shard.pixels] = ctx.download_state()["image"].reshape(-1, 4)
+        covered[shard.pixels] = True
+        ctx.close()
+    assert covered.all()
+    assert frame.tobytes() == img.tobytes() == st["image"].tobytes()
+
+
 def test_rccl_send_recv_branch_executes_on_one_device(monkeypatch):
     """The framebuffer gather's RCCL branch (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd,
     yt_multi.hip) on the hardware there is: YTHIP_GATHER=rccl-self builds a one-rank communicator

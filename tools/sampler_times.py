@@ -42,7 +42,7 @@ for sampler in (os.environ.get("SAMPLERS") or "falsecolor,eyelight,naive,pathtes
     ctx.make_trace_state(flat, p)
     ctx.trace_samples(p)
     ctx.set_profiling(1); ctx.reset_stats()
-    for _ in range(3):
+    for _ in range(int(os.environ.get("LAUNCHES", "3"))):
         ctx.trace_samples(p)
     s = ctx.get_stats(); ctx.set_profiling(0)
     ms = s["trace_ms"] / s["trace_launches"]

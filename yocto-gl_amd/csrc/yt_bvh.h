@@ -824,6 +824,67 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           cur = REF_INST + (first << 1);
           continue;
         }
+#ifndef YT_NO_DIRECT_ENTER  // (development builds: -DYT_NO_DIRECT_ENTER pushes every survivor and lets the pops enter them)
+        // ... and the FIRST survivor in the reference's order — the one the next pop would bring back — is entered right
+        // here with the transformed ray its pretest computed: no second fetch of its record, no second transform_ray, no
+        // three more divisions.  The instances are tested last to first; the latest survivor is held back and pushed only
+        // when an earlier one turns up.  Its tmax-dependent half, t0 <= tmax * k, is taken now: nothing happens between
+        // here and the pop that would have taken it.
+        for (int k = num - 1; k >= 4; k--) push(REF_INST + ((first + k) << 1), 0);  // (never: leaves hold <= 4) untested
+        bool  have = false, cirr = false;
+        vec3f co = {0, 0, 0}, cd = {0, 0, 0}, cdinv = {0, 0, 0};
+        float ct0 = 0;
+        int   ck = 0, croot = REF_NONE, ckind = KIND_NONE;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          if (k >= num) continue;
+          float4 m0, m1, m2, m3, m4;
+          int4   m5;
+#ifndef YT_NO_TINST_LEAF
+          load_instance_record(sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
+#else
+          load_instance_record(sc.tinst, sc.tlas_prims[first + k], m0, m1, m2, m3, m4, m5);
+#endif
+          if (__float_as_int(m4.z) == REF_NONE) continue;
+          frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
+          vec3f   io   = transform_point(inv, wo);
+          vec3f   id   = transform_vector(inv, wd);
+          vec3f   idin = {1 / id.x, 1 / id.y, 1 / id.z};
+          float   t0   = 0;
+          const bool irr  = !ray_is_tame(io, idin, tmin);
+          const bool pass = irr || slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0);
+          if (!pass) continue;
+          if (have) push(REF_INST + (((first + ck) << 1) | 1), ct0);
+          have = true, cirr = irr, co = io, cd = id, cdinv = idin, ct0 = irr ? 0.0f : t0, ck = k;
+          croot = __float_as_int(m4.z), ckind = __float_as_int(m4.w);
+        }
+        cur = REF_NONE;
+        if (have && ct0 <= tmaxk) {
+          if (cirr) {  // irregular at this instance's level: the caller redoes the ray binary (what enter() does)
+            best = Hit{HIT_ABORT, -1, 0, 0, 0, false};
+            done = true;
+            continue;
+          }
+#ifndef YT_NO_TINST_LEAF
+          const int4 m5 = reinterpret_cast<const int4*>(sc.tinst_leaf + (first + ck))[5];
+          cur_inst      = m5.z;
+#else
+          cur_inst      = sc.tlas_prims[first + ck];
+          const int4 m5 = reinterpret_cast<const int4*>(sc.tinst + cur_inst)[5];
+#endif
+          o = co, d = cd, dinv = cdinv;
+          tame     = true;
+          sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
+          kind     = TRI == 1 ? KIND_TRIANGLES : ckind;
+          if (TRI == 2 && kind != KIND_TRIANGLES) kind = KIND_QUADS;
+          leafbias = m5.x;
+          blas_hit = false;
+          cur_last = true;
+          push(REF_EXIT, 0);
+          cur = croot;
+        }
+        continue;
+#else
         float tk[4];
         bool  pk[4];
 #pragma unroll
@@ -834,6 +895,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           if (pk[k]) push(REF_INST + (((first + k) << 1) | 1), tk[k]);
         cur = REF_NONE;
         continue;
+#endif
       }
       for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
       cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
