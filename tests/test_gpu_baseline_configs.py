@@ -21,6 +21,9 @@ def hair_scene():
     unsequenced rng arguments, so the geometry is compiler-dependent) and fed as
     the same arrays to both sides."""
     rs = ry.RefScene.new()
+    # (SURVEY.md §8d gives the geometry, materials, environment, frame size and spp of cfg5 but no camera; its probe popped
+    #  193.7 nodes per sample.  From cfg2's camera (0, 3, 8) the ball covers a twentieth of the frame — 46 nodes per sample —,
+    #  from here 290: the survey's probe stood about 3.9 units away.  This camera is the one every round has tested with.)
     rs.add_camera_lookat((0, 0.5, 3.2), (0, 0, 0), lens=0.035, film=0.036, aspect=16 / 9)
     base = rs.add_sphere(32, 1.0)
     hair = rs.add_hair(base, (8, 100000), (0.2, 0.2), (0.002, 0.001))

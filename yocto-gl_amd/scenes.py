@@ -255,6 +255,7 @@ def hair_scene(roots_file=None, steps=8, length=(0.2, 0.2), radius=(0.002, 0.001
     base = HAIR_ROOTS[3]
     strands = len(bpos)
     sc = FlatScene()
+    # the camera of the parity tests (SURVEY.md §8d names none for this scene: tests/test_gpu_baseline_configs.py::hair_scene)
     sc.add_camera(lookat_frame((0, 0.5, 3.2), (0, 0, 0)), lens=0.035, film=0.036, aspect=16 / 9,
                   focus=float(np.sqrt(f32(0.5 * 0.5 + 3.2 * 3.2), dtype=f32)), aperture=0.0)
     s_base = add_shape(sc, base)
