@@ -75,6 +75,7 @@ class hash_pool {
       for (size_t k = 0; k < n; k++) fn(k);
       return;
     }
+    auto one_at_a_time = std::lock_guard{callers};  // (the shim's callers hold its residency lock anyway)
     std::function<void(size_t)> f = fn;
     {
       auto lock = std::unique_lock{m};
@@ -119,7 +120,7 @@ class hash_pool {
     }
   }
   std::vector<std::thread>     threads;
-  std::mutex                   m;
+  std::mutex                   m, callers;
   std::condition_variable      wake, idle;
   std::function<void(size_t)>* job = nullptr;
   size_t                       total = 0, pending = 0;
