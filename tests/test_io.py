@@ -40,6 +40,16 @@ def test_trace_params_json_round_trip_and_update_semantics():
     for bad in ['{"sampler": "nope"}', '{"samples": "many"}', '{"nocaustics": 1}', '[1]', '{"samples" 3}']:
         with pytest.raises(yt.YthipError):
             yt.params_from_json(bad)
+    # this library's one extra field, the tolerance-mode switch: off = a file the reference's own keys describe completely;
+    # on = one more key, which the reference's from_json ignores (json.value(key, default) per known key)
+    assert d.fastmath == 0 and "fastmath" not in obj
+    f = yt.trace_params(fastmath=1, samples=3)
+    fobj = json.loads(yt.params_to_json(f))
+    assert list(fobj) == FIELDS + ["fastmath"] and fobj["fastmath"] is True
+    assert yt.params_from_json(yt.params_to_json(f)).fastmath == 1
+    assert yt.params_from_json('{"fastmath": false}', yt.trace_params(fastmath=1)).fastmath == 0
+    with pytest.raises(yt.YthipError):
+        yt.params_from_json('{"fastmath": 1}')
 
 
 @needs_ref
