@@ -366,6 +366,10 @@ const char* ythip_last_error(const ythip_ctx* ctx) { return ctx ? ctx->err.c_str
 
 int ythip_set_stream(ythip_ctx* ctx, void* hip_stream) {
   if (!ctx) return YTHIP_ERR_INVALID;
+  // (the shared chunk of the small uploads remembers the stream its copies went to: it is closed — its event recorded — while
+  //  that stream is still the context's, so that the ring never holds a stream the caller may destroy after switching away)
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  HIPCHECK(ctx, ctx->xfer.close_small());
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return YTHIP_OK;
 }
