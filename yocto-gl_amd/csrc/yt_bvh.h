@@ -329,13 +329,9 @@ YT_FN bool slab_rec(vec3f o, vec3f dinv, float tmin, float4 r0, float4 r1, float
 // however many lanes are active).  When every lane that executes a load asks for the SAME record — camera rays of a tile
 // in the upper levels of their walks, every ray entering the one instance of a scene, every light-pdf walk of one light —
 // the record can come through s_load instead: the baked traversal data never changes during a launch, so it may be read
-// through the constant address space.  wave_uniform(x, u): u = x of the first active lane; true when all active lanes agree.
+// through the constant address space.  wave_uniform(x, u) (yt_scene.h): u = x of the first active lane; true when all active lanes agree.
 typedef float v4f_ __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const v4f_ cv4f;
-YT_FN bool wave_uniform(int x, int& u) {
-  u = __builtin_amdgcn_readfirstlane(x);
-  return __ballot(x != u) == 0ull;
-}
 YT_FN float4 ldc4(const void* p, int k) {  // float4 #k at the (uniform) address p, by scalar load
   const v4f_ v = ((cv4f*)p)[k];
   return float4{v.x, v.y, v.z, v.w};
@@ -739,6 +735,18 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         }
 #endif
         const float4* Qp = sc.wide + 8 * (int64_t)cur;
+#ifdef YT_WHOLE_RECORD
+        {
+          float4 q0 = Qp[0], q1 = Qp[1], q2 = Qp[2], q3 = Qp[3], q4 = Qp[4], q5 = Qp[5], q6 = Qp[6], q7 = Qp[7];
+#if YT_WHOLE_RECORD >= 2
+          asm volatile("" : "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+#else
+          asm volatile("" : "+v"(q1.z));
+#endif
+          wide_step(q0, q1, q2, q3, q4, q5, q6, q7);
+          continue;
+        }
+#endif
         wide_step(Qp[0], Qp[1], Qp[2], Qp[3], Qp[4], Qp[5], Qp[6], Qp[7]);
         continue;
       }

@@ -223,15 +223,22 @@ YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv
   // the common cases, and three records are 14 + 12 + 21 dwords per lane of vector loads otherwise.
   Surface        s;
   ythip_instance inst;
+#ifdef YT_SURFACE_BY_VALUE  // (yt_scene.h, ld_record: the divergent case fetched whole too, not field by field behind the branches that use
+                            //  the fields; its own macro: it costs the general class ~100 more spilled VGPRs, to be measured on its own)
+#define YT_LD_RECORD(p) ld_record(p)
+#else
+#define YT_LD_RECORD(p) (*(p))
+#endif
   if (int u; SCALAR_LOADS && wave_uniform(instance, u)) inst = ldc_record(sc.instances + u);
-  else inst = sc.instances[instance];
+  else inst = YT_LD_RECORD(sc.instances + instance);
   s.frame = ldframe(inst.frame);
   if (int u; SCALAR_LOADS && wave_uniform(inst.shape, u)) s.shc = ldc_record(sc.shapes + u);
-  else s.shc = sc.shapes[inst.shape];
+  else s.shc = YT_LD_RECORD(sc.shapes + inst.shape);
   if (TRI == 1) s.shc.kind_eval = KIND_TRIANGLES;
   if (TRI == 2 && s.shc.kind_eval != KIND_TRIANGLES) s.shc.kind_eval = KIND_QUADS;
   if (int u; SCALAR_LOADS && wave_uniform(inst.material, u)) s.mat = ldc_record(sc.materials + u);
-  else s.mat = sc.materials[inst.material];
+  else s.mat = YT_LD_RECORD(sc.materials + inst.material);
+#undef YT_LD_RECORD
   s.e     = load_element(sc, s.shc, element);
   s.uv    = uv;
   return s;
@@ -241,19 +248,36 @@ YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv
 YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel, vec2f ruv) {
   if (sc.num_lights <= 0) return {0, 0, 0};  // (reference: out-of-bounds read; ytrace never gets here)
   auto        light_id = sample_uniform(sc.num_lights, rl);
+#ifdef YT_RECORDS_BY_VALUE  // (yt_scene.h: ld_record)
+  const DLight light = load_record(sc.lights, light_id);
+#else
   const auto& light    = sc.lights[light_id];
+#endif
   if (light.instance != YTHIP_INVALIDID) {
+#ifdef YT_RECORDS_BY_VALUE
+    const ythip_instance inst = load_record(sc.instances, light.instance);
+    const DShape         sh   = load_record(sc.shapes, inst.shape);
+#else
     const auto& inst    = sc.instances[light.instance];
     const auto& sh      = sc.shapes[inst.shape];
+#endif
     auto        element = sample_discrete(sc.cdf + light.cdf_offset, light.cdf_count, rel);
     auto        uv      = (sh.kind_eval == KIND_TRIANGLES) ? sample_triangle(ruv) : ruv;
     auto        e       = load_element(sc, sh, element);
     auto        lpos    = eval_position(sc, ldframe(inst.frame), sh, e, uv);
     return normalize(lpos - position);
   } else if (light.environment != YTHIP_INVALIDID) {
+#ifdef YT_RECORDS_BY_VALUE
+    const ythip_environment environment = load_record(sc.environments, light.environment);
+#else
     const auto& environment = sc.environments[light.environment];
+#endif
     if (environment.emission_tex != YTHIP_INVALIDID) {
+#ifdef YT_RECORDS_BY_VALUE
+      const ythip_texture tex = load_record(sc.textures, environment.emission_tex);
+#else
       const auto& tex = sc.textures[environment.emission_tex];
+#endif
       auto        idx = sample_discrete(sc.cdf + light.cdf_offset, light.cdf_count, rel);
       auto        uv  = vec2f{div_((idx % tex.width) + 0.5f, (float)tex.width), div_((idx / tex.width) + 0.5f, (float)tex.height)};
       float sx, cx, sy, cy;
@@ -298,7 +322,11 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
     } else if (light.environment != YTHIP_INVALIDID) {
       const auto environment = SCALAR_LOADS ? ldc_record(sc.environments + light.environment) : sc.environments[light.environment];
       if (environment.emission_tex != YTHIP_INVALIDID) {
+#ifdef YT_RECORDS_BY_VALUE
+        const ythip_texture tex = SCALAR_LOADS ? ldc_record(sc.textures + environment.emission_tex) : ld_record(sc.textures + environment.emission_tex);
+#else
         const auto& tex      = sc.textures[environment.emission_tex];
+#endif
         auto        wl       = transform_direction(ldframe(sc.env_inv + 12 * light.environment), direction);
         auto        texcoord = vec2f{div_(ytm::atan2f(wl.z, wl.x), 2 * pif), div_(ytm::acosf(clamp_(wl.y, -1.0f, 1.0f)), pif)};
         if (texcoord.x < 0) texcoord.x += 1;

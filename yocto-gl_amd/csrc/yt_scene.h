@@ -103,6 +103,36 @@ YT_FN T ldc_record(const T* p) {
   __builtin_memcpy(&v, w, sizeof(T));
   return v;
 }
+// wave_uniform(x, u): u = x of the first active lane; true when all active lanes agree (the rationale is at ldc4 in yt_bvh.h)
+YT_FN bool wave_uniform(int x, int& u) {
+  u = __builtin_amdgcn_readfirstlane(x);
+  return __ballot(x != u) == 0ull;
+}
+// -DYT_RECORDS_BY_VALUE (measured lead for round 5; off: the shipped code is unchanged).  A small POD record read
+// through a reference is fetched field by field where each field is first used — hipcc narrows the loads to the words used and
+// sinks them behind the branches — so a record whose fields are tested one after the other (a texture's width, height, clamp,
+// nearest, is_float; a light's instance, then its cdf range) costs one dependent L1 round trip PER FIELD.  ld_record: the record by
+// value, every word fetched at once (the empty asm keeps the loads whole and where they are); load_record: through the scalar
+// cache instead when the wavefront agrees on the index.
+template <typename T>
+YT_FN T ld_record(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword records");
+  constexpr int N = (int)(sizeof(T) / 4);
+  int           w[N];
+  const int*    q = reinterpret_cast<const int*>(p);
+#pragma unroll
+  for (int k = 0; k < N; k++) w[k] = q[k];
+#pragma unroll
+  for (int k = 0; k < N; k++) asm volatile("" : "+v"(w[k]));
+  T v;
+  __builtin_memcpy(&v, w, sizeof(T));
+  return v;
+}
+template <typename T>
+YT_FN T load_record(const T* base, int idx) {
+  if (int u; SCALAR_LOADS && wave_uniform(idx, u)) return ldc_record(base + u);
+  return ld_record(base + idx);
+}
 
 YT_FN vec3f ld3(const float* p, int i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
 YT_FN vec2f ld2(const float* p, int i) { return {p[2 * i], p[2 * i + 1]}; }
@@ -189,7 +219,11 @@ YT_FN vec4f lookup_texture(const DScene& sc, const ythip_texture& t, int i, int 
 }
 YT_FN vec4f eval_texture(const DScene& sc, int texture, vec2f uv, bool as_linear) {
   if (texture == YTHIP_INVALIDID) return {1, 1, 1, 1};
+#ifdef YT_RECORDS_BY_VALUE
+  const ythip_texture t = load_record(sc.textures, texture);
+#else
   const auto& t = sc.textures[texture];
+#endif
   if (t.width == 0 || t.height == 0) return {0, 0, 0, 0};
   auto sx = t.width, sy = t.height;
   auto s = 0.0f, tt = 0.0f;
