@@ -9,9 +9,14 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_restated_libm_equals_glibc(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("flags", [[], ["-DYT_LIBM_NO_TABLES"]], ids=["shipped", "no-tables"])
+def test_restated_libm_equals_glibc(tmp_path, flags):
+    """(no-tables: the round-5 lead that picks atanf's interval constants without a table load)"""
     exe = str(tmp_path / "libm_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-pthread", "-o", exe,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-pthread", *flags, "-o", exe,
                     os.path.join(ROOT, "tests", "cpp", "libm_check.cpp"), "-lm"], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "libm_check: OK" in r.stdout, r.stdout + r.stderr

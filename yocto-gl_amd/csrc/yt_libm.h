@@ -405,6 +405,11 @@ YT_LIBM_BIG float atanf(float x) {
          -3.6531571299e-02f, 1.6285819933e-02f};
   float   w, s1, s2, z;
   int32_t hx = (int32_t)asuint(x), ix = hx & 0x7fffffff, id;
+  // -DYT_LIBM_NO_TABLES (lead for round 5; off: unchanged): atanhi[id] / atanlo[id] with a run-time id become two
+  // DEPENDENT loads from a constant table in global memory on the device (hipcc -S: global_load_dword, s_waitcnt vmcnt(0), twice) —
+  // in every eval_environment.  The interval's two constants are picked where the interval is decided instead; same floats.
+  float hi = 0, lo = 0;
+  (void)hi, (void)lo;
   if (ix >= 0x4c000000) {  // |x| >= 2^25
     if (ix > 0x7f800000) return x + x;
     if (hx > 0) return atanhi[3] + atanlo[3];
@@ -417,18 +422,18 @@ YT_LIBM_BIG float atanf(float x) {
     x = fabsf_(x);
     if (ix < 0x3f980000) {    // |x| < 1.1875
       if (ix < 0x3f300000) {  // 7/16 <= |x| < 11/16
-        id = 0;
+        id = 0, hi = atanhi[0], lo = atanlo[0];
         x  = (2.0f * x - 1.0f) / (2.0f + x);
       } else {  // 11/16 <= |x| < 19/16
-        id = 1;
+        id = 1, hi = atanhi[1], lo = atanlo[1];
         x  = (x - 1.0f) / (x + 1.0f);
       }
     } else {
       if (ix < 0x401c0000) {  // |x| < 2.4375
-        id = 2;
+        id = 2, hi = atanhi[2], lo = atanlo[2];
         x  = (x - 1.5f) / (1.0f + 1.5f * x);
       } else {  // 2.4375 <= |x| < 2^25
-        id = 3;
+        id = 3, hi = atanhi[3], lo = atanlo[3];
         x  = -1.0f / x;
       }
     }
@@ -438,7 +443,11 @@ YT_LIBM_BIG float atanf(float x) {
   s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
   s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
   if (id < 0) return x - x * (s1 + s2);
+#ifdef YT_LIBM_NO_TABLES
+  z = hi - ((x * (s1 + s2) - lo) - x);
+#else
   z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+#endif
   return (hx < 0) ? -z : z;
 }
 

@@ -68,6 +68,9 @@ struct DScene {
   const float* radius;
   const float*   pixelsf;
   const uint8_t* pixelsb;
+#ifdef YT_SRGB_LUT
+  const float*   srgb_lut;  // srgb_to_rgb(b / 255.0f) for b = 0 ... 255, filled on the device by the same function (ythip.hip)
+#endif
   // bvh
   const float4*     pairs;      // sibling-pair records (4 float4 each), all trees
   const float4*     wide;       // grandchildren ("quad") records (8 float4 each), same ids as `pairs`
@@ -202,7 +205,44 @@ YT_FN float srgb_to_rgb(float srgb) {  // yocto_color.h:235 (double-typed thresh
                                    : ytm::powf(div_(srgb + 0.055f, 1.0f + 0.055f), 2.4f);
 }
 YT_FN vec3f srgb_to_rgb(vec3f c) { return {srgb_to_rgb(c.x), srgb_to_rgb(c.y), srgb_to_rgb(c.z)}; }
+// -DYT_SRGB_LUT, -DYT_TEXELS_TOGETHER (leads for round 5; off: unchanged).
+//  * A byte texel has 256 possible values per channel, and srgb_to_rgb of each is a double-precision powf (two table loads, ~150
+//    instructions): twelve of them per bilinear lookup of an sRGB texture.  With the LUT the decoded value comes from a 1-KB table
+//    that a device kernel fills with this very function at scene upload — the same floats by construction.
+//  * The four taps of a bilinear lookup are fetched one after the other (hipcc -S: load, s_waitcnt vmcnt(0), convert, next address):
+//    four dependent round trips.  TEXELS_TOGETHER fetches the four raw texels first and converts afterwards; the weighted sum
+//    keeps the reference's order.
+struct RawTexel {
+  float4   f;
+  unsigned b;
+};
+YT_FN RawTexel fetch_texel(const DScene& sc, const ythip_texture& t, int i, int j) {
+  RawTexel r   = {{0, 0, 0, 0}, 0};
+  auto     idx = t.offset + (int64_t)j * t.width + i;
+  if (t.is_float) r.f = reinterpret_cast<const float4*>(sc.pixelsf)[idx];
+  else r.b = reinterpret_cast<const unsigned*>(sc.pixelsb)[idx];
+  return r;
+}
+YT_FN vec4f decode_texel(const DScene& sc, const ythip_texture& t, const RawTexel& r, bool as_linear) {
+  vec4f color;
+  if (t.is_float) {
+    color = {r.f.x, r.f.y, r.f.z, r.f.w};
+  } else {
+    const unsigned bx = r.b & 255u, by = (r.b >> 8) & 255u, bz = (r.b >> 16) & 255u, bw = r.b >> 24;
+#ifdef YT_SRGB_LUT
+    if (as_linear && !t.linear) return {sc.srgb_lut[bx], sc.srgb_lut[by], sc.srgb_lut[bz], div_((float)bw, 255.0f)};
+#endif
+    color = {div_((float)bx, 255.0f), div_((float)by, 255.0f), div_((float)bz, 255.0f), div_((float)bw, 255.0f)};
+  }
+  if (as_linear && !t.linear) {
+    return {srgb_to_rgb(color.x), srgb_to_rgb(color.y), srgb_to_rgb(color.z), color.w};
+  }
+  return color;
+}
 YT_FN vec4f lookup_texture(const DScene& sc, const ythip_texture& t, int i, int j, bool as_linear) {
+#if defined(YT_SRGB_LUT) || defined(YT_TEXELS_TOGETHER)
+  return decode_texel(sc, t, fetch_texel(sc, t, i, j), as_linear);
+#else
   vec4f color;
   auto  idx = t.offset + (int64_t)j * t.width + i;
   if (t.is_float) {
@@ -216,6 +256,7 @@ YT_FN vec4f lookup_texture(const DScene& sc, const ythip_texture& t, int i, int 
     return {srgb_to_rgb(color.x), srgb_to_rgb(color.y), srgb_to_rgb(color.z), color.w};
   }
   return color;
+#endif
 }
 YT_FN vec4f eval_texture(const DScene& sc, int texture, vec2f uv, bool as_linear) {
   if (texture == YTHIP_INVALIDID) return {1, 1, 1, 1};
@@ -242,10 +283,21 @@ YT_FN vec4f eval_texture(const DScene& sc, int texture, vec2f uv, bool as_linear
   if (t.nearest) {
     return lookup_texture(sc, t, i, j, as_linear);
   } else {
+#ifdef YT_TEXELS_TOGETHER
+    RawTexel r00 = fetch_texel(sc, t, i, j), r01 = fetch_texel(sc, t, i, jj), r10 = fetch_texel(sc, t, ii, j), r11 = fetch_texel(sc, t, ii, jj);
+    if (t.is_float) {  // (the empty asm keeps the four fetches ahead of the first conversion)
+      asm volatile("" : "+v"(r00.f.x), "+v"(r01.f.x), "+v"(r10.f.x), "+v"(r11.f.x));
+    } else {
+      asm volatile("" : "+v"(r00.b), "+v"(r01.b), "+v"(r10.b), "+v"(r11.b));
+    }
+    return decode_texel(sc, t, r00, as_linear) * (1 - u) * (1 - v) + decode_texel(sc, t, r01, as_linear) * (1 - u) * v +
+           decode_texel(sc, t, r10, as_linear) * u * (1 - v) + decode_texel(sc, t, r11, as_linear) * u * v;
+#else
     return lookup_texture(sc, t, i, j, as_linear) * (1 - u) * (1 - v) +
            lookup_texture(sc, t, i, jj, as_linear) * (1 - u) * v +
            lookup_texture(sc, t, ii, j, as_linear) * u * (1 - v) +
            lookup_texture(sc, t, ii, jj, as_linear) * u * v;
+#endif
   }
 }
 

@@ -265,6 +265,11 @@ void classify_scene(ythip_ctx* ctx, const ythip_material* materials, int num_mat
 }
 }  // namespace
 
+#ifdef YT_SRGB_LUT
+// the 256 values srgb_to_rgb can take on a byte texel, by the function the kernels would call (yt_scene.h: decode_texel)
+__global__ void __launch_bounds__(256) k_srgb_lut(float* lut) { lut[threadIdx.x] = srgb_to_rgb(div_((float)threadIdx.x, 255.0f)); }
+#endif
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -492,6 +497,15 @@ int upload_scene_impl(ythip_ctx* ctx, const ythip_scene* sc, bool from_staging) 
   UP(radius, sc->radius, sc->num_radius);
   UP(pixelsf, sc->pixelsf, sc->num_pixelsf * 4);
   UP(pixelsb, sc->pixelsb, sc->num_pixelsb * 4);
+#ifdef YT_SRGB_LUT
+  {
+    float* lut = nullptr;
+    if ((rc = dalloc(ctx, ctx->scene_allocs, &lut, 256))) return rc;
+    hipLaunchKernelGGL(k_srgb_lut, dim3(1), dim3(256), 0, ctx->stream, lut);
+    HIPCHECK(ctx, hipGetLastError());
+    ds.srgb_lut = lut;
+  }
+#endif
   std::vector<DShape> shapes(sc->num_shapes);
   for (int k = 0; k < sc->num_shapes; k++) {
     auto& s  = sc->shapes[k];
