@@ -284,10 +284,18 @@ YT_FN vec4f eval_texture(const DScene& sc, int texture, vec2f uv, bool as_linear
     return lookup_texture(sc, t, i, j, as_linear);
   } else {
 #ifdef YT_TEXELS_TOGETHER
-    RawTexel r00 = fetch_texel(sc, t, i, j), r01 = fetch_texel(sc, t, i, jj), r10 = fetch_texel(sc, t, ii, j), r11 = fetch_texel(sc, t, ii, jj);
-    if (t.is_float) {  // (the empty asm keeps the four fetches ahead of the first conversion)
-      asm volatile("" : "+v"(r00.f.x), "+v"(r01.f.x), "+v"(r10.f.x), "+v"(r11.f.x));
+    // (one branch on the texel type, then four independent fetches in a row; the empty asm keeps them ahead of the first conversion)
+    const int64_t o00 = t.offset + (int64_t)j * t.width + i, o01 = t.offset + (int64_t)jj * t.width + i,
+                  o10 = t.offset + (int64_t)j * t.width + ii, o11 = t.offset + (int64_t)jj * t.width + ii;
+    RawTexel r00 = {{0, 0, 0, 0}, 0}, r01 = r00, r10 = r00, r11 = r00;
+    if (t.is_float) {
+      const float4* px = reinterpret_cast<const float4*>(sc.pixelsf);
+      r00.f = px[o00], r01.f = px[o01], r10.f = px[o10], r11.f = px[o11];
+      asm volatile("" : "+v"(r00.f.x), "+v"(r00.f.y), "+v"(r00.f.z), "+v"(r00.f.w), "+v"(r01.f.x), "+v"(r01.f.y), "+v"(r01.f.z), "+v"(r01.f.w),
+                   "+v"(r10.f.x), "+v"(r10.f.y), "+v"(r10.f.z), "+v"(r10.f.w), "+v"(r11.f.x), "+v"(r11.f.y), "+v"(r11.f.z), "+v"(r11.f.w));
     } else {
+      const unsigned* px = reinterpret_cast<const unsigned*>(sc.pixelsb);
+      r00.b = px[o00], r01.b = px[o01], r10.b = px[o10], r11.b = px[o11];
       asm volatile("" : "+v"(r00.b), "+v"(r01.b), "+v"(r10.b), "+v"(r11.b));
     }
     return decode_texel(sc, t, r00, as_linear) * (1 - u) * (1 - v) + decode_texel(sc, t, r01, as_linear) * (1 - u) * v +
