@@ -84,3 +84,39 @@ def test_the_round5_kit_still_compiles():
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-fsyntax-only", *kit,
                             os.path.join(ROOT, "yocto-gl_amd", "csrc", unit)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, unit + "\n" + r.stderr[-3000:]
+
+
+def test_bench_line_stays_under_4k_whatever_the_detail_holds():
+    """Round 4's 25.8 KB bench line could not be parsed by the driver.  compact_line() projects the full record onto
+    a line under 4 KB — checked here on that very record, and on an inflated 8-rank record with three modes per workload."""
+    import copy
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    full = json.load(open(os.path.join(root, "profiles", "r04_bench.json")))
+    assert len(json.dumps(full)) > 20000
+    text = bench.compact_line(full, "bench_detail.json")
+    assert len(text) < bench.LINE_LIMIT == 4096 and "\n" not in text
+    line = json.loads(text)
+    assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert "counters_per_launch" not in line["roofline"] and "truncated" not in line
+    assert [o["name"] for o in line["other_configs"]] == [o["name"] for o in full["other_configs"]]
+    assert all(set(o) <= {"name", "mode", "value", "ms_per_step", "bound", "frac", "lanes", "x"} for o in line["other_configs"])
+    # N = 8, both scaling legs with per-rank times, and a third mode per workload: still one line under the limit
+    big = copy.deepcopy(full)
+    big["n_gpus"] = 8
+    per_rank = {"slice_ms": [1.23456] * 8, "gather_ms": [0.12345] * 8}
+    big["config"].update(collective={"backend": "nccl", "ranks": 8}, per_rank=per_rank, sharding="columns/8",
+                         framebuffer_gather="rccl all_gather + un-permute per step, on the kernel stream")
+    big["weak_scaling"] = {"value": 1.0, "unit": "Msamples/s", "ms_per_step": 1.0, "scaling": "weak", "resolution": [3584, 2016],
+                           "spp": 64, "pixels_per_rank": 903168, "per_rank": per_rank, "note": "x" * 500}
+    big["other_configs"] = big["other_configs"] + [dict(o, mode="own-tree (fastmath = 2)") for o in big["other_configs"][:7]]
+    big["cpu_baseline"].update(host={"nproc": 256, "cgroup_cpu_max": "max 100000", "cpu_model": "AMD EPYC 9575F 64-Core Processor"},
+                               sweep=[{"cpus": k, "Msamples_per_s": 12.345} for k in (1, 16, 64, 128, 256)])
+    text = bench.compact_line(big, "bench_detail.json")
+    assert len(text) < 4096
+    line = json.loads(text)
+    for k in ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "detail"]:
+        assert k in line, k
