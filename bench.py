@@ -111,51 +111,66 @@ def progress(msg):
 
 
 def run_workload(name, device, steps, warmup, count=True, fastmath=0):
-    """One workload through the C ABI: optional counting launch, warm-up, `steps` timed
-    launches (hipEvents on the launch stream).  Returns a dict.  fastmath: ythip_params::fastmath (the
-    tolerance mode: same integrators / rng streams / traversal, fast shading arithmetic — DESIGN.md §4b)."""
+    """One workload in one mode through the C ABI (see run_workload_modes)."""
+    return run_workload_modes(name, device, steps, warmup, [int(fastmath)], count)[0]
+
+
+def run_workload_modes(name, device, steps, warmup, modes, count=True):
+    """One workload through the C ABI, once per mode of `modes` (ythip_params::fastmath: 0 bit-exact, 1 the tolerance
+    mode — same integrators / rng streams / traversal, fast shading arithmetic, DESIGN.md §4b —, 2 the own-tree mode,
+    §4c) on ONE context: optional counting launch (the reference's work counts: mode-independent, taken once), warm-up,
+    `steps` timed launches (hipEvents on the launch stream).  Returns one dict per mode."""
     import ythip as yt
     w = _workloads()[name]
     progress(f"workload {name}: scene")
     flat = w["make"]()
     progress(f"workload {name}: upload + bvh")
     ctx = open_context(device, flat)
-    progress(f"workload {name}: launches")
-    p = yt.trace_params(sampler="path", resolution=w["resolution"], bounces=8, clamp=10.0,
-                        samples=1 << 30, batch=w["spp"], fastmath=int(fastmath))
-    width, height = ctx.make_trace_state(flat, p)
-    cnt = None
-    if count:
-        ctx.set_profiling(2)
-        ctx.reset_stats()
-        ctx.trace_samples(p)
-        cnt = ctx.get_stats()
-        ctx.set_profiling(0)
-    for _ in range(warmup):
-        ctx.trace_samples(p)
-    ctx.set_profiling(1)
-    ctx.reset_stats()
-    for _ in range(steps):
-        ctx.trace_samples(p)
-    st = ctx.get_stats()
-    ctx.set_profiling(0)
     sizes = ctx.bvh_baked_sizes()
-    pool = ctx.pixel_pool_info()
-    ran_fast = ctx.last_launch_fastmath()
+    cnt, outs = None, []
+    for mode in modes:
+        own_info = None
+        if mode == 2:  # the own-tree mode walks the library's own tree (built next to the reference tree)
+            ctx.make_own_bvh(flat)
+            own_info = ctx.own_bvh_info()
+        progress(f"workload {name}: launches (fastmath = {mode})")
+        p = yt.trace_params(sampler="path", resolution=w["resolution"], bounces=8, clamp=10.0,
+                            samples=1 << 30, batch=w["spp"], fastmath=mode)
+        width, height = ctx.make_trace_state(flat, p)
+        if count and cnt is None:
+            ctx.set_profiling(2)
+            ctx.reset_stats()
+            ctx.trace_samples(p)
+            cnt = ctx.get_stats()
+            ctx.set_profiling(0)
+        for _ in range(warmup):
+            ctx.trace_samples(p)
+        ctx.set_profiling(1)
+        ctx.reset_stats()
+        for _ in range(steps):
+            ctx.trace_samples(p)
+        st = ctx.get_stats()
+        ctx.set_profiling(0)
+        pool = ctx.pixel_pool_info()
+        ms = st["trace_ms"] / max(st["trace_launches"], 1)
+        out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"],
+               "fastmath": int(ctx.last_launch_fastmath()),
+               "ms_per_launch": ms, "launches": st["trace_launches"], "samples_per_launch": width * height * w["spp"]}
+        if cnt is not None:
+            nsamp = max(cnt["samples"], 1)
+            out["bytes_per_sample"] = yt.algorithmic_bytes(cnt) / nsamp
+            out["per_sample"] = {k: round(cnt[k] / nsamp, 3) for k in
+                                 ["rays", "nodes", "triangles", "quads", "lines", "points", "instances", "shades"]}
+        if sizes:
+            out["baked_bytes"] = sizes
+        if own_info:
+            out["own_tree"] = {"nodes": own_info["num_nodes"], "bytes": own_info["bytes"], "build_ms": round(own_info["build_ms"], 2),
+                               "bake_ms": round(own_info["bake_ms"], 2)}
+        out["pixel_pool"] = {"on": bool(pool["on"]), "decided": bool(pool["decided"]),
+                             "plain_ms_per_sample": round(pool["plain_ms_per_sample"], 5), "pool_ms_per_sample": round(pool["pool_ms_per_sample"], 5)}
+        outs.append(out)
     ctx.close()
-    ms = st["trace_ms"] / max(st["trace_launches"], 1)
-    out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"], "fastmath": bool(ran_fast),
-           "ms_per_launch": ms, "launches": st["trace_launches"], "samples_per_launch": width * height * w["spp"]}
-    if cnt is not None:
-        nsamp = max(cnt["samples"], 1)
-        out["bytes_per_sample"] = yt.algorithmic_bytes(cnt) / nsamp
-        out["per_sample"] = {k: round(cnt[k] / nsamp, 3) for k in
-                             ["rays", "nodes", "triangles", "quads", "lines", "points", "instances", "shades"]}
-    if sizes:
-        out["baked_bytes"] = sizes
-    out["pixel_pool"] = {"on": bool(pool["on"]), "decided": bool(pool["decided"]),
-                         "plain_ms_per_sample": round(pool["plain_ms_per_sample"], 5), "pool_ms_per_sample": round(pool["pool_ms_per_sample"], 5)}
-    return out
+    return outs
 
 
 # ----------------------------------------------------------------------------
@@ -185,7 +200,7 @@ def rocprof_path():
 
 
 def collect_counters(name, device, timeout=240, fastmath=0):
-    progress(f"counters {name}{' (tolerance mode)' if fastmath else ''}: rocprofv3 --pmc passes of a worker process")
+    progress(f"counters {name}{['', ' (tolerance mode)', ' (own tree)'][int(fastmath)]}: rocprofv3 --pmc passes of a worker process")
     return _collect_counters(name, device, timeout, fastmath)
 
 
@@ -201,7 +216,7 @@ def _collect_counters(name, device, timeout=240, fastmath=0, passes=None):
         out = tempfile.mkdtemp(prefix="ythip_pmc_", dir="/tmp")
         cmd = [prof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--",
                                             sys.executable, os.path.abspath(__file__), "--worker", name,
-                                            "--worker-device", str(device)] + (["--worker-fastmath"] if fastmath else [])
+                                            "--worker-device", str(device)] + (["--worker-fastmath", str(int(fastmath))] if fastmath else [])
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
@@ -224,7 +239,7 @@ def _collect_counters(name, device, timeout=240, fastmath=0, passes=None):
         for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                if not (k.startswith("yt::k_trace") or k.startswith("yt_fast::k_trace")):  # (yt_fast: the tolerance-mode unit)
+                if not k.startswith(("yt::k_trace", "yt_fast::k_trace", "yt_own::k_trace")):  # (yt_fast / yt_own: the other two units)
                     continue
                 kernel = k
                 d = per.setdefault(row["Counter_Name"], {})
@@ -389,34 +404,42 @@ def other_workloads(device, args, calib):
     res, deferred = [], []
     # every workload bit-exact (the reference's bytes), then the BASELINE workloads once more in the tolerance mode
     # (ythip_params::fastmath: statistically equal images, tests/test_gpu_fastmath.py) — what bit-exactness costs
-    todo = [(n, 0) for n in ["cfg2b", "configs3", "configs4", "cornell9m", "materials1", "features1"]] + \
-           [(n, 1) for n in ["configs1", "cfg2b", "configs3", "configs4", "cornell9m", "materials1", "features1"]]
-    for name, fast in todo:
+    every = ["configs1", "cfg2b", "configs3", "configs4", "cornell9m", "materials1", "features1"]
+    runs = []
+    for name in every:  # one worker process per workload: scene, context and trees once, then mode after mode
+        modes = [1, 2] if name == "configs1" else [0, 1, 2]  # (the primary line IS the bit-exact configs[1])
         try:
-            run = run_workload_isolated(name, device, fastmath=fast)
-            e = {"workload": f"{run['label']}, {run['width']}x{run['height']}x{run['spp']}spp, "
-                             f"sampler=path bounces=8 clamp=10",
-                 "name": name,
-                 "mode": "tolerance (ythip_params::fastmath = 1): statistically equal image, exact hit records" if run.get("fastmath")
-                         else "bit-exact (the reference's trace_state, byte for byte)",
-                 "fastmath_ran": bool(run.get("fastmath")),
-                 "value": round(run["samples_per_launch"] / run["ms_per_launch"] / 1e3, 3), "unit": "Msamples/s",
-                 "ms_per_step": round(run["ms_per_launch"], 3), "steps": run["launches"],
-                 "bytes_per_sample": round(run["bytes_per_sample"], 1), "per_sample": run["per_sample"],
-                 "roofline": roofline_of(run, None, None, calib)}
-            if "baked_bytes" in run:
-                e["baked_bvh_bytes"] = run["baked_bytes"]
-            e["pixel_pool"] = run.get("pixel_pool")
-            res.append(e)
-            if not run.get("fastmath") or args.tolerance_counters:  # (the tolerance entries' counter passes are opt-in)
-                deferred.append((name, run, e))
+            runs += run_workload_isolated(name, device, modes=modes)
         except Exception as ex:  # reported, never required
-            res.append({"workload": name, "name": name, "fastmath": bool(fast), "error": str(ex)[:300]})
+            res.append({"workload": name, "name": name, "error": str(ex)[:300]})
+    for run in sorted(runs, key=lambda r: r["mode_asked"]):  # (all bit-exact entries, then tolerance, then own-tree)
+        name = run["name"]
+        e = {"workload": f"{run['label']}, {run['width']}x{run['height']}x{run['spp']}spp, "
+                         f"sampler=path bounces=8 clamp=10",
+             "name": name,
+             "mode": ["bit-exact (the reference's trace_state, byte for byte)",
+                      "tolerance (ythip_params::fastmath = 1): statistically equal image, exact hit records",
+                      "own-tree (ythip_params::fastmath = 2): statistically equal image, the library's own SAH tree in "
+                      "64-B nodes of 8-bit boxes"][run["mode_asked"]],
+             "fastmath_ran": int(run.get("fastmath", 0)),
+             "value": round(run["samples_per_launch"] / run["ms_per_launch"] / 1e3, 3), "unit": "Msamples/s",
+             "ms_per_step": round(run["ms_per_launch"], 3), "steps": run["launches"],
+             "bytes_per_sample": round(run["bytes_per_sample"], 1), "per_sample": run["per_sample"],
+             "roofline": roofline_of(run, None, None, calib)}
+        if "baked_bytes" in run:
+            e["baked_bvh_bytes"] = run["baked_bytes"]
+        if "own_tree" in run:
+            e["own_tree"] = run["own_tree"]
+        e["pixel_pool"] = run.get("pixel_pool")
+        res.append(e)
+        if not run["mode_asked"] or args.tolerance_counters:  # (the other modes' counter passes are opt-in)
+            deferred.append((name, run, e))
     # what the tolerance mode buys, per workload
+    res.sort(key=lambda e: 0 if "error" not in e else 1)
     exact = {e["name"]: e["value"] for e in res if "value" in e and e["mode"].startswith("bit-exact")}
     exact["configs1"] = args.primary_value  # (the primary line is the bit-exact configs[1])
     for e in res:
-        if "value" in e and e["mode"].startswith("tolerance") and e["name"] in exact:
+        if "value" in e and not e["mode"].startswith("bit-exact") and e["name"] in exact:
             e["speedup_over_bit_exact"] = round(e["value"] / exact[e["name"]], 3)
     return res, deferred
 
@@ -427,7 +450,7 @@ def fill_counters(deferred, device, calib):
     nothing it does (or suffers) can touch the timed numbers already taken."""
     for name, run, entry in deferred:
         try:
-            counters, kernel = collect_counters(name, device, fastmath=1 if run.get("fastmath") else 0)
+            counters, kernel = collect_counters(name, device, fastmath=int(run.get("mode_asked", 0)))
             roof = roofline_of(run, counters, kernel if counters else entry["roofline"].get("kernel"), calib)
             if counters is None:
                 roof["note"] = kernel
@@ -524,21 +547,24 @@ def weak_resolution(base, world, tile=16):
 def worker_main(args):
     """`--worker NAME`: one warm-up + WORKER_STEPS launches of the workload, nothing printed; run under
     rocprofv3 --pmc by collect_counters()."""
-    if args.worker_json:  # the timed run of one of the other workloads, in a process of its own
-        run = run_workload(args.worker, args.worker_device, steps=2, warmup=OTHER_WARMUP, fastmath=args.worker_fastmath)
-        print("YTHIP_RUN " + json.dumps(run), flush=True)
+    if args.worker_json:  # the timed runs of one of the other workloads (every mode asked for), in a process of its own
+        modes = [int(m) for m in args.worker_modes.split(",")]
+        runs = run_workload_modes(args.worker, args.worker_device, steps=2, warmup=OTHER_WARMUP, modes=modes)
+        for m, run in zip(modes, runs):
+            run["mode_asked"] = m
+        print("YTHIP_RUN " + json.dumps(runs), flush=True)
         return
     run_workload(args.worker, args.worker_device, steps=WORKER_STEPS, warmup=OTHER_WARMUP, count=False, fastmath=args.worker_fastmath)
 
 
-def run_workload_isolated(name, device, timeout=420, fastmath=0):
-    """run_workload(name) in a worker process: a failure there (a device fault kills the process
-    it happens in) costs that entry, not the line."""
+def run_workload_isolated(name, device, timeout=420, modes=(0,)):
+    """run_workload_modes(name) in a worker process: a failure there (a device fault kills the process
+    it happens in) costs that workload's entries, not the line."""
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", name, "--worker-device", str(device),
-                        "--worker-json"] + (["--worker-fastmath"] if fastmath else []), capture_output=True, text=True,
+                        "--worker-json", "--worker-modes", ",".join(str(int(m)) for m in modes)], capture_output=True, text=True,
                        timeout=timeout, env=env)
     for line in r.stdout.splitlines():
         if line.startswith("YTHIP_RUN "):
@@ -560,7 +586,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N=1: skip the short runs of the other workloads")
     ap.add_argument("--tolerance-counters", action="store_true",
-                    help="N=1: rocprofv3 --pmc passes for the tolerance-mode entries too (default: timed only)")
+                    help="N=1: rocprofv3 --pmc passes for the tolerance-mode and own-tree entries too (default: timed only)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
                     help="where the full record goes (raw counters, long labels, per-sample work, the CPU thread sweep); "
                          "the printed line stays under 4 KB and names this file")
@@ -582,7 +608,8 @@ def main():
     ap.add_argument("--worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--worker-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--worker-json", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--worker-fastmath", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--worker-fastmath", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--worker-modes", default="0", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.worker:
         return worker_main(args)

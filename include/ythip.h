@@ -191,8 +191,18 @@ enum {
  *             forms (reciprocals for divisions, hardware sin / cos / exp / log / sqrt, fused multiply-adds).
  *             The image agrees with the reference's statistically (mean within 0.5 %, 8x8-block error
  *             below the reference's own seed-to-seed spread: tests/test_gpu_fastmath.py), not bit for bit.
- *             Scenes the wide walk cannot serve (tiny or very deep trees) and the debug samplers
- *             (diagram, falsecolor) render with the exact kernels either way. */
+ *             A tree too deep for the wide walk's stack, a context forced to the binary walk
+ *             (ythip_set_traversal 0) and the debug samplers (diagram, falsecolor) render with the exact
+ *             kernels either way; ythip_last_launch_fastmath tells which mode the last launch ran.
+ *             2: the OWN-TREE mode — the tolerance mode's arithmetic AND a traversal that no longer follows
+ *             the reference's trees: the SAH tree of the device builder, two levels per 64-B node of 8-bit
+ *             boxes (ythip_build_own_bvh must have been called; without it trace_samples fails).  Radiance
+ *             within the same stated tolerance of the reference (tests/test_gpu_own_tree.py, against
+ *             oracle/_ref); hit records equal to the reference's except at exact ties and box-edge grazes.
+ *             ythip_intersect_batch is not affected by this field: hit indices of a ray batch stay bit-exact.
+ * The struct is 80 bytes (the reference's trace_params + fastmath): a caller built against another layout must not
+ * pass it — check ythip_abi_version() == YTHIP_ABI_VERSION and ythip_params_size() == sizeof(ythip_params). */
+#define YTHIP_ABI_VERSION 5
 typedef struct ythip_params {
   int32_t  camera, resolution, sampler, falsecolor, samples, bounces;
   float    clamp;
@@ -242,6 +252,8 @@ typedef struct ythip_ctx ythip_ctx;
 
 /* One context per process/GPU.  Mirrors make_cutrace_context
  * (libs/yocto/yocto_cutrace.h:88, yocto_cutrace.cpp:385-520). */
+int         ythip_abi_version(void);  /* YTHIP_ABI_VERSION of the library that was loaded */
+int         ythip_params_size(void);  /* its sizeof(ythip_params) */
 int         ythip_create(int device, ythip_ctx** out);
 void        ythip_destroy(ythip_ctx* ctx);
 const char* ythip_last_error(const ythip_ctx* ctx); /* ctx may be NULL */
@@ -284,6 +296,12 @@ int ythip_update_environments(ythip_ctx* ctx, const ythip_environment* environme
  * yocto_bvh.cpp:238-302,321-396): host-side build that reproduces the
  * reference's node order bit-for-bit, then upload. */
 int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* scene, int highquality);
+/* The own tree of ythip_params::fastmath = 2 (see ythip_params): built NEXT TO the resident reference tree, which
+ * stays what every other mode, ythip_intersect_batch and ythip_bvh_download use.  Anything that changes geometry or the
+ * reference tree drops it (upload_scene, build / upload / update_bvh, update_shape_vertices, update_instance_frames).
+ * scene may be NULL: the geometry as resident (the context's host copies, which follow the update_* calls).
+ * ythip_own_bvh_info: its node count (64 B each), leaf records (16 B each) and build times; YTHIP_ERR_STATE without one. */
+int ythip_build_own_bvh(ythip_ctx* ctx, const ythip_scene* scene);
 /* Where make_bvh runs.  mode 1 (default): shapes with >= min_prims primitives
  * (default 16384; <= 0 keeps the current value) are built ON THE DEVICE by a
  * level-synchronous restatement of make_bvh + split_middle / split_sah
@@ -304,6 +322,7 @@ typedef struct ythip_build_info {
   int32_t device_tlas;  /* 1: the instance tree was built on the device                      */
 } ythip_build_info;
 int ythip_bvh_build_info(ythip_ctx* ctx, ythip_build_info* info);
+int ythip_own_bvh_info(ythip_ctx* ctx, int64_t* num_nodes, int64_t* num_leaf4, ythip_build_info* info);
 /* The baked traversal arrays, for tests: pairs are 64-B records
  * (num_pairs), quads 128-B records (num_pairs), leaf data 16-B records. */
 int ythip_bvh_baked_sizes(ythip_ctx* ctx, int64_t* num_pairs, int64_t* num_leaf4);
@@ -571,8 +590,9 @@ typedef struct ythip_pool_info {
 int ythip_set_pixel_pool(ythip_ctx* ctx, int mode, int workgroups); /* workgroups <= 0: keep (default 16 per CU) */
 int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info);
 
-/* 1 when the last trace_samples / trace_sample launch of this context ran the tolerance-mode kernels
- * (ythip_params::fastmath was set AND such a kernel exists for the sampler and the resident scene), else 0. */
+/* The mode the last trace_samples / trace_sample launch of this context ran: 0 the bit-exact kernels, 1 the
+ * tolerance-mode kernels, 2 the own-tree kernels (ythip_params::fastmath asked for it AND such a kernel exists for the
+ * sampler and the resident scene). */
 int ythip_last_launch_fastmath(ythip_ctx* ctx);
 
 /* Which BVH walk k_trace's extend stage and the test entries below use: 0 the
@@ -589,6 +609,10 @@ int ythip_set_traversal(ythip_ctx* ctx, int mode);
 int ythip_intersect_batch(ythip_ctx* ctx, const ythip_ray* rays, int64_t n,
     int find_any, ythip_hit* hits);
 /* intersect_instance_bvh for a batch (yocto_bvh.cpp:619-628). */
+/* the same batch through the OWN tree's walk (instances may be NULL = intersect_scene; no find_any): a measuring
+ * entry — tests/test_gpu_own_tree.py counts how often its records differ from ythip_intersect_batch's */
+int ythip_intersect_batch_own(ythip_ctx* ctx, const int32_t* instances, const ythip_ray* rays, int64_t n,
+                              ythip_hit* hits);
 int ythip_intersect_instance_batch(ythip_ctx* ctx, const int32_t* instances,
     const ythip_ray* rays, int64_t n, int find_any, ythip_hit* hits);
 /* The device's restatement of the reference platform's libm (yt_libm.h: glibc 2.35's sinf,

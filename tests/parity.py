@@ -219,6 +219,15 @@ class RefBundle:
         return st.get()
 
 
+REF_RENDERS = {}  # (name, resolution, spp) -> the compiled reference's trace_state: full-size renders cost its CPU seconds once per session
+
+
+def ref_render_cached(key, flat, params):
+    if key not in REF_RENDERS:
+        REF_RENDERS[key] = RefBundle(flat).render(params)
+    return REF_RENDERS[key]
+
+
 def gpu_context(flat, highquality=False, device=0):
     ctx = yt.Context(device)
     ctx.upload_scene(flat)

@@ -106,7 +106,11 @@ def test_render_at_baseline_size_vs_live_reference(cfg, name, res, spp):
     flat, ctx, rb = cfg(name)
     params = yt.trace_params(sampler="path", resolution=res, samples=spp, batch=spp // 2 if name == "cfg2" else spp)
     gpu = P.gpu_render(ctx, flat, params)
-    ref = rb.render(params)
+    # (shared with tests/test_gpu_own_tree.py: one CPU render per config and session)
+    key = ({"cfg2": "cfg2", "cfg2b": "cfg2b", "cfg4": "cfg4", "cfg5": "cfg5_testcam"}[name], res, spp)
+    if key not in P.REF_RENDERS:
+        P.REF_RENDERS[key] = rb.render(params)
+    ref = P.REF_RENDERS[key]
     assert gpu["samples"] == ref["samples"] == spp
     assert int(gpu["hits"].max()) == spp
     P.assert_identical(gpu, ref, f"{name} at {res} x {spp} spp")

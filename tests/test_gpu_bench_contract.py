@@ -98,8 +98,12 @@ def test_default_line_carries_the_contract(tmp_path):
         f = o["roofline"]["fractions"]
         assert set(f) == {"hbm", "l2", "valu", "ta"} and all(0 < x <= 1 for x in f.values()), (o["workload"], f)
     assert all(o["roofline"]["kernel"].startswith("yt::k_trace") for o in exact)
-    assert all(o["fastmath_ran"] for o in fast)  # the tolerance-mode unit really ran
+    assert all(o["fastmath_ran"] == 1 for o in fast)  # the tolerance-mode unit really ran
     assert all(0.9 < o["speedup_over_bit_exact"] < 2 for o in fast)
+    own = [o for o in j["other_configs"] if o.get("mode", "").startswith("own-tree")]
+    assert [o["name"] for o in own] == [o["name"] for o in fast]
+    assert all(o["fastmath_ran"] == 2 and o["own_tree"]["nodes"] > 0 for o in own)  # ... and so did the own-tree unit, on its tree
+    assert all(0.8 < o["speedup_over_bit_exact"] < 4 for o in own)
     assert "800,000 line segments" in exact[2]["workload"]
     assert exact[4]["roofline"]["kernel"].endswith("3>") and exact[5]["roofline"]["kernel"].endswith("0>")  # opaque-textured / general class
     big = exact[3]

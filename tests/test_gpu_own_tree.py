@@ -1,0 +1,206 @@
+"""The OWN-TREE mode (`-m gpu`): ythip_params::fastmath = 2 renders with the kernels of csrc/yt_owntree.hip — the
+tolerance mode's arithmetic and a traversal of the library's own tree (csrc/yt_own.h: SAH, two levels per 64-B node of
+8-bit boxes) instead of the reference's.
+
+north_star's contract: bit-exact BVH hit indices *for a fixed ray batch* — that is ythip_intersect_batch, which this
+mode does not touch (asserted below) — and radiance within a stated tolerance.  The stated tolerance is BASELINE.md
+§3.5's statistical gate, here taken DIRECTLY AGAINST oracle/_ref (the compiled reference) at equal spp and seed, at the
+BASELINE sizes:
+
+  * image mean (rgb) within 0.5 %, every colour channel within 1 %, every cell of a 4 x 4 grid of image regions within
+    2 % (a localised bias — one lobe, one texture path — would show there);
+  * mean absolute error of the 8x8-block means <= OWN_BLOCK_RATIO x the reference's own seed-to-seed spread (the same
+    measure between two reference-exact renders with different seeds).  Most paths still follow the reference's rng
+    streams — they part only where a hit differs — so the error sits far below the spread;
+  * the walk itself: on 200 k random rays + every primary ray of the frame, the fraction of rays whose (hit, instance,
+    element) equals the reference's is printed and asserted >= HIT_AGREEMENT; the rest must be ties / grazes: equal
+    distance within 1e-4 relative, or a hit / miss flip at a box edge.
+"""
+import numpy as np
+import pytest
+
+import parity as P
+from parity import ry, yt, ysc
+from test_gpu_fastmath import blocks
+
+pytestmark = pytest.mark.gpu
+
+OWN_BLOCK_RATIO = 0.5   # block error of the own-tree render / seed-to-seed spread (measured: see profiles/r05_own_tree_gates.txt)
+FAST_BLOCK_RATIO = 0.1  # the tolerance mode shares every rng stream with the reference: a tenth of the spread at most
+HIT_AGREEMENT = 0.999   # rays whose own-tree hit record names the reference's (instance, element)
+
+
+def region_means(img, w, h, n=4):
+    a = np.asarray(img, np.float64).reshape(h, w, -1)[:, :, :3]
+    return np.array([[a[j * h // n:(j + 1) * h // n, i * w // n:(i + 1) * w // n].mean() for i in range(n)] for j in range(n)])
+
+
+def statistical_gate(what, ref, other_seed, got, w, h, ratio):
+    """BASELINE.md §3.5 against `ref` (a reference-exact state); `other_seed` = the same render with another seed."""
+    assert np.isfinite(got["image"]).all()
+    r, g = ref["image"][:, :3].astype(np.float64), got["image"][:, :3].astype(np.float64)
+    rel_mean = abs(g.mean() - r.mean()) / max(r.mean(), 1e-9)
+    rel_chan = np.abs(g.mean(0) - r.mean(0)) / np.maximum(r.mean(0), 1e-9)
+    rr, rg = region_means(ref["image"], w, h), region_means(got["image"], w, h)
+    rel_region = (np.abs(rg - rr) / np.maximum(rr, 1e-3 * max(rr.max(), 1e-9))).max()
+    be, bo, bg = blocks(ref["image"], w, h), blocks(other_seed["image"], w, h), blocks(got["image"], w, h)
+    spread, err = np.abs(bo - be).mean(), np.abs(bg - be).mean()
+    same_rng = float((got["rngs"].reshape(len(got["rngs"]), -1) == ref["rngs"].reshape(len(ref["rngs"]), -1)).all(1).mean())
+    hits_differ = int((got["hits"] != ref["hits"]).sum())
+    print(f"[gate] {what}: mean rel {rel_mean:.2e}, worst channel {rel_chan.max():.2e}, worst 4x4 region {rel_region:.2e}; "
+          f"8x8-block MAE {err:.3e} vs seed-to-seed spread {spread:.3e} (ratio {err / max(spread, 1e-30):.4f}); pixels that end "
+          f"with the reference's rng state {same_rng:.4f}; hit counters differing in {hits_differ} of {len(ref['hits'])} pixels")
+    assert rel_mean <= 0.005, (what, rel_mean)
+    assert rel_chan.max() <= 0.01, (what, rel_chan)
+    assert rel_region <= 0.02, (what, rel_region)
+    assert err <= ratio * spread, (what, err, spread)
+    return dict(rel_mean=rel_mean, err=err, spread=spread, same_rng=same_rng, hits_differ=hits_differ)
+
+
+def hit_agreement(what, own, exact):
+    """Own-tree hit records against the reference's (= the exact walk's).  Returns the fraction of rays that name the
+    same (hit, instance, element); asserts that what differs is a tie / graze."""
+    n = len(exact)
+    same_flag = own["hit"] == exact["hit"]
+    both = (own["hit"] != 0) & (exact["hit"] != 0)
+    same_prim = both & (own["instance"] == exact["instance"]) & (own["element"] == exact["element"])
+    agree = (same_flag & (~both | same_prim)).mean()
+    # where both hit: the distances agree (same primitive: rounding of the fast triangle test; another one: a tie)
+    d_own, d_ex = own["distance"][both].astype(np.float64), exact["distance"][both].astype(np.float64)
+    rel = np.abs(d_own - d_ex) / np.maximum(np.abs(d_ex), 1e-6)
+    far_off = int((rel > 1e-3).sum())
+    flips = int((~same_flag).sum())
+    print(f"[hits] {what}: {n} rays, identical (hit, instance, element) {agree:.6f}; other primitive at the same distance "
+          f"{int((both & ~same_prim).sum())}; hit / miss flips {flips}; distances off by > 1e-3 rel {far_off}")
+    assert agree >= HIT_AGREEMENT, (what, agree)
+    assert far_off <= max(2, n // 20000), (what, far_off)   # a different primitive is only ever a tie / an overlap
+    assert flips <= max(2, n // 2000), (what, flips)        # grazes of a box / triangle edge
+    return agree
+
+
+BASELINE = {  # name -> (scene, resolution, spp): the BASELINE configs at their full size + the general kernel class
+    "cfg2": (ysc.plane_scene, 1280, 64),
+    "cfg2b": (P.scene_cornell_1m, 1024, 64),
+    "cfg4": (ysc.instanced_scene, 1920, 256),
+    "cfg5": (ysc.hair_scene, 1280, 64),
+    "features1": (lambda: ysc.load_corpus_scene("features1"), 1280, 64),
+    "materials1": (lambda: ysc.load_corpus_scene("materials1"), 1280, 64),
+}
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            flat = (BASELINE[name][0] if name in BASELINE else P.SCENES[name])()
+            ctx = P.gpu_context(flat)
+            ctx.make_own_bvh(flat)
+            cache[name] = (flat, ctx)
+        return cache[name]
+
+    yield get
+    for _, ctx in cache.values():
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", ["cornellbox", "materials", "instances", "lines_points", "cfg2", "cfg2b", "cfg4", "cfg5"])
+def test_own_walk_names_the_references_hits(scenes, name):
+    flat, ctx = scenes(name)
+    info = ctx.own_bvh_info()
+    assert info["num_nodes"] > 0 and info["num_leaf4"] > 0
+    res = BASELINE[name][1] if name in BASELINE else 256
+    p = yt.trace_params(resolution=res, samples=1)
+    ctx.make_trace_state(flat, p)
+    rays = np.concatenate([ctx.camera_rays(p), P.random_rays(flat, 200_000, seed=23)])
+    exact = ctx.intersect_batch(rays)  # (== the reference's records: tests/test_gpu_baseline_configs.py, test_gpu_parity.py)
+    own = ctx.intersect_batch_own(rays)
+    hit_agreement(name, own, exact)
+    # ... and the exact entry is what it was (the own tree is built NEXT TO the reference tree)
+    assert ctx.intersect_batch(rays).tobytes() == exact.tobytes()
+    if name == "cornellbox" and P.have_ref():
+        rb = P.RefBundle(flat)
+        assert P.hits_equal(exact, ry.intersect_batch(rb.bvh, rb.scene, rays))
+    if len(flat.instances) > 1:  # intersect_instance_bvh: one instance per ray
+        inst = np.random.default_rng(5).integers(0, len(flat.instances), 50_000).astype("i4")
+        rr = P.random_rays(flat, 50_000, seed=29)
+        hit_agreement(name + " (per-instance walks)", ctx.intersect_batch_own(rr, inst), ctx.intersect_instance_batch(inst, rr))
+
+
+@pytest.mark.parametrize("name", list(BASELINE))
+def test_own_tree_and_tolerance_mode_at_baseline_size_against_the_reference(scenes, name):
+    """One render per mode at the BASELINE size, each gated directly against oracle/_ref.
+    Without the compiled reference on the box the exact HIP render stands in (it is the reference's bytes:
+    tests/test_gpu_baseline_configs.py asserts that at these very sizes)."""
+    flat, ctx = scenes(name)
+    _, res, spp = BASELINE[name]
+    if name == "cfg4":
+        spp = 64  # (the gate needs three exact-size renders and one CPU render: a quarter of configs[3]'s 256 spp)
+    kw = dict(sampler="path", resolution=res, samples=spp, batch=spp)
+    exact = P.gpu_render(ctx, flat, yt.trace_params(**kw))
+    assert ctx.last_launch_fastmath() == 0
+    w, h = ctx.width, ctx.height
+    if P.have_ref():
+        ref = P.ref_render_cached((name, res, spp), flat, yt.trace_params(**kw))
+        P.assert_identical(exact, ref, f"{name}: exact render vs oracle/_ref")
+    else:
+        ref = exact
+    other = P.gpu_render(ctx, flat, yt.trace_params(seed=20240917, **kw))
+    fast = P.gpu_render(ctx, flat, yt.trace_params(fastmath=1, **kw))
+    assert ctx.last_launch_fastmath() == 1
+    own = P.gpu_render(ctx, flat, yt.trace_params(fastmath=2, **kw))
+    assert ctx.last_launch_fastmath() == 2, "the own-tree kernels did not run"
+    statistical_gate(f"{name} {w}x{h}x{spp} tolerance mode vs reference", ref, other, fast, w, h, FAST_BLOCK_RATIO)
+    statistical_gate(f"{name} {w}x{h}x{spp} own tree vs reference", ref, other, own, w, h, OWN_BLOCK_RATIO)
+
+
+@pytest.mark.parametrize("sampler", ["pathdirect", "pathmis", "naive", "eyelight", "pathtest"])
+def test_own_tree_mode_of_the_other_samplers(scenes, sampler):
+    flat, ctx = scenes("materials")
+    kw = dict(sampler=sampler, resolution=192, samples=32, batch=32)
+    exact = P.gpu_render(ctx, flat, yt.trace_params(**kw))
+    w, h = ctx.width, ctx.height
+    other = P.gpu_render(ctx, flat, yt.trace_params(seed=20240917, **kw))
+    own = P.gpu_render(ctx, flat, yt.trace_params(fastmath=2, **kw))
+    assert ctx.last_launch_fastmath() == 2
+    statistical_gate(f"materials {sampler} own tree", exact, other, own, w, h, 1.0)  # (192 x 108 x 32 spp: few blocks, loose ratio)
+
+
+def test_own_tree_must_be_built_is_dropped_by_edits_and_leaves_the_exact_mode_alone():
+    flat = P.SCENES["instances"]()
+    ctx = P.gpu_context(flat)
+    pe = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8)
+    po = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8, fastmath=2)
+    before = P.gpu_render(ctx, flat, pe)
+    with pytest.raises(yt.YthipError, match="own tree"):
+        P.gpu_render(ctx, flat, po)  # asked for without a tree: fails loudly, nothing falls back
+    with pytest.raises(yt.YthipError):
+        ctx.own_bvh_info()
+    ctx.make_own_bvh(flat)
+    info = ctx.own_bvh_info()
+    assert info["num_nodes"] > 0 and info["bytes"] == 64 * info["num_nodes"] + 16 * info["num_leaf4"]
+    a = P.gpu_render(ctx, flat, po)
+    assert ctx.last_launch_fastmath() == 2 and np.isfinite(a["image"]).all()
+    # the reference tree and the exact kernels are untouched by the build: the same bytes as before, a downloadable tree
+    P.assert_identical(P.gpu_render(ctx, flat, pe), before, "exact render after the own-tree build")
+    assert ctx.last_launch_fastmath() == 0
+    assert len(ctx.download_bvh().nodes) > 0
+    # 4 x 2 samples == 8 samples (the mode changes the walk, not the bookkeeping)
+    P.assert_identical(P.gpu_render(ctx, flat, yt.trace_params(sampler="path", resolution=128, samples=8, batch=2, fastmath=2)), a,
+                       "own tree: 4 x 2 samples vs 8")
+    # the debug views have no own-tree kernel: the flag is accepted and the exact kernel runs
+    pf = yt.trace_params(sampler="falsecolor", falsecolor="normal", resolution=96, samples=1, fastmath=2)
+    P.gpu_render(ctx, flat, pf)
+    assert ctx.last_launch_fastmath() == 0
+    # a geometry edit drops the tree (it is stale): asked for again it fails until it is rebuilt
+    frames = np.asarray([flat.instances[0]["frame"]], "f4").reshape(1, 12).copy()
+    frames[0, 9:] += 0.05
+    ctx.update_instance_frames([0], frames)
+    ctx.update_bvh([0], [])
+    with pytest.raises(yt.YthipError, match="own tree"):
+        P.gpu_render(ctx, flat, po)
+    ctx.make_own_bvh()  # (from the geometry as resident: the edited frame)
+    b = P.gpu_render(ctx, flat, po)
+    assert ctx.last_launch_fastmath() == 2 and np.isfinite(b["image"]).all()
+    ctx.close()

@@ -36,7 +36,11 @@ if os.environ.get('SPECIALIZE'):  # 0: the general kernel class whatever the sce
     ctx.set_specialization(int(os.environ['SPECIALIZE']))
 spp = int(os.environ.get('SPP', '64'))
 RES = int(os.environ.get('RES', '1280'))
-FAST = int(os.environ.get("FASTMATH", "0"))  # 1: the tolerance mode (params.fastmath)
+FAST = int(os.environ.get("FASTMATH", "0"))  # 1: the tolerance mode (params.fastmath), 2: the own-tree mode
+if FAST == 2:
+    ctx.make_own_bvh(flat)
+    oi = ctx.own_bvh_info()
+    print(f"[own tree] {oi['num_nodes']} nodes, {oi['bytes'] / 1e6:.1f} MB, build {oi['build_ms']:.1f} ms + bake {oi['bake_ms']:.1f} ms, depth {oi['max_depth']}")
 for sampler in (os.environ.get("SAMPLERS") or "falsecolor,eyelight,naive,pathtest,path").split(","):
     p = yt.trace_params(sampler=sampler, resolution=RES, samples=1 << 30, batch=spp, fastmath=FAST)
     ctx.make_trace_state(flat, p)

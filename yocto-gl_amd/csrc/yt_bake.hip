@@ -31,34 +31,6 @@ __global__ void __launch_bounds__(YT_BLOCK) k_gather_tinst(const DInstanceT* tin
   out[k]       = r;
 }
 
-#ifdef YT_WIDE8
-// Great-grandchildren ("oct") records from the baked pair and quad records, one thread per internal node: for each of
-// the quad record's four slots g — a grandchild — its two children out of g's pair record (or g itself + an empty slot
-// when g is a leaf; two empty slots when g is empty), and the axes of the seven nodes involved.
-__global__ void __launch_bounds__(YT_BLOCK) k_bake_oct(const float4* pairs, const float4* quads, long long n, float4* oct) {
-  const long long k = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
-  if (k >= n) return;
-  const float4* Q    = quads + 8 * k;
-  float4*       O    = oct + 16 * k;
-  int           axes = __float_as_int(Q[1].w) & 63;
-  const float4  none0 = {0, 0, 0, 0}, none1 = {0, 0, __int_as_float(REF_NONE), 0};
-  for (int g = 0; g < 4; g++) {
-    const float4 s0 = Q[2 * g], s1 = Q[2 * g + 1];
-    const int    ref = __float_as_int(s1.z);
-    float4*      D   = O + 4 * g;
-    if (ref >= 0 && ref < REF_INST) {  // internal: its two children
-      const float4* P = pairs + 4 * (long long)ref;
-      D[0] = P[0], D[1] = {P[1].x, P[1].y, P[1].z, 0}, D[2] = P[2], D[3] = {P[3].x, P[3].y, P[3].z, 0};
-      axes |= (__float_as_int(P[1].w) & 3) << (6 + 2 * g);
-    } else if (ref == REF_NONE) {
-      D[0] = none0, D[1] = none1, D[2] = none0, D[3] = none1;
-    } else {  // a leaf: itself, then nothing
-      D[0] = s0, D[1] = {s1.x, s1.y, s1.z, 0}, D[2] = none0, D[3] = none1;
-    }
-  }
-  O[1].w = __int_as_float(axes);
-}
-#endif
 
 int bake_bvh(ythip_ctx* ctx) {
   auto& b        = ctx->h_bvh;
@@ -362,11 +334,7 @@ int bake_bvh(ythip_ctx* ctx) {
     // The wide walk advances two levels per step and can leave up to THREE pending siblings per
     // step: 3 * ceil(depth / 2) entries per tree.  Trees between that bound and the
     // binary one are walked binary — the reference renders them, so they are not refused.
-#ifdef YT_WIDE8  // (three levels per step, up to seven pending siblings per step)
-    auto wide_need      = [](int depth) { return 7 * ((depth + 2) / 3); };
-#else
     auto wide_need      = [](int depth) { return 3 * ((depth + 1) / 2); };
-#endif
     ctx->wide_stack_ok = wide_need(tlas_depth) + wide_need(deepest_blas) + 5 <= 128;
   }
   // per-instance traversal records
@@ -413,19 +381,135 @@ int bake_bvh(ythip_ctx* ctx) {
     HIPCHECK(ctx, hipGetLastError());
     ctx->ds.tinst_leaf = d_tl;
   }
-#ifdef YT_WIDE8
-  {
-    float4* d_oct = nullptr;
-    if ((rc = dalloc(ctx, ctx->bvh_allocs, &d_oct, (size_t)npairs * 16 + 16))) return rc;
-    if (npairs > 0)
-      hipLaunchKernelGGL(k_bake_oct, dim3(grid_for(npairs)), dim3(YT_BLOCK), 0, ctx->stream, d_pairs, d_quads, (long long)npairs, d_oct);
-    HIPCHECK(ctx, hipGetLastError());
-    ctx->ds.oct = d_oct;
-  }
-#endif
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   ctx->have_bvh = true;
   return YTHIP_OK;
+}
+
+// ---- the own tree (ythip_params::fastmath = 2; yt_own.h) ---------------------------------------------
+// One 64-B compressed node per quad record, same ids: a frame {origin, a power-of-two scale per axis} and the four
+// slots' boxes as 8-bit grid coordinates rounded OUTWARDS (lo down, hi up — the decoded box contains the float box),
+// the refs, the three split axes.  An axis without extent gets the smallest normal scale (every coordinate 0).
+namespace {
+__global__ void __launch_bounds__(YT_BLOCK) k_own_compress(const float4* quads, long long n, uint4* own) {
+  const long long k = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  const float4* Q = quads + 8 * k;
+  float         lo[4][3], hi[4][3];
+  int           ref[4];
+  float         org[3] = {flt_max, flt_max, flt_max}, top[3] = {-flt_max, -flt_max, -flt_max};
+  bool          any    = false;
+  for (int s = 0; s < 4; s++) {
+    const float4 a = Q[2 * s], b = Q[2 * s + 1];
+    ref[s] = __float_as_int(b.z);
+    lo[s][0] = a.x, lo[s][1] = a.y, lo[s][2] = b.x, hi[s][0] = a.z, hi[s][1] = a.w, hi[s][2] = b.y;
+    if (ref[s] == REF_NONE) continue;
+    any = true;
+    for (int c = 0; c < 3; c++) org[c] = fminf(org[c], lo[s][c]), top[c] = fmaxf(top[c], hi[s][c]);
+  }
+  if (!any) org[0] = org[1] = org[2] = top[0] = top[1] = top[2] = 0;
+  unsigned eb[3], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};  // per axis: exponent byte; the four slots' bytes packed
+  for (int c = 0; c < 3; c++) {
+    const float ext = top[c] - org[c];
+    int         e   = 1;
+    if (ext > 0 && ext < flt_max) {
+      int ex;
+      (void)frexpf(ext / 255.0f, &ex);  // ext / 255 = m * 2^ex, m in [0.5, 1): 2^ex >= ext / 255
+      e = min(max(ex + 127, 1), 254);
+    }
+    for (bool fits = false; !fits;) {  // (a rounding on the last grid line: one exponent up and again — at most once or twice)
+      const float sc = __uint_as_float((unsigned)e << 23), inv = 1.0f / sc;
+      fits           = true;
+      unsigned wl = 0, wh = 0;
+      for (int s = 0; s < 4 && fits; s++) {
+        if (ref[s] == REF_NONE) {  // empty slot: an inverted box (its ref, REF_NONE, is what keeps it out)
+          wl |= 255u << (8 * s);
+          continue;
+        }
+        int l = (int)floorf((lo[s][c] - org[c]) * inv), h = (int)ceilf((hi[s][c] - org[c]) * inv);
+        l     = min(max(l, 0), 255), h = max(h, 0);
+        while (l > 0 && fmaf((float)l, sc, org[c]) > lo[s][c]) l--;
+        while (h <= 255 && fmaf((float)h, sc, org[c]) < hi[s][c]) h++;
+        if (h > 255) {
+          fits = e >= 254;  // (cannot grow further: clamp — only with extents near flt_max)
+          h    = 255;
+        }
+        wl |= (unsigned)l << (8 * s), wh |= (unsigned)h << (8 * s);
+      }
+      if (fits) qlo[c] = wl, qhi[c] = wh;
+      else e++;
+    }
+    eb[c] = (unsigned)e;
+  }
+  const unsigned axes = (unsigned)__float_as_int(Q[1].w) & 63u;
+  uint4*         N    = own + 4 * k;
+  N[0] = {__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]), eb[0] | eb[1] << 8 | eb[2] << 16 | axes << 24};
+  N[1] = {qlo[0], qlo[1], qlo[2], qhi[0]};
+  N[2] = {qhi[1], qhi[2], (unsigned)ref[0], (unsigned)ref[1]};
+  N[3] = {(unsigned)ref[2], (unsigned)ref[3], 0u, 0u};
+}
+}  // namespace
+
+void drop_own_bvh(ythip_ctx* ctx) {
+  free_all(ctx->own_allocs);
+  for (auto& t : ctx->own_trees) ytgpu::free_tree(&t);
+  ctx->own_trees.clear();
+  ctx->own      = BvhView{};
+  ctx->have_own = false;
+}
+
+// The SAH tree of the device / host builders (highquality = true whatever the resident reference tree was built with),
+// baked like the reference tree into a SECOND set of traversal records, + the compressed nodes.  The resident
+// reference tree — what the exact and the tolerance mode, ythip_intersect_batch and ythip_bvh_download use — is set
+// aside during the build and put back untouched.
+int build_own_bvh(ythip_ctx* ctx, const ythip_scene& sc) {
+  if (!ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "build_own_bvh: build or upload the reference bvh first");
+  drop_own_bvh(ctx);
+  // set the reference tree aside (build_bvh_mixed / bake_bvh free and overwrite whatever the context holds)
+  const BvhView keep_view = BvhView::of(ctx->ds);
+  auto keep_hbvh = std::move(ctx->h_bvh);
+  auto keep_trees = std::move(ctx->d_trees);
+  auto keep_onhost = std::move(ctx->d_tree_on_host);
+  auto keep_allocs = std::move(ctx->bvh_allocs);
+  const auto keep_info = ctx->build_info;
+  const bool keep_ok = ctx->wide_stack_ok;
+  const int64_t keep_largest = ctx->largest_tree, keep_pairs = ctx->num_pairs, keep_leaf4 = ctx->num_leaf4;
+  ctx->h_bvh = ythost::flat_bvh{};
+  ctx->d_trees.clear(), ctx->d_tree_on_host.clear(), ctx->bvh_allocs.clear();
+  int rc = build_bvh_mixed(ctx, sc, true, ctx->bvh_builder != 0);
+  if (rc == YTHIP_OK) {
+    uint4* d_own = nullptr;
+    rc           = dalloc(ctx, ctx->bvh_allocs, &d_own, (size_t)ctx->num_pairs * 4 + 4);
+    if (rc == YTHIP_OK && ctx->num_pairs > 0) {
+      hipLaunchKernelGGL(k_own_compress, dim3(grid_for(ctx->num_pairs)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds.wide,
+          (long long)ctx->num_pairs, d_own);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = fail(ctx, YTHIP_ERR_HIP, "own-tree compression failed");
+    }
+    if (rc == YTHIP_OK) {
+      ctx->own          = BvhView::of(ctx->ds);
+      ctx->own.own      = d_own;
+      ctx->own_nodes    = ctx->num_pairs;
+      ctx->own_leaf4    = ctx->num_leaf4;
+      ctx->own_stack_ok = ctx->wide_stack_ok;
+      ctx->own_info     = ctx->build_info;
+      ctx->own_allocs   = std::move(ctx->bvh_allocs);
+      ctx->own_trees    = std::move(ctx->d_trees);  // (the instance tree's prims are the TLAS-leaf order the records point into)
+      ctx->have_own     = true;
+    }
+  }
+  if (rc != YTHIP_OK) {
+    free_all(ctx->bvh_allocs);
+    free_device_trees(ctx);
+  }
+  // the reference tree back in place
+  keep_view.apply(ctx->ds);
+  ctx->h_bvh = std::move(keep_hbvh), ctx->d_trees = std::move(keep_trees), ctx->d_tree_on_host = std::move(keep_onhost);
+  ctx->bvh_allocs = std::move(keep_allocs);
+  ctx->build_info = keep_info, ctx->wide_stack_ok = keep_ok;
+  ctx->largest_tree = keep_largest, ctx->num_pairs = keep_pairs, ctx->num_leaf4 = keep_leaf4;
+  ctx->have_bvh = true;
+  return rc;
 }
 
 void free_device_trees(ythip_ctx* ctx) {

@@ -78,7 +78,6 @@ struct alignas(8) StackEntry {
 typedef __attribute__((address_space(3))) StackEntry lds_entry;
 struct Stack {
   lds_entry* lds;  // &s_stack[0][threadIdx.x]
-  unsigned   pf_zone = 0;  // YT_PREFETCH: LDS byte offset of the prefetch landing area (YT_BLOCK dwords)
 };
 #define YT_STACK_INIT(stack, s_stack) (stack).lds = (lds_entry*)&(s_stack)[0][threadIdx.x]
 
@@ -87,56 +86,11 @@ struct Stack {
 // staging costs a prologue per workgroup plus a branch per step.  tools/experiments/README.md.)
 typedef __attribute__((address_space(3))) float4 lds_float4;
 
-// push / pop of the per-lane stack (locals `lds`, `sp`, `spill`, `cnt` of the enclosing walk).
-//   default:        entries [0, L) in the lane's LDS column, [L, L + S) in scratch
-//   YT_RING_STACK:  the TOP L entries in LDS (a ring indexed by sp mod L), older ones evicted to
-//                   scratch one at a time — a depth-first walk works at the top of its stack, so
-//                   with deep trees the hot end stays in LDS instead of in scratch
-#ifdef YT_STACK_STATS  // development builds: pushes (Counters::quads) and pushes landing beyond the LDS levels (::lines)
-#define YT_STACK_STAT(L) cnt.quads++; if (sp >= (L)) cnt.lines++;
-#else
-#define YT_STACK_STAT(L)
-#endif
-#ifdef YT_RING_STACK
-#define YT_STACK_OPS(L, S)                                                                        \
-  static_assert(((L) & ((L)-1)) == 0 || (L) == 0, "ring stack: LDS levels must be a power of two"); \
-  int  lo   = 0; /* entries [lo, sp) are in LDS, [0, lo) in scratch */                            \
-  auto push = [&](int ref, float t0) {                                                            \
-    YT_STACK_STAT(L)                                                                              \
-    StackEntry v = {ref, __float_as_int(t0)};                                                     \
-    if ((L) == 0) {                                                                               \
-      if (sp < (S)) spill[sp] = v;                                                                \
-      sp++;                                                                                       \
-      return;                                                                                     \
-    }                                                                                             \
-    if (sp - lo == (L)) { /* ring full: the oldest LDS entry goes to scratch */                   \
-      if (lo < (S)) {                                                                             \
-        StackEntry e;                                                                             \
-        e.ref = lds[(lo & ((L)-1)) * YT_BLOCK].ref, e.t0 = lds[(lo & ((L)-1)) * YT_BLOCK].t0;     \
-        spill[lo] = e;                                                                            \
-        lo++;                                                                                     \
-      } else {                                                                                    \
-        return; /* beyond 128 entries: dropped (the reference's array<int,128> would overflow) */ \
-      }                                                                                           \
-    }                                                                                             \
-    lds[(sp & ((L)-1)) * YT_BLOCK].ref = v.ref, lds[(sp & ((L)-1)) * YT_BLOCK].t0 = v.t0;         \
-    sp++;                                                                                         \
-  };                                                                                              \
-  auto pop = [&]() -> StackEntry {                                                                \
-    sp--;                                                                                         \
-    if ((L) == 0) return sp < (S) ? spill[sp] : StackEntry{REF_EXIT, 0};                          \
-    if (sp < lo) { /* LDS part empty: the entry is in scratch */                                  \
-      lo = sp;                                                                                    \
-      return spill[sp];                                                                           \
-    }                                                                                             \
-    StackEntry v;                                                                                 \
-    v.ref = lds[(sp & ((L)-1)) * YT_BLOCK].ref, v.t0 = lds[(sp & ((L)-1)) * YT_BLOCK].t0;         \
-    return v;                                                                                     \
-  };
-#else
+// push / pop of the per-lane stack (locals `lds`, `sp`, `spill` of the enclosing walk): entries [0, L) in the lane's
+// LDS column, [L, L + S) in scratch.  (A ring that keeps the TOP L entries in LDS was measured -4 ... +1 %: pushes land
+// beyond the 8 LDS levels in 0-3.6 % of the cases.  tools/experiments/r05_removed_macros.patch.)
 #define YT_STACK_OPS(L, S)                                                                        \
   auto push = [&](int ref, float t0) {                                                            \
-    YT_STACK_STAT(L)                                                                              \
     StackEntry v = {ref, __float_as_int(t0)};                                                     \
     if (sp < (L))                                                                                 \
       lds[sp * YT_BLOCK].ref = v.ref, lds[sp * YT_BLOCK].t0 = v.t0;                               \
@@ -153,7 +107,6 @@ typedef __attribute__((address_space(3))) float4 lds_float4;
     }                                                                                             \
     return (sp < (L) + (S)) ? spill[sp - (L)] : StackEntry{REF_EXIT, 0};                          \
   };
-#endif
 
 struct Hit {
   int   instance, element;
@@ -305,23 +258,7 @@ YT_FN bool ray_is_tame(vec3f o, vec3f dinv, float tmin) {
 // fp32: two IEEE operations per lane and instruction, same rounding as the scalar forms).
 typedef float v2f __attribute__((ext_vector_type(2)));
 YT_FN bool slab_rec(vec3f o, vec3f dinv, float tmin, float4 r0, float4 r1, float& t0) {
-#ifdef YT_PK_SLAB
-  const v2f oxy = {o.x, o.y}, dxy = {dinv.x, dinv.y}, ozz = {o.z, o.z}, dzz = {dinv.z, dinv.z};
-  const v2f a = (v2f{r0.x, r0.y} - oxy) * dxy;  // it_min.xy
-  const v2f b = (v2f{r0.z, r0.w} - oxy) * dxy;  // it_max.xy
-  const v2f c = (v2f{r1.x, r1.y} - ozz) * dzz;  // it_min.z, it_max.z
-  auto vmin = [](float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-  auto vmax = [](float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-  auto vmin3 = [](float x, float y, float z) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
-  auto vmax3 = [](float x, float y, float z) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
-  float nx = vmin(a.x, b.x), ny = vmin(a.y, b.y), nz = vmin(c.x, c.y);
-  float fx = vmax(a.x, b.x), fy = vmax(a.y, b.y), fz = vmax(c.x, c.y);
-  t0       = vmax(vmax3(nx, ny, nz), tmin);
-  auto far = vmin3(fx, fy, fz);
-  return t0 <= far * BBOX_K;
-#else
   return slab<true>(o, dinv, tmin, {r0.x, r0.y, r1.x}, {r0.z, r0.w, r1.y}, t0);
-#endif
 }
 
 // Wavefront-uniform reads through the SCALAR cache (round 4).  The vector-memory address path is this kernel's co-bound
@@ -350,49 +287,6 @@ YT_FN void load_instance_record(const DInstanceT* base, int idx, float4& m0, flo
   m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
   m5 = reinterpret_cast<const int4*>(ti)[5];
 }
-
-// Software prefetch (YT_PREFETCH): gfx950 has no prefetch instruction, but a load that lands in
-// LDS (global_load_lds_dword: M0 = LDS byte offset, destination M0 + 4 * lane) needs no VGPR and
-// nobody has to wait for it; the line it touches is then in the L2 (and the CU's vector L1) when the
-// walk comes back for it.  `zone` = a 256-B landing area nobody reads.
-YT_FN void prefetch_line(const void* p, unsigned zone) {
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(p), "s"(zone) : "memory", "m0");
-}
-
-
-// prefetch of pushed nodes (YT_PREFETCH = 1: the entry pushed last — popped soonest; 2: every pushed entry)
-#if defined(YT_PREFETCH)
-#define YT_PF_DECL int pf_ref = REF_NONE;
-#if YT_PREFETCH >= 2
-#define YT_PF_NOTE(r) yt_prefetch_ref(sc, (r), cur_inst, kind, leafbias, st.pf_zone);
-#define YT_PF_ISSUE (void)pf_ref;
-#else
-#define YT_PF_NOTE(r) pf_ref = (r);
-#define YT_PF_ISSUE if (pf_ref != REF_NONE) yt_prefetch_ref(sc, pf_ref, cur_inst, kind, leafbias, st.pf_zone);
-#endif
-#else
-#define YT_PF_DECL
-#define YT_PF_NOTE(r)
-#define YT_PF_ISSUE
-#endif
-YT_FN void yt_prefetch_ref(const DScene& sc, int ref, int cur_inst, int kind, int leafbias, unsigned zone) {
-  if (ref >= 0) {  // internal node: its 128-B quad record
-    prefetch_line(sc.wide + 8 * (int64_t)ref, zone);
-  } else if (cur_inst >= 0) {  // BLAS leaf: the first line of its primitives
-    const int first = ref & 0x0fffffff;
-    prefetch_line(sc.leafdata + (leafbias + first * leaf_stride(kind)), zone);
-  }
-}
-
-#ifdef YT_WALK_PROFILE  // development builds: where the wavefronts of the (while-while) walk spend their cycles
-// [0] cycles in the descend phase  [1] lane-iterations of it (sum of active lanes per inner iteration)  [2] inner iterations
-// [3] cycles in the leaf / entry phase  [4] lanes holding a BLAS leaf at its start  [5] phase-2 rounds  [6] lanes holding an instance entry / exit
-// [7] primitive-test lane-rounds (sum over leaf rounds of lanes still testing)  [8] primitive-test rounds
-__device__ unsigned long long g_walkprof[16];
-#define YT_WP(i, v) do { if (wp_on) wp[i] += (unsigned long long)(v); } while (0)
-#else
-#define YT_WP(i, v)
-#endif
 
 // The traversal.  `only_instance` < 0: intersect_scene_bvh (yocto_bvh.cpp:554-617);
 // otherwise intersect_instance_bvh of that instance (yocto_bvh.cpp:619-628).
@@ -484,12 +378,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   };
   // entry `k` of the TLAS-leaf order (a continuation entry's code >> 1)
   auto enter_leaf_entry = [&](int k, bool tested) -> int {
-#ifndef YT_NO_TINST_LEAF
     return enter(sc.tinst_leaf, k, -1, tested);
-#else  // development builds: the two dependent fetches of rounds 1-3 (tlas_prims -> tinst)
-    const int inst = sc.tlas_prims[k];
-    return enter(sc.tinst, inst, inst, tested);
-#endif
   };
   // PRETEST (the wide walk; round 4, +4 ... +10 % on scenes with instances, profiles/r04_traversal.txt): the tmax-INDEPENDENT half of an instance's root-box test — transform_ray + intersect_bbox's
   // interval (yocto_bvh.cpp:619-628 with :470-477) — made for all (up to 4) instances of a TLAS leaf when the leaf is
@@ -501,11 +390,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   auto pretest = [&](int k, float& t0) -> bool {
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-#ifndef YT_NO_TINST_LEAF
     load_instance_record(sc.tinst_leaf, k, m0, m1, m2, m3, m4, m5);
-#else
-    load_instance_record(sc.tinst, sc.tlas_prims[k], m0, m1, m2, m3, m4, m5);
-#endif
     t0 = 0;
     if (__float_as_int(m4.z) == REF_NONE) return false;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
@@ -515,14 +400,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     if (!ray_is_tame(io, idin, tmin)) return true;
     return slab<false>(io, idin, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0);
   };
-#if !defined(YT_NO_PRETEST) && defined(YT_EARLY_BOOKKEEPING)
-#error "YT_EARLY_BOOKKEEPING pushes instance entries whose bit 0 is the `last` flag; the pretest reads it as `tested`"
-#endif
-#if !defined(YT_NO_PRETEST)
   constexpr bool PRETEST = WIDE;
-#else  // development builds: every instance's root box tested when its entry is popped, as in rounds 1-3
-  constexpr bool PRETEST = false;
-#endif
 
   // back to the TLAS level: restore the world ray.  Returns true when the
   // find_any early-out of intersect_scene_bvh fires (yocto_bvh.cpp:613: checked
@@ -557,19 +435,9 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
 
   const float4* pairs = sc.pairs;
   bool          done  = false;
-#ifdef YT_WALK_PROFILE
-  unsigned long long wp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const bool         wp_on = WIDE && only_instance < 0;
-  const long long    wp_tstart = __builtin_readcyclecounter();
-#endif
   while (!done) {
-#ifdef YT_WALK_PROFILE
-    long long wp_t0 = __builtin_readcyclecounter();
-#endif
     // ---- (1) descend: until this lane holds a leaf / instance entry ----------
     while (true) {
-      YT_WP(1, __popcll(__ballot(1)));
-      YT_WP(2, 1);
       if (cur == REF_NONE) {
         if (sp == 0) {
           done = true;
@@ -579,95 +447,11 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         cur          = e.ref;
         // culled at pop time (with PRETEST the instance entries carry their root box's t0 too)
         if ((PRETEST ? e.ref != REF_EXIT : e.ref < REF_INST) && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;
-#ifdef YT_TIGHT_POP
-        // a culled entry costs this lane a pop, not a whole lock-step iteration of the loop
-        while (cur == REF_NONE && sp > 0) {
-          e   = pop();
-          cur = e.ref;
-          if (e.ref < REF_INST && !(__int_as_float(e.t0) <= tmaxk)) cur = REF_NONE;
-        }
-#endif
         if (cur == REF_NONE) continue;
       }
       if ((unsigned)cur >= (unsigned)REF_INST) {
-#ifdef YT_EARLY_BOOKKEEPING  // measured, mixed (-6 ... +5 %), off: profiles/r03_traversal_experiments.txt
-        // the cheap bookkeeping stays in the descend phase (a lock-step round of phase 2 costs every
-        // lane of the wavefront the instance-entry and the leaf code): leaving an instance ...
-        if (cur == REF_EXIT) {
-          cur = REF_NONE;
-          if (exit_instance()) {
-            done = true;
-            break;
-          }
-          continue;
-        }
-        // ... and expanding a TLAS leaf into its continuation entries (yocto_bvh.cpp:600-609)
-        if (cur < 0 && cur_inst < 0) {
-          const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
-          for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
-          cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
-          continue;
-        }
-#endif
         break;  // BLAS leaf or instance entry → phase 2
       }
-#ifdef YT_WIDE8  // experiment: THREE levels per dependent fetch — 256-B records of a node's eight great-grandchildren
-      if constexpr (WIDE) {
-        // The record (yt_bake.hip: k_bake_oct) is two quad-shaped halves: half h = the (up to) four grandchildren-of-child-h,
-        // i.e. for each of child h's two children g its two children (or g itself + an empty slot when g is a leaf).  The
-        // half the reference visits SECOND goes first here — everything of it that passes is pushed, last visited first —
-        // then the near half, whose first survivor becomes `cur`: one pending entry carried through both, exactly the
-        // quad step's push logic twice.  Same visit order (ray_dsign of the node, of the child, of the grandchild), same
-        // pop-time test per slot, skipped ancestor tests implied as for the quad records (a box contains its descendants').
-        const float4* Op   = sc.oct + 16 * (int64_t)cur;
-        const int     axes = __float_as_int(Op[1].w);  // node | child0 << 2 | child1 << 4 | grandchildren 0..3 << 6, 8, 10, 12
-        const bool    ns   = ((sign >> (axes & 3)) & 1) != 0;  // ray_dsign[node.axis]: child 1's half is visited first
-        cnt.steps++;
-        int   pr = REF_NONE;
-        float pt = 0;
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
-          const int     h  = pass == 0 ? (ns ? 0 : 1) : (ns ? 1 : 0);  // pass 0: the half visited second
-          const float4* Qp = Op + 8 * h;
-          float4        a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
-          float ta, tb, tc, td;
-          bool  fa = slab_rec(o, dinv, tmin, a0, a1, ta);
-          bool  fb = slab_rec(o, dinv, tmin, b0, b1, tb);
-          bool  fc = slab_rec(o, dinv, tmin, c0, c1, tc);
-          bool  fd = slab_rec(o, dinv, tmin, d0, d1, td);
-          int ra = (fa && ta <= tmaxk) ? __float_as_int(a1.z) : REF_NONE;
-          int rb = (fb && tb <= tmaxk) ? __float_as_int(b1.z) : REF_NONE;
-          int rc = (fc && tc <= tmaxk) ? __float_as_int(c1.z) : REF_NONE;
-          int rd = (fd && td <= tmaxk) ? __float_as_int(d1.z) : REF_NONE;
-          // a, b = children of grandchild 2h (or itself); c, d = of grandchild 2h + 1
-          const bool hs = ((sign >> ((axes >> (2 + 2 * h)) & 3)) & 1) != 0;   // child h's axis: its child 1 first
-          const bool ls = ((sign >> ((axes >> (6 + 4 * h)) & 3)) & 1) != 0;   // grandchild 2h's axis
-          const bool rs = ((sign >> ((axes >> (8 + 4 * h)) & 3)) & 1) != 0;   // grandchild 2h + 1's axis
-          int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
-          float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
-          int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
-          float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
-          if (v3r != REF_NONE) {
-            if (pr != REF_NONE) push(pr, pt);
-            pr = v3r, pt = v3t;
-          }
-          if (v2r != REF_NONE) {
-            if (pr != REF_NONE) push(pr, pt);
-            pr = v2r, pt = v2t;
-          }
-          if (v1r != REF_NONE) {
-            if (pr != REF_NONE) push(pr, pt);
-            pr = v1r, pt = v1t;
-          }
-          if (v0r != REF_NONE) {
-            if (pr != REF_NONE) push(pr, pt);
-            pr = v0r, pt = v0t;
-          }
-        }
-        cur = pr;
-        continue;
-      }
-#endif
       if constexpr (WIDE) {
         // internal node, two levels at once: its grandchildren in the order the
         // reference's walk reaches them, each pushed with its own pop-time test
@@ -698,21 +482,19 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           // last to first: whatever passed is pushed, the nearest one becomes `cur`
           int   pr = REF_NONE;
           float pt = 0;
-          YT_PF_DECL
           if (v3r != REF_NONE) pr = v3r, pt = v3t;
           if (v2r != REF_NONE) {
-            if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+            if (pr != REF_NONE) push(pr, pt);
             pr = v2r, pt = v2t;
           }
           if (v1r != REF_NONE) {
-            if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+            if (pr != REF_NONE) push(pr, pt);
             pr = v1r, pt = v1t;
           }
           if (v0r != REF_NONE) {
-            if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+            if (pr != REF_NONE) push(pr, pt);
             pr = v0r, pt = v0t;
           }
-          YT_PF_ISSUE
           cur = pr;
         };
         // Wavefront-uniform steps through the scalar cache (wave_uniform / ldc4 above): when every lane that takes a node
@@ -724,29 +506,13 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           wide_step(ldc4(Qs, 0), ldc4(Qs, 1), ldc4(Qs, 2), ldc4(Qs, 3), ldc4(Qs, 4), ldc4(Qs, 5), ldc4(Qs, 6), ldc4(Qs, 7));
           continue;
         }
-#ifdef YT_HALF_STEP  // experiment (profiles/r04_traversal.txt §6: slower): the record in two halves of 64 B
-        {
-          const float4* Qp = sc.wide + 8 * (int64_t)cur;
-          float4 c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
-          asm volatile("" : "+v"(c0.x), "+v"(c1.x), "+v"(d0.x), "+v"(d1.x) : : "memory");  // (the second half is fetched after the first has arrived)
-          float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3];
-          wide_step(a0, a1, b0, b1, c0, c1, d0, d1);
-          continue;
-        }
-#endif
         const float4* Qp = sc.wide + 8 * (int64_t)cur;
-#ifdef YT_WHOLE_RECORD
         {
           float4 q0 = Qp[0], q1 = Qp[1], q2 = Qp[2], q3 = Qp[3], q4 = Qp[4], q5 = Qp[5], q6 = Qp[6], q7 = Qp[7];
-#if YT_WHOLE_RECORD >= 2
-          asm volatile("" : "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
-#else
           asm volatile("" : "+v"(q1.z));
-#endif
           wide_step(q0, q1, q2, q3, q4, q5, q6, q7);
           continue;
         }
-#endif
         wide_step(Qp[0], Qp[1], Qp[2], Qp[3], Qp[4], Qp[5], Qp[6], Qp[7]);
         continue;
       }
@@ -787,17 +553,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         cur = n2 ? r2 : REF_NONE;
       }
     }
-#ifdef YT_WALK_PROFILE
-    {
-      long long wp_t1 = __builtin_readcyclecounter();
-      YT_WP(0, wp_t1 - wp_t0);
-      wp_t0 = wp_t1;
-    }
-#endif
     if (done) break;
-    YT_WP(5, 1);
-    YT_WP(4, __popcll(__ballot(cur < 0 && cur_inst >= 0)));
-    YT_WP(6, __popcll(__ballot(cur >= REF_INST || (cur < 0 && cur_inst < 0))));
 
     // ---- (2) leaves, instance entries ----------------------------------------
     if (cur >= REF_INST) {
@@ -832,7 +588,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           cur = REF_INST + (first << 1);
           continue;
         }
-#ifndef YT_NO_DIRECT_ENTER  // (development builds: -DYT_NO_DIRECT_ENTER pushes every survivor and lets the pops enter them)
         // ... and the FIRST survivor in the reference's order — the one the next pop would bring back — is entered right
         // here with the transformed ray its pretest computed: no second fetch of its record, no second transform_ray, no
         // three more divisions.  The instances are tested last to first; the latest survivor is held back and pushed only
@@ -848,11 +603,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           if (k >= num) continue;
           float4 m0, m1, m2, m3, m4;
           int4   m5;
-#ifndef YT_NO_TINST_LEAF
           load_instance_record(sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
-#else
-          load_instance_record(sc.tinst, sc.tlas_prims[first + k], m0, m1, m2, m3, m4, m5);
-#endif
           if (__float_as_int(m4.z) == REF_NONE) continue;
           frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
           vec3f   io   = transform_point(inv, wo);
@@ -873,13 +624,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
             done = true;
             continue;
           }
-#ifndef YT_NO_TINST_LEAF
           const int4 m5 = reinterpret_cast<const int4*>(sc.tinst_leaf + (first + ck))[5];
           cur_inst      = m5.z;
-#else
-          cur_inst      = sc.tlas_prims[first + ck];
-          const int4 m5 = reinterpret_cast<const int4*>(sc.tinst + cur_inst)[5];
-#endif
           o = co, d = cd, dinv = cdinv;
           tame     = true;
           sign     = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
@@ -892,18 +638,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           cur = croot;
         }
         continue;
-#else
-        float tk[4];
-        bool  pk[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) pk[k] = k < num && pretest(first + k, tk[k]);
-        for (int k = num - 1; k >= 4; k--) push(REF_INST + ((first + k) << 1), 0);  // (never: leaves hold <= 4) untested
-#pragma unroll
-        for (int k = 3; k >= 0; k--)
-          if (pk[k]) push(REF_INST + (((first + k) << 1) | 1), tk[k]);
-        cur = REF_NONE;
-        continue;
-#endif
       }
       for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
       cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
@@ -916,17 +650,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       const float4* L = sc.leafdata + (leafbias + first * 3);
       // two triangles per round trip (the pool is padded, over-reads are ignored)
       for (int k0 = 0; k0 < num; k0 += 2) {
-        YT_WP(7, __popcll(__ballot(1)));
-        YT_WP(8, 1);
-#ifdef YT_NT_LEAF  // development builds: leaf data as a non-temporal stream (keeps trace_state lines in L2?)
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        auto ntl = [](const float4* p) {
-          v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-          return float4{v.x, v.y, v.z, v.w};
-        };
-        float4 a0 = ntl(&L[3 * k0]), b0 = ntl(&L[3 * k0 + 1]), c0 = ntl(&L[3 * k0 + 2]);
-        float4 a1 = ntl(&L[3 * k0 + 3]), b1 = ntl(&L[3 * k0 + 4]), c1 = ntl(&L[3 * k0 + 5]);
-#else
         float4 a0, b0, c0, a1, b1, c1;
         // (a walk of ONE instance — sample_lights_pdf's, every lane at the same light — usually has every lane in the same leaf)
         if (int uoff; SCALAR_LOADS && only_instance >= 0 && wave_uniform(leafbias + first * 3, uoff)) {
@@ -936,7 +659,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
           a1 = L[3 * k0 + 3], b1 = L[3 * k0 + 4], c1 = L[3 * k0 + 5];
         }
-#endif
         if (COUNT) cnt.triangles++;
         auto h = intersect_triangle(o, d, tmin, tmax, {a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x});
         if (h.hit) accept(__float_as_int(c0.y), h);
@@ -949,8 +671,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     } else if (TRI != 1 && kind == KIND_QUADS) {
       const float4* L = sc.leafdata + (leafbias + first * 4);
       for (int k = 0; k < num; k++) {
-        YT_WP(7, __popcll(__ballot(1)));
-        YT_WP(8, 1);
         float4 a = L[4 * k], b = L[4 * k + 1], c = L[4 * k + 2], e4 = L[4 * k + 3];
         if (COUNT) cnt.quads++;
         auto h = intersect_quad(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, {c.y, c.z, c.w});
@@ -959,8 +679,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     } else if (TRI == 0 && kind == KIND_LINES) {
       const float4* L = sc.leafdata + (leafbias + first * 3);
       for (int k = 0; k < num; k++) {
-        YT_WP(7, __popcll(__ballot(1)));
-        YT_WP(8, 1);
         float4 a = L[3 * k], b = L[3 * k + 1], c = L[3 * k + 2];
         if (COUNT) cnt.lines++;
         auto h = intersect_line(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
@@ -969,8 +687,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     } else if (TRI == 0 && kind == KIND_POINTS) {
       const float4* L = sc.leafdata + (leafbias + first * 2);
       for (int k = 0; k < num; k++) {
-        YT_WP(7, __popcll(__ballot(1)));
-        YT_WP(8, 1);
         float4 a = L[2 * k], b = L[2 * k + 1];
         if (COUNT) cnt.points++;
         auto h = intersect_point(o, d, tmin, tmax, {a.x, a.y, a.z}, a.w);
@@ -984,16 +700,6 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       if (exit_instance()) done = true;
     }
   }
-#ifdef YT_WALK_PROFILE
-  if (wp_on) {
-    // (cycles of phase 2 = total - phase 1; every lane carries the same wave-uniform sums, the
-    //  first active lane reports them)
-    wp[3] = (unsigned long long)((long long)__builtin_readcyclecounter() - wp_tstart);  // the whole walk
-    const unsigned long long m = __ballot(1);
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
-      for (int k = 0; k < 9; k++) atomicAdd(&g_walkprof[k], wp[k]);
-  }
-#endif
   return best;
 }
 
@@ -1132,21 +838,19 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
         float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
         int   pr = REF_NONE;
         float pt = 0;
-        YT_PF_DECL
         if (v3r != REF_NONE) pr = v3r, pt = v3t;
         if (v2r != REF_NONE) {
-          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+          if (pr != REF_NONE) push(pr, pt);
           pr = v2r, pt = v2t;
         }
         if (v1r != REF_NONE) {
-          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+          if (pr != REF_NONE) push(pr, pt);
           pr = v1r, pt = v1t;
         }
         if (v0r != REF_NONE) {
-          if (pr != REF_NONE) { push(pr, pt); YT_PF_NOTE(pr) }
+          if (pr != REF_NONE) push(pr, pt);
           pr = v0r, pt = v0t;
         }
-        YT_PF_ISSUE
         cur = pr;
       }
     } else if (nL > 0 && nL * YT_PHASE_L >= nL + nE) {
@@ -1191,12 +895,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
       }
     } else {
       if (wantE) {
-#ifndef YT_NO_TINST_LEAF
         cur = enter(sc.tinst_leaf, (cur - REF_INST) >> 1, -1);
-#else
-        const int inst = sc.tlas_prims[(cur - REF_INST) >> 1];
-        cur            = enter(sc.tinst, inst, inst);
-#endif
       }
     }
   }
@@ -1205,14 +904,18 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
 
 // The production entry: the wide walk, and the binary walk for the rays it declines
 // (irregular at world or instance level, find_any) — the same hit record either way.
-#ifdef YT_PHASED
-constexpr bool PHASED_DEFAULT = true;
-#else
-constexpr bool PHASED_DEFAULT = false;
+#ifdef YT_OWN_TREE  // the own-tree unit (yt_owntree.hip, fastmath = 2): every production walk is yt_own.h's
+template <int TRI>
+YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, Stack& st, Counters& cnt);
 #endif
-template <bool COUNT, bool WIDE, int TRI = 0, bool PHASED = PHASED_DEFAULT>
+template <bool COUNT, bool WIDE, int TRI = 0, bool PHASED = false>
 YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
     Counters& cnt) {
+#ifdef YT_OWN_TREE
+  if constexpr (WIDE && !COUNT) {
+    if (!find_any) return traverse_own<TRI>(sc, wray, only_instance, st, cnt);
+  }
+#endif
   if constexpr (WIDE && !COUNT) {
     if constexpr (PHASED) {
       if (!find_any) {

@@ -57,6 +57,29 @@ struct HostPool {
   }
 };
 
+// The bvh part of a DScene: the resident reference tree's, or the own tree's (fastmath = 2: the kernels get a copy of
+// `ds` with these fields swapped in at launch time, so lights / materials / cameras updated since are seen by both).
+struct BvhView {
+  const float4*     pairs = nullptr, *wide = nullptr, *leafdata = nullptr;
+  const int*        tlas_prims = nullptr;
+  const DInstanceT *tinst = nullptr, *tinst_leaf = nullptr;
+  int               tlas_ref = 0x7ffffffe;  // REF_NONE
+  vec3f             tlas_bmin = {0, 0, 0}, tlas_bmax = {0, 0, 0};
+  const uint4*      own = nullptr;
+  static BvhView    of(const DScene& d) {
+    BvhView v;
+    v.pairs = d.pairs, v.wide = d.wide, v.leafdata = d.leafdata, v.tlas_prims = d.tlas_prims;
+    v.tinst = d.tinst, v.tinst_leaf = d.tinst_leaf, v.tlas_ref = d.tlas_ref, v.tlas_bmin = d.tlas_bmin, v.tlas_bmax = d.tlas_bmax;
+    v.own = d.own;
+    return v;
+  }
+  void apply(DScene& d) const {
+    d.pairs = pairs, d.wide = wide, d.leafdata = leafdata, d.tlas_prims = tlas_prims;
+    d.tinst = tinst, d.tinst_leaf = tinst_leaf, d.tlas_ref = tlas_ref, d.tlas_bmin = tlas_bmin, d.tlas_bmax = tlas_bmax;
+    d.own = own;
+  }
+};
+
 struct ythip_ctx {
   int         device     = 0;
   hipStream_t own_stream = nullptr;
@@ -96,6 +119,7 @@ struct ythip_ctx {
   int                         pool_blocks = 0;           // workgroups of a pool launch (YTHIP_POOL_BLOCKS; default 16 per CU)
   int                         pool_tune   = 0;           // 0 time a plain batch next, 1 time a pool batch next, 2 waiting for both, 3 decided
   bool                        pool_on     = false;       // the decision
+  int                         pool_mode   = 0;           // ... taken for this ythip_params::fastmath (another mode: measured again)
   hipEvent_t                  pool_ev[4]  = {nullptr, nullptr, nullptr, nullptr};  // plain begin / end, pool begin / end
   double                      pool_samples[2] = {0, 0};  // samples per pixel of the two timed launches
   float                       pool_ms[2]  = {0, 0};      // (kept for ythip_pool_info)
@@ -133,6 +157,14 @@ struct ythip_ctx {
   ythip_build_info               build_info             = {};
   int64_t                        num_pairs = 0, num_leaf4 = 0;
   ythost::flat_lights h_lights;
+  // the own tree (ythip_build_own_bvh, ythip_params::fastmath = 2; yt_own.h): a second set of traversal records + the
+  // compressed nodes; dropped whenever the scene's geometry or the reference tree changes
+  BvhView                        own;
+  std::vector<void*>             own_allocs;
+  std::vector<ytgpu::DeviceTree> own_trees;
+  bool                           have_own = false, own_stack_ok = false;
+  int64_t                        own_nodes = 0, own_leaf4 = 0;
+  ythip_build_info               own_info = {};
 
   DScene ds = {};
   DState st = {};
@@ -163,10 +195,14 @@ struct ythip_ctx {
   const int*         stop_host_dev = nullptr;  // ... and its device address (the kernels relay it into d_stop)
   ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
   bool               last_launch_fast = false;  // the last k_trace launch ran the tolerance-mode kernels (yt_fast.hip)
+  int                last_launch_mode = 0;      // ... which mode it ran: 0 bit-exact, 1 tolerance, 2 own tree (yt_owntree.hip)
 };
 
 // yt_fast.hip: the tolerance-mode kernels (same source, -DYT_FAST, own namespace); 0 = launched, 1 = no such kernel
 extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds, const void* st, const void* kp, int lp, int cls);
+// yt_owntree.hip: the same kernels once more over the own tree (-DYT_FAST -DYT_OWN_TREE, own namespace; yt_own.h)
+extern "C" int ythip_own_launch(void* stream, int blocks, const void* ds, const void* st, const void* kp, int lp, int cls);
+extern "C" int ythip_own_intersect(void* stream, const void* ds, const void* rays, const int* instances, long long n, void* hits);
 
 inline void drop_staging_views(ythip_ctx* ctx) {
   // host pools that view the staging memory go with it: the scene they belong to is no longer
@@ -268,3 +304,5 @@ int  bake_bvh(ythip_ctx* ctx);
 void free_device_trees(ythip_ctx* ctx);
 int  ensure_host_bvh(ythip_ctx* ctx);
 int  build_bvh_mixed(ythip_ctx* ctx, const ythip_scene& sc, bool highquality, bool use_device);
+int  build_own_bvh(ythip_ctx* ctx, const ythip_scene& sc);
+void drop_own_bvh(ythip_ctx* ctx);

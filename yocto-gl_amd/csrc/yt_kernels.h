@@ -223,12 +223,7 @@ YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv
   // the common cases, and three records are 14 + 12 + 21 dwords per lane of vector loads otherwise.
   Surface        s;
   ythip_instance inst;
-#ifdef YT_SURFACE_BY_VALUE  // (yt_scene.h, ld_record: the divergent case fetched whole too, not field by field behind the branches that use
-                            //  the fields; its own macro: it costs the general class ~100 more spilled VGPRs, to be measured on its own)
-#define YT_LD_RECORD(p) ld_record(p)
-#else
 #define YT_LD_RECORD(p) (*(p))
-#endif
   if (int u; SCALAR_LOADS && wave_uniform(instance, u)) inst = ldc_record(sc.instances + u);
   else inst = YT_LD_RECORD(sc.instances + instance);
   s.frame = ldframe(inst.frame);
@@ -248,36 +243,19 @@ YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv
 YT_FN vec3f sample_lights(const DScene& sc, vec3f position, float rl, float rel, vec2f ruv) {
   if (sc.num_lights <= 0) return {0, 0, 0};  // (reference: out-of-bounds read; ytrace never gets here)
   auto        light_id = sample_uniform(sc.num_lights, rl);
-#ifdef YT_RECORDS_BY_VALUE  // (yt_scene.h: ld_record)
   const DLight light = load_record(sc.lights, light_id);
-#else
-  const auto& light    = sc.lights[light_id];
-#endif
   if (light.instance != YTHIP_INVALIDID) {
-#ifdef YT_RECORDS_BY_VALUE
     const ythip_instance inst = load_record(sc.instances, light.instance);
     const DShape         sh   = load_record(sc.shapes, inst.shape);
-#else
-    const auto& inst    = sc.instances[light.instance];
-    const auto& sh      = sc.shapes[inst.shape];
-#endif
     auto        element = sample_discrete(sc.cdf + light.cdf_offset, light.cdf_count, rel);
     auto        uv      = (sh.kind_eval == KIND_TRIANGLES) ? sample_triangle(ruv) : ruv;
     auto        e       = load_element(sc, sh, element);
     auto        lpos    = eval_position(sc, ldframe(inst.frame), sh, e, uv);
     return normalize(lpos - position);
   } else if (light.environment != YTHIP_INVALIDID) {
-#ifdef YT_RECORDS_BY_VALUE
     const ythip_environment environment = load_record(sc.environments, light.environment);
-#else
-    const auto& environment = sc.environments[light.environment];
-#endif
     if (environment.emission_tex != YTHIP_INVALIDID) {
-#ifdef YT_RECORDS_BY_VALUE
       const ythip_texture tex = load_record(sc.textures, environment.emission_tex);
-#else
-      const auto& tex = sc.textures[environment.emission_tex];
-#endif
       auto        idx = sample_discrete(sc.cdf + light.cdf_offset, light.cdf_count, rel);
       auto        uv  = vec2f{div_((idx % tex.width) + 0.5f, (float)tex.width), div_((idx / tex.width) + 0.5f, (float)tex.height)};
       float sx, cx, sy, cy;
@@ -309,7 +287,11 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
         auto        area          = sc.cdf[light.cdf_offset + light.cdf_count - 1];
         for (auto bounce = 0; bounce < 100; bounce++) {
           ray3f ray  = make_ray(next_position, direction);
+#ifdef YT_OWN_TREE
+          Hit   isec = traverse_own<TRI>(sc, ray, light.instance, *st, *cnt);
+#else
           Hit   isec = traverse<COUNT, false, TRI>(sc, ray, light.instance, false, *st, *cnt);  // (counts only in the counting launch)
+#endif
           if (!isec.hit) break;
           auto e         = load_element(sc, sh, isec.element);
           auto lposition = eval_position(sc, frame, sh, e, {isec.u, isec.v});
@@ -322,11 +304,7 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
     } else if (light.environment != YTHIP_INVALIDID) {
       const auto environment = SCALAR_LOADS ? ldc_record(sc.environments + light.environment) : sc.environments[light.environment];
       if (environment.emission_tex != YTHIP_INVALIDID) {
-#ifdef YT_RECORDS_BY_VALUE
         const ythip_texture tex = SCALAR_LOADS ? ldc_record(sc.textures + environment.emission_tex) : ld_record(sc.textures + environment.emission_tex);
-#else
-        const auto& tex      = sc.textures[environment.emission_tex];
-#endif
         auto        wl       = transform_direction(ldframe(sc.env_inv + 12 * light.environment), direction);
         auto        texcoord = vec2f{div_(ytm::atan2f(wl.z, wl.x), 2 * pif), div_(ytm::acosf(clamp_(wl.y, -1.0f, 1.0f)), pif)};
         if (texcoord.x < 0) texcoord.x += 1;
@@ -394,9 +372,6 @@ YT_FN void set_first_hit(const DState& s, const Path& P, vec3f albedo, vec3f nor
   auto weight = rcp_((float)(s.sample_base + P.sidx + 1));
   auto alb    = lerp_(ld3(s.albedo, P.pix), albedo, weight);
   auto nrm    = lerp_(ld3(s.normal, P.pix), normal, weight);
-#ifdef YT_EXP_LASTSTORE  // ceiling experiment: accumulator stores only in the batch's last sample — WRONG results
-  if (P.sidx + 1 < s.batch) return;
-#endif
   s.albedo[3 * P.pix] = alb.x, s.albedo[3 * P.pix + 1] = alb.y, s.albedo[3 * P.pix + 2] = alb.z;
   s.normal[3 * P.pix] = nrm.x, s.normal[3 * P.pix + 1] = nrm.y, s.normal[3 * P.pix + 2] = nrm.z;
 }
@@ -910,11 +885,7 @@ YT_FN void finish_sample(const DState& st, const KParams& kp, int slot, const Pa
   const int pix    = P.pix;
   float4    im     = st.image[pix];
   vec4f     image  = {im.x, im.y, im.z, im.w};
-#ifdef YT_EXP_LASTSTORE
-  const bool store = P.sidx + 1 >= st.batch;
-#else
   constexpr bool store = true;
-#endif
   if (hit) {
     // albedo / normal were folded in at the first hit (set_first_hit)
     image = lerp_(image, vec4f{radiance.x, radiance.y, radiance.z, 1}, weight);
@@ -1088,24 +1059,14 @@ YT_FN int max_bounces_of(const KParams& kp) {
 #define YT_WAVES_PER_EU 4
 #endif
 template <int SAMPLER, int LP, bool COUNT, bool WIDE, int CLS = 0>
-#ifndef YT_WAVES_PER_EU_GENERAL  // experiment: occupancy of the general-class kernels
-#define YT_WAVES_PER_EU_GENERAL YT_WAVES_PER_EU
-#endif
-__global__ void __launch_bounds__(YT_BLOCK,
-    (CLS == 0 && !COUNT ? YT_WAVES_PER_EU_GENERAL : YT_WAVES_PER_EU))
+__global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU)
     k_trace(DScene sc, DState st, KParams kp) {
   constexpr bool MATTE = CLS == 1;
   constexpr int  PRIMS = MATTE ? 1 : (CLS == 3 ? 2 : 0);  // what the walks know about the shapes (yt_bvh.h: TRI)
   // majority-phase scene walk (yt_bvh.h::traverse_phased) for the kernels where it wins:
   // simple scenes with area lights (closed rooms: every ray hits, bounce rays as long as
   // camera rays).  Measured, DESIGN.md §6.
-#if defined(YT_PHASED_LP_ALL)
-  constexpr bool PHASED_SCENE = PHASED_DEFAULT || LP == LP_DEFER;
-#elif !defined(YT_NO_PHASED_LP)
-  constexpr bool PHASED_SCENE = PHASED_DEFAULT || (MATTE && LP == LP_DEFER);
-#else
-  constexpr bool PHASED_SCENE = PHASED_DEFAULT;
-#endif
+  constexpr bool PHASED_SCENE = MATTE && LP == LP_DEFER;
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;
   // root-box misses of continuing paths resolved in place (resolve_step); the counting
@@ -1116,10 +1077,6 @@ __global__ void __launch_bounds__(YT_BLOCK,
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   __shared__ WgQueues   Q;
   __shared__ WgState    W;
-#ifdef YT_LDS_PAD  // development builds: occupancy sensitivity (extra LDS per workgroup)
-  __shared__ int s_pad[YT_LDS_PAD / 4];
-  if (st.npix < 0) s_pad[threadIdx.x] = st.npix, st.image[0].x = (float)s_pad[(threadIdx.x + 1) & 63];
-#endif
   int lb = logical_block(st);
   if (lb < 0) return;
   if (stop_requested(st.stop, st.stop_gen)) return;  // cancelled before this tile started
@@ -1139,10 +1096,6 @@ __global__ void __launch_bounds__(YT_BLOCK,
   const int tid = threadIdx.x;
   Stack     stack;
   YT_STACK_INIT(stack, s_stack);
-#ifdef YT_PREFETCH
-  __shared__ int s_pf_zone[YT_BLOCK];  // landing area of the software prefetches (never read)
-  stack.pf_zone = (unsigned)(size_t)(__attribute__((address_space(3))) int*)s_pf_zone;
-#endif
   Counters  cnt         = {0, 0, 0, 0, 0, 0, 0, 0};
   const int max_bounces = max_bounces_of<SAMPLER>(kp);
 
@@ -1249,14 +1202,12 @@ __global__ void __launch_bounds__(YT_BLOCK,
             // the retry needs no ray, so it loops here instead of costing a wavefront iteration
             // each.  Exactly what the next iteration would do: P.o moved by the step, the
             // intersection re-read from next_intersection (the volume branch edits isec.distance).
-#ifndef YT_MIS_RETRY_BY_ITERATION
             while (step == STEP_RETRY && (P.flags & PF_NOEMIT)) {
               float4 ha   = st.nhit_a[slot];
               int    inst = __float_as_int(ha.w);
               P.isec      = {inst, st.nhit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
               step        = step_path<SAMPLER, LP, CLS>(E, P);
             }
-#endif
           }
 #ifdef YT_TIMING
           tmG = E.t_geo;
@@ -1418,11 +1369,7 @@ __global__ void __launch_bounds__(YT_BLOCK,
       }
     }
   }
-#ifdef YT_STACK_STATS
-  flush_counters(st.counters, cnt);
-#else
   if (COUNT || LP != LP_NONE) flush_counters(st.counters, cnt);
-#endif
   if (st.tile_cost && !st.pool_next && threadIdx.x == 0) {
     const long long dt = ((long long)__builtin_readcyclecounter() - t_tile0) >> 6;  // 64-cycle units fit 32 bits
     st.tile_cost[lb]   = (unsigned)(dt < 0 ? 0 : (dt > 0xffffffffll ? 0xffffffffll : dt));

@@ -37,11 +37,7 @@
 #ifdef __HIPCC__
 #define YT_LIBM_FN __device__ __forceinline__
 #define YT_LIBM_TABLE static __device__ const
-#ifdef YT_LIBM_OUTLINE  // development builds: the large functions as real calls (register pressure experiment)
-#define YT_LIBM_BIG __device__ __noinline__
-#else
 #define YT_LIBM_BIG __device__ __forceinline__
-#endif
 #else
 #define YT_LIBM_FN static inline
 #define YT_LIBM_BIG static inline
@@ -443,11 +439,7 @@ YT_LIBM_BIG float atanf(float x) {
   s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
   s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
   if (id < 0) return x - x * (s1 + s2);
-#ifdef YT_LIBM_NO_TABLES
   z = hi - ((x * (s1 + s2) - lo) - x);
-#else
-  z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
-#endif
   return (hx < 0) ? -z : z;
 }
 

@@ -68,19 +68,17 @@ struct DScene {
   const float* radius;
   const float*   pixelsf;
   const uint8_t* pixelsb;
-#ifdef YT_SRGB_LUT
   const float*   srgb_lut;  // srgb_to_rgb(b / 255.0f) for b = 0 ... 255, filled on the device by the same function (ythip.hip)
-#endif
   // bvh
   const float4*     pairs;      // sibling-pair records (4 float4 each), all trees
   const float4*     wide;       // grandchildren ("quad") records (8 float4 each), same ids as `pairs`
-  const float4*     oct;        // -DYT_WIDE8 builds: great-grandchildren records (16 float4 each), same ids; null otherwise
   const float4*     leafdata;   // pre-gathered leaf primitives in leaf order
   const int*        tlas_prims; // instance ids in TLAS leaf order
   const DInstanceT* tinst;      // per instance
   const DInstanceT* tinst_leaf; // the same records gathered in TLAS-leaf order (tinst[tlas_prims[k]], with .instance set)
   int               tlas_ref;   // ref of the TLAS root, REF_NONE if empty
   vec3f             tlas_bmin, tlas_bmax;
+  const uint4*      own;        // fastmath = 2 only: compressed 64-B nodes of the own tree (yt_own.h), same ids as `wide`; null otherwise
   // lights
   const DLight* lights;
   const float*  cdf;
@@ -88,11 +86,7 @@ struct DScene {
 };
 
 // Scalar-cache reads of records every lane asks for alike (round 4; the rationale is at wave_uniform in yt_bvh.h).
-#ifndef YT_NO_SCALAR_LOADS
 constexpr bool SCALAR_LOADS = true;
-#else  // development builds: every record through the vector memory path, as in rounds 1-3
-constexpr bool SCALAR_LOADS = false;
-#endif
 // a POD record through the scalar cache, dword by dword (the compiler merges the loads): `p` wave-uniform, immutable data
 template <typename T>
 YT_FN T ldc_record(const T* p) {
@@ -229,9 +223,7 @@ YT_FN vec4f decode_texel(const DScene& sc, const ythip_texture& t, const RawTexe
     color = {r.f.x, r.f.y, r.f.z, r.f.w};
   } else {
     const unsigned bx = r.b & 255u, by = (r.b >> 8) & 255u, bz = (r.b >> 16) & 255u, bw = r.b >> 24;
-#ifdef YT_SRGB_LUT
     if (as_linear && !t.linear) return {sc.srgb_lut[bx], sc.srgb_lut[by], sc.srgb_lut[bz], div_((float)bw, 255.0f)};
-#endif
     color = {div_((float)bx, 255.0f), div_((float)by, 255.0f), div_((float)bz, 255.0f), div_((float)bw, 255.0f)};
   }
   if (as_linear && !t.linear) {
@@ -240,31 +232,11 @@ YT_FN vec4f decode_texel(const DScene& sc, const ythip_texture& t, const RawTexe
   return color;
 }
 YT_FN vec4f lookup_texture(const DScene& sc, const ythip_texture& t, int i, int j, bool as_linear) {
-#if defined(YT_SRGB_LUT) || defined(YT_TEXELS_TOGETHER)
   return decode_texel(sc, t, fetch_texel(sc, t, i, j), as_linear);
-#else
-  vec4f color;
-  auto  idx = t.offset + (int64_t)j * t.width + i;
-  if (t.is_float) {
-    auto v = reinterpret_cast<const float4*>(sc.pixelsf)[idx];
-    color  = {v.x, v.y, v.z, v.w};
-  } else {
-    auto b = reinterpret_cast<const uchar4*>(sc.pixelsb)[idx];
-    color  = {div_((float)b.x, 255.0f), div_((float)b.y, 255.0f), div_((float)b.z, 255.0f), div_((float)b.w, 255.0f)};
-  }
-  if (as_linear && !t.linear) {
-    return {srgb_to_rgb(color.x), srgb_to_rgb(color.y), srgb_to_rgb(color.z), color.w};
-  }
-  return color;
-#endif
 }
 YT_FN vec4f eval_texture(const DScene& sc, int texture, vec2f uv, bool as_linear) {
   if (texture == YTHIP_INVALIDID) return {1, 1, 1, 1};
-#ifdef YT_RECORDS_BY_VALUE
   const ythip_texture t = load_record(sc.textures, texture);
-#else
-  const auto& t = sc.textures[texture];
-#endif
   if (t.width == 0 || t.height == 0) return {0, 0, 0, 0};
   auto sx = t.width, sy = t.height;
   auto s = 0.0f, tt = 0.0f;
@@ -283,7 +255,6 @@ YT_FN vec4f eval_texture(const DScene& sc, int texture, vec2f uv, bool as_linear
   if (t.nearest) {
     return lookup_texture(sc, t, i, j, as_linear);
   } else {
-#ifdef YT_TEXELS_TOGETHER
     // (one branch on the texel type, then four independent fetches in a row; the empty asm keeps them ahead of the first conversion)
     const int64_t o00 = t.offset + (int64_t)j * t.width + i, o01 = t.offset + (int64_t)jj * t.width + i,
                   o10 = t.offset + (int64_t)j * t.width + ii, o11 = t.offset + (int64_t)jj * t.width + ii;
@@ -300,12 +271,6 @@ YT_FN vec4f eval_texture(const DScene& sc, int texture, vec2f uv, bool as_linear
     }
     return decode_texel(sc, t, r00, as_linear) * (1 - u) * (1 - v) + decode_texel(sc, t, r01, as_linear) * (1 - u) * v +
            decode_texel(sc, t, r10, as_linear) * u * (1 - v) + decode_texel(sc, t, r11, as_linear) * u * v;
-#else
-    return lookup_texture(sc, t, i, j, as_linear) * (1 - u) * (1 - v) +
-           lookup_texture(sc, t, i, jj, as_linear) * (1 - u) * v +
-           lookup_texture(sc, t, ii, j, as_linear) * u * (1 - v) +
-           lookup_texture(sc, t, ii, jj, as_linear) * u * v;
-#endif
   }
 }
 

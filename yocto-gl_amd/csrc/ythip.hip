@@ -39,20 +39,34 @@ int upload_lights_impl(ythip_ctx* ctx) {
 // pathdirect & pathmis always trace inline; the rest never need a light pdf.
 // fast: ythip_params::fastmath — the tolerance-mode kernels of yt_fast.hip where they exist (wide walk, real samplers).
 // The kernels themselves are compiled in the yt_trace_*.hip units (yt_launch.h), by sampler family.
-int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count, bool fast = false) {
+int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count, int mode = 0) {
   // the scene class of the default sampler (yt_kernels.h: step_path's CLS)
   const int cls = kp.sampler == YTHIP_SAMPLER_PATH && ctx->specialize
                       ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0)
                       : 0;
-  // (the tolerance-mode unit has the wide-walk kernels only: they serve every tree the wide walk's stack bound admits —
-  //  use_wide()'s preference for the binary walk on scenes of tiny trees is a matter of speed, not of results)
-  if (fast && !count && ctx->wide_stack_ok && ctx->traversal_mode != 0) {
-    if (ythip_fast_launch(ctx->stream, ctx->launch_blocks(), &ctx->ds, &ctx->st, &kp, lp, cls) == 0) {
-      ctx->last_launch_fast = true;
+  // mode 2 (ythip_params::fastmath = 2): the own-tree kernels of yt_owntree.hip over the tree ythip_build_own_bvh made.
+  // Asked for without such a tree it fails loudly; the debug views (diagram / falsecolor) have no such kernel and render exact.
+  if (mode == 2 && !count) {
+    if (!ctx->have_own) return fail(ctx, YTHIP_ERR_STATE, "fastmath = 2 needs the own tree: call ythip_build_own_bvh after the bvh is resident");
+    if (!ctx->own_stack_ok) return fail(ctx, YTHIP_ERR_INVALID, "own tree too deep for the traversal stack");
+    DScene d = ctx->ds;  // (lights / materials / cameras as resident NOW; only the bvh part is the own tree's)
+    ctx->own.apply(d);
+    if (ythip_own_launch(ctx->stream, ctx->launch_blocks(), &d, &ctx->st, &kp, lp, cls) == 0) {
+      ctx->last_launch_fast = true, ctx->last_launch_mode = 2;
       return YTHIP_OK;
     }
   }
-  ctx->last_launch_fast = false;
+  // mode 1: the tolerance-mode unit has the wide-walk kernels only: they serve every tree the wide walk's stack bound
+  // admits, whatever use_wide() would prefer (tiny trees: a matter of speed, not of results).  A context forced to the
+  // binary walk (ythip_set_traversal 0) or a tree too deep for the wide walk's stack renders with the exact kernels —
+  // ythip_last_launch_fastmath says which ran.
+  if (mode == 1 && !count && ctx->wide_stack_ok && ctx->traversal_mode != 0) {
+    if (ythip_fast_launch(ctx->stream, ctx->launch_blocks(), &ctx->ds, &ctx->st, &kp, lp, cls) == 0) {
+      ctx->last_launch_fast = true, ctx->last_launch_mode = 1;
+      return YTHIP_OK;
+    }
+  }
+  ctx->last_launch_fast = false, ctx->last_launch_mode = 0;
   ytl::Launch l = {ctx->stream, ctx->launch_blocks(), &ctx->ds, &ctx->st, &kp, count, ctx->use_wide(), lp, cls};
   int rc = 1;
   switch (kp.sampler) {
@@ -120,7 +134,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   auto kp          = to_kparams(ctx, params);
   bool count       = (ctx->prof_mode & 2) != 0;
   ctx->st.counters = count ? ctx->d_counters : nullptr;
-#if defined(YT_TIMING) || defined(YT_STACK_STATS)
+#ifdef YT_TIMING
   ctx->st.counters = ctx->d_counters;
 #endif
   int  npix        = ctx->st.nslots;  // path-state arrays are per slot
@@ -179,6 +193,10 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
                        (ctx->have_tile_costs || !ctx->d_tile_cost || ctx->pixel_pool >= 2);
   bool pool = false;
   int  timed = -1;  // 0: this launch is the timed plain batch, 1: the timed pool batch
+  if (params->fastmath != ctx->pool_mode) {  // (the plain / pool choice was measured on another kernel family)
+    ctx->pool_mode = params->fastmath;
+    if (ctx->pixel_pool < 2) ctx->pool_tune = 0, ctx->pool_on = false;
+  }
   if (pool_ok && ctx->pixel_pool >= 2) {
     pool = true;
   } else if (pool_ok) {
@@ -216,7 +234,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   {
     EvScope ev(ctx, 0);
     if (timed >= 0) HIPCHECK(ctx, hipEventRecord(ctx->pool_ev[2 * timed], ctx->stream));
-    int rc = launch_trace_any(ctx, kp, lp, count, params->fastmath != 0);
+    int rc = launch_trace_any(ctx, kp, lp, count, params->fastmath);
     if (rc) return rc;
     if (timed >= 0) {
       HIPCHECK(ctx, hipEventRecord(ctx->pool_ev[2 * timed + 1], ctx->stream));
@@ -265,10 +283,8 @@ void classify_scene(ythip_ctx* ctx, const ythip_material* materials, int num_mat
 }
 }  // namespace
 
-#ifdef YT_SRGB_LUT
 // the 256 values srgb_to_rgb can take on a byte texel, by the function the kernels would call (yt_scene.h: decode_texel)
 __global__ void __launch_bounds__(256) k_srgb_lut(float* lut) { lut[threadIdx.x] = srgb_to_rgb(div_((float)threadIdx.x, 255.0f)); }
-#endif
 
 // ===========================================================================
 // C ABI
@@ -339,12 +355,16 @@ int ythip_create(int device, ythip_ctx** out) {
   return YTHIP_OK;
 }
 
+int ythip_abi_version(void) { return YTHIP_ABI_VERSION; }
+int ythip_params_size(void) { return (int)sizeof(ythip_params); }
+
 void ythip_destroy(ythip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   free_all(ctx->scene_allocs);
   free_all(ctx->bvh_allocs);
+  drop_own_bvh(ctx);
   free_all(ctx->light_allocs);
   free_all(ctx->state_allocs);
   free_device_trees(ctx);
@@ -465,6 +485,7 @@ int ythip_upload_scene_staged(ythip_ctx* ctx) {
 namespace {
 int upload_scene_impl(ythip_ctx* ctx, const ythip_scene* sc, bool from_staging) {
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  drop_own_bvh(ctx);  // (geometry / the reference tree changes: the own tree of fastmath = 2 is stale)
   // validation (the reference would index out of bounds)
   for (int k = 0; k < sc->num_instances; k++) {
     auto& i = sc->instances[k];
@@ -497,7 +518,6 @@ int upload_scene_impl(ythip_ctx* ctx, const ythip_scene* sc, bool from_staging) 
   UP(radius, sc->radius, sc->num_radius);
   UP(pixelsf, sc->pixelsf, sc->num_pixelsf * 4);
   UP(pixelsb, sc->pixelsb, sc->num_pixelsb * 4);
-#ifdef YT_SRGB_LUT
   {
     float* lut = nullptr;
     if ((rc = dalloc(ctx, ctx->scene_allocs, &lut, 256))) return rc;
@@ -505,7 +525,6 @@ int upload_scene_impl(ythip_ctx* ctx, const ythip_scene* sc, bool from_staging) 
     HIPCHECK(ctx, hipGetLastError());
     ds.srgb_lut = lut;
   }
-#endif
   std::vector<DShape> shapes(sc->num_shapes);
   for (int k = 0; k < sc->num_shapes; k++) {
     auto& s  = sc->shapes[k];
@@ -621,7 +640,34 @@ int ythip_build_bvh(ythip_ctx* ctx, const ythip_scene* sc, int highquality) {
   if (!ctx || !sc) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  drop_own_bvh(ctx);
   return build_bvh_mixed(ctx, *sc, highquality != 0, ctx->bvh_builder != 0);
+}
+
+// The own tree of ythip_params::fastmath = 2 (yt_own.h): built next to the resident reference tree, which stays what
+// every other mode and ythip_intersect_batch use.  Dropped by anything that changes geometry or the reference tree
+// (upload_scene, build / upload / update_bvh, update_shape_vertices, update_instance_frames): build it again afterwards.
+int ythip_build_own_bvh(ythip_ctx* ctx, const ythip_scene* sc) {
+  if (!ctx) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  if (sc) return build_own_bvh(ctx, *sc);
+  // no scene given: the geometry as RESIDENT — the context's host copies of shapes, instances, element lists and
+  // positions, which follow ythip_update_shape_vertices / ythip_update_instance_frames (the caller's arrays may not)
+  ythip_scene view   = {};
+  view.shapes        = ctx->h_shapes.data(), view.num_shapes = (int)ctx->h_shapes.size();
+  view.instances     = ctx->h_instances.data(), view.num_instances = (int)ctx->h_instances.size();
+  view.positions     = ctx->h_positions.data(), view.radius = ctx->h_radius.empty() ? nullptr : ctx->h_radius.data();
+  view.points        = ctx->h_points.data(), view.lines = ctx->h_lines.data();
+  view.triangles     = ctx->h_triangles.data(), view.quads = ctx->h_quads.data();
+  return build_own_bvh(ctx, view);
+}
+int ythip_own_bvh_info(ythip_ctx* ctx, int64_t* num_nodes, int64_t* num_leaf4, ythip_build_info* info) {
+  if (!ctx) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  if (num_nodes) *num_nodes = ctx->have_own ? ctx->own_nodes : 0;
+  if (num_leaf4) *num_leaf4 = ctx->have_own ? ctx->own_leaf4 : 0;
+  if (info) *info = ctx->have_own ? ctx->own_info : ythip_build_info{};
+  return ctx->have_own ? YTHIP_OK : fail(ctx, YTHIP_ERR_STATE, "no own tree resident");
 }
 
 // ---- update_scene_bvh (yocto_bvh.cpp:434-451) -------------------------------------------
@@ -642,6 +688,7 @@ int ythip_update_shape_vertices(ythip_ctx* ctx, int32_t shape, const float* posi
     return fail(ctx, YTHIP_ERR_INVALID, "shape %d has %lld radii resident, %lld given", shape, (long long)sh.num_radius,
         (long long)num_radius);
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  drop_own_bvh(ctx);  // (geometry / the reference tree changes: the own tree of fastmath = 2 is stale)
   if (normals && num_normals > 0)  // shading data only: no host copy is kept
     HIPCHECK(ctx, ctx->xfer.h2d(ctx->stream, (void*)(ctx->ds.normals + 3 * sh.normals_offset), normals, (size_t)num_normals * 12));
   if (positions && num_positions > 0) {
@@ -672,6 +719,7 @@ int ythip_update_instance_frames(ythip_ctx* ctx, const int32_t* instances, int32
     if (instances[k] < 0 || instances[k] >= (int)ctx->h_instances.size())
       return fail(ctx, YTHIP_ERR_INVALID, "instance %d out of range [0,%d)", instances[k], (int)ctx->h_instances.size());
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  drop_own_bvh(ctx);  // (geometry / the reference tree changes: the own tree of fastmath = 2 is stale)
   bool scatter = num >= 64;
   if (scatter) {  // (an instance named twice keeps its LAST frame, as a loop of assignments would: those go one by one)
     std::vector<char> seen(ctx->h_instances.size(), 0);
@@ -707,6 +755,7 @@ int ythip_update_bvh(ythip_ctx* ctx, const int32_t* updated_instances, int32_t n
   if (!ctx || (num_shapes > 0 && !updated_shapes)) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "update_bvh needs scene and bvh resident");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  drop_own_bvh(ctx);  // (geometry / the reference tree changes: the own tree of fastmath = 2 is stale)
   auto  t_start = std::chrono::steady_clock::now();
   auto& b       = ctx->h_bvh;
   int   nshapes = (int)ctx->h_shapes.size();
@@ -831,6 +880,7 @@ int ythip_upload_bvh(ythip_ctx* ctx, const ythip_bvh* bvh) {
   if (!ctx || !bvh) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene) return fail(ctx, YTHIP_ERR_STATE, "upload_scene first");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
+  drop_own_bvh(ctx);  // (geometry / the reference tree changes: the own tree of fastmath = 2 is stale)
   free_device_trees(ctx);
   ctx->build_info = {};
   auto& b = ctx->h_bvh;
@@ -1398,7 +1448,7 @@ int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info) {
   return YTHIP_OK;
 }
 
-int ythip_last_launch_fastmath(ythip_ctx* ctx) { return ctx && ctx->last_launch_fast ? 1 : 0; }
+int ythip_last_launch_fastmath(ythip_ctx* ctx) { return ctx ? ctx->last_launch_mode : 0; }
 
 int ythip_cancel(ythip_ctx* ctx) {
   if (!ctx) return YTHIP_ERR_INVALID;
@@ -1433,9 +1483,10 @@ int ythip_trace_samples_async(ythip_ctx* ctx, const ythip_params* params) {
 }
 
 static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_ray* rays, int64_t n,
-    int find_any, ythip_hit* hits) {
+    int find_any, ythip_hit* hits, bool own = false) {
   if (!ctx || (n > 0 && (!rays || !hits))) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   if (!ctx->have_scene || !ctx->have_bvh) return fail(ctx, YTHIP_ERR_STATE, "scene and bvh must be resident");
+  if (own && !(ctx->have_own && ctx->own_stack_ok)) return fail(ctx, YTHIP_ERR_STATE, "no own tree resident (ythip_build_own_bvh)");
   if (n == 0) return YTHIP_OK;
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   if (instances)
@@ -1464,7 +1515,11 @@ static int intersect_impl(ythip_ctx* ctx, const int32_t* instances, const ythip_
   bool count = (ctx->prof_mode & 2) != 0;
   {
   EvScope ev(ctx, 0);  // profiling bit 0: the kernel alone (ythip_get_stats: trace_ms / trace_launches)
-  if (count)
+  if (own) {
+    DScene d = ctx->ds;
+    ctx->own.apply(d);
+    ythip_own_intersect(ctx->stream, &d, d_rays, d_inst, (long long)n, d_hits);
+  } else if (count)
     hipLaunchKernelGGL((k_intersect_batch<true, false>), dim3(grid_for(n)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds,
         d_rays, d_inst, (long long)n, find_any, d_hits, ctx->d_counters);
   else if (ctx->use_wide())
@@ -1487,6 +1542,11 @@ int ythip_intersect_instance_batch(ythip_ctx* ctx, const int32_t* instances, con
     int find_any, ythip_hit* hits) {
   if (!instances && n > 0) return fail(ctx, YTHIP_ERR_INVALID, "null instances");
   return intersect_impl(ctx, instances, rays, n, find_any, hits);
+}
+// the same batch through the OWN tree's walk (fastmath = 2's traversal; instances may be null = intersect_scene): a
+// measuring entry — how often do its hit records differ from ythip_intersect_batch's, i.e. the reference's?
+int ythip_intersect_batch_own(ythip_ctx* ctx, const int32_t* instances, const ythip_ray* rays, int64_t n, ythip_hit* hits) {
+  return intersect_impl(ctx, instances, rays, n, 0, hits, true);
 }
 
 namespace {
@@ -1676,20 +1736,6 @@ int ythip_get_stats(ythip_ctx* ctx, ythip_stats* stats) {
 #endif
     std::fprintf(stderr, "[timing] traversal lane utilisation (sum of lane steps / 64 x longest lane): %.1f%%\n",
         t[7] ? 100.0 * t[6] / t[7] : 0.0);
-  }
-#endif
-#ifdef YT_WALK_PROFILE
-  {
-    unsigned long long w[16] = {};
-    HIPCHECK(ctx, hipMemcpyFromSymbol(w, HIP_SYMBOL(yt::g_walkprof), sizeof(w)));
-    unsigned long long zero[16] = {};
-    HIPCHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(yt::g_walkprof), zero, sizeof(zero)));
-    if (w[3])
-      std::fprintf(stderr,
-          "[walk] descend phase %.1f%% of the walk cycles, %.1f of 64 lanes per inner iteration | leaf/entry phase %.1f%%: "
-          "%.1f lanes with a BLAS leaf + %.1f with an entry per round, %.1f lanes per primitive round (%.2f rounds per leaf round)\n",
-          100.0 * w[0] / w[3], w[2] ? (double)w[1] / w[2] : 0.0, 100.0 * (w[3] - w[0]) / w[3], w[5] ? (double)w[4] / w[5] : 0.0,
-          w[5] ? (double)w[6] / w[5] : 0.0, w[8] ? (double)w[7] / w[8] : 0.0, w[5] ? (double)w[8] / w[5] : 0.0);
   }
 #endif
   *stats           = ctx->stats;

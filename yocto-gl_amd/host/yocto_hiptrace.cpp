@@ -192,17 +192,18 @@ void flatten(const trace_lights& l, flat_lights& f) {
 }
 
 // the tolerance mode (ythip_params::fastmath) is not a field of the reference's trace_params: a process-wide switch
-std::atomic<bool>& fast_math() {
-  static std::atomic<bool> on{[] {
+// (0 bit-exact, 1 the tolerance mode, 2 the own-tree mode: include/ythip.h, ythip_params::fastmath)
+std::atomic<int>& fast_math() {
+  static std::atomic<int> level{[] {
     auto e = std::getenv("YOCTO_HIP_FASTMATH");
-    return e && std::atoi(e) != 0;
+    return e ? std::min(std::max(std::atoi(e), 0), 2) : 0;
   }()};
-  return on;
+  return level;
 }
 
 ythip_params flat(const trace_params& p) {
   ythip_params q   = {};
-  q.fastmath       = fast_math().load() ? 1 : 0;
+  q.fastmath       = fast_math().load();
   q.camera         = p.camera;
   q.resolution     = p.resolution;
   q.sampler        = (int)p.sampler;
@@ -549,7 +550,8 @@ void ensure_scene(residency& r, const scene_data& scene, bool need_view = false)
 }
 
 void ensure_resident(residency& r, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights) {
-  ensure_scene(r, scene);
+  const bool own = fast_math().load() == 2;  // the own-tree mode builds its tree from the flat view of the geometry
+  ensure_scene(r, scene, own);
   auto bs = stamp_of(bvh);
   if (bs != r.bvh) {
     flat_bvh f;
@@ -557,6 +559,10 @@ void ensure_resident(residency& r, const scene_data& scene, const trace_bvh& bvh
     on_all(r, [&](ythip_ctx* c) { return ythip_upload_bvh(c, &f.view); });
     r.bvh = bs;
   }
+  if (own)  // (the library drops its own tree whenever geometry or the reference tree changes: ask it)
+    on_all(r, [&](ythip_ctx* c) {
+      return ythip_own_bvh_info(c, nullptr, nullptr, nullptr) == YTHIP_OK ? YTHIP_OK : ythip_build_own_bvh(c, &r.staged);
+    });
   auto ls = stamp_of(lights);
   if (ls != r.lights) {
     flat_lights f;
@@ -758,8 +764,10 @@ void invalidate() {
   r.scene    = {};
   r.bvh = r.lights = 0;
 }
-void set_fast_math(bool on) { fast_math().store(on); }
-bool get_fast_math() { return fast_math().load(); }
+void set_fast_math(bool on) { fast_math().store(on ? 1 : 0); }
+bool get_fast_math() { return fast_math().load() != 0; }
+void set_fast_math_level(int level) { fast_math().store(std::min(std::max(level, 0), 2)); }
+int  get_fast_math_level() { return fast_math().load(); }
 void set_residency_check(residency_check mode) {
   auto& r    = cache();
   auto  lock = std::lock_guard{r.mutex};

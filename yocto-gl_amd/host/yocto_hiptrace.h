@@ -51,6 +51,12 @@ int hip_device_count();
 // seed-to-seed spread), not bit for bit; trace_params has no such field, hence a switch.
 void set_fast_math(bool on);
 bool get_fast_math();
+// ... and one step further (level 2, or YOCTO_HIP_FASTMATH=2): the OWN-TREE mode — the tolerance mode's arithmetic and
+// a traversal of libythip's own tree (SAH, two levels per 64-B node of 8-bit boxes) instead of the trace_bvh's: the
+// same statistical agreement, hit records that may differ from the CPU tracer's at exact ties and box-edge grazes.
+// The tree is built on the device the first time a batch needs it and again after geometry edits.
+void set_fast_math_level(int level);  // 0 bit-exact (default), 1 tolerance, 2 own tree
+int  get_fast_math_level();
 
 // The device mirrors follow in-place edits of the scene the way the reference does (it
 // reads everything fresh on every call): cameras, materials, environments and instances

@@ -486,6 +486,11 @@ _SIGNATURES = {
     "ythip_update_materials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ythip_update_environments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ythip_build_bvh": (C.c_int, [C.c_void_p, C.POINTER(CScene), C.c_int]),
+    "ythip_build_own_bvh": (C.c_int, [C.c_void_p, C.POINTER(CScene)]),
+    "ythip_own_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(CBuildInfo)]),
+    "ythip_intersect_batch_own": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ythip_abi_version": (C.c_int, []),
+    "ythip_params_size": (C.c_int, []),
     "ythip_upload_bvh": (C.c_int, [C.c_void_p, C.POINTER(CBvh)]),
     "ythip_set_bvh_builder": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "ythip_bvh_build_info": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -587,6 +592,9 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+ABI_VERSION = 5  # include/ythip.h: YTHIP_ABI_VERSION
+
+
 def load_library(path=LIB_PATH):
     """Load libythip.so and bind every symbol of include/ythip.h.  Raises if the
     library or a symbol is missing — there is no fallback."""
@@ -601,6 +609,11 @@ def load_library(path=LIB_PATH):
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    # the structs of this file are include/ythip.h's at ABI version 5 (a caller built against another layout of
+    # ythip_params would hand the library a garbage `fastmath`)
+    if lib.ythip_abi_version() != ABI_VERSION or lib.ythip_params_size() != C.sizeof(CParams):
+        raise YthipError(f"{path}: ABI version {lib.ythip_abi_version()} / sizeof(ythip_params) {lib.ythip_params_size()}, "
+                         f"these bindings are for version {ABI_VERSION} / {C.sizeof(CParams)} bytes")
     _lib = lib
     return lib
 
@@ -745,8 +758,9 @@ class Context:
         return {k: getattr(info, k) for k, _ in CPoolInfo._fields_}
 
     def last_launch_fastmath(self):
-        """True when the last trace launch ran the tolerance-mode kernels (params.fastmath, yt_fast.hip)."""
-        return bool(self.lib.ythip_last_launch_fastmath(self.h))
+        """The mode the last trace launch ran: 0 bit-exact, 1 the tolerance-mode kernels (yt_fast.hip), 2 the own-tree
+        kernels (yt_owntree.hip) — params.fastmath where such a kernel exists."""
+        return int(self.lib.ythip_last_launch_fastmath(self.h))
 
     def update_cameras(self, cameras):
         """Re-upload only the cameras (interactive camera edits, apps/ytrace.cpp:189-204)."""
@@ -767,6 +781,19 @@ class Context:
         cs = scene.c_struct()
         self._check(self.lib.ythip_build_bvh(self.h, C.byref(cs), int(highquality)),
                     "build_bvh")
+
+    def make_own_bvh(self, scene=None):
+        """The own tree of trace_params(fastmath=2): built next to the resident reference tree (make_trace_bvh first).
+        Without a scene: from the geometry as resident (it follows update_shape_vertices / update_instance_frames)."""
+        cs = scene.c_struct() if scene is not None else None
+        self._check(self.lib.ythip_build_own_bvh(self.h, C.byref(cs) if cs is not None else None), "build_own_bvh")
+
+    def own_bvh_info(self):
+        n, l4, info = C.c_int64(), C.c_int64(), CBuildInfo()
+        self._check(self.lib.ythip_own_bvh_info(self.h, C.byref(n), C.byref(l4), C.byref(info)), "own_bvh_info")
+        d = {k: getattr(info, k) for k, _ in CBuildInfo._fields_}
+        d.update(num_nodes=n.value, num_leaf4=l4.value, bytes=64 * n.value + 16 * l4.value)
+        return d
 
     def set_bvh_builder(self, mode, min_prims=0):
         """mode "device" (default: shapes >= min_prims are built on the GPU) or "host"."""
@@ -999,6 +1026,15 @@ class Context:
         self._check(self.lib.ythip_intersect_batch(
             self.h, _ptr(rays), len(rays), int(find_any), _ptr(hits)),
             "intersect_batch")
+        return hits
+
+    def intersect_batch_own(self, rays, instances=None):
+        """The same batch through the own tree's walk (the traversal of fastmath = 2): a measuring entry."""
+        rays = np.ascontiguousarray(rays, ray_dt)
+        inst = None if instances is None else np.ascontiguousarray(instances, "i4")
+        hits = np.zeros(len(rays), hit_dt)
+        self._check(self.lib.ythip_intersect_batch_own(self.h, _ptr(inst), _ptr(rays), len(rays), _ptr(hits)),
+                    "intersect_batch_own")
         return hits
 
     def intersect_instance_batch(self, instances, rays, find_any=False):
