@@ -13,8 +13,9 @@ BASELINE sizes:
     measure between two reference-exact renders with different seeds).  Most paths still follow the reference's rng
     streams — they part only where a hit differs — so the error sits far below the spread;
   * the walk itself: on 200 k random rays + every primary ray of the frame, the fraction of rays whose (hit, instance,
-    element) equals the reference's is printed and asserted >= HIT_AGREEMENT; the rest must be ties / grazes: equal
-    distance within 1e-4 relative, or a hit / miss flip at a box edge.
+    element) equals the reference's is printed and asserted >= HIT_IDENTICAL, and >= HIT_AGREEMENT once exact ties
+    (another primitive at the reference's distance: coincident faces, shared edges) count as agreement; the rest must
+    be grazes: a hit / miss flip at a box or triangle edge.
 """
 import numpy as np
 import pytest
@@ -25,9 +26,12 @@ from test_gpu_fastmath import blocks
 
 pytestmark = pytest.mark.gpu
 
-OWN_BLOCK_RATIO = 0.5   # block error of the own-tree render / seed-to-seed spread (measured: see profiles/r05_own_tree_gates.txt)
+OWN_BLOCK_RATIO = 0.15  # block error of the own-tree render / seed-to-seed spread (measured: see profiles/r05_own_tree_gates.txt)
 FAST_BLOCK_RATIO = 0.1  # the tolerance mode shares every rng stream with the reference: a tenth of the spread at most
-HIT_AGREEMENT = 0.999   # rays whose own-tree hit record names the reference's (instance, element)
+HIT_IDENTICAL = 0.99    # rays whose own-tree hit record names the reference's (instance, element) (measured: 1.0 on triangle
+                        # scenes, 0.9987 on the Cornell box — its blocks stand ON the floor —, 0.9962 on the hair: consecutive
+                        # segments of a strand share an end point, and a ray that meets the joint meets both at one distance) ...
+HIT_AGREEMENT = 0.9999  # ... or another primitive at exactly the reference's distance (coincident faces, shared edges)
 
 
 def region_means(img, w, h, n=4):
@@ -58,24 +62,29 @@ def statistical_gate(what, ref, other_seed, got, w, h, ratio):
 
 
 def hit_agreement(what, own, exact):
-    """Own-tree hit records against the reference's (= the exact walk's).  Returns the fraction of rays that name the
-    same (hit, instance, element); asserts that what differs is a tie / graze."""
+    """Own-tree hit records against the reference's (= the exact walk's): the share of rays that name the same (hit,
+    instance, element), and the share that does so OR names another primitive at the same distance (an exact tie:
+    coincident faces — the Cornell box's blocks stand ON the floor —, shared edges; which of the two wins depends on the
+    visit order, which is the tree's).  Asserts both, and that nothing else differs but grazes."""
     n = len(exact)
     same_flag = own["hit"] == exact["hit"]
     both = (own["hit"] != 0) & (exact["hit"] != 0)
     same_prim = both & (own["instance"] == exact["instance"]) & (own["element"] == exact["element"])
-    agree = (same_flag & (~both | same_prim)).mean()
-    # where both hit: the distances agree (same primitive: rounding of the fast triangle test; another one: a tie)
-    d_own, d_ex = own["distance"][both].astype(np.float64), exact["distance"][both].astype(np.float64)
-    rel = np.abs(d_own - d_ex) / np.maximum(np.abs(d_ex), 1e-6)
-    far_off = int((rel > 1e-3).sum())
-    flips = int((~same_flag).sum())
-    print(f"[hits] {what}: {n} rays, identical (hit, instance, element) {agree:.6f}; other primitive at the same distance "
-          f"{int((both & ~same_prim).sum())}; hit / miss flips {flips}; distances off by > 1e-3 rel {far_off}")
-    assert agree >= HIT_AGREEMENT, (what, agree)
-    assert far_off <= max(2, n // 20000), (what, far_off)   # a different primitive is only ever a tie / an overlap
-    assert flips <= max(2, n // 2000), (what, flips)        # grazes of a box / triangle edge
-    return agree
+    d_own, d_ex = own["distance"].astype(np.float64), exact["distance"].astype(np.float64)
+    rel = np.where(both, np.abs(d_own - d_ex) / np.maximum(np.abs(d_ex), 1e-6), 0.0)
+    tie = both & ~same_prim & (rel <= 1e-5)
+    identical = (same_flag & (~both | same_prim)).mean()
+    identical_or_tie = (same_flag & (~both | same_prim | tie)).mean()
+    far_off = int((rel > 1e-3).sum())   # a different surface altogether
+    flips = int((~same_flag).sum())     # hit here, miss there: a graze of a box / triangle edge
+    print(f"[hits] {what}: {n} rays, identical (hit, instance, element) {identical:.6f}; identical or an exact tie "
+          f"{identical_or_tie:.6f} ({int(tie.sum())} ties); hit / miss flips {flips}; another surface (distance off by > 1e-3 rel) "
+          f"{far_off}")
+    assert identical >= HIT_IDENTICAL, (what, identical)
+    assert identical_or_tie >= HIT_AGREEMENT, (what, identical_or_tie)
+    assert far_off <= max(2, n // 20000), (what, far_off)
+    assert flips <= max(2, n // 5000), (what, flips)
+    return identical
 
 
 BASELINE = {  # name -> (scene, resolution, spp): the BASELINE configs at their full size + the general kernel class

@@ -2,7 +2,7 @@
 """The workload table of DESIGN.md §5 from ONE bench.py line (the tables and the driver line used to be
 different runs):   python tools/bench_table.py profiles/r04_bench.json  [previous.json]
 Prints a markdown table: Msamples/s (previous round in parentheses), ms / step, the four fractions, lane utilisation,
-wait share, L2 hit rate, TA cycles per wave-level load; bit-exact rows first, then the tolerance-mode rows."""
+wait share, L2 hit rate, TA cycles per wave-level load; bit-exact rows first, then the tolerance-mode rows, then the own-tree rows."""
 import json
 import sys
 
@@ -11,9 +11,9 @@ prev = {}
 if len(sys.argv) > 2:
     p = json.load(open(sys.argv[2]))
     prev["configs1"] = p["value"]
-    for e, n in zip(p.get("other_configs", []), ["cfg2b", "configs3", "configs4", "cornell9m"]):
-        if "value" in e:
-            prev[n] = e["value"]
+    for k, e in enumerate(p.get("other_configs", [])):  # (rounds 1-3 had no names: cfg2b, configs[3], configs[4], cornell9m in this order)
+        if "value" in e and e.get("mode", "bit-exact").startswith("bit-exact"):
+            prev[e.get("name") or (["cfg2b", "configs3", "configs4", "cornell9m"] + [None] * 16)[k]] = e["value"]
 NAMES = {"configs1": "configs[1] 1M-triangle plane, 1280×720×64", "cfg2b": "cfg2b 1M-triangle Cornell box, 1024²×64",
          "configs3": "configs[3] 10 k instances, 1920×1080×256", "configs4": "configs[4] make_hair, 800 k segments, 1280×720×64",
          "cornell9m": "9M-triangle Cornell box (> Infinity Cache), 1024²×16", "materials1": "corpus materials1 (class 3), 1280×533×64",
@@ -25,7 +25,7 @@ def row(name, value, ms, r, mode, speed=None):
     was = f" ({prev[name]:,.0f})" if mode == "exact" and name in prev else ""
     sp = f" ×{speed:.2f}" if speed else ""
     bound = max(f, key=f.get) if f else "-"
-    cells = [NAMES.get(name, name) + ("" if mode == "exact" else " — tolerance mode"), f"**{value:,.0f}**{was}{sp}", f"{ms:.2f}"]
+    cells = [NAMES.get(name, name) + {"exact": "", "fast": " — tolerance mode", "own": " — own tree"}[mode], f"**{value:,.0f}**{was}{sp}", f"{ms:.2f}"]
     cells += [("**%.2f**" % f[k]) if k == bound else ("%.2f" % f[k]) if k in f else "-" for k in ("hbm", "l2", "valu", "ta")]
     cells += ["%.2f" % r["lane_utilisation"] if "lane_utilisation" in r else "-", "%.2f" % r["wave_wait_share"] if "wave_wait_share" in r else "-",
               "%d %%" % round(100 * r["l2_hit_rate"]) if "l2_hit_rate" in r else "-",
@@ -33,13 +33,17 @@ def row(name, value, ms, r, mode, speed=None):
     return "| " + " | ".join(cells) + " |"
 
 
-print("| workload | Msamples/s (round 3) | ms / step | hbm | l2 | valu | ta | lanes | waiting | L2 hit | TA cycles / wave load |")
+print("| workload | Msamples/s (previous round) | ms / step | hbm | l2 | valu | ta | lanes | waiting | L2 hit | TA cycles / wave load |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 print(row("configs1", j["value"], j["ms_per_step"], j.get("roofline", {}), "exact"))
-for mode in ("bit-exact", "tolerance"):
+for mode in ("bit-exact", "tolerance", "own-tree"):
     for e in j.get("other_configs", []):
         if "value" in e and e["mode"].startswith(mode):
-            print(row(e["name"], e["value"], e["ms_per_step"], e["roofline"], "exact" if mode == "bit-exact" else "fast", e.get("speedup_over_bit_exact")))
+            print(row(e["name"], e["value"], e["ms_per_step"], e["roofline"], {"bit-exact": "exact", "tolerance": "fast", "own-tree": "own"}[mode],
+                      e.get("speedup_over_bit_exact")))
 c = j.get("cpu_baseline") or {}
 if "value" in c:
-    print(f"\nCPU reference on the box's {c['cores']} threads: {c['value']:.1f} Msamples/s on configs[1] ({c['sample'].split(',')[0]}).")
+    h = c.get("host") or {}
+    print(f"\nCPU reference (oracle/_ref) on configs[1]: {c['value']:.1f} Msamples/s with {c['cores']} CPUs of the lease "
+          f"({h.get('cpu_model', '?')}, {h.get('nproc', '?')} logical CPUs, cgroup cpu.max `{h.get('cgroup_cpu_max', '?')}`); "
+          f"affinity sweep: " + ", ".join(f"{e['cpus']} → {e['Msamples_per_s']:.1f}" for e in c.get("sweep", [])) + ".")

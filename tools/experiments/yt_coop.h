@@ -1,5 +1,5 @@
 // yt_coop.h — the wide walk with wavefront-cooperative sections, compiled with -DYT_COOP_LEAF (line leaves) and / or
-// -DYT_COOP_TLAS (the root-box tests of a TLAS leaf's instances).  DESIGN.md §6 (round 4) has the measurements.
+// -DYT_COOP_TLAS (the root-box tests of a TLAS leaf's instances).  docs/HISTORY.md (round 4) has the measurements.
 //
 // Line leaves tested by the whole wavefront.  On the hair (BASELINE configs[4]) the leaf phase is 60-70 % of a walk's
 // cycles and runs with 6-20 of the 64 lanes holding a leaf, each testing its <= 4 segments one after the other

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Any set of hardware counters for a bench workload's k_trace launches:
-    python tools/pmc_any.py WORKLOAD[:fast] COUNTER [COUNTER ...] [-- COUNTER ...]      ("--" starts another rocprofv3 pass)
+    python tools/pmc_any.py WORKLOAD[:fast|:own] COUNTER [COUNTER ...] [-- COUNTER ...]      ("--" starts another rocprofv3 pass)
 Runs `bench.py --worker WORKLOAD` under rocprofv3 --pmc (counters only), prints the per-launch means of the worker's timed
 launches, and a few ratios when their ingredients are there (TA busy share, L1 accesses per VALU instruction ...)."""
 import os
@@ -22,7 +22,7 @@ for a in sys.argv[2:]:
 if cur:
     passes.append(cur)
 # (every pass under its own short timeout: a counter set the profiler cannot schedule has been seen to hang, not fail)
-vals, kernel = bench._collect_counters(name, 0, int(os.environ.get("PMC_TIMEOUT", "90")), 1 if fast == "fast" else 0, passes)
+vals, kernel = bench._collect_counters(name, 0, int(os.environ.get("PMC_TIMEOUT", "90")), {"fast": 1, "own": 2}.get(fast, 0), passes)
 if vals is None:
     sys.exit(f"{name}: {kernel}")
 print(f"{sys.argv[1]}  kernel {kernel}")

@@ -387,9 +387,9 @@ int bake_bvh(ythip_ctx* ctx) {
 }
 
 // ---- the own tree (ythip_params::fastmath = 2; yt_own.h) ---------------------------------------------
-// One 64-B compressed node per quad record, same ids: a frame {origin, a power-of-two scale per axis} and the four
-// slots' boxes as 8-bit grid coordinates rounded OUTWARDS (lo down, hi up — the decoded box contains the float box),
-// the refs, the three split axes.  An axis without extent gets the smallest normal scale (every coordinate 0).
+// One 64-B compressed node per quad record, same ids (layout: yt_own.h): a frame {origin, a power-of-two scale per axis}
+// and the four slots' boxes as 8-bit grid coordinates rounded OUTWARDS (lo down, hi up — the decoded box contains the
+// float box), the refs, the three split axes.  An axis without extent gets the smallest normal scale (every coordinate 0).
 namespace {
 __global__ void __launch_bounds__(YT_BLOCK) k_own_compress(const float4* quads, long long n, uint4* own) {
   const long long k = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
@@ -443,10 +443,10 @@ __global__ void __launch_bounds__(YT_BLOCK) k_own_compress(const float4* quads, 
   }
   const unsigned axes = (unsigned)__float_as_int(Q[1].w) & 63u;
   uint4*         N    = own + 4 * k;
-  N[0] = {__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]), eb[0] | eb[1] << 8 | eb[2] << 16 | axes << 24};
+  N[0] = {__float_as_uint(org[0]), __float_as_uint(org[1]), __float_as_uint(org[2]), eb[2] << 23 | axes};
   N[1] = {qlo[0], qlo[1], qlo[2], qhi[0]};
   N[2] = {qhi[1], qhi[2], (unsigned)ref[0], (unsigned)ref[1]};
-  N[3] = {(unsigned)ref[2], (unsigned)ref[3], 0u, 0u};
+  N[3] = {(unsigned)ref[2], (unsigned)ref[3], eb[0] << 23, eb[1] << 23};
 }
 }  // namespace
 

@@ -905,7 +905,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
 // The production entry: the wide walk, and the binary walk for the rays it declines
 // (irregular at world or instance level, find_any) — the same hit record either way.
 #ifdef YT_OWN_TREE  // the own-tree unit (yt_owntree.hip, fastmath = 2): every production walk is yt_own.h's
-template <int TRI>
+template <int TRI, bool PHASED = false>
 YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, Stack& st, Counters& cnt);
 #endif
 template <bool COUNT, bool WIDE, int TRI = 0, bool PHASED = false>
@@ -913,7 +913,7 @@ YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, b
     Counters& cnt) {
 #ifdef YT_OWN_TREE
   if constexpr (WIDE && !COUNT) {
-    if (!find_any) return traverse_own<TRI>(sc, wray, only_instance, st, cnt);
+    if (!find_any) return traverse_own<TRI, PHASED>(sc, wray, only_instance, st, cnt);
   }
 #endif
   if constexpr (WIDE && !COUNT) {

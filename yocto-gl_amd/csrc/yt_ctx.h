@@ -227,7 +227,7 @@ inline void free_staging(ythip_ctx* ctx) {
 // The wide walk halves a ray's chain of dependent fetches and costs a little more
 // arithmetic per level.  It pays when the waves have the machine to themselves
 // (small slices: one GPU of eight, previews) and on large trees; on scenes made of
-// tiny trees the 4-slot records are mostly empty.  Measured in DESIGN.md §6.
+// tiny trees the 4-slot records are mostly empty.  Measured in docs/HISTORY.md.
 inline bool ythip_ctx::use_wide() const {
   if (!wide_stack_ok) return false;  // trees too deep for the wide walk's pushes (bake_bvh): the binary walk
   if (traversal_mode != 2) return traversal_mode == 1;

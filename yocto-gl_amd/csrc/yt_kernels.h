@@ -103,7 +103,7 @@ struct DState {
   // workgroup records the cycles its tile took for the next launch's order.  null: off.
   const int* tile_perm;
   unsigned*  tile_cost;
-  // pixel pool (opt-in, YTHIP_PIXEL_POOL=1): fewer workgroups than tiles; a lane whose pixel has taken its
+  // pixel pool (opt-in, YTHIP_PIXEL_POOL=1; docs/HISTORY.md): fewer workgroups than tiles; a lane whose pixel has taken its
   // batch takes the next pixel of the queue (tiles in launch order, 64 entries each) instead of going idle.  null: off.
   int* pool_next;
   int  pool_total;  // queue length = nblocks * YT_BLOCK
@@ -1055,7 +1055,7 @@ YT_FN int max_bounces_of(const KParams& kp) {
 // tile's path state (≈40 KB) stays in the XCD's L2 between iterations.  The
 // ray and the hit record never leave registers between extend and shade.
 // ===========================================================================
-#ifndef YT_WAVES_PER_EU  // development builds: occupancy experiments
+#ifndef YT_WAVES_PER_EU  // development builds: occupancy experiments (docs/HISTORY.md)
 #define YT_WAVES_PER_EU 4
 #endif
 template <int SAMPLER, int LP, bool COUNT, bool WIDE, int CLS = 0>
@@ -1065,7 +1065,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU)
   constexpr int  PRIMS = MATTE ? 1 : (CLS == 3 ? 2 : 0);  // what the walks know about the shapes (yt_bvh.h: TRI)
   // majority-phase scene walk (yt_bvh.h::traverse_phased) for the kernels where it wins:
   // simple scenes with area lights (closed rooms: every ray hits, bounce rays as long as
-  // camera rays).  Measured, DESIGN.md §6.
+  // camera rays).  Measured, docs/HISTORY.md.
   constexpr bool PHASED_SCENE = MATTE && LP == LP_DEFER;
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   constexpr bool MIS = SAMPLER == YTHIP_SAMPLER_PATHMIS;

@@ -11,7 +11,8 @@
 //     trace_params::highqualitybvh says), collapsed two levels per node like the quad records, and each node
 //     COMPRESSED into 64 B (k_own_compress, yt_bake.hip): a frame {origin, one power-of-two scale per axis} + the four
 //     children's boxes as 8-bit grid coordinates, rounded outwards (conservative), + their refs.  One dependent fetch
-//     of FOUR 16-B loads advances two levels (the quad walk: eight);
+//     of FOUR 16-B loads advances two levels (the quad walk: eight).  The closed-room kernels run it with the
+//     majority-phase schedule of yt_bvh.h (+10-12 % there, a loss elsewhere: as for the exact kernels);
 //   * the slab test in the node's frame: per node A = scale / d, B = (origin - o) / d, then one fused multiply-add per
 //     plane, t = q * A + B (q straight from a byte: v_cvt_f32_ubyteN).  The near / far planes are chosen per AXIS by the
 //     ray's direction sign, a word select, not per plane by min / max;
@@ -21,7 +22,7 @@
 //     TLAS-leaf pretest and the direct enter are the exact walk's — they are what made it fast, not what made it exact.
 //
 // Same ref encoding, leaf data and instance records as yt_bvh.h (of the SAH tree: DScene of this mode is a copy whose
-// bvh pointers are the own tree's — yt_ctx.h: ds_own).
+// bvh pointers are the own tree's — yt_ctx.h: BvhView).
 #pragma once
 
 #include "yt_bvh.h"
@@ -30,11 +31,13 @@
 namespace yt {
 
 // node layout (4 x uint4)
-//   q0  origin.x  origin.y  origin.z  ex | ey << 8 | ez << 16 | axes << 24     (e*: the scale's IEEE exponent field)
-//   q1  lo.x[4]   lo.y[4]   lo.z[4]   hi.x[4]        (byte s of a word = slot s; slots as in the quad record:
-//   q2  hi.y[4]   hi.z[4]   ref[0]    ref[1]          0, 1 = children of child 0 (or child 0 itself + empty), 2, 3 of child 1)
-//   q3  ref[2]    ref[3]    0         0
+//   q0  origin.x  origin.y  origin.z  scale.z | axes     (a scale is a power of two: its float has an empty mantissa, the axes ride in it)
+//   q1  lo.x[4]   lo.y[4]   lo.z[4]   hi.x[4]            (byte s of a word = slot s; slots as in the quad record:
+//   q2  hi.y[4]   hi.z[4]   ref[0]    ref[1]              0, 1 = children of child 0 (or child 0 itself + empty), 2, 3 of child 1)
+//   q3  ref[2]    ref[3]    scale.x   scale.y
 //   axes = node axis | child 0's axis << 2 | child 1's axis << 4   (the quad record's)
+// No slack factor on the far side (the reference's 1.00000024): the grid boxes are rounded outwards by up to a cell, and the
+// measured hit agreement is the same with and without it (profiles/r05_own_tree.txt).
 constexpr float OWN_TINY = 1e-20f;  // |d| below this counts as this (keeps 1 / d finite: no inf * 0 in the plane equations)
 
 YT_FN float own_rcp(float x) {
@@ -85,7 +88,7 @@ YT_FN uint4 ldcu4(const void* p, int k) {  // uint4 #k at the (uniform) address 
 }
 
 // intersect_scene_bvh (only_instance < 0) / intersect_instance_bvh on the own tree.  TRI as in traverse().
-template <int TRI>
+template <int TRI, bool PHASED>
 YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, Stack& st, Counters& cnt) {
   constexpr int LDS_LEVELS = YT_LDS_DEPTH, SPILL_LEVELS = 128 - YT_LDS_DEPTH;
   Hit           best       = {-1, -1, 0, 0, 0, false};
@@ -148,137 +151,121 @@ YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, S
     tmax = h.t;
   };
 
-  bool done = false;
-  while (!done) {
-    // ---- (1) descend: until this lane holds a leaf / instance entry ------------------------------------------------
-    while (true) {
-      if (cur == REF_NONE) {
-        if (sp == 0) {
-          done = true;
-          break;
-        }
-        const StackEntry e = pop();
-        cur                = e.ref;
-        if (e.ref != REF_EXIT && !(__int_as_float(e.t0) <= tmax)) cur = REF_NONE;  // culled at pop time
-        if (cur == REF_NONE) continue;
-      }
-      if ((unsigned)cur >= (unsigned)REF_INST) break;  // leaf, instance entry or exit: phase 2
-      cnt.steps++;
-      // the node step on a record given by value (the wavefront-uniform form hands it scalar registers)
-      auto step = [&](const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3) __attribute__((always_inline)) {
-        const unsigned e = n0.w;
-        const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23),
-                    sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
-        const float ax = sx * idir.x, ay = sy * idir.y, az = sz * idir.z;
-        const float bx = (__uint_as_float(n0.x) - o.x) * idir.x, by = (__uint_as_float(n0.y) - o.y) * idir.y,
-                    bz = (__uint_as_float(n0.z) - o.z) * idir.z;
-        // the near / far plane words of each axis, by the direction's sign
-        const bool     nx = (sign & 1) != 0, ny = (sign & 2) != 0, nz = (sign & 4) != 0;
-        const unsigned wnx = nx ? n1.w : n1.x, wfx = nx ? n1.x : n1.w;
-        const unsigned wny = ny ? n2.x : n1.y, wfy = ny ? n1.y : n2.x;
-        const unsigned wnz = nz ? n2.y : n1.z, wfz = nz ? n1.z : n2.y;
+  // ---- the four step kinds, each on this lane's `cur` ---------------------------------------------------------------
+  // (1) an internal node: the record by value (the wavefront-uniform form hands it scalar registers)
+  auto step = [&](const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3) __attribute__((always_inline)) {
+    const unsigned e = n0.w;
+    const float sx = __uint_as_float(n3.z), sy = __uint_as_float(n3.w), sz = __uint_as_float(e & 0x7f800000u);
+    const float ax = sx * idir.x, ay = sy * idir.y, az = sz * idir.z;
+    const float bx = (__uint_as_float(n0.x) - o.x) * idir.x, by = (__uint_as_float(n0.y) - o.y) * idir.y,
+                bz = (__uint_as_float(n0.z) - o.z) * idir.z;
+    // the near / far plane words of each axis, by the direction's sign
+    const bool     nx = (sign & 1) != 0, ny = (sign & 2) != 0, nz = (sign & 4) != 0;
+    const unsigned wnx = nx ? n1.w : n1.x, wfx = nx ? n1.x : n1.w;
+    const unsigned wny = ny ? n2.x : n1.y, wfy = ny ? n1.y : n2.x;
+    const unsigned wnz = nz ? n2.y : n1.z, wfz = nz ? n1.z : n2.y;
 #define YT_OWN_SLOT(S, REF, T0, R)                                                                                      \
   float T0;                                                                                                             \
   int   R;                                                                                                              \
   {                                                                                                                     \
-    const float near_ = own_max3(own_byte<S>(wnx) * ax + bx, own_byte<S>(wny) * ay + by, own_byte<S>(wnz) * az + bz);   \
-    const float far_  = own_min3(own_byte<S>(wfx) * ax + bx, own_byte<S>(wfy) * ay + by, own_byte<S>(wfz) * az + bz);   \
-    T0                = __builtin_fmaxf(near_, tmin);                                                                   \
-    R                 = (T0 <= far_ * BBOX_K && T0 <= tmax) ? (int)(REF) : REF_NONE;                                    \
+const float near_ = own_max3(own_byte<S>(wnx) * ax + bx, own_byte<S>(wny) * ay + by, own_byte<S>(wnz) * az + bz);   \
+const float far_  = own_min3(own_byte<S>(wfx) * ax + bx, own_byte<S>(wfy) * ay + by, own_byte<S>(wfz) * az + bz);   \
+T0                = __builtin_fmaxf(near_, tmin);                                                                   \
+R                 = (T0 <= __builtin_fminf(far_, tmax)) ? (int)(REF) : REF_NONE;                                    \
   }
-        YT_OWN_SLOT(0, n2.z, ta, ra)
-        YT_OWN_SLOT(1, n2.w, tb, rb)
-        YT_OWN_SLOT(2, n3.x, tc, rc)
-        YT_OWN_SLOT(3, n3.y, td, rd)
+    YT_OWN_SLOT(0, n2.z, ta, ra)
+    YT_OWN_SLOT(1, n2.w, tb, rb)
+    YT_OWN_SLOT(2, n3.x, tc, rc)
+    YT_OWN_SLOT(3, n3.y, td, rd)
 #undef YT_OWN_SLOT
-        // near child first along each split axis (the exact walk's order: yocto_bvh.cpp:498-504 applied twice)
-        const int  axes = (int)(e >> 24);
-        const bool hs = ((sign >> (axes & 3)) & 1) != 0, ls = ((sign >> ((axes >> 2) & 3)) & 1) != 0,
-                   rs = ((sign >> ((axes >> 4) & 3)) & 1) != 0;
-        const int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
-        const float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
-        const int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
-        const float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
-        // last to first: whatever passed is pushed, the nearest one becomes `cur`
-        int   pr = REF_NONE;
-        float pt = 0;
-        if (v3r != REF_NONE) pr = v3r, pt = v3t;
-        if (v2r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
-          pr = v2r, pt = v2t;
-        }
-        if (v1r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
-          pr = v1r, pt = v1t;
-        }
-        if (v0r != REF_NONE) {
-          if (pr != REF_NONE) push(pr, pt);
-          pr = v0r, pt = v0t;
-        }
-        cur = pr;
-      };
-      if (int ucur; SCALAR_LOADS && wave_uniform(cur, ucur)) {  // every stepping lane at the same node: one scalar fetch
-        const uint4* Ns = sc.own + 4 * (int64_t)ucur;
-        step(ldcu4(Ns, 0), ldcu4(Ns, 1), ldcu4(Ns, 2), ldcu4(Ns, 3));
-        continue;
-      }
-      const uint4* Np = sc.own + 4 * (int64_t)cur;
-      step(Np[0], Np[1], Np[2], Np[3]);
+    // near child first along each split axis (the exact walk's order: yocto_bvh.cpp:498-504 applied twice)
+    const int  axes = (int)(e & 63u);
+    const bool hs = ((sign >> (axes & 3)) & 1) != 0, ls = ((sign >> ((axes >> 2) & 3)) & 1) != 0,
+               rs = ((sign >> ((axes >> 4) & 3)) & 1) != 0;
+    const int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
+    const float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
+    const int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
+    const float v0t = hs ? r0t : l0t, v1t = hs ? r1t : l1t, v2t = hs ? l0t : r0t, v3t = hs ? l1t : r1t;
+    // last to first: whatever passed is pushed, the nearest one becomes `cur`
+    int   pr = REF_NONE;
+    float pt = 0;
+    if (v3r != REF_NONE) pr = v3r, pt = v3t;
+    if (v2r != REF_NONE) {
+      if (pr != REF_NONE) push(pr, pt);
+      pr = v2r, pt = v2t;
     }
-    if (done) break;
-
-    // ---- (2) leaves, instance entries ------------------------------------------------------------------------------
-    if (cur >= REF_INST) {
-      if (cur == REF_EXIT) {  // back to the TLAS level: the world ray again
-        cur = REF_NONE;
-        o = wo, d = wd, idir = widir, sign = wsign, cur_inst = -1;
-        continue;
-      }
-      const int code = cur - REF_INST;  // a pushed instance of a TLAS leaf: entry k << 1 | "root box tested"
-      cur            = enter(sc.tinst_leaf, code >> 1, -1, (code & 1) != 0);
-      continue;
+    if (v1r != REF_NONE) {
+      if (pr != REF_NONE) push(pr, pt);
+      pr = v1r, pt = v1t;
     }
-    const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
-    if (cur_inst < 0) {
-      // TLAS leaf: the root boxes of its (<= 4) instances tested at once — independent fetches, one round trip; what
-      // the ray can enter is pushed far end first with its t0, the FIRST survivor entered right here with the ray its
-      // test transformed (yt_bvh.h: PRETEST / direct enter)
-      if (num == 1) {
-        cur = REF_INST + (first << 1);
-        continue;
-      }
-      for (int k = num - 1; k >= 4; k--) push(REF_INST + ((first + k) << 1), 0);  // (never: leaves hold <= 4) untested
-      bool  have = false;
-      vec3f co = {0, 0, 0}, cd = {0, 0, 0}, cidir = {0, 0, 0};
-      float ct0 = 0;
-      int   ck = 0, croot = REF_NONE, ckind = KIND_NONE;
-#pragma unroll
-      for (int k = 3; k >= 0; k--) {
-        if (k >= num) continue;
-        float4 m0, m1, m2, m3, m4;
-        int4   m5;
-        load_instance_record(sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
-        if (__float_as_int(m4.z) == REF_NONE) continue;
-        const frame3f inv   = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
-        const vec3f   io    = transform_point(inv, wo);
-        const vec3f   id    = transform_vector(inv, wd);
-        const vec3f   iidir = {own_rcp(id.x), own_rcp(id.y), own_rcp(id.z)};
-        float         t0    = 0;
-        if (!own_box(io, iidir, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0)) continue;
-        if (have) push(REF_INST + (((first + ck) << 1) | 1), ct0);
-        have = true, co = io, cd = id, cidir = iidir, ct0 = t0, ck = k;
-        croot = __float_as_int(m4.z), ckind = __float_as_int(m4.w);
-      }
+    if (v0r != REF_NONE) {
+      if (pr != REF_NONE) push(pr, pt);
+      pr = v0r, pt = v0t;
+    }
+    cur = pr;
+  };
+  auto node_step = [&]() __attribute__((always_inline)) {
+    cnt.steps++;
+    if (int ucur; SCALAR_LOADS && wave_uniform(cur, ucur)) {  // every stepping lane at the same node: one scalar fetch
+      const uint4* Ns = sc.own + 4 * (int64_t)ucur;
+      step(ldcu4(Ns, 0), ldcu4(Ns, 1), ldcu4(Ns, 2), ldcu4(Ns, 3));
+      return;
+    }
+    const uint4* Np = sc.own + 4 * (int64_t)cur;
+    step(Np[0], Np[1], Np[2], Np[3]);
+  };
+  // (2) REF_EXIT (back to the TLAS level: the world ray again) or a pushed instance of a TLAS leaf
+  auto entry_step = [&]() __attribute__((always_inline)) {
+    if (cur == REF_EXIT) {
       cur = REF_NONE;
-      if (have && ct0 <= tmax) {
-        const int4 m5 = reinterpret_cast<const int4*>(sc.tinst_leaf + (first + ck))[5];
-        cur           = descend(co, cd, cidir, m5.z, croot, ckind, m5.x);
-      }
-      continue;
+      o = wo, d = wd, idir = widir, sign = wsign, cur_inst = -1;
+      return;
+    }
+    const int code = cur - REF_INST;  // entry k << 1 | "root box tested"
+    cur            = enter(sc.tinst_leaf, code >> 1, -1, (code & 1) != 0);
+  };
+  // (3) a TLAS leaf: the root boxes of its (<= 4) instances tested at once — independent fetches, one round trip; what
+  // the ray can enter is pushed far end first with its t0, the FIRST survivor entered right here with the ray its test
+  // transformed (yt_bvh.h: PRETEST / direct enter)
+  auto tlas_leaf_step = [&]() __attribute__((always_inline)) {
+    const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+    if (num == 1) {
+      cur = REF_INST + (first << 1);
+      return;
+    }
+    for (int k = num - 1; k >= 4; k--) push(REF_INST + ((first + k) << 1), 0);  // (never: leaves hold <= 4) untested
+    bool  have = false;
+    vec3f co = {0, 0, 0}, cd = {0, 0, 0}, cidir = {0, 0, 0};
+    float ct0 = 0;
+    int   ck = 0, croot = REF_NONE, ckind = KIND_NONE;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+      if (k >= num) continue;
+      float4 m0, m1, m2, m3, m4;
+      int4   m5;
+      load_instance_record(sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
+      if (__float_as_int(m4.z) == REF_NONE) continue;
+      const frame3f inv   = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
+      const vec3f   io    = transform_point(inv, wo);
+      const vec3f   id    = transform_vector(inv, wd);
+      const vec3f   iidir = {own_rcp(id.x), own_rcp(id.y), own_rcp(id.z)};
+      float         t0    = 0;
+      if (!own_box(io, iidir, tmin, {m3.x, m3.y, m3.z}, {m3.w, m4.x, m4.y}, t0)) continue;
+      if (have) push(REF_INST + (((first + ck) << 1) | 1), ct0);
+      have = true, co = io, cd = id, cidir = iidir, ct0 = t0, ck = k;
+      croot = __float_as_int(m4.z), ckind = __float_as_int(m4.w);
     }
     cur = REF_NONE;
+    if (have && ct0 <= tmax) {
+      const int4 m5 = reinterpret_cast<const int4*>(sc.tinst_leaf + (first + ck))[5];
+      cur           = descend(co, cd, cidir, m5.z, croot, ckind, m5.x);
+    }
+  };
+  // (4) a BLAS leaf: its (<= 4) primitives, any order
+  auto leaf_step = [&]() __attribute__((always_inline)) {
+    const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+    cur = REF_NONE;
     cnt.steps++;
-    // BLAS leaf: its (<= 4) primitives, any order
     if (TRI == 1 || kind == KIND_TRIANGLES) {
       const float4* L = sc.leafdata + (leafbias + first * 3);
       for (int k0 = 0; k0 < num; k0 += 2) {  // two triangles per round trip (the pool is padded, over-reads are ignored)
@@ -323,6 +310,50 @@ YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, S
         const float4 a = L[2 * k], b = L[2 * k + 1];
         auto h = intersect_point(o, d, tmin, tmax, {a.x, a.y, a.z}, a.w);
         if (h.hit) accept(__float_as_int(b.x), h);
+      }
+    }
+  };
+  // pop until this lane holds something to do; false when its stack is empty
+  auto next = [&]() __attribute__((always_inline)) -> bool {
+    while (cur == REF_NONE) {
+      if (sp == 0) return false;
+      const StackEntry e = pop();
+      cur                = e.ref;
+      if (e.ref != REF_EXIT && !(__int_as_float(e.t0) <= tmax)) cur = REF_NONE;  // culled at pop time
+    }
+    return true;
+  };
+
+  if constexpr (!PHASED) {
+    // while-while: descend until this lane holds a leaf / an entry, then everybody's leaves and entries
+    while (true) {
+      bool alive = true;
+      while ((alive = next()) && (unsigned)cur < (unsigned)REF_INST) node_step();
+      if (!alive) break;
+      if (cur >= REF_INST) entry_step();
+      else if (cur_inst < 0) tlas_leaf_step();
+      else leaf_step();
+    }
+  } else {
+    // majority phase (yt_bvh.h: traverse_phased): every lane does its private bookkeeping (pops, culls, exits), then the
+    // wavefront runs the ONE step kind most of its lanes wait for
+    bool alive = true;
+    while (true) {
+      if (alive) {
+        while ((alive = next()) && cur == REF_EXIT) entry_step();
+      }
+      const bool wantW = alive && (unsigned)cur < (unsigned)REF_INST;
+      const bool wantL = alive && cur < 0 && cur_inst >= 0;
+      const bool wantE = alive && !wantW && !wantL;  // an instance entry or a TLAS leaf
+      const int  nW = __popcll(__ballot(wantW)), nL = __popcll(__ballot(wantL)), nE = __popcll(__ballot(wantE));
+      if (nW + nL + nE == 0) break;
+      if (nW > 0 && nW * YT_PHASE_W >= nW + nL + nE) {
+        if (wantW) node_step();
+      } else if (nL > 0 && nL * YT_PHASE_L >= nL + nE) {
+        if (wantL) leaf_step();
+      } else if (wantE) {
+        if (cur >= REF_INST) entry_step();
+        else tlas_leaf_step();
       }
     }
   }
