@@ -635,6 +635,19 @@ int main() {
       hip::trace_cancel(context);
       EXPECT(!context.done && state.samples == 0, "second cancelled batch: done %d samples %d", (int)context.done.load(), state.samples);
     }
+    // a batch that runs to its end takes its cancel word with it (the table kept one entry per context address)
+    {
+      auto small = params;
+      small.sampler = trace_sampler_type::eyelight, small.resolution = 64, small.samples = 2, small.batch = 2;
+      auto st = make_trace_state(scene, small);
+      {
+        auto shortlived = make_trace_context(small);
+        hip::trace_start(shortlived, st, scene, bvh, lights, small);
+        shortlived.worker.get();  // ran to its end: nobody calls trace_cancel
+        EXPECT(shortlived.done && st.samples == 2, "short batch: done %d samples %d", (int)shortlived.done.load(), st.samples);
+      }
+      EXPECT(hip::pending_cancel_words() == 0, "%zu cancel words left behind by finished batches", hip::pending_cancel_words());
+    }
     // the back-end keeps working after a cancel
     params.sampler = trace_sampler_type::eyelight, params.resolution = 64, params.samples = 2, params.batch = 2;
     auto cpu = make_trace_state(scene, params), gpu = make_trace_state(scene, params);

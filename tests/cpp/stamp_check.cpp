@@ -61,6 +61,21 @@ int main() {
   std::printf("sampled stamp: %d of 500 single-bit edits seen (256 of %zu elements are looked at)\n", seen, a.size());
   if (seen > 5) failures++, std::printf("FAIL: the sampled stamp sees more than it can\n");
   residency_mode().store(0);
+  // a job that throws leaves the pool usable: the exception reaches the caller, the next job runs
+  {
+    bool caught = false;
+    try {
+      hash_pool::get().run(1000, [](size_t k) {
+        if (k == 137) throw std::runtime_error("job 137");
+      });
+    } catch (const std::runtime_error&) {
+      caught = true;
+    }
+    if (!caught && std::thread::hardware_concurrency() > 1) failures++, std::printf("FAIL: the job's exception was swallowed\n");
+    std::atomic<size_t> sum{0};
+    hash_pool::get().run(1000, [&](size_t k) { sum += k; });
+    if (sum != 999 * 1000 / 2) failures++, std::printf("FAIL: the pool lost indices after a throwing job\n");
+  }
   // cost
   std::vector<float> big(25 * 1000 * 1000);  // 100 MB
   for (size_t k = 0; k < big.size(); k += 1024) big[k] = (float)k;

@@ -5,9 +5,10 @@ north_star's bar for radiance is "within a stated float tolerance" (+ bit-exact 
 BASELINE.md §3.5's statistical gate, against the bit-exact render (= the reference's bytes, test_gpu_parity.py) at
 equal spp and equal seed:
 
-  * image mean (rgb) within 0.5 %;
-  * mean absolute error of the 8x8-block means <= the reference's own seed-to-seed spread (the same measure between
-    two bit-exact renders with different seeds) — in fact far below it, since both renders follow the same rng streams;
+  * image mean (rgb) within 0.5 %, every colour channel within 1 %, every cell of a 4 x 4 grid of image regions within 2 %;
+  * mean absolute error of the 8x8-block means <= 0.1 x the reference's own seed-to-seed spread (the same measure between
+    two bit-exact renders with different seeds): both renders follow the same rng streams, so "below the noise" would be no
+    gate at all (the same gates DIRECTLY against oracle/_ref at the BASELINE sizes: tests/test_gpu_own_tree.py);
   * hit records are not touched by the mode (ythip_intersect_batch always runs the bit-exact kernels; inside k_trace the
     traversal arithmetic is the exact one — yt_bvh.h has no fast path), checked by the hit-index known answer after a
     fast render and by `hits` (the per-pixel hit counters) agreeing in all but a handful of pixels.
@@ -26,8 +27,21 @@ def blocks(img, w, h):
     return a.reshape(a.shape[0] // 8, 8, a.shape[1] // 8, 8, 3).mean((1, 3))
 
 
-def gate(ctx, flat, what, resolution, spp, sampler="path", **kw):
-    """Renders exact (seed A), exact (seed B) and fast (seed A); asserts the two gates; returns the measures."""
+BLOCK_RATIO = 0.1  # the tolerance mode shares every rng stream with the exact render: its block error must be a small fraction of
+                   # the seed-to-seed spread (measured: 0.0002-0.03, profiles/r04_fastmath_gates.txt), not merely below it
+HITS_TOL = 2e-3    # share of pixels whose hit counter may differ (measured per workload: 0 on every test scene and sampler, 0 on
+                   # configs[1] / configs[3] / cornell9m, 3.0e-4 on cfg2b, 7.4e-4 on the hair: a path that parts from the
+                   # reference's at a graze may end on the other side of a hit / miss decision)
+
+
+def region_means(img, w, h, n=4):
+    a = np.asarray(img, np.float64).reshape(h, w, -1)[:, :, :3]
+    return np.array([[a[j * h // n:(j + 1) * h // n, i * w // n:(i + 1) * w // n].mean() for i in range(n)] for j in range(n)])
+
+
+def gate(ctx, flat, what, resolution, spp, sampler="path", hits_tol=HITS_TOL, **kw):
+    """Renders exact (seed A), exact (seed B) and fast (seed A); asserts the gates (image mean 0.5 %, every channel 1 %, every
+    cell of a 4 x 4 grid of regions 2 %, block error <= BLOCK_RATIO x spread, hit counters); returns the measures."""
     pa = yt.trace_params(sampler=sampler, resolution=resolution, samples=spp, batch=spp, **kw)
     pb = yt.trace_params(sampler=sampler, resolution=resolution, samples=spp, batch=spp, seed=20240917, **kw)
     pf = yt.trace_params(sampler=sampler, resolution=resolution, samples=spp, batch=spp, fastmath=1, **kw)
@@ -49,9 +63,15 @@ def gate(ctx, flat, what, resolution, spp, sampler="path", **kw):
     print(f"[fastmath] {what}: mean {mf:.6f} vs {me:.6f} (rel {rel_mean:.2e}); 8x8-block MAE {err:.3e} vs seed-to-seed spread "
           f"{spread:.3e} (ratio {err / max(spread, 1e-30):.4f}); pixels with identical rng streams {same_rng:.4f}; "
           f"hit counters differing in {hits_differ} of {len(exact['hits'])} pixels")
+    e3, f3 = exact["image"][:, :3].astype(np.float64), fast["image"][:, :3].astype(np.float64)
+    rel_chan = np.abs(f3.mean(0) - e3.mean(0)) / np.maximum(e3.mean(0), 1e-9)
+    re_, rf = region_means(exact["image"], w, h), region_means(fast["image"], w, h)
+    rel_region = (np.abs(rf - re_) / np.maximum(re_, 1e-3 * max(re_.max(), 1e-9))).max()
     assert rel_mean <= 0.005, (what, rel_mean)
-    assert err <= spread, (what, err, spread)
-    assert hits_differ <= max(8, len(exact["hits"]) // 200), (what, hits_differ)
+    assert rel_chan.max() <= 0.01, (what, rel_chan)
+    assert rel_region <= 0.02, (what, rel_region)
+    assert err <= BLOCK_RATIO * spread, (what, err, spread)
+    assert hits_differ <= max(2, int(hits_tol * len(exact["hits"]))), (what, hits_differ)
     return dict(rel_mean=rel_mean, err=err, spread=spread, same_rng=same_rng)
 
 

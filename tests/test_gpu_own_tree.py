@@ -22,7 +22,7 @@ import pytest
 
 import parity as P
 from parity import ry, yt, ysc
-from test_gpu_fastmath import blocks
+from test_gpu_fastmath import blocks, region_means
 
 pytestmark = pytest.mark.gpu
 
@@ -32,11 +32,6 @@ HIT_IDENTICAL = 0.99    # rays whose own-tree hit record names the reference's (
                         # scenes, 0.9987 on the Cornell box — its blocks stand ON the floor —, 0.9962 on the hair: consecutive
                         # segments of a strand share an end point, and a ray that meets the joint meets both at one distance) ...
 HIT_AGREEMENT = 0.9999  # ... or another primitive at exactly the reference's distance (coincident faces, shared edges)
-
-
-def region_means(img, w, h, n=4):
-    a = np.asarray(img, np.float64).reshape(h, w, -1)[:, :, :3]
-    return np.array([[a[j * h // n:(j + 1) * h // n, i * w // n:(i + 1) * w // n].mean() for i in range(n)] for j in range(n)])
 
 
 def statistical_gate(what, ref, other_seed, got, w, h, ratio):

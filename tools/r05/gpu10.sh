@@ -7,11 +7,11 @@ export TMPDIR=/tmp
 { date; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15; date; } > $out/suite.txt 2>&1
 {
   date; nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null
-  t0=$(date +%s.%N)
+  t0=$(date +%s%N)
   python bench.py > $out/bench_line.json 2> $out/bench.err
   rc=$?
-  t1=$(date +%s.%N)
-  echo "bench rc=$rc wall $(echo "$t1 - $t0" | bc) s, line bytes: $(wc -c < $out/bench_line.json)"
+  t1=$(date +%s%N)
+  echo "bench rc=$rc wall $(( (t1 - t0) / 1000000 )) ms, line bytes: $(wc -c < $out/bench_line.json)"
   cp bench_detail.json $out/bench_detail.json
   tail -5 $out/bench.err
 } > $out/bench.txt 2>&1

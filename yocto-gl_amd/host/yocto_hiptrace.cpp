@@ -1152,6 +1152,18 @@ void trace_start(trace_context& context, trace_state& state, const scene_data& s
     t.words[&context] = word;  // (replaces the word of an earlier batch of this context: that batch has been joined)
   }
   context.worker = std::async(std::launch::async, [&, word]() {
+    // the table entry leaves with the batch, however the batch ends (a context destroyed after a batch that ran to its
+    // end must not leave its address behind: the next context allocated there would inherit a dead word) — only if it
+    // still is THIS batch's word
+    struct forget {
+      const trace_context*                ctx;
+      const std::shared_ptr<cancel_word>& word;
+      ~forget() {
+        auto& t    = cancel_words();
+        auto  lock = std::lock_guard{t.mutex};
+        if (auto it = t.words.find(ctx); it != t.words.end() && it->second == word) t.words.erase(it);
+      }
+    } forget_word{&context, word};
     if (context.stop) return;
     trace_impl(state, scene, bvh, lights, params, false, &context.stop, word.get());  // includes the denoise hand-off
     if (context.stop) return;
@@ -1172,6 +1184,11 @@ void trace_cancel(trace_context& context) {
   }
   if (word) word->store(1);  // the library relays it to this context's batch in flight, and to no other
   if (context.worker.valid()) context.worker.get();
+}
+size_t pending_cancel_words() {
+  auto& t    = cancel_words();
+  auto  lock = std::lock_guard{t.mutex};
+  return t.words.size();
 }
 // trace_preview — yocto_trace.cpp:1660-1676
 void trace_preview(color_image& image, trace_context& context, trace_state& state, const scene_data& scene,

@@ -177,6 +177,9 @@ void trace_cancel(trace_context& context);
 void trace_preview(color_image& image, trace_context& context, trace_state& state, const scene_data& scene,
     const trace_bvh& bvh, const trace_lights& lights, const trace_params& params);
 
+// Contexts with a live cancel word (a batch started and not yet ended); 0 when nothing is in flight (test hook).
+size_t pending_cancel_words();
+
 // Drop every cached device mirror and the context (e.g. before the scene's
 // storage is reused for different content of the same sizes).
 void release();

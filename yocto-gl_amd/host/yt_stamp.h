@@ -13,10 +13,12 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace yocto::hip::stamp {
@@ -67,7 +69,8 @@ class hash_pool {
     static hash_pool p;
     return p;
   }
-  // runs fn(k) for k in [0, n) on the pool + the calling thread
+  // runs fn(k) for k in [0, n) on the pool + the calling thread.  An exception thrown by fn (on any thread) is
+  // rethrown here AFTER every worker has checked out of the job: the pool's bookkeeping stays balanced.
   template <typename F>
   void run(size_t n, F&& fn) {
     if (n == 0) return;
@@ -79,13 +82,14 @@ class hash_pool {
     std::function<void(size_t)> f = fn;
     {
       auto lock = std::unique_lock{m};
-      job = &f, total = n, next.store(0), pending = threads.size(), generation++;
+      job = &f, total = n, next.store(0), pending = threads.size(), generation++, failure = nullptr;
     }
     wake.notify_all();
-    for (size_t k; (k = next.fetch_add(1)) < n;) f(k);
+    drain(f, n);
     auto lock = std::unique_lock{m};
     idle.wait(lock, [&] { return pending == 0; });
     job = nullptr;
+    if (auto e = std::exchange(failure, nullptr)) std::rethrow_exception(e);
   }
 
  private:
@@ -114,9 +118,20 @@ class hash_pool {
         if (quit) return;
         seen = generation, f = job, n = total;
       }
-      for (size_t k; (k = next.fetch_add(1)) < n;) (*f)(k);
+      drain(*f, n);
       auto lock = std::unique_lock{m};
       if (--pending == 0) idle.notify_one();
+    }
+  }
+  // takes indices until none is left; the first exception ends the job for everybody (the rest of the indices is
+  // skipped) and is kept for run() to rethrow
+  void drain(std::function<void(size_t)>& f, size_t n) {
+    try {
+      for (size_t k; (k = next.fetch_add(1)) < n;) f(k);
+    } catch (...) {
+      next.store(n);
+      auto lock = std::unique_lock{m};
+      if (!failure) failure = std::current_exception();
     }
   }
   std::vector<std::thread>     threads;
@@ -127,6 +142,7 @@ class hash_pool {
   std::atomic<size_t>          next{0};
   uint64_t                     generation = 0;
   bool                         quit       = false;
+  std::exception_ptr           failure;
 };
 
 // how the large arrays are stamped: every byte (default) or the 256-element sample of rounds 1-3
@@ -167,7 +183,7 @@ struct array_hasher {
       }
       return h;
     }
-    constexpr size_t PIECE = 1u << 20;
+    constexpr size_t PIECE = 1u << 20, INLINE_PIECES = 8;
     struct piece {
       const unsigned char* p;
       size_t               bytes;
@@ -176,7 +192,11 @@ struct array_hasher {
     for (auto& s : spans)
       for (size_t off = 0; off < s.bytes; off += PIECE) pieces.push_back({s.p + off, std::min(PIECE, s.bytes - off)});
     std::vector<uint64_t> out(pieces.size());
-    hash_pool::get().run(pieces.size(), [&](size_t k) { out[k] = hash_piece(pieces[k].p, pieces[k].bytes); });
+    // small scenes are hashed in place: waking up to 31 threads costs more than 8 MiB of hashing (~80 us)
+    if (pieces.size() <= INLINE_PIECES)
+      for (size_t k = 0; k < pieces.size(); k++) out[k] = hash_piece(pieces[k].p, pieces[k].bytes);
+    else
+      hash_pool::get().run(pieces.size(), [&](size_t k) { out[k] = hash_piece(pieces[k].p, pieces[k].bytes); });
     return out.empty() ? h : fnv(out.data(), out.size() * sizeof(uint64_t), h);
   }
 };
