@@ -1,0 +1,80 @@
+// imgcodec_check — yt_jpeg.h / yt_exr.h against the reference's own decoders (stb_image, tinyexr: the objects of
+// oracle/_ref), file by file, every byte of the RGBA result.  Test infrastructure (tests/test_sceneio.py builds and runs
+// it where oracle/_ref exists).
+//   imgcodec_check file...      prints one line per file; exit code = number of mismatches
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "../../yocto-gl_amd/csrc/yt_exr.h"
+#include "../../yocto-gl_amd/csrc/yt_jpeg.h"
+
+extern "C" {
+unsigned char* stbi_load_from_memory(const unsigned char* buffer, int len, int* x, int* y, int* comp, int req_comp);
+const char*    stbi_failure_reason(void);
+int            LoadEXR(float** out_rgba, int* width, int* height, const char* filename, const char** err);
+}
+
+int main(int argc, char** argv) {
+  int bad = 0;
+  for (int a = 1; a < argc; a++) {
+    std::string   path = argv[a];
+    std::ifstream f(path, std::ios::binary);
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const bool    exr = path.size() > 4 && (path.substr(path.size() - 4) == ".exr" || path.substr(path.size() - 4) == ".EXR");
+    std::string   why;
+    if (exr) {
+      float*      ref = nullptr;
+      int         w = 0, h = 0;
+      const char* err = nullptr;
+      const bool  ref_ok = LoadEXR(&ref, &w, &h, path.c_str(), &err) == 0;
+      ytexr::Info info;
+      bool        ok = ytexr::header(bytes.data(), bytes.size(), info, why);
+      std::vector<float> mine;
+      if (ok) mine.resize((size_t)info.width * info.height * 4), ok = ytexr::decode(bytes.data(), bytes.size(), info, mine.data(), why);
+      if (ok != ref_ok) {
+        std::printf("MISMATCH %s: reference %s (%s), here %s (%s)\n", path.c_str(), ref_ok ? "reads" : "refuses", err ? err : "", ok ? "reads" : "refuses", why.c_str());
+        bad++;
+      } else if (!ok) {
+        std::printf("both refuse %s: reference \"%s\", here \"%s\"\n", path.c_str(), err ? err : "", why.c_str());
+      } else if (w != info.width || h != info.height || std::memcmp(ref, mine.data(), mine.size() * 4) != 0) {
+        size_t diff = 0;
+        if (w == info.width && h == info.height)
+          for (size_t k = 0; k < mine.size(); k++) diff += std::memcmp(&ref[k], &mine[k], 4) != 0;
+        std::printf("MISMATCH %s: %dx%d vs %dx%d, %zu of %zu floats differ\n", path.c_str(), w, h, info.width, info.height, diff, mine.size());
+        bad++;
+      } else std::printf("same %s: %dx%d, compression %d, %zu channels\n", path.c_str(), w, h, info.compression, info.channels.size());
+      std::free(ref);
+    } else {
+      int            w = 0, h = 0, n = 0;
+      unsigned char* ref = stbi_load_from_memory(bytes.data(), (int)bytes.size(), &w, &h, &n, 4);
+      ytjpeg::Info   info;
+      bool           ok = ytjpeg::header(bytes.data(), bytes.size(), info, why);
+      std::vector<uint8_t> mine;
+      if (ok) mine.resize((size_t)info.width * info.height * 4), ok = ytjpeg::decode(bytes.data(), bytes.size(), mine.data(), why);
+      if (ok != (ref != nullptr)) {
+        std::printf("MISMATCH %s: reference %s (%s), here %s (%s)\n", path.c_str(), ref ? "reads" : "refuses", ref ? "" : stbi_failure_reason(), ok ? "reads" : "refuses", why.c_str());
+        bad++;
+      } else if (!ok) {
+        std::printf("both refuse %s: reference \"%s\", here \"%s\"\n", path.c_str(), stbi_failure_reason(), why.c_str());
+      } else if (w != info.width || h != info.height || std::memcmp(ref, mine.data(), mine.size()) != 0) {
+        size_t diff = 0, first = 0;
+        if (w == info.width && h == info.height)
+          for (size_t k = 0; k < mine.size(); k++)
+            if (ref[k] != mine[k]) {
+              if (!diff) first = k;
+              diff++;
+            }
+        std::printf("MISMATCH %s: %dx%d vs %dx%d, %zu of %zu bytes differ (first at %zu: %d vs %d)\n", path.c_str(), w, h, info.width, info.height, diff,
+            mine.size(), first, diff ? ref[first] : 0, diff ? mine[first] : 0);
+        bad++;
+      } else std::printf("same %s: %dx%d, %d components\n", path.c_str(), w, h, info.components);
+      std::free(ref);
+    }
+  }
+  return bad > 255 ? 255 : bad;
+}

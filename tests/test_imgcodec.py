@@ -1,0 +1,399 @@
+"""JPEG and OpenEXR textures of ythip_load_scene (`-m "not gpu"`; SURVEY.md §8(f) rank 4, VERDICT r4 "missing" 5):
+yocto-gl_amd/csrc/yt_jpeg.h and yt_exr.h against what the reference's load_texture gets from stb_image / tinyexr
+(yocto_sceneio.cpp:1796-1850) — every byte of the RGBA result:
+
+  * file by file through tests/cpp/imgcodec_check.cpp, which links the decoders of oracle/_ref: the reference's own JPEG
+    and EXR files where they are present, JPEGs written by PIL in every sampling / progressive / restart / colour-space /
+    size combination it offers, EXRs written by the small encoder below (NONE / RLE / ZIPS / ZIP, HALF / FLOAT / UINT,
+    both line orders, data windows off the origin, 1 to 5 channels, layer names) and by tinyexr itself (PIZ);
+  * and through the scene loader: a scene.json with such textures, all pools against the reference's load_scene;
+  * what is refused is refused by both, or by name here (tiled EXR).
+"""
+import io
+import json
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import parity as P
+from parity import ry, yt
+from test_sceneio import assert_same_scene, write_ply, write_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("YOCTO_REF", "/root/reference")
+needs_ref = pytest.mark.skipif(not P.have_ref(), reason="oracle/_ref not built / did not travel")
+needs_objects = pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "stb_image.o")),
+                                   reason="the reference decoders' objects (oracle/_ref/*.o) are not here")
+PIL = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("codec") / "imgcodec_check")
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "imgcodec_check.cpp"),
+                    os.path.join(ref, "stb_image.o"), os.path.join(ref, "tinyexr.o"), "-lz", "-lpthread"], check=True)
+
+    def run(paths, expect_bad=0):
+        out = ""
+        for k in range(0, len(paths), 200):
+            r = subprocess.run([exe] + [str(p) for p in paths[k:k + 200]], capture_output=True, text=True, timeout=600)
+            out += r.stdout
+            assert expect_bad is None or r.returncode == (expect_bad if k == 0 else 0), r.stdout[-4000:] + r.stderr[-2000:]
+        return out
+
+    return run
+
+
+# ---------------------------------------------------------------------------------------------------
+# JPEG
+# ---------------------------------------------------------------------------------------------------
+def picture(rng, w, h, channels):
+    """Smooth gradients + edges + noise: something for every DCT coefficient and for the chroma filters."""
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, channels))
+    for c in range(channels):
+        img[..., c] = 127 + 100 * np.sin(x * (0.05 + 0.07 * c) + c) * np.cos(y * (0.04 + 0.03 * c))
+        img[..., c] += 60 * ((x // max(1, 3 + c) + y // max(1, 5 - c)) % 2)
+    img += rng.normal(0, 12, img.shape)
+    return np.clip(img, 0, 255).astype("u1")
+
+
+def to_image(a, mode):
+    h, w = a.shape[:2]
+    return PIL.frombytes(mode, (w, h), np.ascontiguousarray(a).tobytes())
+
+
+def jpeg_cases(rng, d):
+    paths = []
+    sizes = [(1, 1), (7, 5), (8, 8), (16, 16), (17, 33), (33, 17), (100, 75), (257, 129)]
+    for mode, ch in (("RGB", 3), ("L", 1), ("CMYK", 4)):
+        for w, h in sizes:
+            img = to_image(picture(rng, w, h, ch), mode)
+            for sub in ((0, 1, 2) if mode == "RGB" else (None,)):
+                for prog in (False, True):
+                    for quality in (35, 90):
+                        kw = dict(quality=quality, progressive=prog, optimize=bool(w & 1))
+                        if sub is not None:
+                            kw["subsampling"] = sub
+                        if w >= 33 and quality == 90:
+                            kw["restart_marker_blocks"] = 3
+                        if h >= 33 and quality == 35:
+                            kw["restart_marker_rows"] = 1
+                        name = d / f"{mode}_{w}x{h}_s{sub}_p{int(prog)}_q{quality}.jpg"
+                        try:
+                            img.save(name, "JPEG", **kw)
+                        except TypeError:  # an older PIL without restart markers
+                            kw.pop("restart_marker_blocks", None), kw.pop("restart_marker_rows", None)
+                            img.save(name, "JPEG", **kw)
+                        paths.append(name)
+    # RGB kept as RGB (no colour transform: Adobe marker, transform 0), 4:1:1-like samplings by hand-picked factors
+    img = to_image(picture(rng, 40, 24, 3), "RGB")
+    for k, kw in enumerate((dict(keep_rgb=True), dict(keep_rgb=True, progressive=True), dict(subsampling="4:1:1"),
+                            dict(subsampling="4:4:0"), dict(quality=100, subsampling=0), dict(quality=1))):
+        name = d / f"extra{k}.jpg"
+        try:
+            img.save(name, "JPEG", **kw)
+            paths.append(name)
+        except (TypeError, ValueError, KeyError, OSError):
+            pass
+    return paths
+
+
+@needs_objects
+def test_jpeg_every_sampling_scan_type_and_colour_space(checker, tmp_path):
+    rng = np.random.default_rng(5)
+    paths = jpeg_cases(rng, tmp_path)
+    assert len(paths) >= 150
+    out = checker(paths)
+    assert out.count("same ") == len(paths), out[-3000:]
+    # the scans really were of both kinds, the samplings really differed
+    data = {p.name: open(p, "rb").read() for p in paths}
+    assert any(b"\xff\xc2" in v for v in data.values()) and any(b"\xff\xc0" in v for v in data.values())
+    assert any(b"\xff\xdd" in v for v in data.values())  # DRI: restart intervals
+
+
+@needs_objects
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "docs", "images")), reason="the reference's pictures are not here (GPU box)")
+def test_the_references_own_jpeg_and_exr_files(checker):
+    import glob
+    paths = sorted(glob.glob(os.path.join(REF, "docs", "images", "*.jpg")) + glob.glob(os.path.join(REF, "images", "*.jpg")) +
+                   glob.glob(os.path.join(REF, "tests", "_data", "textures", "*.exr")))
+    assert len(paths) >= 30
+    out = checker(paths)
+    assert out.count("same ") == len(paths), out[-3000:]
+
+
+@needs_objects
+def test_damaged_jpegs_are_refused_or_read_exactly_as_the_reference_does(checker, tmp_path):
+    rng = np.random.default_rng(9)
+    good = tmp_path / "good.jpg"
+    to_image(picture(rng, 64, 48, 3), "RGB").save(good, "JPEG", quality=80, restart_marker_blocks=4)
+    data = open(good, "rb").read()
+    sos = data.index(b"\xff\xda")
+    cases = {
+        "noeoi": data[:-2],                                     # refused by both: no EOI
+        "nosoi": b"\x00\x00" + data[2:],
+        "junk_in_scan": data[:sos + 300] + bytes(rng.integers(0, 255, 64).astype("u1")) + data[sos + 364:],
+        "fill_bytes": data[:2] + b"\xff\xff\xff" + data[2:],    # fill bytes before a marker
+        "twelve_bit": data.replace(b"\xff\xc0\x00\x11\x08", b"\xff\xc0\x00\x11\x0c"),
+        "zero_width": data[:data.index(b"\xff\xc0") + 7] + b"\x00\x00" + data[data.index(b"\xff\xc0") + 9:],
+    }
+    paths = []
+    for name, body in cases.items():
+        open(tmp_path / (name + ".jpg"), "wb").write(body)
+        paths.append(tmp_path / (name + ".jpg"))
+    out = checker(paths)
+    assert "MISMATCH" not in out, out
+    assert out.count("both refuse") >= 4 and out.count("same ") >= 1, out
+    # a scan that ends early: both read it; the blocks the scan never reached are zero-coefficient blocks here (grey / black) and
+    # whatever malloc returned in stb_image, so only the rows above the cut can be compared — done here on the first MCU row
+    cut = tmp_path / "cut.jpg"
+    open(cut, "wb").write(data[:sos + 200] + b"\xff\xd9")
+    out = checker([cut], expect_bad=None)
+    assert "same " in out or "64x48 vs 64x48" in out, out  # (read by both; "same" when malloc happened to return zeros)
+    if "first at" in out:
+        assert int(out.split("first at ")[1].split(":")[0]) >= 64 * 4 * 8, out  # nothing differs inside the first row of blocks
+
+
+# ---------------------------------------------------------------------------------------------------
+# OpenEXR: a small scan-line writer
+# ---------------------------------------------------------------------------------------------------
+def _attr(name, kind, body):
+    return name.encode() + b"\0" + kind.encode() + b"\0" + struct.pack("<I", len(body)) + body
+
+
+def _rle(data):
+    out, i, n = bytearray(), 0, len(data)
+    while i < n:
+        j = i + 1
+        while j < n and data[j] == data[i] and j - i < 127:
+            j += 1
+        if j - i >= 3:
+            out += struct.pack("b", j - i - 1) + data[i:i + 1]
+            i = j
+        else:
+            j = i
+            while j < n and j - i < 127 and not (j + 2 < n and data[j] == data[j + 1] == data[j + 2]):
+                j += 1
+            out += struct.pack("b", -(j - i)) + data[i:j]
+            i = j
+    return bytes(out)
+
+
+def _predict(raw):
+    a = np.frombuffer(raw, "u1")
+    t = np.concatenate([a[0::2], a[1::2]]).astype(int)
+    d = t.copy()
+    d[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+    return d.astype("u1").tobytes()
+
+
+def write_exr(path, planes, compression, line_order=0, origin=(0, 0), drop_attr=None, chunk_count=False, zero_offsets=False):
+    """planes: list of (name, array[h][w] of float16 / float32 / uint32), in the order the file lists them."""
+    h, w = planes[0][1].shape
+    types = {np.dtype("float16"): 1, np.dtype("float32"): 2, np.dtype("uint32"): 0}
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", types[a.dtype], 0, 1, 1) for n, a in planes) + b"\0"
+    x0, y0 = origin
+    box = struct.pack("<4i", x0, y0, x0 + w - 1, y0 + h - 1)
+    attrs = {"channels": _attr("channels", "chlist", chlist), "compression": _attr("compression", "compression", bytes([compression])),
+             "dataWindow": _attr("dataWindow", "box2i", box), "displayWindow": _attr("displayWindow", "box2i", box),
+             "lineOrder": _attr("lineOrder", "lineOrder", bytes([line_order])),
+             "pixelAspectRatio": _attr("pixelAspectRatio", "float", struct.pack("<f", 1)),
+             "screenWindowCenter": _attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)),
+             "screenWindowWidth": _attr("screenWindowWidth", "float", struct.pack("<f", 1)),
+             "comment": _attr("comment", "string", b"written by a test"), "empty": _attr("empty", "string", b"")}
+    block = {0: 1, 1: 1, 2: 1, 3: 16}[compression]
+    nblocks = (h + block - 1) // block
+    if chunk_count:
+        attrs["chunkCount"] = _attr("chunkCount", "int", struct.pack("<i", nblocks))
+    if drop_attr:
+        attrs.pop(drop_attr)
+    head = struct.pack("<IBBBB", 20000630, 2, 0, 0, 0) + b"".join(attrs.values()) + b"\0"
+    chunks = []
+    order = range(nblocks) if line_order == 0 else reversed(range(nblocks))
+    for b in order:
+        lines = range(b * block, min(h, (b + 1) * block))
+        raw = b"".join(a[y].astype(a.dtype.newbyteorder("<")).tobytes() for y in lines for _, a in planes)
+        body = raw
+        if compression in (2, 3):
+            z = zlib.compress(_predict(raw), 6)
+            body = z if len(z) < len(raw) else raw
+        elif compression == 1:
+            z = _rle(_predict(raw))
+            body = z if len(z) < len(raw) else raw
+        chunks.append((y0 + b * block, body))
+    table_at = len(head)
+    at = table_at + 8 * nblocks
+    offsets, blob = {}, b""
+    for line, body in chunks:
+        offsets[line] = at + len(blob)
+        blob += struct.pack("<ii", line, len(body)) + body
+    table = b"".join(struct.pack("<Q", 0 if zero_offsets else offsets[y0 + b * block]) for b in range(nblocks))
+    open(path, "wb").write(head + table + blob)
+
+
+def exr_planes(rng, w, h, names, dtype):
+    out = []
+    for n in names:
+        if dtype == "uint32":
+            a = rng.integers(0, 2 ** 32, (h, w), dtype=np.uint32)
+        else:
+            a = (rng.uniform(-4, 60, (h, w)) * (rng.uniform(0, 1, (h, w)) > 0.2)).astype(dtype)
+            if dtype == "float16" and a.size >= 8:  # denormals, infinities, nan, -0: the conversion's corners
+                a.flat[:8] = np.array([0x0001, 0x03ff, 0x8001, 0x7c00, 0xfc00, 0x7e01, 0x8000, 0x0400], "u2").view("f2")
+        out.append((n, a))
+    return out
+
+
+def exr_cases(rng, d):
+    paths = []
+    for comp in (0, 1, 2, 3):
+        for dtype in ("float16", "float32", "uint32"):
+            for w, h in ((1, 1), (5, 3), (16, 16), (19, 37)):
+                for names in (["A", "B", "G", "R"], ["B", "G", "R"], ["Y"]):
+                    for line_order in (0, 1):
+                        if line_order and (w, h) != (19, 37):
+                            continue
+                        p = d / f"c{comp}_{dtype}_{w}x{h}_{''.join(names)}_{line_order}.exr"
+                        write_exr(p, exr_planes(rng, w, h, names, dtype), comp, line_order,
+                                  origin=(3, -7) if h == 37 else (0, 0), chunk_count=w == 5, zero_offsets=(w == 16 and comp != 0))
+                        paths.append(p)
+    # mixed types in one file, layer-qualified names, more than four channels
+    mixed = [("A", rng.uniform(0, 1, (9, 11)).astype("float32")), ("B", rng.uniform(0, 1, (9, 11)).astype("float16")),
+             ("G", rng.integers(0, 2 ** 32, (9, 11), dtype=np.uint32)), ("R", rng.uniform(0, 1, (9, 11)).astype("float16"))]
+    write_exr(d / "mixed.exr", mixed, 3), paths.append(d / "mixed.exr")
+    layered = exr_planes(rng, 6, 4, ["diffuse.B", "diffuse.G", "diffuse.R"], "float16")
+    write_exr(d / "layered.exr", layered, 2), paths.append(d / "layered.exr")
+    five = exr_planes(rng, 6, 4, ["A", "B", "G", "R", "Z"], "float32")
+    write_exr(d / "five.exr", five, 1), paths.append(d / "five.exr")
+    return paths
+
+
+@needs_objects
+def test_exr_every_compression_type_window_and_channel_list(checker, tmp_path):
+    rng = np.random.default_rng(21)
+    paths = exr_cases(rng, tmp_path)
+    assert len(paths) >= 120
+    out = checker(paths)
+    assert out.count("same ") == len(paths), out[-3000:]
+
+
+PIZ_WRITER = r"""
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "tinyexr.h"
+// piz_writer out.exr width height channels half(0/1) seed: noise + gradients, saved by tinyexr with PIZ compression
+int main(int argc, char** argv) {
+  const int w = atoi(argv[2]), h = atoi(argv[3]), nc = atoi(argv[4]), half = atoi(argv[5]);
+  unsigned  s = (unsigned)atoi(argv[6]);
+  std::vector<std::vector<float>> planes(nc, std::vector<float>((size_t)w * h));
+  for (int c = 0; c < nc; c++)
+    for (int i = 0; i < w * h; i++) {
+      s = s * 1664525u + 1013904223u;
+      planes[c][i] = (float)((i % w) * 0.01 + (i / w) * 0.02 * c) + ((s >> 8) % 1000) * (c == 1 ? 0.001f : 0.05f);
+    }
+  EXRHeader header;
+  InitEXRHeader(&header);
+  EXRImage image;
+  InitEXRImage(&image);
+  image.num_channels = nc;
+  std::vector<float*> ptr(nc);
+  const char* names[4] = {"A", "B", "G", "R"};
+  for (int c = 0; c < nc; c++) ptr[c] = planes[c].data();
+  image.images = (unsigned char**)ptr.data();
+  image.width = w, image.height = h;
+  header.num_channels = nc;
+  header.channels = (EXRChannelInfo*)malloc(sizeof(EXRChannelInfo) * nc);
+  header.pixel_types = (int*)malloc(sizeof(int) * nc);
+  header.requested_pixel_types = (int*)malloc(sizeof(int) * nc);
+  for (int c = 0; c < nc; c++) {
+    strncpy(header.channels[c].name, nc == 1 ? "Y" : names[nc == 3 ? c + 1 : c], 255);
+    header.pixel_types[c] = TINYEXR_PIXELTYPE_FLOAT;
+    header.requested_pixel_types[c] = half ? TINYEXR_PIXELTYPE_HALF : TINYEXR_PIXELTYPE_FLOAT;
+  }
+  header.compression_type = TINYEXR_COMPRESSIONTYPE_PIZ;
+  const char* err = nullptr;
+  if (SaveEXRImageToFile(&image, &header, argv[1], &err) != TINYEXR_SUCCESS) return std::printf("%s\n", err ? err : "?"), 1;
+  return 0;
+}
+"""
+
+
+@needs_objects
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "exts", "tinyexr", "tinyexr", "tinyexr.h")), reason="tinyexr's header is not here (GPU box)")
+def test_exr_piz_files_written_by_tinyexr(checker, tmp_path):
+    src, exe = tmp_path / "piz_writer.cpp", tmp_path / "piz_writer"
+    src.write_text(PIZ_WRITER)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(REF, "exts", "tinyexr", "tinyexr"), "-o", str(exe), str(src),
+                    os.path.join(ROOT, "oracle", "_ref", "tinyexr.o"), "-lpthread"], check=True)
+    paths = []
+    for k, (w, h, nc, half) in enumerate([(1, 1, 1, 1), (7, 3, 3, 1), (64, 64, 4, 1), (33, 70, 3, 0), (130, 35, 4, 0), (200, 100, 1, 1),
+                                          (17, 33, 4, 1)]):
+        p = tmp_path / f"piz{k}_{w}x{h}_{nc}_{half}.exr"
+        subprocess.run([str(exe), str(p), str(w), str(h), str(nc), str(half), str(k + 1)], check=True)
+        assert open(p, "rb").read().count(b"compression\0compression\0\x01\0\0\0\x04") == 1
+        paths.append(p)
+    out = checker(paths)
+    assert out.count("same ") == len(paths), out[-3000:]
+
+
+@needs_objects
+def test_exr_refusals(checker, tmp_path):
+    rng = np.random.default_rng(2)
+    planes = exr_planes(rng, 6, 5, ["B", "G", "R"], "float16")
+    write_exr(tmp_path / "ok.exr", planes, 3)
+    data = open(tmp_path / "ok.exr", "rb").read()
+    cases = {"magic": b"\0" + data[1:], "cut": data[:len(data) - 20], "multipart": data[:5] + b"\x10" + data[6:]}
+    for drop in ("compression", "channels", "lineOrder", "dataWindow", "screenWindowWidth"):
+        write_exr(tmp_path / f"no_{drop}.exr", planes, 3, drop_attr=drop)
+    write_exr(tmp_path / "nored.exr", exr_planes(rng, 4, 4, ["B", "G", "Z"], "float32"), 0)
+    write_exr(tmp_path / "late_red.exr", exr_planes(rng, 4, 4, ["A", "AO", "B", "G", "R"], "float32"), 0)  # R is the FIFTH channel
+    for name, body in cases.items():
+        open(tmp_path / (name + ".exr"), "wb").write(body)
+    paths = sorted(tmp_path.glob("*.exr"))
+    out = checker(paths)
+    assert "MISMATCH" not in out, out
+    assert out.count("both refuse") == len(paths) - 1 and out.count("same ") == 1, out
+    # tiled files: refused here by name (tinyexr reads them)
+    tiled = data[:5] + b"\x02" + data[6:]
+    open(tmp_path / "tiled.exr", "wb").write(tiled)
+    assert "tiled EXR files are not read here" in checker([tmp_path / "tiled.exr"], expect_bad=None)
+
+
+# ---------------------------------------------------------------------------------------------------
+# through the scene loader
+# ---------------------------------------------------------------------------------------------------
+@needs_ref
+def test_a_scene_with_jpeg_and_exr_textures_loads_as_the_reference_loads_it(tmp_path):
+    rng = np.random.default_rng(17)
+    os.mkdir(tmp_path / "shapes"), os.mkdir(tmp_path / "textures")
+    write_ply(tmp_path / "shapes/tri.ply", rng.uniform(-1, 1, (3, 3)), triangles=[[0, 1, 2]])
+    to_image(picture(rng, 37, 21, 3), "RGB").save(tmp_path / "textures/wood.jpg", "JPEG", quality=85)
+    to_image(picture(rng, 16, 16, 3), "RGB").save(tmp_path / "textures/prog.jpeg", "JPEG", quality=60, progressive=True, subsampling=2)
+    to_image(picture(rng, 9, 9, 1), "L").save(tmp_path / "textures/grey.JPG", "JPEG")
+    to_image(picture(rng, 12, 10, 3), "RGB").save(tmp_path / "textures/really_a_png.jpg", "PNG")
+    to_image(picture(rng, 12, 10, 3), "RGB").save(tmp_path / "textures/really_a_jpeg.png", "JPEG")
+    write_exr(tmp_path / "textures/sky.exr", exr_planes(rng, 32, 16, ["A", "B", "G", "R"], "float16"), 3)
+    write_exr(tmp_path / "textures/flat.EXR", exr_planes(rng, 5, 4, ["B", "G", "R"], "float32"), 0)
+    textures = [{"name": n, "uri": "textures/" + n} for n in
+                ("wood.jpg", "prog.jpeg", "grey.JPG", "really_a_png.jpg", "really_a_jpeg.png", "sky.exr", "flat.EXR")]
+    doc = {"asset": {"version": "5.0"}, "shapes": [{"uri": "shapes/tri.ply"}], "textures": textures,
+           "environments": [{"emission": [1, 1, 1], "emission_tex": 5}]}
+    path = write_scene(tmp_path, doc)
+    got, _, _ = yt.load_scene_file(path)
+    ref = ry.RefScene.load(path).flat()
+    assert_same_scene(got, ref, "jpeg + exr textures")
+    assert list(got.textures["is_float"]) == [0, 0, 0, 0, 0, 1, 1] and list(got.textures["linear"]) == [0, 0, 0, 0, 0, 1, 1]
+    # a texture that cannot be read: the reference's words (its spelling included) + the reason
+    open(tmp_path / "textures/wood.jpg", "wb").write(b"\xff\xd8\xff\xe0 not much of a JPEG")
+    with pytest.raises(yt.YthipError, match="cannot raed .*wood.jpg.*corrupt JPEG"):
+        yt.load_scene_file(path)
+    with pytest.raises(RuntimeError, match="cannot raed"):
+        ry.RefScene.load(path)

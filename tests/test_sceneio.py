@@ -194,7 +194,7 @@ def test_find_camera_follows_the_reference_order(scene_dir):
     (lambda d: d.__setitem__("subdivs", [{"name": "s"}]), "subdivs"),
     (lambda d: d["shapes"].append({"uri": "shapes/none.ply"}), "cannot open"),
     (lambda d: d["shapes"].append({"uri": "shapes/thing.obj"}), "unsupported format"),
-    (lambda d: d.__setitem__("textures", [{"uri": "t.jpg"}]), "unsupported format"),
+    (lambda d: d.__setitem__("textures", [{"uri": "t.tga"}]), "unsupported format"),
     (lambda d: d.__setitem__("cameras", [{"lens": "wide"}]), "cannot parse"),
     (lambda d: d.__setitem__("cameras", [{"frame": [1, 2, 3]}]), "cannot parse"),
     (lambda d: d.__setitem__("materials", [{"name": 5}]), "cannot parse"),

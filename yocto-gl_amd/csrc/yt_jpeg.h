@@ -14,7 +14,8 @@
 //   * YCbCr -> RGB in 20-bit fixed point with constants rounded to 12 bits, the Cb term of green truncated to its high
 //     16 bits (:3604-3632); Adobe APP14 transform 0 = RGB / CMYK as they are, 2 = YCCK; component ids 'R','G','B' = RGB;
 //   * a stream that runs into a marker or the end of the file decodes zeros from there on; a file without its EOI marker
-//     is refused, as stb_image refuses it (:3355-3397).
+//     is refused, as stb_image refuses it (:3355-3397).  Blocks a scan never reaches are blocks of zero coefficients here;
+//     stb_image leaves their samples as malloc returned them.
 //
 // tests/test_sceneio.py compares every pixel with the reference's loader on the reference's own JPEG files and on files
 // written by PIL in every sampling / progressive / restart / colour-space combination it offers.
@@ -22,6 +23,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 

@@ -16,10 +16,12 @@
 // What is read: the builtin JSON format, versions 4.2 / 5.0 (what save_scene writes) and 4.0 (files
 // without asset.version: named elements that refer to each other by name), shapes in PLY, textures
 // in Radiance HDR (stbi_loadf's reader, stb_image.h:7080-7197 of the reference's vendored copy: RLE
-// and flat scanlines) and PNG (stbi_load's results: every colour type, bit depth, tRNS, Adam7;
-// inflate through zlib).  Anything else — subdivs (tesselate_subdivs is scene processing, re-used
+// and flat scanlines), PNG (stbi_load's results: every colour type, bit depth, tRNS, Adam7;
+// inflate through zlib), JPEG (yt_jpeg.h: stb_image's baseline / progressive decoder restated, its
+// inverse DCT, upsampling and colour arithmetic bit for bit) and OpenEXR (yt_exr.h: tinyexr's LoadEXR
+// on scan-line files, NONE / RLE / ZIPS / ZIP / PIZ).  Anything else — subdivs (tesselate_subdivs is scene processing, re-used
 // from the reference: SURVEY.md §2), format 4.1, PLY instance files, OBJ / glTF / PBRT scenes,
-// JPEG / EXR / TGA / BMP textures, .ypreset — fails loudly by name: those stay with the
+// tiled EXR / TGA / BMP textures, .ypreset — fails loudly by name: those stay with the
 // reference's loader, whose scene_data goes through ythip_upload_scene as before.
 //
 // No device code here; the file is a .hip unit only so that the one build rule covers it.
@@ -43,6 +45,8 @@
 #include <vector>
 
 #include "../../include/ythip.h"
+#include "yt_exr.h"
+#include "yt_jpeg.h"
 
 namespace ytio {
 int fail(int code, const std::string& msg);  // yt_io.hip: sets ythip_io_last_error() of this thread
@@ -724,13 +728,17 @@ std::string join(const std::string& dir, const std::string& uri) {  // path_join
   return (std::filesystem::u8path(dir) / std::filesystem::u8path(uri)).generic_u8string();
 }
 
-enum TexKind { TEX_HDR, TEX_PNG };
+enum TexKind { TEX_HDR, TEX_PNG, TEX_JPG, TEX_EXR };
 struct TextureFile {
   std::string path;
   TexKind     kind;
   FileBytes   bytes;
   HdrInfo     hdr;
   PngInfo     png;
+  ytjpeg::Info jpg;
+  ytexr::Info  exr;
+  int          width = 0, height = 0;  // whatever the format
+  bool         is_float() const { return kind == TEX_HDR || kind == TEX_EXR; }
 };
 
 template <typename Fn>
@@ -1188,17 +1196,32 @@ static int scene_open_impl(const char* path, ythip_scene_file** out, ythip_scene
     auto e   = lower_ext(tf.path);
     if (e == ".hdr" || e == ".HDR") tf.kind = TEX_HDR;
     else if (e == ".png" || e == ".PNG") tf.kind = TEX_PNG;
+    else if (e == ".jpg" || e == ".JPG" || e == ".jpeg" || e == ".JPEG") tf.kind = TEX_JPG;
+    else if (e == ".exr" || e == ".EXR") tf.kind = TEX_EXR;
     else {
-      why = "unsupported format " + tf.path + " (textures are read from Radiance HDR and PNG here)";
+      why = "unsupported format " + tf.path + " (textures are read from Radiance HDR, OpenEXR, PNG and JPEG here)";
       return false;
     }
     if (!tf.bytes.load(tf.path)) {
       why = "cannot open " + tf.path;
       return false;
     }
-    std::string detail;
-    bool ok = tf.kind == TEX_HDR ? hdr_header(tf.bytes.data.data(), tf.bytes.data.size(), tf.hdr, detail)
-                                 : png_parse(tf.bytes.data.data(), tf.bytes.data.size(), tf.png, false, detail);
+    std::string    detail;
+    const uint8_t* bytes = tf.bytes.data.data();
+    const size_t   count = tf.bytes.data.size();
+    // stbi_load goes by what the file IS, not by what it is called (load_texture only picks 8-bit or float by the
+    // extension): a PNG called .jpg is read as a PNG and the other way round
+    static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    const bool           is_png     = count >= 8 && std::memcmp(bytes, png_sig, 8) == 0;
+    if (tf.kind == TEX_JPG && is_png) tf.kind = TEX_PNG;
+    else if (tf.kind == TEX_PNG && !is_png && count >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8) tf.kind = TEX_JPG;
+    bool ok = false;
+    switch (tf.kind) {
+      case TEX_HDR: ok = hdr_header(bytes, count, tf.hdr, detail), tf.width = tf.hdr.width, tf.height = tf.hdr.height; break;
+      case TEX_PNG: ok = png_parse(bytes, count, tf.png, false, detail), tf.width = tf.png.width, tf.height = tf.png.height; break;
+      case TEX_JPG: ok = ytjpeg::header(bytes, count, tf.jpg, detail), tf.width = tf.jpg.width, tf.height = tf.jpg.height; break;
+      case TEX_EXR: ok = ytexr::header(bytes, count, tf.exr, detail), tf.width = tf.exr.width, tf.height = tf.exr.height; break;
+    }
     if (!ok) {
       why = "cannot raed " + tf.path + " (" + detail + ")";  // (the reference's spelling, load_texture's read_error)
       return false;
@@ -1233,8 +1256,8 @@ static int scene_open_impl(const char* path, ythip_scene_file** out, ythip_scene
   for (size_t k = 0; k < ntex; k++) {
     auto& t  = f->textures[k];
     auto& tf = f->texture_files[k];
-    bool  hdr = tf.kind == TEX_HDR;
-    t.width = hdr ? tf.hdr.width : tf.png.width, t.height = hdr ? tf.hdr.height : tf.png.height;
+    bool  hdr = tf.is_float();
+    t.width = tf.width, t.height = tf.height;
     t.linear   = hdr ? 1 : 0;  // load_texture overwrites what the json said (yocto_sceneio.cpp:1819, :1830)
     t.is_float = hdr ? 1 : 0;
     int64_t& total = hdr ? c.num_pixelsf : c.num_pixelsb;
@@ -1306,6 +1329,10 @@ static int scene_read_impl(ythip_scene_file* f, const ythip_scene* dst, int thre
     bool        ok;
     if (tf.kind == TEX_HDR) {
       ok = hdr_decode(tf.bytes.data.data(), tf.bytes.data.size(), tf.hdr, W(dst->pixelsf) + t.offset * 4, detail);
+    } else if (tf.kind == TEX_EXR) {
+      ok = ytexr::decode(tf.bytes.data.data(), tf.bytes.data.size(), tf.exr, W(dst->pixelsf) + t.offset * 4, detail);
+    } else if (tf.kind == TEX_JPG) {
+      ok = ytjpeg::decode(tf.bytes.data.data(), tf.bytes.data.size(), W(dst->pixelsb) + t.offset * 4, detail);
     } else {
       PngInfo png;  // (a second read of the same handle decodes again: the parsed chunks are not kept)
       ok = png_parse(tf.bytes.data.data(), tf.bytes.data.size(), png, true, detail) && png_decode(png, W(dst->pixelsb) + t.offset * 4, detail);
