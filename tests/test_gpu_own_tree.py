@@ -32,6 +32,9 @@ HIT_IDENTICAL = 0.99    # rays whose own-tree hit record names the reference's (
                         # scenes, 0.9987 on the Cornell box — its blocks stand ON the floor —, 0.9962 on the hair: consecutive
                         # segments of a strand share an end point, and a ray that meets the joint meets both at one distance) ...
 HIT_AGREEMENT = 0.9999  # ... or another primitive at exactly the reference's distance (coincident faces, shared edges)
+HIT_IDENTICAL_BY_SCENE = {"cfg5": 0.975}  # the hair with the one-reciprocal line test (own_line): 0.9841 identical, 17 811 ties of
+                                          # 1.12 M rays — a strand's joints again, now also where rounding decides between two
+                                          # segments at distances one ulp apart; identical-or-tie stays 0.99996
 
 
 def statistical_gate(what, ref, other_seed, got, w, h, ratio):
@@ -56,7 +59,7 @@ def statistical_gate(what, ref, other_seed, got, w, h, ratio):
     return dict(rel_mean=rel_mean, err=err, spread=spread, same_rng=same_rng, hits_differ=hits_differ)
 
 
-def hit_agreement(what, own, exact):
+def hit_agreement(what, own, exact, identical_min=HIT_IDENTICAL):
     """Own-tree hit records against the reference's (= the exact walk's): the share of rays that name the same (hit,
     instance, element), and the share that does so OR names another primitive at the same distance (an exact tie:
     coincident faces — the Cornell box's blocks stand ON the floor —, shared edges; which of the two wins depends on the
@@ -75,7 +78,7 @@ def hit_agreement(what, own, exact):
     print(f"[hits] {what}: {n} rays, identical (hit, instance, element) {identical:.6f}; identical or an exact tie "
           f"{identical_or_tie:.6f} ({int(tie.sum())} ties); hit / miss flips {flips}; another surface (distance off by > 1e-3 rel) "
           f"{far_off}")
-    assert identical >= HIT_IDENTICAL, (what, identical)
+    assert identical >= identical_min, (what, identical)
     assert identical_or_tie >= HIT_AGREEMENT, (what, identical_or_tie)
     assert far_off <= max(2, n // 20000), (what, far_off)
     assert flips <= max(2, n // 5000), (what, flips)
@@ -120,7 +123,7 @@ def test_own_walk_names_the_references_hits(scenes, name):
     rays = np.concatenate([ctx.camera_rays(p), P.random_rays(flat, 200_000, seed=23)])
     exact = ctx.intersect_batch(rays)  # (== the reference's records: tests/test_gpu_baseline_configs.py, test_gpu_parity.py)
     own = ctx.intersect_batch_own(rays)
-    hit_agreement(name, own, exact)
+    hit_agreement(name, own, exact, HIT_IDENTICAL_BY_SCENE.get(name, HIT_IDENTICAL))
     # ... and the exact entry is what it was (the own tree is built NEXT TO the reference tree)
     assert ctx.intersect_batch(rays).tobytes() == exact.tobytes()
     if name == "cornellbox" and P.have_ref():

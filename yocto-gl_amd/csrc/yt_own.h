@@ -17,7 +17,8 @@
 //     plane, t = q * A + B (q straight from a byte: v_cvt_f32_ubyteN).  The near / far planes are chosen per AXIS by the
 //     ray's direction sign, a word select, not per plane by min / max;
 //   * no parity obligations: reciprocals instead of IEEE divisions, zero direction components nudged to 1e-20 (no
-//     inf * 0), no "tame ray" test and no binary redo, fused multiply-adds everywhere, Möller–Trumbore with one v_rcp.
+//     inf * 0), no "tame ray" test and no binary redo, fused multiply-adds everywhere, Möller–Trumbore with one v_rcp, line
+//     and point tests on one reciprocal each (own_line / own_point: hair +4.6 %, lines_points +8.5 %).
 //     The visit order (near child first by the split axes' signs), the pop-time cull against the current tmax, the
 //     TLAS-leaf pretest and the direct enter are the exact walk's — they are what made it fast, not what made it exact.
 //
@@ -80,6 +81,33 @@ YT_FN PrimHit own_triangle(vec3f o, vec3f d, float tmin, float tmax, vec3f p0, v
   return {u, v, t, true};
 }
 
+// intersect_line / intersect_point (yocto_geometry.h:716-757, :697-713) on reciprocals and fused multiply-adds; `dd2` = |d|^2
+// of the level's ray (kept with the ray: it does not change from segment to segment)
+YT_FN PrimHit own_line(vec3f o, vec3f dd, float dd2, float tmin, float tmax, vec3f p0, vec3f p1, float r0, float r1) {
+  const vec3f v = {p1.x - p0.x, p1.y - p0.y, p1.z - p0.z}, w = {o.x - p0.x, o.y - p0.y, o.z - p0.z};
+  const float a = dd2, b = dd.x * v.x + dd.y * v.y + dd.z * v.z, c = v.x * v.x + v.y * v.y + v.z * v.z;
+  const float d = dd.x * w.x + dd.y * w.y + dd.z * w.z, e = v.x * w.x + v.y * w.y + v.z * w.z;
+  const float det = a * c - b * b;
+  if (det == 0) return {0, 0, flt_max, false};
+  const float inv = __builtin_amdgcn_rcpf(det);
+  const float t   = (b * e - c * d) * inv;
+  if (!(t >= tmin && t <= tmax)) return {0, 0, flt_max, false};
+  const float s   = __builtin_fminf(__builtin_fmaxf((a * e - b * d) * inv, 0.0f), 1.0f);
+  const vec3f prl = {w.x + dd.x * t - v.x * s, w.y + dd.y * t - v.y * s, w.z + dd.z * t - v.z * s};
+  const float d2  = prl.x * prl.x + prl.y * prl.y + prl.z * prl.z;
+  const float r   = r0 + (r1 - r0) * s;
+  if (d2 > r * r) return {0, 0, flt_max, false};
+  return {s, __builtin_sqrtf(d2) * __builtin_amdgcn_rcpf(r), t, true};
+}
+YT_FN PrimHit own_point(vec3f o, vec3f d, float dd2, float tmin, float tmax, vec3f p, float r) {
+  const vec3f w = {p.x - o.x, p.y - o.y, p.z - o.z};
+  const float t = (w.x * d.x + w.y * d.y + w.z * d.z) * __builtin_amdgcn_rcpf(dd2);
+  if (!(t >= tmin && t <= tmax)) return {0, 0, flt_max, false};
+  const vec3f q = {w.x - d.x * t, w.y - d.y * t, w.z - d.z * t};
+  if (q.x * q.x + q.y * q.y + q.z * q.z > r * r) return {0, 0, flt_max, false};
+  return {0, 0, t, true};
+}
+
 typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const v4u_ cv4u;
 YT_FN uint4 ldcu4(const void* p, int k) {  // uint4 #k at the (uniform) address p, by scalar load (yt_bvh.h: ldc4)
@@ -100,6 +128,7 @@ YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, S
   const int     wsign = sign_of(widir);
   vec3f         o = wo, d = wd, idir = widir;
   int           sign = wsign, cur_inst = -1, kind = KIND_NONE, leafbias = 0;
+  float         dd2 = 0;  // |d|^2 of the level's ray: lines / points only (set where the level's ray is)
 
   lds_entry* const lds = st.lds;
   int              sp  = 0;
@@ -109,6 +138,7 @@ YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, S
   // down into an instance whose record is at hand: the level's ray, the exit marker, the BLAS root
   auto descend = [&](vec3f io, vec3f id, vec3f iidir, int inst, int root, int k, int bias) -> int {
     o = io, d = id, idir = iidir;
+    if (TRI == 0) dd2 = id.x * id.x + id.y * id.y + id.z * id.z;
     sign     = sign_of(idir);
     cur_inst = inst;
     kind     = TRI == 1 ? KIND_TRIANGLES : k;
@@ -301,14 +331,14 @@ R                 = (T0 <= __builtin_fminf(far_, tmax)) ? (int)(REF) : REF_NONE;
       const float4* L = sc.leafdata + (leafbias + first * 3);
       for (int k = 0; k < num; k++) {
         const float4 a = L[3 * k], b = L[3 * k + 1], c = L[3 * k + 2];
-        auto h = intersect_line(o, d, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
+        auto h = own_line(o, d, dd2, tmin, tmax, {a.x, a.y, a.z}, {a.w, b.x, b.y}, b.z, b.w);
         if (h.hit) accept(__float_as_int(c.x), h);
       }
     } else if (TRI == 0 && kind == KIND_POINTS) {
       const float4* L = sc.leafdata + (leafbias + first * 2);
       for (int k = 0; k < num; k++) {
         const float4 a = L[2 * k], b = L[2 * k + 1];
-        auto h = intersect_point(o, d, tmin, tmax, {a.x, a.y, a.z}, a.w);
+        auto h = own_point(o, d, dd2, tmin, tmax, {a.x, a.y, a.z}, a.w);
         if (h.hit) accept(__float_as_int(b.x), h);
       }
     }
