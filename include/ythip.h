@@ -563,7 +563,7 @@ void ythip_ply_close(ythip_ply* ply);
  * stbi_loadf / LoadEXR / stbi_load(…, 4) return,
  * shapes and textures on `threads` threads (<= 0: one per hardware thread).  The pools equal the
  * reference loader's scene_data flattened, byte for byte.  Not read here, refused by name: subdivs,
- * format 4.1, PLY instance files, non-PLY shapes, tiled EXR / TGA / BMP / .ypreset textures.
+ * format 4.1, PLY instance files, non-PLY shapes, TGA / BMP / .ypreset textures.
  * ythip_load_scene = open + ythip_scene_staging + read + ythip_upload_scene_staged (`staged`, optional,
  * receives the pools: pass it to ythip_build_bvh / ythip_build_lights).  ythip_scene_find_camera mirrors
  * find_camera (yocto_scene.cpp:656-675); ythip_scene_name: `what` 0 camera, 1 instance, 2 environment,

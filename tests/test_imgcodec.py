@@ -5,9 +5,9 @@ yocto-gl_amd/csrc/yt_jpeg.h and yt_exr.h against what the reference's load_textu
   * file by file through tests/cpp/imgcodec_check.cpp, which links the decoders of oracle/_ref: the reference's own JPEG
     and EXR files where they are present, JPEGs written by PIL in every sampling / progressive / restart / colour-space /
     size combination it offers, EXRs written by the small encoder below (NONE / RLE / ZIPS / ZIP, HALF / FLOAT / UINT,
-    both line orders, data windows off the origin, 1 to 5 channels, layer names) and by tinyexr itself (PIZ);
+    both line orders, data windows off the origin, 1 to 5 channels, layer names, tiled files) and by tinyexr itself (PIZ);
   * and through the scene loader: a scene.json with such textures, all pools against the reference's load_scene;
-  * what is refused is refused by both, or by name here (tiled EXR).
+  * what is refused is refused by both.
 """
 import io
 import json
@@ -193,8 +193,10 @@ def _predict(raw):
     return d.astype("u1").tobytes()
 
 
-def write_exr(path, planes, compression, line_order=0, origin=(0, 0), drop_attr=None, chunk_count=False, zero_offsets=False):
-    """planes: list of (name, array[h][w] of float16 / float32 / uint32), in the order the file lists them."""
+def write_exr(path, planes, compression, line_order=0, origin=(0, 0), drop_attr=None, chunk_count=False, zero_offsets=False, tile=None,
+              levels=0):
+    """planes: list of (name, array[h][w] of float16 / float32 / uint32), in the order the file lists them.  tile = (tx, ty): a
+    tiled file (one level; `levels` = the mode byte of the tile description)."""
     h, w = planes[0][1].shape
     types = {np.dtype("float16"): 1, np.dtype("float32"): 2, np.dtype("uint32"): 0}
     chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", types[a.dtype], 0, 1, 1) for n, a in planes) + b"\0"
@@ -213,6 +215,28 @@ def write_exr(path, planes, compression, line_order=0, origin=(0, 0), drop_attr=
         attrs["chunkCount"] = _attr("chunkCount", "int", struct.pack("<i", nblocks))
     if drop_attr:
         attrs.pop(drop_attr)
+    def pack(raw):
+        if compression in (2, 3):
+            z = zlib.compress(_predict(raw), 6)
+            return z if len(z) < len(raw) else raw
+        if compression == 1:
+            z = _rle(_predict(raw))
+            return z if len(z) < len(raw) else raw
+        return raw
+
+    if tile:
+        tx, ty = tile
+        attrs["tiles"] = _attr("tiles", "tiledesc", struct.pack("<IIB", tx, ty, levels))
+        head = struct.pack("<IBBBB", 20000630, 2, 2, 0, 0) + b"".join(attrs.values()) + b"\0"
+        coords = [(i, j) for j in range((h + ty - 1) // ty) for i in range((w + tx - 1) // tx)]
+        at, blob, table = len(head) + 8 * len(coords), b"", b""
+        for i, j in coords:
+            rows, cols = range(j * ty, min(h, (j + 1) * ty)), slice(i * tx, min(w, (i + 1) * tx))
+            body = pack(b"".join(a[y, cols].astype(a.dtype.newbyteorder("<")).tobytes() for y in rows for _, a in planes))
+            table += struct.pack("<Q", at + len(blob))
+            blob += struct.pack("<5i", i, j, 0, 0, len(body)) + body
+        open(path, "wb").write(head + table + blob)
+        return
     head = struct.pack("<IBBBB", 20000630, 2, 0, 0, 0) + b"".join(attrs.values()) + b"\0"
     chunks = []
     order = range(nblocks) if line_order == 0 else reversed(range(nblocks))
@@ -271,6 +295,12 @@ def exr_cases(rng, d):
     write_exr(d / "layered.exr", layered, 2), paths.append(d / "layered.exr")
     five = exr_planes(rng, 6, 4, ["A", "B", "G", "R", "Z"], "float32")
     write_exr(d / "five.exr", five, 1), paths.append(d / "five.exr")
+    # tiled files: full and clipped edge tiles, every compression type a tile can have here, one- and four-channel
+    for comp in (0, 1, 2, 3):
+        for (w, h), tile in (((32, 32), (16, 16)), ((37, 21), (16, 8)), ((9, 40), (8, 32)), ((16, 16), (16, 16))):
+            for names, dtype in ((["A", "B", "G", "R"], "float16"), (["Y"], "float32")):
+                p = d / f"tiled_c{comp}_{w}x{h}_{tile[0]}x{tile[1]}_{''.join(names)}.exr"
+                write_exr(p, exr_planes(rng, w, h, names, dtype), comp, tile=tile), paths.append(p)
     return paths
 
 
@@ -361,10 +391,9 @@ def test_exr_refusals(checker, tmp_path):
     out = checker(paths)
     assert "MISMATCH" not in out, out
     assert out.count("both refuse") == len(paths) - 1 and out.count("same ") == 1, out
-    # tiled files: refused here by name (tinyexr reads them)
-    tiled = data[:5] + b"\x02" + data[6:]
-    open(tmp_path / "tiled.exr", "wb").write(tiled)
-    assert "tiled EXR files are not read here" in checker([tmp_path / "tiled.exr"], expect_bad=None)
+    # a scan-line file that claims to be tiled (no tile description): refused by both
+    open(tmp_path / "tiled.exr", "wb").write(data[:5] + b"\x02" + data[6:])
+    assert "both refuse" in checker([tmp_path / "tiled.exr"])
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@
 // tinyexr (exts/tinyexr/tinyexr.h of the reference: LoadEXRWithLayer :11613-11860, ParseEXRHeader :10549-10810,
 // DecodeEXRImage :11351-11500, DecodeChunk :10940-11300, DecodePixelData :9811-10430) does with them:
 //
-//   * single-part scan-line files, compression NONE / RLE / ZIPS / ZIP / PIZ; channels HALF (widened to float), FLOAT,
+//   * single-part scan-line and tiled files (level 0 of a tiled file, as tinyexr), compression NONE / RLE / ZIPS / ZIP / PIZ; channels HALF (widened to float), FLOAT,
 //     UINT (its BITS end up in the float, as in tinyexr, which reads the uint plane through a float pointer);
 //   * the eight attributes tinyexr insists on must be there (channels, compression, dataWindow, displayWindow, lineOrder,
 //     pixelAspectRatio, screenWindowCenter, screenWindowWidth);
@@ -14,8 +14,8 @@
 //   * a DECREASING_Y file lands flipped, as in tinyexr (row = height - 1 - (line - dataWindow.min.y));
 //   * chunk by chunk through the offset table (a zero entry: the table is rebuilt by walking the chunks).
 //
-// Refused by name (tinyexr reads them; nothing in the reference's corpus has them): tiled files, sub-sampled channels.
-// Rows no chunk covers are zero here (tinyexr leaves them as malloc returned them).
+// Refused by name (tinyexr misreads them): sub-sampled channels.  Rows no chunk covers are zero here (tinyexr leaves them as
+// malloc returned them; that includes the short edge tiles of a DECREASING_Y tiled file, which it flips inside a full-size tile).
 #pragma once
 
 #include <zlib.h>
@@ -37,6 +37,8 @@ struct Info {
   int                  width = 0, height = 0;
   int                  compression = 0, line_order = 0, min_x = 0, min_y = 0, max_y = 0;
   int                  chunk_count = 0;
+  bool                 tiled = false;
+  int                  tile_x = 0, tile_y = 0;  // tiled: the tile size
   size_t               header_end  = 0;  // offset of the chunk offset table
   size_t               pixel_bytes = 0;  // bytes of one pixel over all channels
   std::vector<Channel> channels;
@@ -70,7 +72,7 @@ inline bool header(const uint8_t* data, size_t size, Info& info, std::string& wh
   const bool tiled = data[5] & 0x2, long_names = data[5] & 0x4, non_image = data[5] & 0x8, multipart = data[5] & 0x10;
   (void)long_names;
   if (multipart || non_image) return why = "multipart or deep EXR files are not supported (nor by the reference's LoadEXR)", false;
-  if (tiled) return why = "tiled EXR files are not read here (scan-line files are)", false;
+  info.tiled = tiled;
   size_t at = 8;
   bool   has[8] = {false, false, false, false, false, false, false, false};
   int    max_x = 0;
@@ -127,6 +129,10 @@ inline bool header(const uint8_t* data, size_t size, Info& info, std::string& wh
     else if (name == "screenWindowCenter" && len >= 8) has[6] = true;
     else if (name == "screenWindowWidth" && len >= 4) has[7] = true;
     else if (name == "chunkCount" && len >= 4) info.chunk_count = (int)rd32(v);
+    else if (name == "tiles" && tiled) {
+      if (len != 9 || rd32(v) > 0x7fffffffu || rd32(v + 4) > 0x7fffffffu) return why = "corrupt EXR: tile sizes are invalid", false;
+      info.tile_x = (int)rd32(v), info.tile_y = (int)rd32(v + 4);
+    }
   }
   static const char* names[8] = {"compression", "channels", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio",
       "screenWindowCenter", "screenWindowWidth"};
@@ -137,6 +143,8 @@ inline bool header(const uint8_t* data, size_t size, Info& info, std::string& wh
   if (w < 1 || h < 1 || w > 1024 * 8192 || h > 1024 * 8192) return why = "corrupt EXR: invalid data window", false;
   if ((double)w * (double)h * 16.0 > 2147483647.0 * 4.0) return why = "EXR image is too large", false;
   info.width = (int)w, info.height = (int)h;
+  if (tiled && (info.tile_x < 1 || info.tile_y < 1 || info.tile_x > info.width || info.tile_y > info.height))
+    return why = "corrupt EXR: tile sizes are invalid", false;
   size_t off = 0;
   for (auto& c : info.channels) c.offset = off, off += c.type == 1 ? 2 : 4;
   info.pixel_bytes = off;
@@ -404,7 +412,7 @@ inline void wav2_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t m
 }
 
 // one chunk: `lines` scan lines of `width` pixels, channel by channel inside each line
-inline bool uncompress_chunk(uint8_t* dst, size_t want, const uint8_t* src, size_t src_size, const Info& info, int lines) {
+inline bool uncompress_chunk(uint8_t* dst, size_t want, const uint8_t* src, size_t src_size, const Info& info, int width, int lines) {
   if (want == src_size) return std::memcpy(dst, src, src_size), true;  // stored as it was
   constexpr int        BITMAP_SIZE = 8192;
   std::vector<uint8_t> bitmap(BITMAP_SIZE, 0);
@@ -437,8 +445,8 @@ inline bool uncompress_chunk(uint8_t* dst, size_t want, const uint8_t* src, size
   uint16_t*          t = tmp.data();
   for (auto& c : info.channels) {
     const int sz = c.type == 1 ? 1 : 2;
-    planes.push_back({t, info.width, lines, sz});
-    t += (size_t)info.width * lines * sz;
+    planes.push_back({t, width, lines, sz});
+    t += (size_t)width * lines * sz;
   }
   for (auto& pl : planes)
     for (int j = 0; j < pl.size; j++) wav2_decode(pl.start + j, pl.nx, pl.size, pl.ny, pl.nx * pl.size, maxValue);
@@ -456,11 +464,49 @@ inline bool uncompress_chunk(uint8_t* dst, size_t want, const uint8_t* src, size
 }
 }  // namespace piz
 
+// one chunk's pixel data -> rows of the RGBA image: `lines` rows of `width` pixels land at (x0, row0 + v) — or, line_order 1,
+// at (x0, flip - (row0 + v)): tinyexr's reading of DECREASING_Y
+inline bool decode_block(const Info& info, const uint8_t* src, size_t len, int width, int lines, int x0, int64_t row0, int64_t flip,
+    float* out, std::vector<uint8_t>& raw) {
+  const size_t   want = (size_t)width * (size_t)lines * info.pixel_bytes;
+  const uint8_t* px   = src;
+  if (info.compression == 0) {
+    if (len < want) return false;
+  } else {
+    raw.assign(want, 0);
+    const bool ok = info.compression == 1   ? unrle(raw.data(), want, src, len)
+                    : info.compression == 4 ? piz::uncompress_chunk(raw.data(), want, src, len, info, width, lines)
+                                            : unzip(raw.data(), want, src, len);
+    if (!ok) return false;
+    px = raw.data();
+  }
+  for (int v = 0; v < lines; v++) {
+    const int64_t row = info.line_order == 0 ? row0 + v : flip - (row0 + v);
+    if (row < 0 || row >= info.height) continue;
+    float*         o = out + ((size_t)row * (size_t)info.width + (size_t)x0) * 4;
+    const uint8_t* l = px + (size_t)v * info.pixel_bytes * (size_t)width;
+    for (int comp = 0; comp < 4; comp++) {
+      if (info.idx[comp] < 0) continue;
+      const Channel& c = info.channels[(size_t)info.idx[comp]];
+      const uint8_t* s = l + c.offset * (size_t)width;
+      if (c.type == 1) {
+        for (int u = 0; u < width; u++) o[4 * u + comp] = half_bits_to_float((uint16_t)(s[2 * u] | s[2 * u + 1] << 8));
+      } else {  // FLOAT, or UINT whose bits tinyexr hands over as they are
+        for (int u = 0; u < width; u++) std::memcpy(&o[4 * u + comp], s + 4 * (size_t)u, 4);
+      }
+    }
+  }
+  return true;
+}
+
 // pixels: RGBA floats, width * height * 4
 inline bool decode(const uint8_t* data, size_t size, const Info& info, float* out, std::string& why) {
-  const int    block  = info.compression == 3 ? 16 : info.compression == 4 ? 32 : 1;
-  const size_t blocks = info.chunk_count > 0 ? (size_t)info.chunk_count : ((size_t)info.height + block - 1) / block;
-  if (blocks > ((size_t)info.height + block - 1) / block + 16 || size - info.header_end < blocks * 8) return why = "corrupt EXR: insufficient data size in offset table", false;
+  const int    block   = info.compression == 3 ? 16 : info.compression == 4 ? 32 : 1;
+  const size_t tiles_x = info.tiled ? ((size_t)info.width + info.tile_x - 1) / info.tile_x : 0;
+  const size_t tiles_y = info.tiled ? ((size_t)info.height + info.tile_y - 1) / info.tile_y : 0;
+  const size_t natural = info.tiled ? tiles_x * tiles_y : ((size_t)info.height + block - 1) / block;
+  const size_t blocks  = info.chunk_count > 0 ? (size_t)info.chunk_count : natural;
+  if (blocks > natural + 16 || size - info.header_end < blocks * 8) return why = "corrupt EXR: insufficient data size in offset table", false;
   std::vector<uint64_t> offsets(blocks);
   bool                  rebuild = false;
   for (size_t k = 0; k < blocks; k++) {
@@ -468,7 +514,7 @@ inline bool decode(const uint8_t* data, size_t size, const Info& info, float* ou
     if (offsets[k] >= size) return why = "corrupt EXR: invalid offset value", false;
     rebuild = rebuild || offsets[k] == 0;
   }
-  if (rebuild) {  // an unfinished file: the chunks follow the table back to back
+  if (rebuild) {  // an unfinished file: the chunks follow the table back to back (tinyexr walks them as scan-line chunks)
     size_t at = info.header_end + 8 * blocks;
     for (size_t k = 0; k < blocks; k++) {
       if (at + 8 >= size) return why = "corrupt EXR: cannot reconstruct the line offset table", false;
@@ -483,44 +529,32 @@ inline bool decode(const uint8_t* data, size_t size, const Info& info, float* ou
   if (info.idx[3] < 0)
     for (size_t k = 0; k < npix; k++) out[4 * k + 3] = 1.0f;
   std::vector<uint8_t> raw;
+  const char*          bad = "corrupt EXR: invalid data found when decoding pixels";
   for (size_t k = 0; k < blocks; k++) {
     const uint64_t off = offsets[k];
-    if (off + 8 > size) return why = "corrupt EXR: invalid data found when decoding pixels", false;
+    if (info.tiled) {
+      if (off + 20 > size) return why = bad, false;
+      const int32_t tx = (int32_t)rd32(data + off), ty = (int32_t)rd32(data + off + 4), lx = (int32_t)rd32(data + off + 8),
+                    ly = (int32_t)rd32(data + off + 12), len = (int32_t)rd32(data + off + 16);
+      if (lx != 0 || ly != 0) return why = "mip / rip levels among the first tiles of an EXR file are not supported (nor by the reference)", false;
+      if (len < 4 || (uint64_t)len > size - (off + 20)) return why = bad, false;
+      if (tx < 0 || ty < 0 || (int64_t)tx * info.tile_x > info.width || (int64_t)ty * info.tile_y > info.height) return why = bad, false;
+      const int64_t x0 = (int64_t)tx * info.tile_x, y0 = (int64_t)ty * info.tile_y;
+      const int     tw = (int)std::min<int64_t>(info.tile_x, info.width - x0), th = (int)std::min<int64_t>(info.tile_y, info.height - y0);
+      if (tw <= 0 || th <= 0) continue;  // (a tile that starts on the image's edge: nothing of it is copied)
+      // DECREASING_Y: tinyexr flips the rows inside the full-size tile buffer
+      if (!decode_block(info, data + off + 20, (size_t)len, tw, th, (int)x0, y0, 2 * y0 + info.tile_y - 1, out, raw)) return why = bad, false;
+      continue;
+    }
+    if (off + 8 > size) return why = bad, false;
     int64_t       line = (int32_t)rd32(data + off);
     const int32_t len  = (int32_t)rd32(data + off + 4);
-    if (len <= 0 || (uint64_t)len > size - (off + 8) || line > (2 << 20) || line < -(2 << 20)) return why = "corrupt EXR: invalid data found when decoding pixels", false;
+    if (len <= 0 || (uint64_t)len > size - (off + 8) || line > (2 << 20) || line < -(2 << 20)) return why = bad, false;
     const int64_t end   = std::min<int64_t>(line + block, (int64_t)info.max_y + 1);
     const int     lines = (int)(end - line);
     line -= info.min_y;
-    if (lines <= 0 || line < 0 || line + lines > info.height) return why = "corrupt EXR: invalid data found when decoding pixels", false;
-    const size_t   want = (size_t)info.width * (size_t)lines * info.pixel_bytes;
-    const uint8_t* src  = data + off + 8;
-    const uint8_t* px   = src;
-    if (info.compression == 0) {
-      if ((size_t)len < want) return why = "corrupt EXR: invalid data found when decoding pixels", false;
-    } else {
-      raw.assign(want, 0);
-      bool ok = info.compression == 1   ? unrle(raw.data(), want, src, (size_t)len)
-                : info.compression == 4 ? piz::uncompress_chunk(raw.data(), want, src, (size_t)len, info, lines)
-                                        : unzip(raw.data(), want, src, (size_t)len);
-      if (!ok) return why = "corrupt EXR: invalid data found when decoding pixels", false;
-      px = raw.data();
-    }
-    for (int v = 0; v < lines; v++) {
-      const size_t row = info.line_order == 0 ? (size_t)(line + v) : (size_t)info.height - 1 - (size_t)(line + v);
-      float*       o   = out + row * (size_t)info.width * 4;
-      const uint8_t* l = px + (size_t)v * info.pixel_bytes * (size_t)info.width;
-      for (int comp = 0; comp < 4; comp++) {
-        if (info.idx[comp] < 0) continue;
-        const Channel& c = info.channels[(size_t)info.idx[comp]];
-        const uint8_t* s = l + c.offset * (size_t)info.width;
-        if (c.type == 1) {
-          for (int u = 0; u < info.width; u++) o[4 * u + comp] = half_bits_to_float((uint16_t)(s[2 * u] | s[2 * u + 1] << 8));
-        } else {  // FLOAT, or UINT whose bits tinyexr hands over as they are
-          for (int u = 0; u < info.width; u++) std::memcpy(&o[4 * u + comp], s + 4 * (size_t)u, 4);
-        }
-      }
-    }
+    if (lines <= 0 || line < 0 || line + lines > info.height) return why = bad, false;
+    if (!decode_block(info, data + off + 8, (size_t)len, info.width, lines, 0, line, (int64_t)info.height - 1, out, raw)) return why = bad, false;
   }
   return true;
 }

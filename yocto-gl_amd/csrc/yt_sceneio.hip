@@ -19,9 +19,9 @@
 // and flat scanlines), PNG (stbi_load's results: every colour type, bit depth, tRNS, Adam7;
 // inflate through zlib), JPEG (yt_jpeg.h: stb_image's baseline / progressive decoder restated, its
 // inverse DCT, upsampling and colour arithmetic bit for bit) and OpenEXR (yt_exr.h: tinyexr's LoadEXR
-// on scan-line files, NONE / RLE / ZIPS / ZIP / PIZ).  Anything else — subdivs (tesselate_subdivs is scene processing, re-used
+// on scan-line and tiled files, NONE / RLE / ZIPS / ZIP / PIZ).  Anything else — subdivs (tesselate_subdivs is scene processing, re-used
 // from the reference: SURVEY.md §2), format 4.1, PLY instance files, OBJ / glTF / PBRT scenes,
-// tiled EXR / TGA / BMP textures, .ypreset — fails loudly by name: those stay with the
+// TGA / BMP textures, .ypreset — fails loudly by name: those stay with the
 // reference's loader, whose scene_data goes through ythip_upload_scene as before.
 //
 // No device code here; the file is a .hip unit only so that the one build rule covers it.
