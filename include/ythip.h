@@ -559,11 +559,11 @@ void ythip_ply_close(ythip_ply* ply);
  * `counts`; ythip_scene_read fills caller pools of those sizes (every pointer of `pools`, writable — the
  * pools of ythip_scene_staging, or plain memory): records with the reference's defaults and fix-ups
  * (lookat, add_missing_camera :2119-2139, add_missing_radius :2142-2148, load_texture's `linear`),
- * shapes converted by ythip_ply_read, textures (Radiance HDR, OpenEXR scan-line files, PNG, JPEG) decoded to what
- * stbi_loadf / LoadEXR / stbi_load(…, 4) return,
+ * shapes converted by ythip_ply_read, textures (Radiance HDR, OpenEXR, PNG, JPEG, BMP, TGA — by content, as
+ * stb_image sniffs it) decoded to what stbi_loadf / LoadEXR / stbi_load(…, 4) return,
  * shapes and textures on `threads` threads (<= 0: one per hardware thread).  The pools equal the
  * reference loader's scene_data flattened, byte for byte.  Not read here, refused by name: subdivs,
- * format 4.1, PLY instance files, non-PLY shapes, TGA / BMP / .ypreset textures.
+ * format 4.1, PLY instance files, non-PLY shapes, GIF / PSD / PIC / PNM content and .ypreset textures.
  * ythip_load_scene = open + ythip_scene_staging + read + ythip_upload_scene_staged (`staged`, optional,
  * receives the pools: pass it to ythip_build_bvh / ythip_build_lights).  ythip_scene_find_camera mirrors
  * find_camera (yocto_scene.cpp:656-675); ythip_scene_name: `what` 0 camera, 1 instance, 2 environment,

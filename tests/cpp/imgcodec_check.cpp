@@ -1,4 +1,4 @@
-// imgcodec_check — yt_jpeg.h / yt_exr.h against the reference's own decoders (stb_image, tinyexr: the objects of
+// imgcodec_check — yt_jpeg.h / yt_exr.h / yt_bmptga.h against the reference's own decoders (stb_image, tinyexr: the objects of
 // oracle/_ref), file by file, every byte of the RGBA result.  Test infrastructure (tests/test_sceneio.py builds and runs
 // it where oracle/_ref exists).
 //   imgcodec_check file...      prints one line per file; exit code = number of mismatches
@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "../../yocto-gl_amd/csrc/yt_bmptga.h"
 #include "../../yocto-gl_amd/csrc/yt_exr.h"
 #include "../../yocto-gl_amd/csrc/yt_jpeg.h"
 
@@ -53,9 +54,18 @@ int main(int argc, char** argv) {
       int            w = 0, h = 0, n = 0;
       unsigned char* ref = stbi_load_from_memory(bytes.data(), (int)bytes.size(), &w, &h, &n, 4);
       ytjpeg::Info   info;
-      bool           ok = ytjpeg::header(bytes.data(), bytes.size(), info, why);
+      const std::string ext = path.size() > 4 ? path.substr(path.size() - 4) : "";
+      bool           ok;
       std::vector<uint8_t> mine;
-      if (ok) mine.resize((size_t)info.width * info.height * 4), ok = ytjpeg::decode(bytes.data(), bytes.size(), mine.data(), why);
+      if (ext == ".bmp" || ext == ".tga") {
+        ytimg::Size sz;
+        ok = ext == ".bmp" ? ytimg::bmp::header(bytes.data(), bytes.size(), sz, why) : (ytimg::tga::test(bytes.data(), bytes.size()) && ytimg::tga::header(bytes.data(), bytes.size(), sz, why));
+        info = {sz.width, sz.height, 0};
+        if (ok) mine.resize((size_t)info.width * info.height * 4), ok = ext == ".bmp" ? ytimg::bmp::decode(bytes.data(), bytes.size(), mine.data(), why) : ytimg::tga::decode(bytes.data(), bytes.size(), mine.data(), why);
+      } else {
+        ok = ytjpeg::header(bytes.data(), bytes.size(), info, why);
+        if (ok) mine.resize((size_t)info.width * info.height * 4), ok = ytjpeg::decode(bytes.data(), bytes.size(), mine.data(), why);
+      }
       if (ok != (ref != nullptr)) {
         std::printf("MISMATCH %s: reference %s (%s), here %s (%s)\n", path.c_str(), ref ? "reads" : "refuses", ref ? "" : stbi_failure_reason(), ok ? "reads" : "refuses", why.c_str());
         bad++;

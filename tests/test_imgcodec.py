@@ -1,5 +1,5 @@
-"""JPEG and OpenEXR textures of ythip_load_scene (`-m "not gpu"`; SURVEY.md §8(f) rank 4, VERDICT r4 "missing" 5):
-yocto-gl_amd/csrc/yt_jpeg.h and yt_exr.h against what the reference's load_texture gets from stb_image / tinyexr
+"""JPEG, OpenEXR, BMP and TGA textures of ythip_load_scene (`-m "not gpu"`; SURVEY.md §8(f) rank 4, VERDICT r4 "missing" 5):
+yocto-gl_amd/csrc/yt_jpeg.h, yt_exr.h and yt_bmptga.h against what the reference's load_texture gets from stb_image / tinyexr
 (yocto_sceneio.cpp:1796-1850) — every byte of the RGBA result:
 
   * file by file through tests/cpp/imgcodec_check.cpp, which links the decoders of oracle/_ref: the reference's own JPEG
@@ -397,6 +397,141 @@ def test_exr_refusals(checker, tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------
+# BMP and TGA
+# ---------------------------------------------------------------------------------------------------
+def write_bmp(path, rows, bpp, header=40, masks=None, compress=None, palette=None, top_down=False):
+    """rows: array[h][w] of pixel VALUES (palette indices, or packed 16 / 32-bit words, or (b, g, r) triples for 24 bits)."""
+    h, w = rows.shape[:2]
+    if bpp == 24:
+        raw = [rows[y].astype("u1").tobytes() for y in range(h)]
+    elif bpp == 32:
+        raw = [rows[y].astype("<u4").tobytes() for y in range(h)]
+    elif bpp == 16:
+        raw = [rows[y].astype("<u2").tobytes() for y in range(h)]
+    else:
+        per = 8 // bpp
+        raw = []
+        for y in range(h):
+            v = np.zeros((w + per - 1) // per * per, int)
+            v[:w] = rows[y]
+            v = v.reshape(-1, per)
+            raw.append(bytes(int(sum(int(x) << ((per - 1 - k) * bpp) for k, x in enumerate(r))) for r in v))
+    body = b"".join(r + b"\0" * (-len(r) % 4) for r in (raw if top_down else raw[::-1]))
+    compress = (3 if masks and header == 40 else 0) if compress is None else compress
+    pal = b""
+    if palette is not None:
+        pal = b"".join(bytes([int(c[2]), int(c[1]), int(c[0])]) + (b"" if header == 12 else b"\0") for c in palette)
+    if header == 12:
+        info = struct.pack("<IHHHH", 12, w, h, 1, bpp)
+    else:
+        info = struct.pack("<IiiHHIIiiII", header, w, -h if top_down else h, 1, bpp, compress, len(body), 2835, 2835, 0, 0)
+        if header == 40 and compress == 3:
+            info += struct.pack("<3I", *masks[:3])
+        elif header == 56:
+            info += struct.pack("<4I", *(masks or (0, 0, 0, 0)))
+        elif header in (108, 124):
+            info += struct.pack("<4I", *(masks or (0, 0, 0, 0))) + b"\0" * (52 if header == 108 else 68)
+    offset = 14 + len(info) + len(pal)
+    open(path, "wb").write(b"BM" + struct.pack("<IHHI", offset + len(body), 0, 0, offset) + info + pal + body)
+
+
+def write_tga(path, pixels, image_type, bpp, cmap=None, cmap_bits=0, top_left=False, rle=False, id_bytes=b""):
+    """pixels: list of per-pixel byte strings, row-major in FILE order."""
+    h, w = pixels.shape[:2]
+    flat = [bytes(px) for row in pixels for px in row]
+    body = b""
+    if rle:
+        i = 0
+        while i < len(flat):
+            run = 1
+            while i + run < len(flat) and run < 128 and flat[i + run] == flat[i]:
+                run += 1
+            if run >= 2:
+                body += bytes([0x80 | (run - 1)]) + flat[i]
+                i += run
+            else:
+                lit = 1
+                while i + lit < len(flat) and lit < 128 and flat[i + lit] != flat[i + lit - 1]:
+                    lit += 1
+                body += bytes([lit - 1]) + b"".join(flat[i:i + lit])
+                i += lit
+    else:
+        body = b"".join(flat)
+    head = struct.pack("<BBBHHBHHHHBB", len(id_bytes), 1 if cmap is not None else 0, image_type + (8 if rle else 0), 0,
+                       len(cmap) if cmap is not None else 0, cmap_bits, 0, 0, w, h, bpp, 0x20 if top_left else 0)
+    open(path, "wb").write(head + id_bytes + (b"".join(cmap) if cmap is not None else b"") + body)
+
+
+@needs_objects
+def test_bmp_and_tga_every_layout(checker, tmp_path):
+    rng = np.random.default_rng(31)
+    paths = []
+
+    def add(name):
+        paths.append(tmp_path / name)
+        return paths[-1]
+
+    # written by PIL: 1 / 8-bit palettes, 24 and 32 bits (V4 / V5 headers with masks); TGA grey, grey + alpha, colour map, 24, 32 bits,
+    # run-length or not, both row orders
+    for mode, ch in (("1", 1), ("L", 1), ("P", 1), ("RGB", 3), ("RGBA", 4)):
+        for w, h in ((1, 1), (7, 5), (16, 9), (33, 17)):
+            a = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+            im = PIL.frombytes("L" if mode in ("1", "P") else mode, (w, h), a.tobytes())
+            if mode == "1":
+                im = im.convert("1")
+            if mode == "P":
+                im = PIL.frombytes("P", (w, h), a.tobytes())
+                im.putpalette([int(v) for v in rng.integers(0, 256, 768)])
+            im.save(add(f"pil_{mode}_{w}x{h}.bmp"), "BMP")
+            if mode != "1":
+                for rle in (False, True):
+                    for ori in (1, -1):
+                        im.save(add(f"pil_{mode}_{w}x{h}_{int(rle)}_{ori}.tga"), "TGA", rle=rle, orientation=ori)
+    # by hand: what PIL does not write
+    for w, h in ((5, 3), (8, 8), (13, 2)):
+        pal16 = rng.integers(0, 256, (16, 3))
+        write_bmp(add(f"bmp4_{w}x{h}.bmp"), rng.integers(0, 16, (h, w)), 4, palette=pal16)
+        # (a core header: stb_image takes (offset - 38) / 3 = 12 of the 16 palette entries and leaves the rest unset: indices < 12)
+        write_bmp(add(f"bmp4core_{w}x{h}.bmp"), rng.integers(0, 12, (h, w)), 4, header=12, palette=pal16)
+        write_bmp(add(f"bmp1_{w}x{h}.bmp"), rng.integers(0, 2, (h, w)), 1, palette=pal16[:2], top_down=True)
+        write_bmp(add(f"bmp8td_{w}x{h}.bmp"), rng.integers(0, 200, (h, w)), 8, palette=rng.integers(0, 256, (200, 3)), top_down=True)
+        write_bmp(add(f"bmp16_555_{w}x{h}.bmp"), rng.integers(0, 1 << 15, (h, w)), 16)
+        write_bmp(add(f"bmp16_565_{w}x{h}.bmp"), rng.integers(0, 1 << 16, (h, w)), 16, masks=(0xf800, 0x07e0, 0x001f))
+        write_bmp(add(f"bmp16_4444_{w}x{h}.bmp"), rng.integers(0, 1 << 16, (h, w)), 16, header=108, masks=(0x0f00, 0x00f0, 0x000f, 0xf000), compress=3)
+        write_bmp(add(f"bmp24core_{w}x{h}.bmp"), rng.integers(0, 256, (h, w * 3)), 24, header=12)
+        write_bmp(add(f"bmp32_noalpha_{w}x{h}.bmp"), rng.integers(0, 1 << 24, (h, w)), 32)  # the alpha byte is 0 everywhere: read as opaque
+        write_bmp(add(f"bmp32_alpha_{w}x{h}.bmp"), rng.integers(0, 1 << 32, (h, w), dtype=np.uint64), 32, top_down=True)
+        write_bmp(add(f"bmp32_masks_{w}x{h}.bmp"), rng.integers(0, 1 << 32, (h, w), dtype=np.uint64), 32, masks=(0xff000000, 0x00ff0000, 0x0000ff00))
+        write_bmp(add(f"bmp32_v5_{w}x{h}.bmp"), rng.integers(0, 1 << 32, (h, w), dtype=np.uint64), 32, header=124,
+                  masks=(0x000000ff, 0x0000ff00, 0x00ff0000, 0xff000000), compress=3)
+        write_bmp(add(f"bmp32_56_{w}x{h}.bmp"), rng.integers(0, 1 << 32, (h, w), dtype=np.uint64), 32, header=56)
+        px = lambda n: rng.integers(0, 256, (h, w, n), dtype=np.uint8)
+        for rle in (False, True):
+            for tl in (False, True):
+                k = f"{w}x{h}_{int(rle)}{int(tl)}"
+                write_tga(add(f"tga16_{k}.tga"), px(2), 2, 16, rle=rle, top_left=tl)
+                write_tga(add(f"tga15_{k}.tga"), px(2), 2, 15, rle=rle, top_left=tl)
+                write_tga(add(f"tga_ga_{k}.tga"), px(2), 3, 16, rle=rle, top_left=tl, id_bytes=b"hello")
+                cm16 = [bytes(rng.integers(0, 256, 2, dtype=np.uint8)) for _ in range(40)]
+                write_tga(add(f"tga_cm16_{k}.tga"), rng.integers(0, 50, (h, w, 1), dtype=np.uint8), 1, 8, cmap=cm16, cmap_bits=16, rle=rle, top_left=tl)
+                cm32 = [bytes(rng.integers(0, 256, 4, dtype=np.uint8)) for _ in range(300)]
+                idx = rng.integers(0, 310, (h, w))
+                pix16 = np.stack([idx & 255, idx >> 8], -1).astype(np.uint8)
+                write_tga(add(f"tga_cm32_{k}.tga"), pix16, 1, 16, cmap=cm32, cmap_bits=32, rle=rle, top_left=tl)
+    out = checker(paths)
+    assert out.count("same ") == len(paths) >= 180, out[-3000:]
+    # refusals: run-length BMP, an embedded PNG, a colour-mapped TGA without a map — by both
+    bad = []
+    write_bmp(tmp_path / "rle8.bmp", rng.integers(0, 4, (4, 4)), 8, palette=rng.integers(0, 256, (4, 3)), compress=1), bad.append(tmp_path / "rle8.bmp")
+    write_bmp(tmp_path / "png.bmp", rng.integers(0, 4, (4, 4)), 24 // 3 * 3, compress=5), bad.append(tmp_path / "png.bmp")
+    write_bmp(tmp_path / "wide.bmp", rng.integers(0, 1 << 30, (4, 4)), 32, masks=(0x3ff00000, 0x000ffc00, 0x000003ff)), bad.append(tmp_path / "wide.bmp")
+    write_bmp(tmp_path / "nomask.bmp", rng.integers(0, 4, (4, 4)), 16, masks=(0, 0x07e0, 0x001f)), bad.append(tmp_path / "nomask.bmp")
+    write_tga(tmp_path / "nomap.tga", rng.integers(0, 4, (4, 4, 1), dtype=np.uint8), 1, 8, cmap=[], cmap_bits=24), bad.append(tmp_path / "nomap.tga")
+    out = checker(bad)
+    assert out.count("both refuse") == len(bad), out
+
+
+# ---------------------------------------------------------------------------------------------------
 # through the scene loader
 # ---------------------------------------------------------------------------------------------------
 @needs_ref
@@ -411,15 +546,19 @@ def test_a_scene_with_jpeg_and_exr_textures_loads_as_the_reference_loads_it(tmp_
     to_image(picture(rng, 12, 10, 3), "RGB").save(tmp_path / "textures/really_a_jpeg.png", "JPEG")
     write_exr(tmp_path / "textures/sky.exr", exr_planes(rng, 32, 16, ["A", "B", "G", "R"], "float16"), 3)
     write_exr(tmp_path / "textures/flat.EXR", exr_planes(rng, 5, 4, ["B", "G", "R"], "float32"), 0)
+    to_image(picture(rng, 11, 6, 3), "RGB").save(tmp_path / "textures/tile.bmp", "BMP")
+    to_image(picture(rng, 9, 14, 4), "RGBA").save(tmp_path / "textures/decal.tga", "TGA", rle=True)
+    to_image(picture(rng, 8, 8, 3), "RGB").save(tmp_path / "textures/really_a_bmp.tga", "BMP")
     textures = [{"name": n, "uri": "textures/" + n} for n in
-                ("wood.jpg", "prog.jpeg", "grey.JPG", "really_a_png.jpg", "really_a_jpeg.png", "sky.exr", "flat.EXR")]
+                ("wood.jpg", "prog.jpeg", "grey.JPG", "really_a_png.jpg", "really_a_jpeg.png", "sky.exr", "flat.EXR", "tile.bmp",
+                 "decal.tga", "really_a_bmp.tga")]
     doc = {"asset": {"version": "5.0"}, "shapes": [{"uri": "shapes/tri.ply"}], "textures": textures,
            "environments": [{"emission": [1, 1, 1], "emission_tex": 5}]}
     path = write_scene(tmp_path, doc)
     got, _, _ = yt.load_scene_file(path)
     ref = ry.RefScene.load(path).flat()
     assert_same_scene(got, ref, "jpeg + exr textures")
-    assert list(got.textures["is_float"]) == [0, 0, 0, 0, 0, 1, 1] and list(got.textures["linear"]) == [0, 0, 0, 0, 0, 1, 1]
+    assert list(got.textures["is_float"]) == [0, 0, 0, 0, 0, 1, 1, 0, 0, 0] and list(got.textures["linear"]) == [0, 0, 0, 0, 0, 1, 1, 0, 0, 0]
     # a texture that cannot be read: the reference's words (its spelling included) + the reason
     open(tmp_path / "textures/wood.jpg", "wb").write(b"\xff\xd8\xff\xe0 not much of a JPEG")
     with pytest.raises(yt.YthipError, match="cannot raed .*wood.jpg.*corrupt JPEG"):

@@ -194,7 +194,7 @@ def test_find_camera_follows_the_reference_order(scene_dir):
     (lambda d: d.__setitem__("subdivs", [{"name": "s"}]), "subdivs"),
     (lambda d: d["shapes"].append({"uri": "shapes/none.ply"}), "cannot open"),
     (lambda d: d["shapes"].append({"uri": "shapes/thing.obj"}), "unsupported format"),
-    (lambda d: d.__setitem__("textures", [{"uri": "t.tga"}]), "unsupported format"),
+    (lambda d: d.__setitem__("textures", [{"uri": "t.gif"}]), "unsupported format"),
     (lambda d: d.__setitem__("cameras", [{"lens": "wide"}]), "cannot parse"),
     (lambda d: d.__setitem__("cameras", [{"frame": [1, 2, 3]}]), "cannot parse"),
     (lambda d: d.__setitem__("materials", [{"name": 5}]), "cannot parse"),
@@ -455,7 +455,7 @@ def test_png_errors(tmp_path):
     write_png(good, rng.integers(0, 256, (4, 4, 3)), 2, 8)
     data = open(good, "rb").read()
     at = data.index(b"IDAT") + 6  # inside the first IDAT's deflate stream
-    for bad, message in ((data[:40], "truncated|bad chunk"), (b"JUNK" + data[4:], "not a PNG"), (data[:8] + data[33:], "IHDR"),
+    for bad, message in ((data[:40], "truncated|bad chunk"), (b"JUNK" + data[4:], "not a PNG|unknown image type"), (data[:8] + data[33:], "IHDR"),
                          (data.replace(b"IDAT", b"IDAX"), "not known|no IDAT"), (data[:at] + b"\xff" * 8 + data[at + 8:], "zlib|pixels|filter")):
         open(tmp_path / "textures/t.png", "wb").write(bad)
         with pytest.raises(yt.YthipError, match=message):

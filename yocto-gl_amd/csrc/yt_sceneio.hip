@@ -19,9 +19,9 @@
 // and flat scanlines), PNG (stbi_load's results: every colour type, bit depth, tRNS, Adam7;
 // inflate through zlib), JPEG (yt_jpeg.h: stb_image's baseline / progressive decoder restated, its
 // inverse DCT, upsampling and colour arithmetic bit for bit) and OpenEXR (yt_exr.h: tinyexr's LoadEXR
-// on scan-line and tiled files, NONE / RLE / ZIPS / ZIP / PIZ).  Anything else — subdivs (tesselate_subdivs is scene processing, re-used
+// on scan-line and tiled files, NONE / RLE / ZIPS / ZIP / PIZ), BMP and TGA (yt_bmptga.h: stb_image's readers).  Anything else — subdivs (tesselate_subdivs is scene processing, re-used
 // from the reference: SURVEY.md §2), format 4.1, PLY instance files, OBJ / glTF / PBRT scenes,
-// TGA / BMP textures, .ypreset — fails loudly by name: those stay with the
+// GIF / PSD / PIC / PNM content, .ypreset textures — fails loudly by name: those stay with the
 // reference's loader, whose scene_data goes through ythip_upload_scene as before.
 //
 // No device code here; the file is a .hip unit only so that the one build rule covers it.
@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "../../include/ythip.h"
+#include "yt_bmptga.h"
 #include "yt_exr.h"
 #include "yt_jpeg.h"
 
@@ -728,7 +729,7 @@ std::string join(const std::string& dir, const std::string& uri) {  // path_join
   return (std::filesystem::u8path(dir) / std::filesystem::u8path(uri)).generic_u8string();
 }
 
-enum TexKind { TEX_HDR, TEX_PNG, TEX_JPG, TEX_EXR };
+enum TexKind { TEX_HDR, TEX_PNG, TEX_JPG, TEX_EXR, TEX_BMP, TEX_TGA };
 struct TextureFile {
   std::string path;
   TexKind     kind;
@@ -1198,8 +1199,10 @@ static int scene_open_impl(const char* path, ythip_scene_file** out, ythip_scene
     else if (e == ".png" || e == ".PNG") tf.kind = TEX_PNG;
     else if (e == ".jpg" || e == ".JPG" || e == ".jpeg" || e == ".JPEG") tf.kind = TEX_JPG;
     else if (e == ".exr" || e == ".EXR") tf.kind = TEX_EXR;
+    else if (e == ".bmp" || e == ".BMP") tf.kind = TEX_BMP;
+    else if (e == ".tga" || e == ".TGA") tf.kind = TEX_TGA;
     else {
-      why = "unsupported format " + tf.path + " (textures are read from Radiance HDR, OpenEXR, PNG and JPEG here)";
+      why = "unsupported format " + tf.path + " (textures are read from Radiance HDR, OpenEXR, PNG, JPEG, BMP and TGA here)";
       return false;
     }
     if (!tf.bytes.load(tf.path)) {
@@ -1210,17 +1213,44 @@ static int scene_open_impl(const char* path, ythip_scene_file** out, ythip_scene
     const uint8_t* bytes = tf.bytes.data.data();
     const size_t   count = tf.bytes.data.size();
     // stbi_load goes by what the file IS, not by what it is called (load_texture only picks 8-bit or float by the
-    // extension): a PNG called .jpg is read as a PNG and the other way round
-    static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
-    const bool           is_png     = count >= 8 && std::memcmp(bytes, png_sig, 8) == 0;
-    if (tf.kind == TEX_JPG && is_png) tf.kind = TEX_PNG;
-    else if (tf.kind == TEX_PNG && !is_png && count >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8) tf.kind = TEX_JPG;
+    // extension): a PNG called .jpg is read as a PNG, and so on — in stb_image's order of tests (png, bmp, gif, psd, pic,
+    // jpeg, pnm, hdr, tga: stb_image.h:1117-1180)
+    if (tf.kind != TEX_HDR && tf.kind != TEX_EXR) {
+      static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+      auto                 starts     = [&](const char* t) { return count >= std::strlen(t) && std::memcmp(bytes, t, std::strlen(t)) == 0; };
+      const char*          other      = nullptr;
+      if (count >= 8 && std::memcmp(bytes, png_sig, 8) == 0) tf.kind = TEX_PNG;
+      else if (ytimg::bmp::test(bytes, count)) tf.kind = TEX_BMP;
+      else if (starts("GIF87a") || starts("GIF89a")) other = "GIF";
+      else if (starts("8BPS")) other = "PSD";
+      else if (count >= 4 && bytes[0] == 0x53 && bytes[1] == 0x80 && bytes[2] == 0xf6 && bytes[3] == 0x34) other = "Softimage PIC";
+      else if (count >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8) tf.kind = TEX_JPG;
+      else if (starts("P5") || starts("P6")) other = "PNM";
+      else if (starts("#?RADIANCE\n") || starts("#?RGBE\n")) other = "Radiance HDR (as an 8-bit texture)";
+      else if (ytimg::tga::test(bytes, count)) tf.kind = TEX_TGA;
+      else {
+        why = "cannot raed " + tf.path + " (unknown image type)";
+        return false;
+      }
+      if (other) {
+        why = "unsupported format " + tf.path + " (" + other + " content is not read here)";
+        return false;
+      }
+    }
     bool ok = false;
     switch (tf.kind) {
       case TEX_HDR: ok = hdr_header(bytes, count, tf.hdr, detail), tf.width = tf.hdr.width, tf.height = tf.hdr.height; break;
       case TEX_PNG: ok = png_parse(bytes, count, tf.png, false, detail), tf.width = tf.png.width, tf.height = tf.png.height; break;
       case TEX_JPG: ok = ytjpeg::header(bytes, count, tf.jpg, detail), tf.width = tf.jpg.width, tf.height = tf.jpg.height; break;
       case TEX_EXR: ok = ytexr::header(bytes, count, tf.exr, detail), tf.width = tf.exr.width, tf.height = tf.exr.height; break;
+      case TEX_BMP: {
+        ytimg::Size sz;
+        ok = ytimg::bmp::header(bytes, count, sz, detail), tf.width = sz.width, tf.height = sz.height;
+      } break;
+      case TEX_TGA: {
+        ytimg::Size sz;
+        ok = ytimg::tga::header(bytes, count, sz, detail), tf.width = sz.width, tf.height = sz.height;
+      } break;
     }
     if (!ok) {
       why = "cannot raed " + tf.path + " (" + detail + ")";  // (the reference's spelling, load_texture's read_error)
@@ -1333,6 +1363,10 @@ static int scene_read_impl(ythip_scene_file* f, const ythip_scene* dst, int thre
       ok = ytexr::decode(tf.bytes.data.data(), tf.bytes.data.size(), tf.exr, W(dst->pixelsf) + t.offset * 4, detail);
     } else if (tf.kind == TEX_JPG) {
       ok = ytjpeg::decode(tf.bytes.data.data(), tf.bytes.data.size(), W(dst->pixelsb) + t.offset * 4, detail);
+    } else if (tf.kind == TEX_BMP) {
+      ok = ytimg::bmp::decode(tf.bytes.data.data(), tf.bytes.data.size(), W(dst->pixelsb) + t.offset * 4, detail);
+    } else if (tf.kind == TEX_TGA) {
+      ok = ytimg::tga::decode(tf.bytes.data.data(), tf.bytes.data.size(), W(dst->pixelsb) + t.offset * 4, detail);
     } else {
       PngInfo png;  // (a second read of the same handle decodes again: the parsed chunks are not kept)
       ok = png_parse(tf.bytes.data.data(), tf.bytes.data.size(), png, true, detail) && png_decode(png, W(dst->pixelsb) + t.offset * 4, detail);
