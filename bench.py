@@ -104,10 +104,13 @@ def open_context(device, flat):
     return ctx
 
 
+_T0 = time.time()
+
+
 def progress(msg):
-    """Progress notes on stderr (stdout carries the one JSON line)."""
+    """Progress notes on stderr (stdout carries the one JSON line), with the seconds since the process started."""
     if os.environ.get("YTHIP_BENCH_PROGRESS", "1") != "0":
-        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+        print(f"[bench +{time.time() - _T0:5.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
 def run_workload(name, device, steps, warmup, count=True, fastmath=0):
