@@ -1,7 +1,8 @@
 """The file readers under AddressSanitizer + UBSan against damaged inputs (`-m "not gpu"`): tests/cpp/io_fuzz.cpp is
 built with g++ from the two host-code units of the library (csrc/yt_io.hip, csrc/yt_sceneio.hip) and run on a scene
 that exercises every reader path — binary and ascii PLY, triangles / quads / lines / points, PNG in several colour
-types incl. palette + tRNS + Adam7 + 16 bit, Radiance HDR run-length and flat — with one file damaged per iteration.
+types incl. palette + tRNS + Adam7 + 16 bit, Radiance HDR run-length and flat, JPEG baseline / progressive / grey / CMYK, OpenEXR
+ZIP / RLE / tiled / flat, BMP and TGA — with one file damaged per iteration.
 The readers may load or refuse; a sanitizer report, a crash or a hang fails the test."""
 import json
 import os
@@ -86,6 +87,30 @@ def scene(tmp_path_factory):
     write_hdr(d / "textures/rle.hdr", rgbe, "rle")
     write_hdr(d / "textures/flat.hdr", rgbe[:, :5], "flat")
     textures += [{"name": "rle", "uri": "textures/rle.hdr"}, {"name": "flat", "uri": "textures/flat.hdr"}]
+    # round 5's readers: JPEG (baseline, progressive + restart intervals, grey, CMYK), OpenEXR (ZIP, RLE, tiled, flat), BMP, TGA
+    try:
+        from PIL import Image as PIL
+        import test_imgcodec as tc
+        pic = lambda w, h, ch: tc.picture(rng, w, h, ch)
+        tc.to_image(pic(40, 24, 3), "RGB").save(d / "textures/base.jpg", "JPEG", quality=70, subsampling=2, restart_marker_blocks=2)
+        tc.to_image(pic(33, 17, 3), "RGB").save(d / "textures/prog.jpg", "JPEG", quality=80, progressive=True, subsampling=1)
+        tc.to_image(pic(17, 9, 1), "L").save(d / "textures/grey.jpg", "JPEG")
+        tc.to_image(pic(16, 16, 4), "CMYK").save(d / "textures/cmyk.jpg", "JPEG", progressive=True)
+        tc.to_image(pic(13, 7, 3), "RGB").save(d / "textures/pal.bmp", "BMP")
+        tc.to_image(pic(13, 7, 4), "RGBA").save(d / "textures/rgba.bmp", "BMP")
+        pal = PIL.frombytes("P", (9, 5), bytes(rng.integers(0, 256, 45, dtype=np.uint8)))
+        pal.putpalette([int(v) for v in rng.integers(0, 256, 768)])
+        pal.save(d / "textures/p8.bmp", "BMP")
+        tc.to_image(pic(12, 10, 4), "RGBA").save(d / "textures/rle.tga", "TGA", rle=True)
+        pal.save(d / "textures/cmap.tga", "TGA")
+        tc.write_exr(d / "textures/zip.exr", tc.exr_planes(rng, 19, 37, ["A", "B", "G", "R"], "float16"), 3)
+        tc.write_exr(d / "textures/rle.exr", tc.exr_planes(rng, 16, 5, ["B", "G", "R"], "float32"), 1, line_order=1)
+        tc.write_exr(d / "textures/tiled.exr", tc.exr_planes(rng, 21, 13, ["Y"], "float16"), 2, tile=(8, 8))
+        tc.write_exr(d / "textures/flat.exr", tc.exr_planes(rng, 4, 3, ["B", "G", "R"], "uint32"), 0)
+        textures += [{"name": n, "uri": "textures/" + n} for n in ("base.jpg", "prog.jpg", "grey.jpg", "cmyk.jpg", "pal.bmp", "rgba.bmp", "p8.bmp",
+                                                                    "rle.tga", "cmap.tga", "zip.exr", "rle.exr", "tiled.exr", "flat.exr")]
+    except ImportError:
+        pass
     doc = {"asset": {"version": "4.2"},
            "cameras": [{"name": "c", "lookat": [0, 0, 3, 0, 0, 0, 0, 1, 0], "lens": 0.05}],
            "textures": textures,
@@ -109,7 +134,7 @@ def scene(tmp_path_factory):
 def test_the_fuzz_scenes_load_undamaged(scene):
     from parity import yt
     flat, names, _ = yt.load_scene_file(os.path.join(scene[0], "scene.json"))
-    assert len(flat.shapes) == 4 and len(flat.textures) == 8 and flat.shapes["num_quads"][3] == 5
+    assert len(flat.shapes) == 4 and len(flat.textures) in (8, 21) and flat.shapes["num_quads"][3] == 5
     flat, names, _ = yt.load_scene_file(os.path.join(scene[1], "scene.json"))
     assert names["shapes"] == ["tri", "hair", "dots", "ascii"] and names["textures"] == ["rle", "flat", "t0", "t3"]  # (order of first mention: emission_tex before color_tex)
 

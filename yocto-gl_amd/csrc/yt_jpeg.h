@@ -120,10 +120,11 @@ struct Component {
 
 inline uint8_t clamp8(int x) { return (unsigned)x > 255 ? (x < 0 ? 0 : 255) : (uint8_t)x; }
 
-// one pass of the integer inverse DCT (constants scaled by 4096)
-#define YTJ_F2F(x) ((int)(((x)*4096 + 0.5)))
+// one pass of the integer inverse DCT (constants scaled by 4096).  64-bit intermediates: the coefficients of a valid stream
+// never leave 32 bits (the results are stb_image's), those of a damaged one cannot overflow here.
+#define YTJ_F2F(x) ((int64_t)(((x)*4096 + 0.5)))
 #define YTJ_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                            \
-  int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                      \
+  int64_t t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                  \
   p2 = s2, p3 = s6;                                                                            \
   p1 = (p2 + p3) * YTJ_F2F(0.5411961f);                                                        \
   t2 = p1 + p3 * YTJ_F2F(-1.847759065f);                                                       \
@@ -141,10 +142,10 @@ inline uint8_t clamp8(int x) { return (unsigned)x > 255 ? (x < 0 ? 0 : 255) : (u
   t3 += p1 + p4, t2 += p2 + p3, t1 += p2 + p4, t0 += p1 + p3;
 
 inline void idct_block(uint8_t* out, int stride, const int16_t* d) {
-  int val[64], *v = val;
+  int64_t val[64], *v = val;
   for (int i = 0; i < 8; i++, d++, v++) {  // columns
     if (d[8] == 0 && d[16] == 0 && d[24] == 0 && d[32] == 0 && d[40] == 0 && d[48] == 0 && d[56] == 0) {
-      v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = d[0] * 4;
+      v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = (int64_t)d[0] * 4;
     } else {
       YTJ_IDCT_1D(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56])
       x0 += 512, x1 += 512, x2 += 512, x3 += 512;  // 12 bits of constants down to 2 bits of extra precision
@@ -156,8 +157,9 @@ inline void idct_block(uint8_t* out, int stride, const int16_t* d) {
   for (int i = 0; i < 8; i++, v += 8, out += stride) {  // rows: 12 + 2 + 3 bits to remove, + 128 to leave the signed range
     YTJ_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
     x0 += 65536 + (128 << 17), x1 += 65536 + (128 << 17), x2 += 65536 + (128 << 17), x3 += 65536 + (128 << 17);
-    out[0] = clamp8((x0 + t3) >> 17), out[7] = clamp8((x0 - t3) >> 17), out[1] = clamp8((x1 + t2) >> 17), out[6] = clamp8((x1 - t2) >> 17);
-    out[2] = clamp8((x2 + t1) >> 17), out[5] = clamp8((x2 - t1) >> 17), out[3] = clamp8((x3 + t0) >> 17), out[4] = clamp8((x3 - t0) >> 17);
+    auto c8 = [](int64_t x) { return x < 0 ? (uint8_t)0 : x > 255 ? (uint8_t)255 : (uint8_t)x; };
+    out[0] = c8((x0 + t3) >> 17), out[7] = c8((x0 - t3) >> 17), out[1] = c8((x1 + t2) >> 17), out[6] = c8((x1 - t2) >> 17);
+    out[2] = c8((x2 + t1) >> 17), out[5] = c8((x2 - t1) >> 17), out[3] = c8((x3 + t0) >> 17), out[4] = c8((x3 - t0) >> 17);
   }
 }
 #undef YTJ_IDCT_1D
@@ -257,9 +259,9 @@ struct Decoder {
     const int t = huff_decode(hdc);
     if (t < 0 || t > 15) return fail("bad huffman code");
     std::memset(data, 0, 64 * sizeof(int16_t));
-    const int diff = t ? extend_receive(t) : 0, dc = comp[b].dc_pred + diff;
+    const int diff = t ? extend_receive(t) : 0, dc = (int)((unsigned)comp[b].dc_pred + (unsigned)diff);
     comp[b].dc_pred = dc;
-    data[0]         = (int16_t)(dc * dq[0]);
+    data[0]         = (int16_t)((unsigned)dc * (unsigned)dq[0]);
     int k           = 1;
     do {
       if (code_bits < 16) grow();
@@ -293,9 +295,9 @@ struct Decoder {
       std::memset(data, 0, 64 * sizeof(int16_t));
       const int t = huff_decode(hdc);
       if (t < 0 || t > 15) return fail("can't merge dc and ac");
-      const int diff = t ? extend_receive(t) : 0, dc = comp[b].dc_pred + diff;
+      const int diff = t ? extend_receive(t) : 0, dc = (int)((unsigned)comp[b].dc_pred + (unsigned)diff);
       comp[b].dc_pred = dc;
-      data[0]         = (int16_t)(dc * (1 << succ_low));
+      data[0]         = (int16_t)((unsigned)dc << succ_low);
     } else if (get_bit()) data[0] = (int16_t)(data[0] + (int16_t)(1 << succ_low));
     return true;
   }
@@ -627,7 +629,7 @@ struct Decoder {
         for (int j = 0; j < h; j++)
           for (int i = 0; i < w; i++) {
             int16_t* data = comp[n].coeff.data() + 64 * ((size_t)i + (size_t)j * comp[n].coeff_w);
-            for (int q = 0; q < 64; q++) data[q] = (int16_t)(data[q] * dequant[comp[n].tq][q]);
+            for (int q = 0; q < 64; q++) data[q] = (int16_t)((unsigned)(int)data[q] * (unsigned)dequant[comp[n].tq][q]);
             idct_block(comp[n].data.data() + (size_t)comp[n].w2 * j * 8 + i * 8, comp[n].w2, data);
           }
       }
