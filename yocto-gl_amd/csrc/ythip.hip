@@ -1384,7 +1384,8 @@ namespace {
 int enqueue_batch(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop) {
   const bool probe = ctx->lpt_probe && ctx->lpt > 0 && ctx->d_tile_cost && !ctx->have_tile_costs &&
                      (ctx->prof_mode & 2) == 0 && params->batch >= 8 && ctx->st.nblocks > 4096 &&
-                     ctx->samples < params->samples;
+                     ctx->samples < params->samples &&
+                     ctx->pixel_pool < 2;  // (a forced pool launch records no tile costs: every batch would be probed — found in round 5)
   if (!probe) return enqueue_samples(ctx, params, stop);
   ythip_params first = *params, rest = *params;
   first.batch        = 1;
