@@ -591,6 +591,33 @@ typedef struct ythip_pool_info {
 int ythip_set_pixel_pool(ythip_ctx* ctx, int mode, int workgroups); /* workgroups <= 0: keep (default 16 per CU) */
 int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info);
 
+/* The scheduler of trace_samples (round 6).  0 (default): the fused persistent kernel — one wavefront owns a 16 x 4 pixel
+ * tile for the whole batch (k_trace).  1: the STREAMING scheduler north_star describes — every pixel in flight, SoA ray /
+ * hit / path state in HBM, and per bounce ("generation") a counting sort of the live paths' next rays by direction octant
+ * and origin cell, a traversal-only extend kernel over the sorted queue, and a shade kernel in pixel order that accumulates,
+ * regenerates and emits the next keys (csrc/yt_stream.h).  It schedules the SAME per-pixel operations — the parallel_for
+ * over pixels of yocto_trace.cpp:1595-1619 says nothing about which worker runs a pixel — so the whole trace_state is the
+ * megakernel's, bit for bit (tests/test_gpu_stream.py).  It serves sampler `path` in the bit-exact mode on scenes the wide
+ * walk serves, batches of >= 4 samples; anything else runs on the fused kernel (ythip_get_stream_info says which ran).
+ * env YTHIP_SCHEDULER=1 makes it the default of new contexts. */
+typedef struct ythip_stream_info {
+  int32_t ran;          /* the last batch ran on the streaming scheduler */
+  int32_t generations;  /* generations that had rays queued */
+  int32_t launched;     /* generations enqueued (the surplus returned at once) */
+  int32_t bins;         /* bins of the counting sort (bounce-ray + camera-ray) */
+  int64_t rays;         /* profiling (ythip_set_profiling bit 0) only: rays walked by ks_extend ... */
+  int64_t lane_steps;   /* ... the traversal steps they took ... */
+  int64_t wave_steps;   /* ... and 64 x the longest lane of every wavefront: lane_steps / wave_steps = how even the walks are */
+} ythip_stream_info;
+int ythip_set_scheduler(ythip_ctx* ctx, int mode);
+/* Tuning of the streaming scheduler's sort (a negative argument keeps the current value; results never depend on it):
+ * order 0 = direction octant major, origin cell minor (default), 1 = cell major, 2 = no sort (the queue in pixel order: the
+ * baseline the sort is measured against); cell_bits 1..5 = the scene's root box cut into 2^bits cells per axis (default 4);
+ * phased 0 / 1 = ks_extend's majority-phase scene walk off / on (default: as the fused kernel — on for matte scenes with
+ * area lights).  env YTHIP_STREAM_ORDER / _CELLS / _PHASED. */
+int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased);
+int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info);
+
 /* The mode the last trace_samples / trace_sample launch of this context ran: 0 the bit-exact kernels, 1 the
  * tolerance-mode kernels, 2 the own-tree kernels (ythip_params::fastmath asked for it AND such a kernel exists for the
  * sampler and the resident scene). */

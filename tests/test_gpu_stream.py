@@ -1,0 +1,147 @@
+"""The streaming scheduler (`-m gpu`; csrc/yt_stream.h, ythip_set_scheduler): every pixel in flight, SoA path state in
+HBM, per bounce a counting sort of the next rays + a traversal-only extend kernel + a shade kernel in pixel order.
+It schedules the same per-pixel operations as the fused kernel, so the whole trace_state must be the reference's,
+byte for byte — on every scene class (matte triangles, no-texture, opaque textured, general; with and without area
+lights), for every sort order incl. the unsorted one, progressive batches, slices, cancellation — and a sampler or
+mode it does not serve must quietly run on the fused kernel."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import parity as P
+from parity import yt
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["cornellbox", "plane", "materials", "instances", "lines_points"]
+
+
+def want_state(flat, params):
+    if P.have_ref():
+        return P.RefBundle(flat).render(params)
+    ref = P.gpu_context(flat)  # (oracle/_ref did not travel: the fused kernel, itself checked against the fixtures elsewhere)
+    want = P.gpu_render(ref, flat, params)
+    ref.close()
+    return want
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_streamed_path_equals_the_reference(scene):
+    flat = P.SCENES[scene]()
+    params = yt.trace_params(sampler="path", resolution=144, samples=12, batch=6)
+    want = want_state(flat, params)
+    for order, cells in ((0, 4), (1, 3), (2, 4)):
+        ctx = P.gpu_context(flat)
+        ctx.set_scheduler(1)
+        ctx.set_stream_options(order=order, cell_bits=cells)
+        got = P.gpu_render(ctx, flat, params)
+        info = ctx.stream_info()
+        ctx.close()
+        assert info["ran"] == 1 and info["generations"] >= params.batch, info
+        P.assert_identical(want, got, f"{scene} streamed, order {order}, {cells} cell bits")
+
+
+@pytest.mark.parametrize("kw", [dict(tentfilter=True), dict(nocaustics=True), dict(envhidden=True), dict(bounces=1), dict(bounces=3, clamp=2.0)])
+def test_streamed_params_variants(kw):
+    flat = P.SCENES["materials"]()
+    params = yt.trace_params(sampler="path", resolution=96, samples=8, batch=8, **kw)
+    want = want_state(flat, params)
+    ctx = P.gpu_context(flat)
+    ctx.set_scheduler(1)
+    got = P.gpu_render(ctx, flat, params)
+    assert ctx.stream_info()["ran"] == 1
+    ctx.close()
+    P.assert_identical(want, got, f"materials streamed {kw}")
+
+
+def test_general_class_and_specialised_classes_agree():
+    """ythip_set_specialization(0) streams the general-class kernels on a matte scene: the same bytes."""
+    flat = P.SCENES["cornellbox"]()
+    params = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8)
+    out = []
+    for spec in (1, 0):
+        ctx = P.gpu_context(flat)
+        ctx.set_scheduler(1)
+        ctx.set_specialization(spec)
+        out.append(P.gpu_render(ctx, flat, params))
+        assert ctx.stream_info()["ran"] == 1
+        ctx.close()
+    P.assert_identical(out[0], out[1], "class 1 vs class 0, streamed")
+
+
+def test_slices_batches_and_scheduler_changes_in_one_render():
+    flat = P.SCENES["instances"]()
+    p = yt.trace_params(sampler="path", resolution=160, samples=16, batch=4)
+    out = []
+    for stream in (1, 0):
+        ctx = P.gpu_context(flat)
+        ctx.set_scheduler(stream)
+        ctx.make_trace_state(flat, p)
+        ctx.trace_samples(p)
+        ctx.trace_sample(p, 9, 3, 4)  # (a single sample in between: always the fused kernel)
+        if stream:
+            ctx.set_scheduler(0)  # a fused batch in the middle of a streamed render
+        ctx.trace_samples(p)
+        if stream:
+            ctx.set_scheduler(1)
+        ctx.trace_samples(p)
+        ctx.trace_samples(p)
+        full = ctx.download_state()
+        cols = P.gpu_render(ctx, flat, p, cols=(1, 3))
+        rows = P.gpu_render(ctx, flat, p, rows=(8, 40))
+        out.append((full, cols, rows))
+        ctx.close()
+    for k, what in enumerate(("full frame", "column slice", "row slice")):
+        P.assert_identical(out[0][k], out[1][k], what)
+
+
+def test_what_the_scheduler_does_not_serve_runs_fused():
+    flat = P.SCENES["cornellbox"]()
+    ctx = P.gpu_context(flat)
+    ctx.set_scheduler(1)
+    for kw in (dict(sampler="pathdirect", batch=4), dict(sampler="path", batch=1), dict(sampler="path", batch=4, bounces=0),
+               dict(sampler="path", batch=4, fastmath=1)):
+        params = yt.trace_params(resolution=64, samples=4, **kw)
+        got = P.gpu_render(ctx, flat, params)
+        assert ctx.stream_info()["ran"] == 0, kw
+        if not kw.get("fastmath"):
+            P.assert_identical(want_state(flat, params), got, f"fused fallback {kw}")
+    ctx.close()
+
+
+def test_cancel_inside_a_streamed_batch():
+    """The caller's stop flag ends a streamed batch at the pixels' next sample boundaries: the call returns CANCELLED,
+    state.samples stays, every pixel holds a whole number of samples (hits counts them) and the next batch runs."""
+    flat = P.SCENES["cornellbox"]()
+    ctx = P.gpu_context(flat)
+    ctx.set_scheduler(1)
+    p = yt.trace_params(sampler="path", resolution=512, samples=100000, batch=2048)
+    ctx.make_trace_state(flat, p)
+    stop = np.zeros(1, np.int32)
+    threading.Timer(0.05, lambda: stop.__setitem__(0, 1)).start()
+    t0 = time.time()
+    with pytest.raises(yt.YthipError, match="cancelled"):
+        ctx.trace_samples(p, stop=stop)
+    assert time.time() - t0 < 5.0
+    st = ctx.download_state()
+    assert st["samples"] == 0
+    assert np.isfinite(st["image"]).all()
+    assert 0 < st["hits"].max() < 2048
+    q = yt.trace_params(sampler="path", resolution=512, samples=100000, batch=4)
+    ctx.trace_samples(q)
+    assert ctx.stream_info()["ran"] == 1
+    ctx.close()
+
+
+def test_profiling_reports_the_walks_evenness():
+    flat = P.SCENES["cornellbox"]()
+    ctx = P.gpu_context(flat)
+    ctx.set_scheduler(1)
+    ctx.set_profiling(1)
+    p = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8)
+    P.gpu_render(ctx, flat, p)
+    info = ctx.stream_info()
+    ctx.close()
+    assert info["rays"] > 128 * 128 * 8 and 0 < info["lane_steps"] <= info["wave_steps"], info

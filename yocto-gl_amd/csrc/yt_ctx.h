@@ -28,6 +28,7 @@
 #include "yt_xfer.h"
 #include "yt_gpubuild.h"
 #include "yt_kernels.h"
+#include "yt_stream_launch.h"
 
 using namespace yt;
 
@@ -194,6 +195,15 @@ struct ythip_ctx {
   int*               stop_host     = nullptr;  // pinned host word ythip_cancel stores the batch number into ...
   const int*         stop_host_dev = nullptr;  // ... and its device address (the kernels relay it into d_stop)
   ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
+  // the streaming scheduler (yt_stream.h; ythip_set_scheduler): generations of extend / shade launches over SoA path state in HBM
+  int                scheduler        = 0;        // 0 the fused persistent kernel (k_trace), 1 streaming generations
+  DStream            ss               = {};       // its arrays live in state_allocs (they go with the state)
+  int                stream_slots     = 0;        // the slot count they were sized for (0: none)
+  int                stream_cell_bits = 4, stream_order = 0, stream_phased = -1, stream_min_batch = 4;  // YTHIP_STREAM_CELLS / _ORDER / _PHASED / _MIN_BATCH
+  int*               stream_counts_host = nullptr;  // pinned: {next queue length, generations run}
+  bool               stream_cancelled = false;    // the last streamed batch was cut short by the caller's stop flag
+  bool               last_launch_stream = false;  // the last batch ran on the streaming scheduler
+  ythip_stream_info  stream_info      = {};
   bool               last_launch_fast = false;  // the last k_trace launch ran the tolerance-mode kernels (yt_fast.hip)
   int                last_launch_mode = 0;      // ... which mode it ran: 0 bit-exact, 1 tolerance, 2 own tree (yt_owntree.hip)
 };

@@ -1,0 +1,306 @@
+// yt_stream.h — the between-bounce STREAMING scheduler of trace_samples (round 6; ythip_set_scheduler(ctx, 1)).
+//
+// k_trace (yt_kernels.h) is a persistent megakernel: one wavefront owns a 16 x 4 pixel tile for a whole batch, so
+// the 64 rays a wavefront walks together are whatever its tile's paths happen to be doing — camera rays next to
+// fifth-bounce rays going in every direction.  On incoherent workloads 10-22 of the 64 lanes of a VALU instruction
+// are live, and no wavefront can trade rays with another.  This file is the other design — the one
+// north_star names: "a wavefront (streaming) path tracer with SoA ray / hit / path-state buffers ... stream
+// compaction for active-path sorting" — built so that it regroups rays BETWEEN bounces, at per-bounce cost:
+//
+//   * every pixel of the slice is in flight (one path slot per pixel of the tile grid, SoA path state in HBM:
+//     ray 32 B, weight / radiance 32 B, rng 16 B, hit record 20 B); a path that ends is accumulated and its pixel's
+//     next sample regenerated in place, so the queues never drain before the batch's tail;
+//   * one GENERATION = every live path advances one bounce:
+//         ks_scan     exclusive prefix over the histogram of the sort keys the previous generation emitted
+//         ks_scatter  counting sort: slot -> its place in the ray queue (the rank came with the histogram's atomic)
+//         ks_extend   intersect_scene_bvh for queue entries [0, n): the walk of k_intersect_batch and nothing else,
+//                     wavefronts = 64 CONSECUTIVE queue entries = rays of one direction octant from one cell of
+//                     the scene box (camera rays: of neighbouring tiles)
+//         ks_shade    one iteration of the integrator's bounce loop per live path, in SLOT order (coalesced state,
+//                     trace_state rows touched as in k_trace), incl. the deferred light-pdf walks, the end-of-sample
+//                     accumulation and the regeneration; emits the next ray's sort key + histogram count;
+//   * dependent launches on one stream; a generation's kernels all return at once when nothing is queued, and the
+//     host stops enqueueing when a read-back of the queue length says zero.
+//
+// Bit-exact by construction: the per-pixel sequence of operations is k_trace's (the same start_sample / step_path /
+// resolve_step / finish_sample on the same values) — only WHICH wavefront executes a ray's walk changes, and hit
+// records do not depend on that.  Whole-trace_state digests equal the megakernel's (tests/test_gpu_stream.py).
+//
+// Restates the scheduling of yocto_trace.cpp:1595-1619 (trace_samples: parallel_for over pixels, each pixel's samples
+// in order) around yocto_trace.cpp:453-596 (trace_path) and yocto_bvh.cpp:554-617 (intersect_scene_bvh).
+#pragma once
+
+#include "yt_kernels.h"
+
+namespace yt {
+
+constexpr unsigned SKEY_DEAD = 0xffffffffu;  // the slot has no ray for the next generation (its pixel's batch is done)
+constexpr int      PF_DEAD   = 0x80;         // Path flag of such a slot (ray_b.w)
+
+struct DStream {
+  // path state, one record per slot of the tile grid (SoA of 16-B pieces; WgState's layout, in HBM)
+  float4 *    ray_a, *ray_b, *wgt, *rad;
+  ulonglong2* rng;
+  float4*     hit_a;  // u, v, distance, instance (-1: miss)
+  int*        hit_e;  // element
+  // the counting sort
+  unsigned *key, *rank;  // per slot: the next ray's key, its arrival number inside the key's bin
+  unsigned *hist, *offs; // per bin: count (zeroed by ks_scan), exclusive prefix
+  int*      queue;       // slots in key order
+  int*      counts;      // [0] rays queued for the running generation (ks_scan), [1] generations run
+  unsigned long long* stats;  // optional (profiling): [0] sum of lane steps, [1] 64 x longest lane per wavefront, [2] wavefronts, [3] rays
+  int   nbins;        // bounce-ray bins: 8 octants x 2^(3 cell_bits) cells
+  int   nprim_bins;   // camera-ray bins (groups of neighbouring tiles), after the bounce-ray bins
+  int   cell_bits, prim_shift;
+  int   order;        // 0: octant major, cell minor; 1: cell major, octant minor; 2: no sort (slot order)
+  vec3f cell_lo, cell_scale;  // cell = (o - lo) * scale, the TLAS root box cut into 2^cell_bits cells per axis
+};
+
+YT_FN unsigned spread3(unsigned x) {  // 10 bits -> every third bit
+  x &= 0x3ff;
+  x = (x | (x << 16)) & 0x30000ff;
+  x = (x | (x << 8)) & 0x300f00f;
+  x = (x | (x << 4)) & 0x30c30c3;
+  x = (x | (x << 2)) & 0x9249249;
+  return x;
+}
+
+// The sort key of a path's next ray.  Camera rays keep their tile neighbourhood (they ARE coherent); everything else goes by
+// direction octant and by the Morton code of the origin's cell.
+YT_FN unsigned stream_key(const DStream& S, int slot, vec3f o, vec3f d, bool primary) {
+  if (S.order == 2) return (unsigned)(slot >> 6) % (unsigned)(S.nbins + S.nprim_bins);  // (wraps: bins are then a few tiles far apart)
+  if (primary) return (unsigned)S.nbins + (unsigned)(slot >> S.prim_shift) % (unsigned)S.nprim_bins;
+  const int   top = (1 << S.cell_bits) - 1;
+  const float cx = (o.x - S.cell_lo.x) * S.cell_scale.x, cy = (o.y - S.cell_lo.y) * S.cell_scale.y, cz = (o.z - S.cell_lo.z) * S.cell_scale.z;
+  // (NaN / out-of-box origins land in the first or last cell: the key only groups rays, it decides nothing)
+  const unsigned ix = (unsigned)min_(max_((int)cx, 0), top), iy = (unsigned)min_(max_((int)cy, 0), top), iz = (unsigned)min_(max_((int)cz, 0), top);
+  const unsigned cell   = spread3(ix) | (spread3(iy) << 1) | (spread3(iz) << 2);
+  const unsigned octant = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+  return S.order == 0 ? (octant << (3 * S.cell_bits)) | cell : (cell << 3) | octant;
+}
+
+// a live slot's state <-> registers (load_path_rest / store_path of yt_kernels.h on the HBM arrays)
+YT_FN void stream_load_rest(const DState& st, const DStream& S, int slot, Path& P, float4 rb) {
+  float4 w = S.wgt[slot], r = S.rad[slot];
+  auto   g = S.rng[slot];
+  int    pi, pj;
+  P.vslot         = slot;
+  P.pix           = slot_pixel(st, slot, pi, pj);
+  P.bounce        = __float_as_int(rb.z);
+  int fw          = __float_as_int(rb.w);
+  P.flags         = fw & 0xff;
+  P.opbounce      = fw >> 8;
+  P.weight        = {w.x, w.y, w.z};
+  P.max_roughness = w.w;
+  P.radiance      = {r.x, r.y, r.z};
+  P.sidx          = __float_as_int(r.w);
+  P.rng           = {g.x, g.y};
+}
+YT_FN void stream_store(const DStream& S, int slot, const Path& P) {
+  S.rng[slot]   = {P.rng.state, P.rng.inc};
+  S.ray_a[slot] = {P.o.x, P.o.y, P.o.z, P.d.x};
+  S.ray_b[slot] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
+  S.wgt[slot]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
+  S.rad[slot]   = {P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)};
+}
+
+// The slot's entry in the next generation's queue: key + histogram count; the returning atomic IS the rank inside the bin.
+// Camera rays of one wavefront (= one tile) share a bin: one atomic for all of them, ranks in lane order, so a tile's camera
+// rays stay next to each other in the queue.  Must be called with the wavefront's live lanes converged on `cls`.
+YT_FN void stream_emit(const DStream& S, int slot, const Path& P, int cls) {
+  unsigned key = SKEY_DEAD, rank = 0;
+  if (cls != OUT_DEAD) {
+    const bool primary = cls == OUT_PRIMARY;
+    key                = stream_key(S, slot, P.o, P.d, primary);
+    // lanes whose key is the wavefront's by construction (a wavefront = the 64 slots of one tile): camera rays, and everything
+    // when the queue is kept in slot order (order 2, the unsorted baseline)
+    const bool               shared = S.order == 2 || primary;
+    const unsigned long long ms     = __ballot(shared);
+    if (shared) {
+      const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)ms) - 1;
+      unsigned  base = 0;
+      if (lane == leader) base = atomicAdd(&S.hist[key], (unsigned)__popcll(ms));
+      rank = (unsigned)__shfl((int)base, leader) + (unsigned)__popcll(ms & ((1ull << lane) - 1ull));
+    } else {
+      rank = atomicAdd(&S.hist[key], 1u);
+    }
+  }
+  S.key[slot]  = key;
+  S.rank[slot] = rank;
+}
+
+#ifdef YT_STREAM_KERNELS  // the plain (non-template) kernels are compiled by ONE unit: yt_stream.hip defines this
+// ---------------------------------------------------------------------------------------------------------------------
+// head of the batch: every pixel's first camera ray (k_trace's prologue)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(YT_BLOCK) ks_init(DScene sc, DState st, KParams kp, DStream S) {
+  const int slot = (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
+  int       i, j;
+  const int pix = slot_pixel(st, slot, i, j);
+  int       cls = OUT_DEAD;
+  Path      P;
+  P.o = {0, 0, 0}, P.d = {0, 0, 0};
+  if (pix >= 0) {
+    auto r  = st.rngs[pix];
+    P.rng   = {r.x, r.y};
+    P.sidx  = 0;
+    P.pix   = pix;
+    P.vslot = slot;
+    start_sample(sc, st, kp, slot, P);
+    stream_store(S, slot, P);
+    cls = OUT_PRIMARY;
+  } else {
+    S.ray_b[slot] = {0, 0, 0, __int_as_float(PF_DEAD)};
+  }
+  stream_emit(S, slot, P, cls);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the counting sort between two generations
+// ---------------------------------------------------------------------------------------------------------------------
+// One workgroup: offs = exclusive prefix of hist, hist = 0, counts[0] = total.  (A few thousand to a few ten thousand bins:
+// a chain of two launches for a multi-block scan would cost more than it saves.)
+constexpr int YT_SCAN_THREADS = 1024;
+__global__ void __launch_bounds__(YT_SCAN_THREADS) ks_scan(DStream S) {
+  __shared__ unsigned s_wave[YT_SCAN_THREADS / 64];
+  const int nb  = S.nbins + S.nprim_bins;
+  const int per = (nb + YT_SCAN_THREADS - 1) / YT_SCAN_THREADS;
+  const int tid = (int)threadIdx.x, b0 = tid * per, b1 = min_(b0 + per, nb);
+  unsigned  sum = 0;
+  for (int b = b0; b < b1; b++) sum += S.hist[b];
+  // inclusive scan over the workgroup: shuffles inside a wavefront, LDS across
+  unsigned x = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned y = (unsigned)__shfl_up((int)x, off);
+    if ((tid & 63) >= off) x += y;
+  }
+  if ((tid & 63) == 63) s_wave[tid >> 6] = x;
+  __syncthreads();
+  unsigned before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < YT_SCAN_THREADS / 64; w++) {
+    if (w < (tid >> 6)) before += s_wave[w];
+    total += s_wave[w];
+  }
+  unsigned run = before + x - sum;
+  for (int b = b0; b < b1; b++) {
+    const unsigned c = S.hist[b];
+    S.offs[b]        = run;
+    S.hist[b]        = 0;
+    run += c;
+  }
+  if (tid == 0) {
+    S.counts[0] = (int)total;
+    if (total) S.counts[1] += 1;
+  }
+}
+
+__global__ void __launch_bounds__(256) ks_scatter(DStream S, int nslots) {
+  if (S.counts[0] == 0) return;
+  const int slot = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (slot >= nslots) return;
+  const unsigned key = S.key[slot];
+  if (key != SKEY_DEAD) S.queue[S.offs[key] + S.rank[slot]] = slot;
+}
+
+#endif  // YT_STREAM_KERNELS
+
+// ---------------------------------------------------------------------------------------------------------------------
+// extend: the walk and nothing else (k_intersect_batch's shape: no shading state, no spills)
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef YT_STREAM_EXTEND_WAVES
+#define YT_STREAM_EXTEND_WAVES 4
+#endif
+template <bool WIDE, int TRI, bool PHASED>
+__global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_EXTEND_WAVES) ks_extend(DScene sc, DStream S) {
+  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  const int n = S.counts[0];
+  const int i = (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
+  if ((int)blockIdx.x * YT_BLOCK >= n) return;
+  unsigned steps = 0;
+  if (i < n) {
+    Stack stack;
+    YT_STACK_INIT(stack, s_stack);
+    Counters     cnt  = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int    slot = S.queue[i];
+    const float4 ra = S.ray_a[slot], rb = S.ray_b[slot];
+    const ray3f  ray = make_ray({ra.x, ra.y, ra.z}, {ra.w, rb.x, rb.y});
+    const Hit    h   = traverse_any<false, WIDE, TRI, PHASED>(sc, ray, -1, false, stack, cnt);
+    S.hit_a[slot]    = {h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)};
+    S.hit_e[slot]    = h.element;
+    steps            = cnt.steps + 1;
+  }
+  if (S.stats) {  // profiling: how even are the walks of a wavefront?
+    unsigned sum = steps, mx = steps;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      sum += __shfl_xor(sum, off);
+      unsigned o = __shfl_xor(mx, off);
+      mx         = o > mx ? o : mx;
+    }
+    const unsigned long long rays = __popcll(__ballot(steps > 0));
+    if ((threadIdx.x & 63) == 0) {
+      unsigned long long* c = S.stats + 8 * (blockIdx.x & 63);
+      atomicAdd(&c[0], (unsigned long long)sum);
+      atomicAdd(&c[1], 64ull * mx);
+      atomicAdd(&c[2], 1ull);
+      atomicAdd(&c[3], rays);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// shade: one iteration of trace_path's bounce loop for every live slot, in slot order — k_trace's shade stage, its
+// deferred light-pdf stage (run by the lanes that deferred, right here: the state is in registers) and its
+// resolve_step (accumulate, regenerate), then the next ray's entry in the sort
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef YT_STREAM_SHADE_WAVES
+#define YT_STREAM_SHADE_WAVES 4
+#endif
+template <int SAMPLER, int LP, int CLS, bool WIDE>
+__global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DScene sc, DState st, KParams kp, DStream S) {
+  constexpr bool MATTE = CLS == 1;
+  constexpr int  PRIMS = MATTE ? 1 : (CLS == 3 ? 2 : 0);
+  constexpr bool PEEK  = SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST || SAMPLER == YTHIP_SAMPLER_NAIVE;
+  __shared__ StackEntry s_stack[LP == LP_DEFER ? YT_LDS_DEPTH : 1][YT_BLOCK];
+  if (S.counts[0] == 0) return;  // nothing was queued for this generation: the batch is done
+  const int  slot    = (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
+  const bool stopped = stop_requested(st.stop, st.stop_gen) || (blockIdx.x == 0 && relay_stop(st));
+  const float4 rb = S.ray_b[slot];
+  const bool   live = !(__float_as_int(rb.w) & PF_DEAD);
+  int  cls = OUT_DEAD;
+  Path P;
+  P.o = {0, 0, 0}, P.d = {0, 0, 0};
+  if (live) {
+    const float4 ra = S.ray_a[slot], ha = S.hit_a[slot];
+    P.o             = {ra.x, ra.y, ra.z};
+    P.d             = {ra.w, rb.x, rb.y};
+    const int inst  = __float_as_int(ha.w);
+    P.isec          = {inst, S.hit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
+    if (inst < 0) P.isec = {-1, -1, 0, 0, 0, false};
+    stream_load_rest(st, S, slot, P, rb);
+    const int max_bounces = max_bounces_of<SAMPLER>(kp);
+    ShadeEnv  E           = {sc, st, kp, slot};
+    int       step;
+    if constexpr (SAMPLER == YTHIP_SAMPLER_NAIVE) step = step_naive<SAMPLER>(E, P);
+    else step = step_path<SAMPLER, LP, CLS>(E, P);
+    if constexpr (LP == LP_DEFER) {
+      if (step == STEP_DEFER) {  // the rest of the loop body behind the light pdf's instance walks (k_trace's walk stage)
+        Stack stack;
+        YT_STACK_INIT(stack, s_stack);
+        Counters     cnt  = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float4 pd   = st.pend[slot];
+        const float  lpdf = sample_lights_pdf<2, false, PRIMS>(sc, P.o, P.d, &stack, &cnt);
+        P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
+        step = step_tail(P);
+      }
+    }
+    cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
+    if (cls == OUT_DEAD) P.flags |= PF_DEAD;
+    stream_store(S, slot, P);
+  }
+  stream_emit(S, slot, P, cls);
+}
+
+}  // namespace yt

@@ -21,6 +21,10 @@ std::string& ythip_thread_error() { return g_error; }
 
 namespace {
 
+void raise_stop_word(ythip_ctx* ctx) {  // (what ythip_cancel does: the batch's number into the pinned word the kernels relay)
+  __atomic_store_n(ctx->stop_host, ctx->stop_gen.load(), __ATOMIC_RELEASE);
+}
+
 int upload_lights_impl(ythip_ctx* ctx) {
   free_all(ctx->light_allocs);
   auto&               L = ctx->h_lights;
@@ -117,6 +121,91 @@ void harvest_events(ythip_ctx* ctx) {
   ctx->ev_next = 0;
 }
 
+// The streaming scheduler's batch (yt_stream.h): ks_init, then generations of (scatter, extend, shade, scan) until a
+// read-back of the next queue's length says zero.  The first `batch` generations are enqueued blind (a sample is at least
+// one generation), the rest in chunks; a chunk's surplus generations return at once on the device.  Blocks until the batch
+// is done (the queue length has to come home), watching the caller's stop flag meanwhile.
+int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp, int lp, int cls, const volatile int32_t* stop) {
+  auto& st = ctx->st;
+  auto& S  = ctx->ss;
+  int   rc;
+  if (ctx->stream_slots != st.nslots) {
+    const size_t ns = (size_t)st.nslots;
+    S               = DStream{};
+    S.prim_shift    = 8;  // camera rays: bins of 4 neighbouring tiles
+    while (((st.nslots >> S.prim_shift) > 16384)) S.prim_shift++;
+    S.nprim_bins = std::max(1, (st.nslots + (1 << S.prim_shift) - 1) >> S.prim_shift);
+    const size_t nb = (size_t)(8 << (3 * 5)) + (size_t)S.nprim_bins;  // (room for the finest cell grid: ythip_set_stream_options)
+#define AL(field, count) \
+  if ((rc = dalloc(ctx, ctx->state_allocs, &S.field, (size_t)(count)))) return rc;
+    AL(ray_a, ns) AL(ray_b, ns) AL(wgt, ns) AL(rad, ns) AL(rng, ns) AL(hit_a, ns) AL(hit_e, ns) AL(key, ns) AL(rank, ns) AL(queue, ns)
+    AL(hist, nb) AL(offs, nb) AL(counts, 16) AL(stats, 8 * 64)
+#undef AL
+    HIPCHECK(ctx, hipMemsetAsync(S.hist, 0, nb * sizeof(unsigned), ctx->stream));
+    HIPCHECK(ctx, hipMemsetAsync(S.stats, 0, 8 * 64 * sizeof(unsigned long long), ctx->stream));
+    ctx->stream_slots = st.nslots;
+  }
+  if (!ctx->stream_counts_host) HIPCHECK(ctx, hipHostMalloc((void**)&ctx->stream_counts_host, 64, hipHostMallocDefault));
+  S.order     = ctx->stream_order;
+  S.cell_bits = std::min(std::max(ctx->stream_cell_bits, 1), 5);
+  S.nbins     = 8 << (3 * S.cell_bits);
+  // the cell grid of the sort keys: the scene's root box
+  const vec3f lo = ctx->ds.tlas_bmin, hi = ctx->ds.tlas_bmax;
+  const float cells = (float)(1 << S.cell_bits);
+  auto        scale = [&](float a, float b) { return (b > a && std::isfinite(b - a)) ? cells / (b - a) : 0.0f; };
+  S.cell_lo    = lo;
+  S.cell_scale = {scale(lo.x, hi.x), scale(lo.y, hi.y), scale(lo.z, hi.z)};
+  DStream run = S;
+  if (!(ctx->prof_mode & 1)) run.stats = nullptr;
+  else HIPCHECK(ctx, hipMemsetAsync(S.stats, 0, 8 * 64 * sizeof(unsigned long long), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(S.counts, 0, 16 * sizeof(int), ctx->stream));
+  const bool phased = ctx->stream_phased >= 0 ? ctx->stream_phased != 0 : (cls == 1 && lp == LP_DEFER);
+  ytl::StreamLaunch l = {ctx->stream, &ctx->ds, &ctx->st, &kp, &run, lp, cls, phased};
+  ctx->stream_cancelled = false;
+  int launched = 0;
+  {
+    EvScope ev(ctx, 0);
+    ytl::stream_begin(l);
+    int chunk = std::max(1, params->batch);
+    if (!ctx->done_event) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->done_event, hipEventDisableTiming));
+    while (true) {
+      ytl::stream_generations(l, chunk);
+      launched += chunk;
+      HIPCHECK(ctx, hipMemcpyAsync(ctx->stream_counts_host, S.counts, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHECK(ctx, hipEventRecord(ctx->done_event, ctx->stream));
+      if (stop) {
+        while (hipEventQuery(ctx->done_event) == hipErrorNotReady) {
+          if (*stop && !ctx->stream_cancelled) {
+            raise_stop_word(ctx);
+            ctx->stream_cancelled = true;
+          }
+          std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+      }
+      HIPCHECK(ctx, hipEventSynchronize(ctx->done_event));
+      if (ctx->stream_counts_host[0] == 0) break;
+      // what is left: the live paths' remaining bounces — a few generations at a time (each surplus one costs four empty launches)
+      chunk = std::max(4, std::min(chunk, 16));
+    }
+  }
+  HIPCHECK(ctx, hipGetLastError());
+  ctx->stream_info             = {};
+  ctx->stream_info.ran         = 1;
+  ctx->stream_info.generations = ctx->stream_counts_host[1];
+  ctx->stream_info.launched    = launched;
+  ctx->stream_info.bins        = S.nbins + S.nprim_bins;
+  if (ctx->prof_mode & 1) {
+    std::vector<unsigned long long> h(8 * 64);
+    HIPCHECK(ctx, hipMemcpy(h.data(), S.stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int b = 0; b < 64; b++) {
+      ctx->stream_info.lane_steps += (int64_t)h[8 * b + 0];
+      ctx->stream_info.wave_steps += (int64_t)h[8 * b + 1];
+      ctx->stream_info.rays += (int64_t)h[8 * b + 3];
+    }
+  }
+  return YTHIP_OK;
+}
+
 // only_pix >= 0: trace_sample() — one sample, numbered `sample`, of that local pixel
 int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile int32_t* stop, int only_pix = -1,
     int sample = 0) {
@@ -182,6 +271,21 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
       if (l.instance != YTHIP_INVALIDID) lp = LP_DEFER;
   }
 
+  // the streaming scheduler (ythip_set_scheduler 1): `path`, bit-exact mode, scenes the wide walk serves, real batches
+  ctx->last_launch_stream = false;
+  ctx->stream_info.ran    = 0;
+  if (ctx->scheduler == 1 && only_pix < 0 && !count && params->fastmath == 0 && ctx->use_wide() && params->batch >= ctx->stream_min_batch) {
+    const int cls = ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
+    ytl::StreamLaunch probe = {ctx->stream, &ctx->ds, &ctx->st, &kp, &ctx->ss, lp, cls, false};
+    if (ytl::stream_supported(probe)) {
+      ctx->st.tile_perm = nullptr, ctx->st.tile_cost = nullptr, ctx->st.pool_next = nullptr, ctx->st.pool_total = 0;
+      int rc = enqueue_stream(ctx, params, kp, lp, cls, stop);
+      if (rc) return rc;
+      ctx->last_launch_fast = false, ctx->last_launch_mode = 0, ctx->last_launch_stream = true;
+      ctx->samples += params->batch;
+      return YTHIP_OK;
+    }
+  }
   // one launch renders the whole batch: every workgroup loops over its tile
   // until its pixels have taken `batch` samples (k_trace)
   ctx->st.tile_perm = nullptr, ctx->st.tile_cost = nullptr;
@@ -339,6 +443,11 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_LPT")) ctx->lpt = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LPT_PROBE")) ctx->lpt_probe = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_PIXEL_POOL")) ctx->pixel_pool = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_SCHEDULER")) ctx->scheduler = std::atoi(e) == 1 ? 1 : 0;
+  if (const char* e = std::getenv("YTHIP_STREAM_CELLS")) ctx->stream_cell_bits = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_STREAM_ORDER")) ctx->stream_order = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_STREAM_PHASED")) ctx->stream_phased = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_STREAM_MIN_BATCH")) ctx->stream_min_batch = std::atoi(e);
   {
     hipDeviceProp_t prop;
     ctx->pool_blocks = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount * 16 : 4096;
@@ -1033,6 +1142,7 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
         col_first, col_stride, width);
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   free_all(ctx->state_allocs);
+  ctx->stream_slots  = 0;  // (the streaming scheduler's arrays went with the state)
   ctx->have_state    = false;
   ctx->have_denoised = false;
   ctx->state_bound   = false;
@@ -1403,8 +1513,8 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volati
   begin_batch(ctx);
   int       rc             = enqueue_batch(ctx, params, stop);
   if (rc) return rc;
-  bool cancelled = false;
-  if (stop) {
+  bool cancelled = ctx->last_launch_stream && ctx->stream_cancelled;  // (a streamed batch watched the flag itself)
+  if (stop && !cancelled) {
     // the reference checks context.stop before every sample of every pixel; here the host
     // watches the caller's flag while the batch runs and relays it to the device
     if (!ctx->done_event) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->done_event, hipEventDisableTiming));
@@ -1446,6 +1556,24 @@ int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info) {
     info->plain_ms_per_sample = (float)(ctx->pool_ms[0] / ctx->pool_samples[0]);
     info->pool_ms_per_sample  = (float)(ctx->pool_ms[1] / ctx->pool_samples[1]);
   }
+  return YTHIP_OK;
+}
+
+int ythip_set_scheduler(ythip_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 1) return fail(ctx, YTHIP_ERR_INVALID, "scheduler must be 0 (fused kernel) or 1 (streaming)");
+  ctx->scheduler = mode;
+  return YTHIP_OK;
+}
+int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased) {
+  if (!ctx || order > 2 || cell_bits == 0 || cell_bits > 5 || phased > 1) return fail(ctx, YTHIP_ERR_INVALID, "stream options: order 0..2, cell_bits 1..5, phased 0..1");
+  if (order >= 0) ctx->stream_order = order;
+  if (cell_bits > 0) ctx->stream_cell_bits = cell_bits;
+  if (phased >= 0) ctx->stream_phased = phased;
+  return YTHIP_OK;
+}
+int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info) {
+  if (!ctx || !info) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  *info = ctx->stream_info;
   return YTHIP_OK;
 }
 

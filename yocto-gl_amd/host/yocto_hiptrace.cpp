@@ -550,8 +550,8 @@ void ensure_scene(residency& r, const scene_data& scene, bool need_view = false)
 }
 
 void ensure_resident(residency& r, const scene_data& scene, const trace_bvh& bvh, const trace_lights& lights) {
-  const bool own = fast_math().load() == 2;  // the own-tree mode builds its tree from the flat view of the geometry
-  ensure_scene(r, scene, own);
+  const bool own = fast_math().load() == 2;
+  ensure_scene(r, scene);
   auto bs = stamp_of(bvh);
   if (bs != r.bvh) {
     flat_bvh f;
@@ -560,8 +560,11 @@ void ensure_resident(residency& r, const scene_data& scene, const trace_bvh& bvh
     r.bvh = bs;
   }
   if (own)  // (the library drops its own tree whenever geometry or the reference tree changes: ask it)
+    // ... and let it build from ITS resident host copies (null scene): those follow ythip_update_instance_frames /
+    // ythip_update_shape_vertices, which the staging view of the last ingest does not (a moved instance was
+    // culled by a TLAS built from its pre-edit frame)
     on_all(r, [&](ythip_ctx* c) {
-      return ythip_own_bvh_info(c, nullptr, nullptr, nullptr) == YTHIP_OK ? YTHIP_OK : ythip_build_own_bvh(c, &r.staged);
+      return ythip_own_bvh_info(c, nullptr, nullptr, nullptr) == YTHIP_OK ? YTHIP_OK : ythip_build_own_bvh(c, nullptr);
     });
   auto ls = stamp_of(lights);
   if (ls != r.lights) {

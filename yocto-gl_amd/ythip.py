@@ -220,6 +220,11 @@ class CPoolInfo(C.Structure):
                 ("plain_ms_per_sample", C.c_float), ("pool_ms_per_sample", C.c_float)]
 
 
+class CStreamInfo(C.Structure):
+    _fields_ = [("ran", C.c_int32), ("generations", C.c_int32), ("launched", C.c_int32), ("bins", C.c_int32),
+                ("rays", C.c_int64), ("lane_steps", C.c_int64), ("wave_steps", C.c_int64)]
+
+
 class CBuildInfo(C.Structure):
     _fields_ = [("device_trees", C.c_int32), ("host_trees", C.c_int32), ("fallbacks", C.c_int32),
                 ("max_depth", C.c_int32), ("device_prims", C.c_int64), ("device_ms", C.c_double),
@@ -508,6 +513,9 @@ _SIGNATURES = {
     "ythip_io_last_error": (C.c_char_p, []),
     "ythip_set_pixel_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ythip_get_pixel_pool": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_set_scheduler": (C.c_int, [C.c_void_p, C.c_int]),
+    "ythip_get_stream_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ythip_set_stream_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ythip_last_launch_fastmath": (C.c_int, [C.c_void_p]),
     "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "ythip_ply_read": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9),
@@ -756,6 +764,20 @@ class Context:
         info = CPoolInfo()
         self._check(self.lib.ythip_get_pixel_pool(self.h, C.byref(info)), "get_pixel_pool")
         return {k: getattr(info, k) for k, _ in CPoolInfo._fields_}
+
+    def set_scheduler(self, mode):
+        """0 the fused persistent kernel (default), 1 the streaming scheduler (csrc/yt_stream.h) — ythip_set_scheduler."""
+        self._check(self.lib.ythip_set_scheduler(self.h, int(mode)), "set_scheduler")
+
+    def set_stream_options(self, order=-1, cell_bits=-1, phased=-1):
+        """The sort of the streaming scheduler (ythip_set_stream_options; -1 keeps): order 0 octant major / 1 cell major /
+        2 unsorted, cell_bits 1..5, phased 0 / 1."""
+        self._check(self.lib.ythip_set_stream_options(self.h, int(order), int(cell_bits), int(phased)), "set_stream_options")
+
+    def stream_info(self):
+        info = CStreamInfo()
+        self._check(self.lib.ythip_get_stream_info(self.h, C.byref(info)), "get_stream_info")
+        return {k: getattr(info, k) for k, _ in CStreamInfo._fields_}
 
     def last_launch_fastmath(self):
         """The mode the last trace launch ran: 0 bit-exact, 1 the tolerance-mode kernels (yt_fast.hip), 2 the own-tree
