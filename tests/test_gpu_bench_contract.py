@@ -149,3 +149,33 @@ def test_two_rank_launch_rehearsed_with_gloo():
     assert s["resolution"] == [448, 252] and s["pixels_per_rank"] == 448 * 252 // 2 and s["value"] > 0  # weak_resolution(320, 2)
     assert len(s["per_rank"]["slice_ms"]) == 2
     assert "cpu_baseline" not in j and "other_configs" not in j  # rank 0 at N=1 only
+
+
+def test_eight_rank_launch_rehearsed_with_gloo():
+    """`bench.py --gpus 8` as the driver launches it at round end: eight processes under
+    torch.distributed.run, rehearsed on this ONE GPU with gloo (all ranks share the device: the timings mean nothing,
+    the plumbing is what is tested) — every rank renders its 1/8 of the tile columns, the frame is gathered, rank 0 prints
+    ONE line under the size limit with eight per-rank slice / gather times, the strong-scaling value and the weak-scaling leg."""
+    env = dict(os.environ, YTHIP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29400 + os.getpid() % 200
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--steps", "2", "--warmup", "1", "--resolution", "640", "--spp", "4"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert len(lines[0]) < LINE_LIMIT, len(lines[0])
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["steps"] == 2 and j["warmup"] == 1
+    w, h = j["config"]["resolution"]
+    assert (w, h) == (640, 360) and j["config"]["pixels_per_rank"] == w * h // 8  # 40 tile columns: 5 per rank
+    assert "configs[2]" in j["config"]["workload"] and j["config"]["sharding"] == "columns/8"
+    assert j["config"]["collective"] == {"backend": "gloo", "ranks": 8}
+    pr = j["config"]["per_rank"]
+    assert len(pr["slice_ms"]) == 8 and len(pr["gather_ms"]) == 8 and all(t > 0 for t in pr["slice_ms"] + pr["gather_ms"])
+    assert abs(j["value"] - w * h * 4 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
+    s = j["weak_scaling"]
+    assert s["pixels_per_rank"] * 8 == s["resolution"][0] * s["resolution"][1] and s["value"] > 0
+    assert len(s["per_rank"]["slice_ms"]) == 8 and len(s["per_rank"]["gather_ms"]) == 8
+    assert "cpu_baseline" not in j and "other_configs" not in j

@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 SCENES = ["cornellbox", "plane", "materials", "instances", "lines_points"]
 
 
+def stream_context(flat):
+    """A context on the streaming scheduler.  The test scenes' trees are tiny (< 64 primitives: the library would walk them
+    binary and the scheduler, which has the wide walk only, would decline), so the wide walk is forced."""
+    ctx = P.gpu_context(flat)
+    ctx.set_traversal(1)
+    ctx.set_scheduler(1)
+    return ctx
+
+
 def want_state(flat, params):
     if P.have_ref():
         return P.RefBundle(flat).render(params)
@@ -33,8 +42,7 @@ def test_streamed_path_equals_the_reference(scene):
     params = yt.trace_params(sampler="path", resolution=144, samples=12, batch=6)
     want = want_state(flat, params)
     for order, cells in ((0, 4), (1, 3), (2, 4)):
-        ctx = P.gpu_context(flat)
-        ctx.set_scheduler(1)
+        ctx = stream_context(flat)
         ctx.set_stream_options(order=order, cell_bits=cells)
         got = P.gpu_render(ctx, flat, params)
         info = ctx.stream_info()
@@ -48,8 +56,7 @@ def test_streamed_params_variants(kw):
     flat = P.SCENES["materials"]()
     params = yt.trace_params(sampler="path", resolution=96, samples=8, batch=8, **kw)
     want = want_state(flat, params)
-    ctx = P.gpu_context(flat)
-    ctx.set_scheduler(1)
+    ctx = stream_context(flat)
     got = P.gpu_render(ctx, flat, params)
     assert ctx.stream_info()["ran"] == 1
     ctx.close()
@@ -62,8 +69,7 @@ def test_general_class_and_specialised_classes_agree():
     params = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8)
     out = []
     for spec in (1, 0):
-        ctx = P.gpu_context(flat)
-        ctx.set_scheduler(1)
+        ctx = stream_context(flat)
         ctx.set_specialization(spec)
         out.append(P.gpu_render(ctx, flat, params))
         assert ctx.stream_info()["ran"] == 1
@@ -77,6 +83,7 @@ def test_slices_batches_and_scheduler_changes_in_one_render():
     out = []
     for stream in (1, 0):
         ctx = P.gpu_context(flat)
+        ctx.set_traversal(1)
         ctx.set_scheduler(stream)
         ctx.make_trace_state(flat, p)
         ctx.trace_samples(p)
@@ -99,8 +106,7 @@ def test_slices_batches_and_scheduler_changes_in_one_render():
 
 def test_what_the_scheduler_does_not_serve_runs_fused():
     flat = P.SCENES["cornellbox"]()
-    ctx = P.gpu_context(flat)
-    ctx.set_scheduler(1)
+    ctx = stream_context(flat)
     for kw in (dict(sampler="pathdirect", batch=4), dict(sampler="path", batch=1), dict(sampler="path", batch=4, bounces=0),
                dict(sampler="path", batch=4, fastmath=1)):
         params = yt.trace_params(resolution=64, samples=4, **kw)
@@ -108,6 +114,10 @@ def test_what_the_scheduler_does_not_serve_runs_fused():
         assert ctx.stream_info()["ran"] == 0, kw
         if not kw.get("fastmath"):
             P.assert_identical(want_state(flat, params), got, f"fused fallback {kw}")
+    ctx.set_traversal(0)  # the binary walk: not served either
+    params = yt.trace_params(sampler="path", resolution=64, samples=4, batch=4)
+    P.assert_identical(want_state(flat, params), P.gpu_render(ctx, flat, params), "fused fallback, binary walk")
+    assert ctx.stream_info()["ran"] == 0
     ctx.close()
 
 
@@ -115,8 +125,7 @@ def test_cancel_inside_a_streamed_batch():
     """The caller's stop flag ends a streamed batch at the pixels' next sample boundaries: the call returns CANCELLED,
     state.samples stays, every pixel holds a whole number of samples (hits counts them) and the next batch runs."""
     flat = P.SCENES["cornellbox"]()
-    ctx = P.gpu_context(flat)
-    ctx.set_scheduler(1)
+    ctx = stream_context(flat)
     p = yt.trace_params(sampler="path", resolution=512, samples=100000, batch=2048)
     ctx.make_trace_state(flat, p)
     stop = np.zeros(1, np.int32)
@@ -137,8 +146,7 @@ def test_cancel_inside_a_streamed_batch():
 
 def test_profiling_reports_the_walks_evenness():
     flat = P.SCENES["cornellbox"]()
-    ctx = P.gpu_context(flat)
-    ctx.set_scheduler(1)
+    ctx = stream_context(flat)
     ctx.set_profiling(1)
     p = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8)
     P.gpu_render(ctx, flat, p)

@@ -61,8 +61,18 @@ extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds_, cons
     case YTHIP_SAMPLER_PATHTEST:
       defer ? launch<YTHIP_SAMPLER_PATHTEST, LP_DEFER>(s, blocks, ds, st, kp) : launch<YTHIP_SAMPLER_PATHTEST, LP_NONE>(s, blocks, ds, st, kp);
       return 0;
-    case YTHIP_SAMPLER_PATHDIRECT: launch<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER>(s, blocks, ds, st, kp); return 0;
-    case YTHIP_SAMPLER_PATHMIS: launch<YTHIP_SAMPLER_PATHMIS, LP_DEFER>(s, blocks, ds, st, kp); return 0;
+    case YTHIP_SAMPLER_PATHDIRECT:  // (by scene class since round 6, as `path`)
+      if (cls == 1) launch<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER, 1>(s, blocks, ds, st, kp);
+      else if (cls == 2) launch<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER, 2>(s, blocks, ds, st, kp);
+      else if (cls == 3) launch<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER, 3>(s, blocks, ds, st, kp);
+      else launch<YTHIP_SAMPLER_PATHDIRECT, LP_DEFER>(s, blocks, ds, st, kp);
+      return 0;
+    case YTHIP_SAMPLER_PATHMIS:
+      if (cls == 1) launch<YTHIP_SAMPLER_PATHMIS, LP_DEFER, 1>(s, blocks, ds, st, kp);
+      else if (cls == 2) launch<YTHIP_SAMPLER_PATHMIS, LP_DEFER, 2>(s, blocks, ds, st, kp);
+      else if (cls == 3) launch<YTHIP_SAMPLER_PATHMIS, LP_DEFER, 3>(s, blocks, ds, st, kp);
+      else launch<YTHIP_SAMPLER_PATHMIS, LP_DEFER>(s, blocks, ds, st, kp);
+      return 0;
     case YTHIP_SAMPLER_NAIVE: launch<YTHIP_SAMPLER_NAIVE, LP_NONE>(s, blocks, ds, st, kp); return 0;
     case YTHIP_SAMPLER_EYELIGHT: launch<YTHIP_SAMPLER_EYELIGHT, LP_NONE>(s, blocks, ds, st, kp); return 0;
     case YTHIP_SAMPLER_FURNACE: launch<YTHIP_SAMPLER_FURNACE, LP_NONE>(s, blocks, ds, st, kp); return 0;

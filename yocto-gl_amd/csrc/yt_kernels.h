@@ -378,12 +378,15 @@ YT_FN void set_first_hit(const DState& s, const Path& P, vec3f albedo, vec3f nor
 YT_FN void count_shade(const DState& s) { count_lanes(s.counters, CNT_SHADES); }
 
 // emission seen along `incoming` from a NEE ray's intersection
-// (yocto_trace.cpp:678-687, 873-884)
+// (yocto_trace.cpp:678-687, 873-884).  CLS: the scene class (step_path)
+template <int CLS = 0>
 YT_FN vec3f nee_emission(const DScene& sc, const Hit& isec, vec3f incoming) {
+  constexpr bool NOTEX = CLS == 1 || CLS == 2, OPAQUE = CLS == 3;
+  constexpr int  PRIMS = CLS == 1 ? 1 : (OPAQUE ? 2 : 0);
   if (!isec.hit) return eval_environment(sc, incoming);
-  auto s        = load_surface(sc, isec.instance, isec.element, {isec.u, isec.v});
-  auto material = eval_material(sc, s.shc, s.mat, s.e, s.uv);
-  auto normal   = eval_shading_normal(sc, s.frame, s.shc, s.mat, s.e, s.uv, -incoming);
+  auto s        = load_surface<PRIMS>(sc, isec.instance, isec.element, {isec.u, isec.v});
+  auto material = eval_material<NOTEX, OPAQUE>(sc, s.shc, s.mat, s.e, s.uv);
+  auto normal   = eval_shading_normal<NOTEX>(sc, s.frame, s.shc, s.mat, s.e, s.uv, -incoming);
   return eval_emission(material, normal, -incoming);
 }
 
@@ -1310,11 +1313,11 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU)
             if (nee) {
               float4 nb      = st.nee_b[slot];
               vec3f  inc     = {na.x, na.y, na.z}, bsdfcos = {nb.x, nb.y, nb.z};
-              auto   pdf     = sample_lights_pdf<2, COUNT>(sc, P.o, inc, &stack, &cnt);
+              auto   pdf     = sample_lights_pdf<2, COUNT, PRIMS>(sc, P.o, inc, &stack, &cnt);
               if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
                 ray3f nray     = make_ray(P.o, inc);
-                Hit   nisec    = traverse_any<COUNT, WIDE>(sc, nray, -1, false, stack, cnt);
-                auto  emission = nee_emission(sc, nisec, inc);
+                Hit   nisec    = traverse_any<COUNT, WIDE, PRIMS>(sc, nray, -1, false, stack, cnt);
+                auto  emission = nee_emission<CLS>(sc, nisec, inc);
                 P.radiance += P.weight * bsdfcos * emission / pdf;
               }
             }
@@ -1332,7 +1335,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU)
                 const float4 b = pass == 0 ? mb : st.nee_d[slot];
                 const vec3f  inc = {a.x, a.y, a.z}, bsdfcos = {b.x, b.y, b.z};
                 const float  bsdf_pdf  = a.w;
-                const float  light_pdf = sample_lights_pdf<2, COUNT>(sc, P.o, inc, &stack, &cnt);
+                const float  light_pdf = sample_lights_pdf<2, COUNT, PRIMS>(sc, P.o, inc, &stack, &cnt);
                 auto         heur      = [](float this_pdf, float other_pdf) {
                   return div_(this_pdf * this_pdf, this_pdf * this_pdf + other_pdf * other_pdf);
                 };
@@ -1340,12 +1343,12 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU)
                                                    : div_(heur(bsdf_pdf, light_pdf), bsdf_pdf);
                 if (bsdfcos != vec3f{0, 0, 0} && mis_weight != 0) {
                   ray3f nray  = make_ray(P.o, inc);
-                  Hit   nisec = traverse_any<COUNT, WIDE>(sc, nray, -1, false, stack, cnt);
+                  Hit   nisec = traverse_any<COUNT, WIDE, PRIMS>(sc, nray, -1, false, stack, cnt);
                   if (pass == 1) {  // next_intersection = intersection (persists across bounces)
                     st.nhit_a[slot] = {nisec.u, nisec.v, nisec.distance, __int_as_float(nisec.hit ? nisec.instance : -1)};
                     st.nhit_e[slot] = nisec.element;
                   }
-                  auto emission = nee_emission(sc, nisec, inc);
+                  auto emission = nee_emission<CLS>(sc, nisec, inc);
                   P.radiance += P.weight * bsdfcos * emission * mis_weight;
                 }
               }

@@ -109,22 +109,27 @@ YT_FN void stream_store(const DStream& S, int slot, const Path& P) {
 // rays stay next to each other in the queue.  Must be called with the wavefront's live lanes converged on `cls`.
 YT_FN void stream_emit(const DStream& S, int slot, const Path& P, int cls) {
   unsigned key = SKEY_DEAD, rank = 0;
-  if (cls != OUT_DEAD) {
-    const bool primary = cls == OUT_PRIMARY;
-    key                = stream_key(S, slot, P.o, P.d, primary);
-    // lanes whose key is the wavefront's by construction (a wavefront = the 64 slots of one tile): camera rays, and everything
-    // when the queue is kept in slot order (order 2, the unsorted baseline)
-    const bool               shared = S.order == 2 || primary;
-    const unsigned long long ms     = __ballot(shared);
-    if (shared) {
-      const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)ms) - 1;
-      unsigned  base = 0;
-      if (lane == leader) base = atomicAdd(&S.hist[key], (unsigned)__popcll(ms));
-      rank = (unsigned)__shfl((int)base, leader) + (unsigned)__popcll(ms & ((1ull << lane) - 1ull));
-    } else {
-      rank = atomicAdd(&S.hist[key], 1u);
-    }
+  const bool   live = cls != OUT_DEAD;
+  if (live) key = stream_key(S, slot, P.o, P.d, cls == OUT_PRIMARY);
+  // One atomic per DISTINCT key of the wavefront, not per lane (neighbouring pixels' rays share octants and cells: 10-20
+  // distinct keys per 64 lanes; a per-lane returning atomic was the slowest part of the first version).  The lanes are
+  // grouped key by key with ballots — no memory traffic —, every group's first lane then fetches the group's base with ONE
+  // wave-level atomic instruction, and the others take it from that lane.
+  const int          lane = (int)(threadIdx.x & 63);
+  unsigned long long todo = __ballot(live);
+  int                leader = lane;
+  unsigned           prefix = 0, count = 0;
+  while (todo) {
+    const int                first = __ffsll((long long)todo) - 1;
+    const unsigned           k     = (unsigned)__shfl((int)key, first);
+    const unsigned long long m     = __ballot(live && key == k) & todo;
+    if (live && key == k) leader = first, prefix = (unsigned)__popcll(m & ((1ull << lane) - 1ull)), count = (unsigned)__popcll(m);
+    todo &= ~m;
   }
+  unsigned base = 0;
+  if (live && leader == lane) base = atomicAdd(&S.hist[key], count);
+  base = (unsigned)__shfl((int)base, leader);
+  rank = base + prefix;
   S.key[slot]  = key;
   S.rank[slot] = rank;
 }
@@ -158,40 +163,49 @@ __global__ void __launch_bounds__(YT_BLOCK) ks_init(DScene sc, DState st, KParam
 // ---------------------------------------------------------------------------------------------------------------------
 // the counting sort between two generations
 // ---------------------------------------------------------------------------------------------------------------------
-// One workgroup: offs = exclusive prefix of hist, hist = 0, counts[0] = total.  (A few thousand to a few ten thousand bins:
-// a chain of two launches for a multi-block scan would cost more than it saves.)
+// One workgroup: offs = exclusive prefix of hist, hist = 0, counts[0] = total.  The bins in tiles of 4096 (one uint4 per
+// thread, coalesced), a running carry from tile to tile.  (4 k - 40 k bins: 1 - 10 tiles.  The first version gave every
+// thread a contiguous run of bins — strided, uncoalesced reads: 50 us per launch at 37 k bins, 460 us at 278 k.)
 constexpr int YT_SCAN_THREADS = 1024;
 __global__ void __launch_bounds__(YT_SCAN_THREADS) ks_scan(DStream S) {
   __shared__ unsigned s_wave[YT_SCAN_THREADS / 64];
-  const int nb  = S.nbins + S.nprim_bins;
-  const int per = (nb + YT_SCAN_THREADS - 1) / YT_SCAN_THREADS;
-  const int tid = (int)threadIdx.x, b0 = tid * per, b1 = min_(b0 + per, nb);
-  unsigned  sum = 0;
-  for (int b = b0; b < b1; b++) sum += S.hist[b];
-  // inclusive scan over the workgroup: shuffles inside a wavefront, LDS across
-  unsigned x = sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    unsigned y = (unsigned)__shfl_up((int)x, off);
-    if ((tid & 63) >= off) x += y;
-  }
-  if ((tid & 63) == 63) s_wave[tid >> 6] = x;
+  __shared__ unsigned s_carry;
+  const int nb  = S.nbins + S.nprim_bins;  // (the arrays are padded to a multiple of 4096)
+  const int tid = (int)threadIdx.x;
+  if (tid == 0) s_carry = 0;
   __syncthreads();
-  unsigned before = 0, total = 0;
+  for (int t0 = 0; t0 < nb; t0 += 4 * YT_SCAN_THREADS) {
+    const int   b = t0 + 4 * tid;
+    uint4       c = reinterpret_cast<const uint4*>(S.hist + b)[0];
+    if (b + 0 >= nb) c.x = 0;
+    if (b + 1 >= nb) c.y = 0;
+    if (b + 2 >= nb) c.z = 0;
+    if (b + 3 >= nb) c.w = 0;
+    const unsigned sum = c.x + c.y + c.z + c.w;
+    unsigned       x   = sum;  // inclusive scan over the workgroup: shuffles inside a wavefront, LDS across
 #pragma unroll
-  for (int w = 0; w < YT_SCAN_THREADS / 64; w++) {
-    if (w < (tid >> 6)) before += s_wave[w];
-    total += s_wave[w];
-  }
-  unsigned run = before + x - sum;
-  for (int b = b0; b < b1; b++) {
-    const unsigned c = S.hist[b];
-    S.offs[b]        = run;
-    S.hist[b]        = 0;
-    run += c;
+    for (int off = 1; off < 64; off <<= 1) {
+      unsigned y = (unsigned)__shfl_up((int)x, off);
+      if ((tid & 63) >= off) x += y;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = x;
+    __syncthreads();
+    unsigned before = s_carry, total = 0;
+#pragma unroll
+    for (int w = 0; w < YT_SCAN_THREADS / 64; w++) {
+      if (w < (tid >> 6)) before += s_wave[w];
+      total += s_wave[w];
+    }
+    const unsigned run = before + x - sum;
+    reinterpret_cast<uint4*>(S.offs + b)[0] = {run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z};
+    reinterpret_cast<uint4*>(S.hist + b)[0] = {0, 0, 0, 0};
+    __syncthreads();
+    if (tid == 0) s_carry += total;
+    __syncthreads();
   }
   if (tid == 0) {
-    S.counts[0] = (int)total;
+    const unsigned total = s_carry;
+    S.counts[0]          = (int)total;
     if (total) S.counts[1] += 1;
   }
 }

@@ -45,9 +45,8 @@ int upload_lights_impl(ythip_ctx* ctx) {
 // The kernels themselves are compiled in the yt_trace_*.hip units (yt_launch.h), by sampler family.
 int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count, int mode = 0) {
   // the scene class of the default sampler (yt_kernels.h: step_path's CLS)
-  const int cls = kp.sampler == YTHIP_SAMPLER_PATH && ctx->specialize
-                      ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0)
-                      : 0;
+  const bool classed = kp.sampler == YTHIP_SAMPLER_PATH || kp.sampler == YTHIP_SAMPLER_PATHDIRECT || kp.sampler == YTHIP_SAMPLER_PATHMIS;
+  const int  cls     = classed && ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
   // mode 2 (ythip_params::fastmath = 2): the own-tree kernels of yt_owntree.hip over the tree ythip_build_own_bvh made.
   // Asked for without such a tree it fails loudly; the debug views (diagram / falsecolor) have no such kernel and render exact.
   if (mode == 2 && !count) {
@@ -77,7 +76,10 @@ int launch_trace_any(ythip_ctx* ctx, const KParams& kp, int lp, bool count, int 
     case YTHIP_SAMPLER_PATH:
     case YTHIP_SAMPLER_PATHTEST: rc = ytl::launch_path(l); break;
     case YTHIP_SAMPLER_PATHDIRECT:
-    case YTHIP_SAMPLER_PATHMIS: rc = ytl::launch_nee(l); break;
+    case YTHIP_SAMPLER_PATHMIS:
+      rc = ytl::launch_nee_class(l);  // (the scene classes 1-3 of the wide walk: yt_trace_nee_cls.hip)
+      if (rc) rc = ytl::launch_nee(l);
+      break;
     case YTHIP_SAMPLER_NAIVE:
     case YTHIP_SAMPLER_EYELIGHT:
     case YTHIP_SAMPLER_DIAGRAM:
@@ -135,7 +137,7 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     S.prim_shift    = 8;  // camera rays: bins of 4 neighbouring tiles
     while (((st.nslots >> S.prim_shift) > 16384)) S.prim_shift++;
     S.nprim_bins = std::max(1, (st.nslots + (1 << S.prim_shift) - 1) >> S.prim_shift);
-    const size_t nb = (size_t)(8 << (3 * 5)) + (size_t)S.nprim_bins;  // (room for the finest cell grid: ythip_set_stream_options)
+    const size_t nb = (((size_t)(8 << (3 * 5)) + (size_t)S.nprim_bins + 4095) / 4096 + 1) * 4096;  // (room for the finest cell grid, padded to ks_scan's tiles)
 #define AL(field, count) \
   if ((rc = dalloc(ctx, ctx->state_allocs, &S.field, (size_t)(count)))) return rc;
     AL(ray_a, ns) AL(ray_b, ns) AL(wgt, ns) AL(rad, ns) AL(rng, ns) AL(hit_a, ns) AL(hit_e, ns) AL(key, ns) AL(rank, ns) AL(queue, ns)
