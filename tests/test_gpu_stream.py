@@ -22,7 +22,7 @@ def stream_context(flat):
     """A context on the streaming scheduler.  The test scenes' trees are tiny (< 64 primitives: the library would walk them
     binary and the scheduler, which has the wide walk only, would decline), so the wide walk is forced."""
     ctx = P.gpu_context(flat)
-    ctx.set_traversal(1)
+    ctx.set_traversal("wide")
     ctx.set_scheduler(1)
     return ctx
 
@@ -49,6 +49,27 @@ def test_streamed_path_equals_the_reference(scene):
         ctx.close()
         assert info["ran"] == 1 and info["generations"] >= params.batch, info
         P.assert_identical(want, got, f"{scene} streamed, order {order}, {cells} cell bits")
+
+
+@pytest.mark.parametrize("scene", ["materials", "instances", "cornellbox"])
+def test_groups_and_the_pixel_queue_change_nothing(scene, monkeypatch):
+    """Two chains of generations on two streams, and fewer path slots than pixels fed by the pixel queue (tiles handed out by the
+    previous batch's costs): the same bytes, over several batches (the second one runs in cost order)."""
+    monkeypatch.setenv("YTHIP_STREAM_MIN_SLOTS", "1024")
+    flat = P.SCENES[scene]()
+    params = yt.trace_params(sampler="path", resolution=200, samples=12, batch=4)
+    want = want_state(flat, params)
+    full = None
+    for groups, frac in ((2, 1.0), (1, 0.3), (2, 0.45), (5, 1.0)):
+        ctx = stream_context(flat)
+        ctx.set_stream_shape(groups, frac)
+        got = P.gpu_render(ctx, flat, params)
+        info = ctx.stream_info()
+        ctx.close()
+        assert info["ran"] == 1 and info["groups"] == groups, info
+        full = full or info["path_slots"]
+        assert (info["path_slots"] < full) == (frac < 1), info
+        P.assert_identical(want, got, f"{scene} streamed, {groups} groups, slot fraction {frac}")
 
 
 @pytest.mark.parametrize("kw", [dict(tentfilter=True), dict(nocaustics=True), dict(envhidden=True), dict(bounces=1), dict(bounces=3, clamp=2.0)])
@@ -83,7 +104,7 @@ def test_slices_batches_and_scheduler_changes_in_one_render():
     out = []
     for stream in (1, 0):
         ctx = P.gpu_context(flat)
-        ctx.set_traversal(1)
+        ctx.set_traversal("wide")
         ctx.set_scheduler(stream)
         ctx.make_trace_state(flat, p)
         ctx.trace_samples(p)
@@ -114,7 +135,7 @@ def test_what_the_scheduler_does_not_serve_runs_fused():
         assert ctx.stream_info()["ran"] == 0, kw
         if not kw.get("fastmath"):
             P.assert_identical(want_state(flat, params), got, f"fused fallback {kw}")
-    ctx.set_traversal(0)  # the binary walk: not served either
+    ctx.set_traversal("binary")  # the binary walk: not served either
     params = yt.trace_params(sampler="path", resolution=64, samples=4, batch=4)
     P.assert_identical(want_state(flat, params), P.gpu_render(ctx, flat, params), "fused fallback, binary walk")
     assert ctx.stream_info()["ran"] == 0
@@ -151,5 +172,7 @@ def test_profiling_reports_the_walks_evenness():
     p = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8)
     P.gpu_render(ctx, flat, p)
     info = ctx.stream_info()
+    gens = ctx.stream_generations()
     ctx.close()
     assert info["rays"] > 128 * 128 * 8 and 0 < info["lane_steps"] <= info["wave_steps"], info
+    assert len(gens) == info["generations"] and gens[0] == 128 * 128 and gens.sum() == info["rays"] and (gens > 0).all()

@@ -42,7 +42,7 @@ def timed(ctx, flat, p, launches, prof=True):
 
 def main():
     scenes = (os.environ.get("SCENES") or "cfg2b,configs3,configs4,features1,materials1").split(",")
-    variants = [tuple(int(x) for x in v.split(":")) for v in (os.environ.get("VARIANTS") or "0:4,1:4,2:4").split(",")]
+    variants = [tuple(float(x) for x in v.split(":")) for v in (os.environ.get("VARIANTS") or "0:4,1:4,2:4").split(",")]
     launches = int(os.environ.get("LAUNCHES", "2"))
     for name in scenes:
         w = bench._workloads()[name]
@@ -60,17 +60,19 @@ def main():
         npix = ctx.npixels
         print(f"{name:10s} {res}x{spp}spp fused            {ms0:9.3f} ms {npix * spp / ms0 / 1e3:9.1f} Msamples/s  state {d0}", flush=True)
         for v in variants:
-            order, cells = v[0], v[1]
-            phased = v[2] if len(v) > 2 else -1
+            order, cells = int(v[0]), int(v[1])
+            phased = int(v[2]) if len(v) > 2 else -1
+            groups, frac = (int(v[3]) if len(v) > 3 else 1), (v[4] if len(v) > 4 else 1.0)
             ctx.set_scheduler(1)
             ctx.set_stream_options(order=order, cell_bits=cells, phased=phased)
-            ms = timed(ctx, flat, p, launches)
+            ctx.set_stream_shape(groups, frac)
+            ms = timed(ctx, flat, p, launches)  # (the pixel queue's order comes from the warm-up batches' costs)
             info = ctx.stream_info()
             ctx.make_trace_state(flat, p)
             ctx.trace_samples(p)
             d = digest(ctx)
             even = info["lane_steps"] / max(1, info["wave_steps"])
-            print(f"{name:10s} stream order {order} cells {cells} phased {phased:2d} {ms:9.3f} ms {npix * spp / ms / 1e3:9.1f} Msamples/s  x{ms0 / ms:.3f}  "
+            print(f"{name:10s} stream order {order} cells {cells} phased {phased:2d} groups {info['groups']} slots {info['path_slots'] / 1e3:.0f}k {ms:9.3f} ms {npix * spp / ms / 1e3:9.1f} Msamples/s  x{ms0 / ms:.3f}  "
                   f"state {d} {'OK' if d == d0 else 'DIFFERENT'}  generations {info['generations']} (+{info['launched'] - info['generations']} empty)  "
                   f"rays {info['rays'] / 1e6:.1f} M  walk evenness {even:.3f}", flush=True)
         ctx.close()

@@ -35,19 +35,25 @@
 namespace yt {
 
 constexpr unsigned SKEY_DEAD = 0xffffffffu;  // the slot has no ray for the next generation (its pixel's batch is done)
+constexpr int      YT_STREAM_GEN_LOG = 8192;
+constexpr int      YT_STREAM_MAX_GROUPS = 8;
 constexpr int      PF_DEAD   = 0x80;         // Path flag of such a slot (ray_b.w)
 
 struct DStream {
-  // path state, one record per slot of the tile grid (SoA of 16-B pieces; WgState's layout, in HBM)
+  // path state, one record per PATH SLOT (SoA of 16-B pieces; WgState's layout, in HBM) — arrays shared by the groups
   float4 *    ray_a, *ray_b, *wgt, *rad;
   ulonglong2* rng;
   float4*     hit_a;  // u, v, distance, instance (-1: miss)
   int*        hit_e;  // element
-  // the counting sort
-  unsigned *key, *rank;  // per slot: the next ray's key, its arrival number inside the key's bin
-  unsigned *hist, *offs; // per bin: count (zeroed by ks_scan), exclusive prefix
-  int*      queue;       // slots in key order
-  int*      counts;      // [0] rays queued for the running generation (ks_scan), [1] generations run
+  int*        vslot;  // the slot of the tile grid whose pixel the path slot renders (Path::vslot; the slot itself without the pixel queue)
+  int*        gen0;   // the generation in which that pixel started its batch (tile costs for the queue's order)
+  unsigned *  key, *rank;  // the next ray's sort key, its arrival number inside the key's bin
+  // one GROUP of path slots = one chain of generations on one stream (two groups overlap each other's launch tails)
+  int       slot0, nslots;  // the group's path slots [slot0, slot0 + nslots), a multiple of 64
+  unsigned *hist, *offs;    // per bin: count (zeroed by ks_scan), exclusive prefix
+  int*      queue;          // the group's slots in key order
+  int*      counts;         // [0] rays queued for the running generation (ks_scan), [1] generations run
+  int*      gen_rays;       // profiling: queue length of generation g, for g < YT_STREAM_GEN_LOG (null: off)
   unsigned long long* stats;  // optional (profiling): [0] sum of lane steps, [1] 64 x longest lane per wavefront, [2] wavefronts, [3] rays
   int   nbins;        // bounce-ray bins: 8 octants x 2^(3 cell_bits) cells
   int   nprim_bins;   // camera-ray bins (groups of neighbouring tiles), after the bounce-ray bins
@@ -67,7 +73,7 @@ YT_FN unsigned spread3(unsigned x) {  // 10 bits -> every third bit
 
 // The sort key of a path's next ray.  Camera rays keep their tile neighbourhood (they ARE coherent); everything else goes by
 // direction octant and by the Morton code of the origin's cell.
-YT_FN unsigned stream_key(const DStream& S, int slot, vec3f o, vec3f d, bool primary) {
+YT_FN unsigned stream_key(const DStream& S, int slot, vec3f o, vec3f d, bool primary) {  // slot: the PIXEL's (Path::vslot)
   if (S.order == 2) return (unsigned)(slot >> 6) % (unsigned)(S.nbins + S.nprim_bins);  // (wraps: bins are then a few tiles far apart)
   if (primary) return (unsigned)S.nbins + (unsigned)(slot >> S.prim_shift) % (unsigned)S.nprim_bins;
   const int   top = (1 << S.cell_bits) - 1;
@@ -84,8 +90,8 @@ YT_FN void stream_load_rest(const DState& st, const DStream& S, int slot, Path& 
   float4 w = S.wgt[slot], r = S.rad[slot];
   auto   g = S.rng[slot];
   int    pi, pj;
-  P.vslot         = slot;
-  P.pix           = slot_pixel(st, slot, pi, pj);
+  P.vslot         = S.vslot[slot];
+  P.pix           = slot_pixel(st, P.vslot, pi, pj);
   P.bounce        = __float_as_int(rb.z);
   int fw          = __float_as_int(rb.w);
   P.flags         = fw & 0xff;
@@ -102,6 +108,7 @@ YT_FN void stream_store(const DStream& S, int slot, const Path& P) {
   S.ray_b[slot] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
   S.wgt[slot]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
   S.rad[slot]   = {P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)};
+  S.vslot[slot] = P.vslot;
 }
 
 // The slot's entry in the next generation's queue: key + histogram count; the returning atomic IS the rank inside the bin.
@@ -110,7 +117,7 @@ YT_FN void stream_store(const DStream& S, int slot, const Path& P) {
 YT_FN void stream_emit(const DStream& S, int slot, const Path& P, int cls) {
   unsigned key = SKEY_DEAD, rank = 0;
   const bool   live = cls != OUT_DEAD;
-  if (live) key = stream_key(S, slot, P.o, P.d, cls == OUT_PRIMARY);
+  if (live) key = stream_key(S, P.vslot, P.o, P.d, cls == OUT_PRIMARY);
   // One atomic per DISTINCT key of the wavefront, not per lane (neighbouring pixels' rays share octants and cells: 10-20
   // distinct keys per 64 lanes; a per-lane returning atomic was the slowest part of the first version).  The lanes are
   // grouped key by key with ballots — no memory traffic —, every group's first lane then fetches the group's base with ONE
@@ -139,21 +146,43 @@ YT_FN void stream_emit(const DStream& S, int slot, const Path& P, int cls) {
 // head of the batch: every pixel's first camera ray (k_trace's prologue)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(YT_BLOCK) ks_init(DScene sc, DState st, KParams kp, DStream S) {
-  const int slot = (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
-  int       i, j;
-  const int pix = slot_pixel(st, slot, i, j);
-  int       cls = OUT_DEAD;
-  Path      P;
-  P.o = {0, 0, 0}, P.d = {0, 0, 0};
+  const int slot = S.slot0 + (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
+  // the pixel of the path slot: the slot's own (every pixel in flight), or — with the pixel queue (DState::pool_next: fewer path
+  // slots than pixels) — entry `slot` of the queue: the tiles in launch order (most expensive first), 64 entries each; the queue's
+  // head starts behind these statically assigned entries (enqueue_stream)
+  int  vs = slot, i, j;
+  Path P;
+  P.o = {0, 0, 0}, P.d = {0, 0, 0}, P.vslot = slot;
+  int pix = -1;
+  if (st.pool_next) {
+    int q = slot;
+    while (q < st.pool_total) {
+      int tile = q / YT_BLOCK;
+      if (st.tile_perm) tile = st.tile_perm[tile];
+      vs  = tile * YT_BLOCK + (q & (YT_BLOCK - 1));
+      pix = slot_pixel(st, vs, i, j);
+      if (pix >= 0) break;
+      // a slot of an edge tile outside the slice: the next entry of the queue (the lanes that are here together with one atomic)
+      const unsigned long long here = __ballot(1);
+      const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)here) - 1;
+      int       base = 0;
+      if (lane == leader) base = atomicAdd(st.pool_next, __popcll(here));
+      q = __shfl(base, leader) + __popcll(here & ((1ull << lane) - 1ull));
+    }
+  } else {
+    pix = slot_pixel(st, vs, i, j);
+  }
+  int cls = OUT_DEAD;
   if (pix >= 0) {
     auto r  = st.rngs[pix];
     P.rng   = {r.x, r.y};
     P.sidx  = 0;
     P.pix   = pix;
-    P.vslot = slot;
+    P.vslot = vs;
     start_sample(sc, st, kp, slot, P);
     stream_store(S, slot, P);
-    cls = OUT_PRIMARY;
+    S.gen0[slot] = 0;
+    cls          = OUT_PRIMARY;
   } else {
     S.ray_b[slot] = {0, 0, 0, __int_as_float(PF_DEAD)};
   }
@@ -206,15 +235,20 @@ __global__ void __launch_bounds__(YT_SCAN_THREADS) ks_scan(DStream S) {
   if (tid == 0) {
     const unsigned total = s_carry;
     S.counts[0]          = (int)total;
-    if (total) S.counts[1] += 1;
+    if (total) {
+      const int g = S.counts[1];
+      if (S.gen_rays && g < YT_STREAM_GEN_LOG) S.gen_rays[g] = (int)total;
+      S.counts[1] = g + 1;
+    }
   }
 }
 
-__global__ void __launch_bounds__(256) ks_scatter(DStream S, int nslots) {
+__global__ void __launch_bounds__(256) ks_scatter(DStream S) {
   if (S.counts[0] == 0) return;
-  const int slot = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  if (slot >= nslots) return;
-  const unsigned key = S.key[slot];
+  const int k = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (k >= S.nslots) return;
+  const int      slot = S.slot0 + k;
+  const unsigned key  = S.key[slot];
   if (key != SKEY_DEAD) S.queue[S.offs[key] + S.rank[slot]] = slot;
 }
 
@@ -279,7 +313,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DSce
   constexpr bool PEEK  = SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST || SAMPLER == YTHIP_SAMPLER_NAIVE;
   __shared__ StackEntry s_stack[LP == LP_DEFER ? YT_LDS_DEPTH : 1][YT_BLOCK];
   if (S.counts[0] == 0) return;  // nothing was queued for this generation: the batch is done
-  const int  slot    = (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
+  const int  slot    = S.slot0 + (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
   const bool stopped = stop_requested(st.stop, st.stop_gen) || (blockIdx.x == 0 && relay_stop(st));
   const float4 rb = S.ray_b[slot];
   const bool   live = !(__float_as_int(rb.w) & PF_DEAD);
@@ -310,8 +344,16 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DSce
         step = step_tail(P);
       }
     }
+    const int pixel_before = P.vslot;
     cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
     if (cls == OUT_DEAD) P.flags |= PF_DEAD;
+    if (st.tile_cost && (cls == OUT_DEAD || P.vslot != pixel_before)) {
+      // the pixel has had its batch: the generations it took go to its tile's cost — the next batch's queue hands the tiles out
+      // most expensive first (yt_order.hip), so that the batch does not end in a long tail of a few slow pixels
+      const int gen = S.counts[1];
+      atomicAdd(&st.tile_cost[pixel_before / YT_BLOCK], (unsigned)(gen - S.gen0[slot] + 1));
+      S.gen0[slot] = gen + 1;
+    }
     stream_store(S, slot, P);
   }
   stream_emit(S, slot, P, cls);

@@ -17,7 +17,7 @@ struct StreamLaunch {
 };
 
 bool stream_supported(const StreamLaunch& l);
-void stream_begin(const StreamLaunch& l);                   // ks_init + the first scan
-void stream_generations(const StreamLaunch& l, int count);  // count x (scatter, extend, shade, scan)
+void stream_begin(const StreamLaunch& l);       // ks_init + the first scan of the group l.ss, on l.stream
+void stream_generation(const StreamLaunch& l);  // scatter, extend, shade, scan
 
 }  // namespace ytl

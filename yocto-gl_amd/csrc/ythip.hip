@@ -127,10 +127,17 @@ void harvest_events(ythip_ctx* ctx) {
 // read-back of the next queue's length says zero.  The first `batch` generations are enqueued blind (a sample is at least
 // one generation), the rest in chunks; a chunk's surplus generations return at once on the device.  Blocks until the batch
 // is done (the queue length has to come home), watching the caller's stop flag meanwhile.
+//   * groups (YTHIP_STREAM_GROUPS, default 1): the path slots in 2 halves, each a chain of generations of its own on its own
+//     stream — one group's shade / sort launches fill the machine while the other's extend launch drains;
+//   * the pixel queue (YTHIP_STREAM_SLOTS = fraction of the tile grid's slots, default 1 = every pixel in flight): fewer path
+//     slots than pixels; a slot whose pixel has had its batch takes the next pixel of a queue that hands the tiles out most
+//     expensive first (the tile costs of the previous batch: generations per pixel) — resolve_step's pixel pool, so that a
+//     batch does not end in a long tail of generations with a few slow pixels left.
 int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp, int lp, int cls, const volatile int32_t* stop) {
   auto& st = ctx->st;
   auto& S  = ctx->ss;
   int   rc;
+  constexpr int MAX_GROUPS = YT_STREAM_MAX_GROUPS;
   if (ctx->stream_slots != st.nslots) {
     const size_t ns = (size_t)st.nslots;
     S               = DStream{};
@@ -140,14 +147,15 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     const size_t nb = (((size_t)(8 << (3 * 5)) + (size_t)S.nprim_bins + 4095) / 4096 + 1) * 4096;  // (room for the finest cell grid, padded to ks_scan's tiles)
 #define AL(field, count) \
   if ((rc = dalloc(ctx, ctx->state_allocs, &S.field, (size_t)(count)))) return rc;
-    AL(ray_a, ns) AL(ray_b, ns) AL(wgt, ns) AL(rad, ns) AL(rng, ns) AL(hit_a, ns) AL(hit_e, ns) AL(key, ns) AL(rank, ns) AL(queue, ns)
-    AL(hist, nb) AL(offs, nb) AL(counts, 16) AL(stats, 8 * 64)
+    AL(ray_a, ns) AL(ray_b, ns) AL(wgt, ns) AL(rad, ns) AL(rng, ns) AL(hit_a, ns) AL(hit_e, ns) AL(vslot, ns) AL(gen0, ns) AL(key, ns) AL(rank, ns)
+    AL(queue, ns) AL(hist, MAX_GROUPS * nb) AL(offs, MAX_GROUPS * nb) AL(counts, MAX_GROUPS * 16) AL(stats, MAX_GROUPS * 8 * 64)
+    AL(gen_rays, MAX_GROUPS * YT_STREAM_GEN_LOG)
 #undef AL
-    HIPCHECK(ctx, hipMemsetAsync(S.hist, 0, nb * sizeof(unsigned), ctx->stream));
-    HIPCHECK(ctx, hipMemsetAsync(S.stats, 0, 8 * 64 * sizeof(unsigned long long), ctx->stream));
-    ctx->stream_slots = st.nslots;
+    HIPCHECK(ctx, hipMemsetAsync(S.hist, 0, MAX_GROUPS * nb * sizeof(unsigned), ctx->stream));
+    ctx->stream_bins_cap = (int)nb;
+    ctx->stream_slots    = st.nslots;
   }
-  if (!ctx->stream_counts_host) HIPCHECK(ctx, hipHostMalloc((void**)&ctx->stream_counts_host, 64, hipHostMallocDefault));
+  if (!ctx->stream_counts_host) HIPCHECK(ctx, hipHostMalloc((void**)&ctx->stream_counts_host, MAX_GROUPS * 16 * sizeof(int), hipHostMallocDefault));
   S.order     = ctx->stream_order;
   S.cell_bits = std::min(std::max(ctx->stream_cell_bits, 1), 5);
   S.nbins     = 8 << (3 * S.cell_bits);
@@ -157,24 +165,83 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
   auto        scale = [&](float a, float b) { return (b > a && std::isfinite(b - a)) ? cells / (b - a) : 0.0f; };
   S.cell_lo    = lo;
   S.cell_scale = {scale(lo.x, hi.x), scale(lo.y, hi.y), scale(lo.z, hi.z)};
-  DStream run = S;
-  if (!(ctx->prof_mode & 1)) run.stats = nullptr;
-  else HIPCHECK(ctx, hipMemsetAsync(S.stats, 0, 8 * 64 * sizeof(unsigned long long), ctx->stream));
-  HIPCHECK(ctx, hipMemsetAsync(S.counts, 0, 16 * sizeof(int), ctx->stream));
+  // path slots: all of the tile grid's, or a fraction of them fed by the pixel queue (at least 256 k where the grid has them)
+  int  pslots = st.nslots;
+  if (ctx->stream_slot_frac > 0 && ctx->stream_slot_frac < 1) {
+    pslots = (int)((double)st.nslots * ctx->stream_slot_frac);
+    pslots = std::max(pslots, std::min(st.nslots, ctx->stream_min_slots));
+    pslots = std::min(st.nslots, (pslots + 127) / 128 * 128);
+  }
+  const bool pool   = pslots < st.nslots;
+  int groups = std::min(std::max(ctx->stream_groups, 1), MAX_GROUPS);
+  while (groups > 1 && pslots / groups < ctx->stream_min_slots / 4) groups--;  // (a chain of generations wants a few thousand wavefronts per launch)
+  st.tile_perm = nullptr, st.tile_cost = nullptr, st.pool_next = nullptr, st.pool_total = 0;
+  if (ctx->d_tile_cost && ctx->lpt > 0) {  // tile costs: generations per pixel, summed per tile (ks_shade) — the next batch's queue order
+    if (pool && ctx->have_tile_costs) {
+      if (ctx->lpt_age % 16 == 0)
+        HIPCHECK(ctx, ytorder::order_by_cost(ctx->stream, ctx->d_tile_cost, st.nblocks, ctx->d_tile_perm, ctx->d_sort_temp, ctx->sort_temp_bytes));
+      ctx->lpt_age++;
+      st.tile_perm = ctx->d_tile_perm;
+    }
+    HIPCHECK(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)st.nblocks * sizeof(unsigned), ctx->stream));
+    st.tile_cost = ctx->d_tile_cost;
+  }
+  if (pool) {
+    if (!ctx->d_pool_next) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_pool_next, 64));
+    st.pool_next = ctx->d_pool_next, st.pool_total = st.nblocks * YT_BLOCK;
+    HIPCHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_pool_next, pslots, 16, ctx->stream));
+  }
+  const bool prof = (ctx->prof_mode & 1) != 0;
+  if (prof) HIPCHECK(ctx, hipMemsetAsync(S.stats, 0, MAX_GROUPS * 8 * 64 * sizeof(unsigned long long), ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(S.counts, 0, MAX_GROUPS * 16 * sizeof(int), ctx->stream));
   const bool phased = ctx->stream_phased >= 0 ? ctx->stream_phased != 0 : (cls == 1 && lp == LP_DEFER);
-  ytl::StreamLaunch l = {ctx->stream, &ctx->ds, &ctx->st, &kp, &run, lp, cls, phased};
+  DStream           G[MAX_GROUPS];
+  ytl::StreamLaunch L[MAX_GROUPS];
+  hipStream_t       streams[MAX_GROUPS];
+  streams[0] = ctx->stream;
+  for (int g = 1; g < groups; g++) {
+    if (!ctx->stream_side[g]) HIPCHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_side[g], hipStreamNonBlocking));
+    if (!ctx->stream_ev[g]) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->stream_ev[g], hipEventDisableTiming));
+    streams[g] = ctx->stream_side[g];
+  }
+  if (groups > 1 && !ctx->stream_ev[0]) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->stream_ev[0], hipEventDisableTiming));
+  // the path slots in `groups` runs of whole wavefronts
+  const int per = ((pslots / 64) + groups - 1) / groups * 64;
+  for (int g = 0; g < groups; g++) {
+    G[g]          = S;
+    G[g].slot0    = std::min(g * per, pslots);
+    G[g].nslots   = std::min((g + 1) * per, pslots) - G[g].slot0;
+    G[g].hist     = S.hist + (size_t)g * ctx->stream_bins_cap;
+    G[g].offs     = S.offs + (size_t)g * ctx->stream_bins_cap;
+    G[g].queue    = S.queue + G[g].slot0;
+    G[g].counts   = S.counts + 16 * g;
+    G[g].stats    = prof ? S.stats + 8 * 64 * g : nullptr;
+    G[g].gen_rays = prof ? S.gen_rays + YT_STREAM_GEN_LOG * g : nullptr;
+    L[g]          = {streams[g], &ctx->ds, &ctx->st, &kp, &G[g], lp, cls, phased};
+  }
   ctx->stream_cancelled = false;
   int launched = 0;
   {
     EvScope ev(ctx, 0);
-    ytl::stream_begin(l);
+    if (groups > 1) {  // the side streams start behind everything the main stream has been given so far
+      HIPCHECK(ctx, hipEventRecord(ctx->stream_ev[0], ctx->stream));
+      for (int g = 1; g < groups; g++) HIPCHECK(ctx, hipStreamWaitEvent(streams[g], ctx->stream_ev[0], 0));
+    }
+    for (int g = 0; g < groups; g++) ytl::stream_begin(L[g]);
     int chunk = std::max(1, params->batch);
     if (!ctx->done_event) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->done_event, hipEventDisableTiming));
     while (true) {
-      ytl::stream_generations(l, chunk);
+      for (int k = 0; k < chunk; k++)
+        for (int g = 0; g < groups; g++) ytl::stream_generation(L[g]);
       launched += chunk;
-      HIPCHECK(ctx, hipMemcpyAsync(ctx->stream_counts_host, S.counts, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      for (int g = 1; g < groups; g++) {  // the main stream (and with it the read-back, and whatever the caller enqueues next) waits for the side streams
+        HIPCHECK(ctx, hipEventRecord(ctx->stream_ev[g], streams[g]));
+        HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->stream_ev[g], 0));
+      }
+      HIPCHECK(ctx, hipMemcpyAsync(ctx->stream_counts_host, S.counts, MAX_GROUPS * 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHECK(ctx, hipEventRecord(ctx->done_event, ctx->stream));
+      // (and the side streams' next chunk behind the read-back: the chains stay in step chunk by chunk)
+      for (int g = 1; g < groups; g++) HIPCHECK(ctx, hipStreamWaitEvent(streams[g], ctx->done_event, 0));
       if (stop) {
         while (hipEventQuery(ctx->done_event) == hipErrorNotReady) {
           if (*stop && !ctx->stream_cancelled) {
@@ -185,26 +252,32 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
         }
       }
       HIPCHECK(ctx, hipEventSynchronize(ctx->done_event));
-      if (ctx->stream_counts_host[0] == 0) break;
+      bool any = false;
+      for (int g = 0; g < groups; g++) any = any || ctx->stream_counts_host[16 * g] != 0;
+      if (!any) break;
       // what is left: the live paths' remaining bounces — a few generations at a time (each surplus one costs four empty launches)
       chunk = std::max(4, std::min(chunk, 16));
     }
   }
   HIPCHECK(ctx, hipGetLastError());
+  if (st.tile_cost) ctx->have_tile_costs = true;
   ctx->stream_info             = {};
   ctx->stream_info.ran         = 1;
-  ctx->stream_info.generations = ctx->stream_counts_host[1];
+  for (int g = 0; g < groups; g++) ctx->stream_info.generations = std::max(ctx->stream_info.generations, ctx->stream_counts_host[16 * g + 1]);
   ctx->stream_info.launched    = launched;
   ctx->stream_info.bins        = S.nbins + S.nprim_bins;
-  if (ctx->prof_mode & 1) {
-    std::vector<unsigned long long> h(8 * 64);
+  ctx->stream_info.groups      = groups;
+  ctx->stream_info.path_slots  = pslots;
+  if (prof) {
+    std::vector<unsigned long long> h(MAX_GROUPS * 8 * 64);
     HIPCHECK(ctx, hipMemcpy(h.data(), S.stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int b = 0; b < 64; b++) {
+    for (int b = 0; b < MAX_GROUPS * 64; b++) {
       ctx->stream_info.lane_steps += (int64_t)h[8 * b + 0];
       ctx->stream_info.wave_steps += (int64_t)h[8 * b + 1];
       ctx->stream_info.rays += (int64_t)h[8 * b + 3];
     }
   }
+  st.tile_perm = nullptr, st.tile_cost = nullptr, st.pool_next = nullptr, st.pool_total = 0;
   return YTHIP_OK;
 }
 
@@ -450,6 +523,9 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_STREAM_ORDER")) ctx->stream_order = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_PHASED")) ctx->stream_phased = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_BATCH")) ctx->stream_min_batch = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_STREAM_GROUPS")) ctx->stream_groups = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_STREAM_MIN_SLOTS")) ctx->stream_min_slots = std::max(128, std::atoi(e));
+  if (const char* e = std::getenv("YTHIP_STREAM_SLOTS")) ctx->stream_slot_frac = std::atof(e);
   {
     hipDeviceProp_t prop;
     ctx->pool_blocks = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount * 16 : 4096;
@@ -485,6 +561,11 @@ void ythip_destroy(ythip_ctx* ctx) {
   }
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->stop_host) (void)hipHostFree(ctx->stop_host);
+  if (ctx->stream_counts_host) (void)hipHostFree(ctx->stream_counts_host);
+  for (auto q : ctx->stream_side)
+    if (q) (void)hipStreamDestroy(q);
+  for (auto e : ctx->stream_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->d_stop) (void)hipFree(ctx->d_stop);
   if (ctx->d_pool_next) (void)hipFree(ctx->d_pool_next);
   for (auto e : ctx->pool_ev)
@@ -1571,6 +1652,22 @@ int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phase
   if (order >= 0) ctx->stream_order = order;
   if (cell_bits > 0) ctx->stream_cell_bits = cell_bits;
   if (phased >= 0) ctx->stream_phased = phased;
+  return YTHIP_OK;
+}
+int ythip_set_stream_shape(ythip_ctx* ctx, int groups, float slot_fraction) {
+  if (!ctx || groups > YT_STREAM_MAX_GROUPS || groups == 0 || slot_fraction > 1) return fail(ctx, YTHIP_ERR_INVALID, "stream shape: groups 1..%d, slot_fraction (0, 1]", YT_STREAM_MAX_GROUPS);
+  if (groups > 0) ctx->stream_groups = groups;
+  if (slot_fraction > 0) ctx->stream_slot_frac = slot_fraction;
+  return YTHIP_OK;
+}
+int ythip_get_stream_generations(ythip_ctx* ctx, int32_t* rays, int32_t capacity, int32_t* written) {
+  if (!ctx || !rays || capacity < 0 || !written) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
+  *written = 0;
+  if (!ctx->stream_slots || !ctx->stream_info.ran) return fail(ctx, YTHIP_ERR_STATE, "no streamed batch to report");
+  const int n = std::min({capacity, (int)ctx->stream_info.generations, (int)YT_STREAM_GEN_LOG});
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  if (n > 0) HIPCHECK(ctx, hipMemcpy(rays, ctx->ss.gen_rays, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  *written = n;
   return YTHIP_OK;
 }
 int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info) {

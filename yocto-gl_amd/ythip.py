@@ -222,7 +222,7 @@ class CPoolInfo(C.Structure):
 
 class CStreamInfo(C.Structure):
     _fields_ = [("ran", C.c_int32), ("generations", C.c_int32), ("launched", C.c_int32), ("bins", C.c_int32),
-                ("rays", C.c_int64), ("lane_steps", C.c_int64), ("wave_steps", C.c_int64)]
+                ("groups", C.c_int32), ("path_slots", C.c_int32), ("rays", C.c_int64), ("lane_steps", C.c_int64), ("wave_steps", C.c_int64)]
 
 
 class CBuildInfo(C.Structure):
@@ -516,6 +516,8 @@ _SIGNATURES = {
     "ythip_set_scheduler": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_get_stream_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_set_stream_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "ythip_set_stream_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "ythip_get_stream_generations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "ythip_last_launch_fastmath": (C.c_int, [C.c_void_p]),
     "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "ythip_ply_read": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9),
@@ -773,6 +775,16 @@ class Context:
         """The sort of the streaming scheduler (ythip_set_stream_options; -1 keeps): order 0 octant major / 1 cell major /
         2 unsorted, cell_bits 1..5, phased 0 / 1."""
         self._check(self.lib.ythip_set_stream_options(self.h, int(order), int(cell_bits), int(phased)), "set_stream_options")
+
+    def set_stream_shape(self, groups=0, slot_fraction=0.0):
+        """groups 1 | 2 chains of generations; slot_fraction (0, 1] paths in flight per pixel of the frame (ythip_set_stream_shape)."""
+        self._check(self.lib.ythip_set_stream_shape(self.h, int(groups), float(slot_fraction)), "set_stream_shape")
+
+    def stream_generations(self):
+        """Queue length of every generation of the last streamed batch (profiling mode 1 during the batch)."""
+        out, n = np.zeros(8192, "i4"), C.c_int32(0)
+        self._check(self.lib.ythip_get_stream_generations(self.h, _ptr(out), len(out), C.byref(n)), "get_stream_generations")
+        return out[:n.value]
 
     def stream_info(self):
         info = CStreamInfo()
