@@ -20,13 +20,13 @@ for u in yt_gpubuild yt_multi yt_order yt_io yt_sceneio; do
   fi
 done
 pids=""
-for u in ythip yt_bake yt_trace_path yt_trace_nee yt_trace_misc yt_fast yt_owntree; do
+for u in ythip yt_bake yt_trace_path yt_trace_nee yt_trace_nee_cls yt_trace_misc yt_fast yt_owntree yt_stream; do
   $HIPCC $FLAGS -DYT_DEV_ONLY_PATH "$@" -c -o build/dev/${u}_$name.o $C/$u.hip & pids="$pids $!"
 done
 for p in $pids; do wait $p; done
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o build/dev/libythip_$name.so build/dev/ythip_$name.o build/dev/yt_trace_path_$name.o \
-  build/dev/yt_trace_nee_$name.o build/dev/yt_trace_misc_$name.o build/dev/yt_bake_$name.o build/dev/yt_gpubuild.o build/dev/yt_multi.o \
+  build/dev/yt_trace_nee_$name.o build/dev/yt_trace_nee_cls_$name.o build/dev/yt_stream_$name.o build/dev/yt_trace_misc_$name.o build/dev/yt_bake_$name.o build/dev/yt_gpubuild.o build/dev/yt_multi.o \
   build/dev/yt_order.o build/dev/yt_io.o build/dev/yt_sceneio.o build/dev/yt_fast_$name.o build/dev/yt_owntree_$name.o -ldl -lz
-rm -f build/dev/ythip_$name.o build/dev/yt_trace_*_$name.o build/dev/yt_bake_$name.o build/dev/yt_fast_$name.o build/dev/yt_owntree_$name.o
+rm -f build/dev/ythip_$name.o build/dev/yt_stream_$name.o build/dev/yt_trace_*_$name.o build/dev/yt_bake_$name.o build/dev/yt_fast_$name.o build/dev/yt_owntree_$name.o
 echo built build/dev/libythip_$name.so

@@ -85,12 +85,46 @@ YT_FN unsigned stream_key(const DStream& S, int slot, vec3f o, vec3f d, bool pri
   return S.order == 0 ? (octant << (3 * S.cell_bits)) | cell : (cell << 3) | octant;
 }
 
+// -DYT_STREAM_NT (development builds): the path state through non-temporal loads / stores — touched once per generation by
+// one wavefront each, 200 MB per generation that would otherwise wash the tree out of the L2s
+#ifdef YT_STREAM_NT
+template <typename T>
+YT_FN T sld(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+YT_FN void sst(T* p, T v) { __builtin_nontemporal_store(v, p); }
+YT_FN float4 sld(const float4* p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+  return {v.x, v.y, v.z, v.w};
+}
+YT_FN void sst(float4* p, float4 a) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 v = {a.x, a.y, a.z, a.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4*>(p));
+}
+YT_FN ulonglong2 sld(const ulonglong2* p) {
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p));
+  return {v.x, v.y};
+}
+YT_FN void sst(ulonglong2* p, ulonglong2 a) {
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  u2 v = {a.x, a.y};
+  __builtin_nontemporal_store(v, reinterpret_cast<u2*>(p));
+}
+#else
+template <typename T>
+YT_FN T sld(const T* p) { return *p; }
+template <typename T>
+YT_FN void sst(T* p, T v) { *p = v; }
+#endif
+
 // a live slot's state <-> registers (load_path_rest / store_path of yt_kernels.h on the HBM arrays)
 YT_FN void stream_load_rest(const DState& st, const DStream& S, int slot, Path& P, float4 rb) {
-  float4 w = S.wgt[slot], r = S.rad[slot];
-  auto   g = S.rng[slot];
+  float4 w = sld(S.wgt + slot), r = sld(S.rad + slot);
+  auto   g = sld(S.rng + slot);
   int    pi, pj;
-  P.vslot         = S.vslot[slot];
+  P.vslot         = sld(S.vslot + slot);
   P.pix           = slot_pixel(st, P.vslot, pi, pj);
   P.bounce        = __float_as_int(rb.z);
   int fw          = __float_as_int(rb.w);
@@ -103,12 +137,12 @@ YT_FN void stream_load_rest(const DState& st, const DStream& S, int slot, Path& 
   P.rng           = {g.x, g.y};
 }
 YT_FN void stream_store(const DStream& S, int slot, const Path& P) {
-  S.rng[slot]   = {P.rng.state, P.rng.inc};
-  S.ray_a[slot] = {P.o.x, P.o.y, P.o.z, P.d.x};
-  S.ray_b[slot] = {P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))};
-  S.wgt[slot]   = {P.weight.x, P.weight.y, P.weight.z, P.max_roughness};
-  S.rad[slot]   = {P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)};
-  S.vslot[slot] = P.vslot;
+  sst(S.rng + slot, ulonglong2{P.rng.state, P.rng.inc});
+  sst(S.ray_a + slot, float4{P.o.x, P.o.y, P.o.z, P.d.x});
+  sst(S.ray_b + slot, float4{P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))});
+  sst(S.wgt + slot, float4{P.weight.x, P.weight.y, P.weight.z, P.max_roughness});
+  sst(S.rad + slot, float4{P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)});
+  sst(S.vslot + slot, P.vslot);
 }
 
 // The slot's entry in the next generation's queue: key + histogram count; the returning atomic IS the rank inside the bin.
@@ -137,8 +171,8 @@ YT_FN void stream_emit(const DStream& S, int slot, const Path& P, int cls) {
   if (live && leader == lane) base = atomicAdd(&S.hist[key], count);
   base = (unsigned)__shfl((int)base, leader);
   rank = base + prefix;
-  S.key[slot]  = key;
-  S.rank[slot] = rank;
+  sst(S.key + slot, key);
+  sst(S.rank + slot, rank);
 }
 
 #ifdef YT_STREAM_KERNELS  // the plain (non-template) kernels are compiled by ONE unit: yt_stream.hip defines this
@@ -272,11 +306,11 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_EXTEND_WAVES) ks_extend(DS
     YT_STACK_INIT(stack, s_stack);
     Counters     cnt  = {0, 0, 0, 0, 0, 0, 0, 0};
     const int    slot = S.queue[i];
-    const float4 ra = S.ray_a[slot], rb = S.ray_b[slot];
+    const float4 ra = sld(S.ray_a + slot), rb = sld(S.ray_b + slot);
     const ray3f  ray = make_ray({ra.x, ra.y, ra.z}, {ra.w, rb.x, rb.y});
     const Hit    h   = traverse_any<false, WIDE, TRI, PHASED>(sc, ray, -1, false, stack, cnt);
-    S.hit_a[slot]    = {h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)};
-    S.hit_e[slot]    = h.element;
+    sst(S.hit_a + slot, float4{h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)});
+    sst(S.hit_e + slot, h.element);
     steps            = cnt.steps + 1;
   }
   if (S.stats) {  // profiling: how even are the walks of a wavefront?
@@ -315,17 +349,17 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DSce
   if (S.counts[0] == 0) return;  // nothing was queued for this generation: the batch is done
   const int  slot    = S.slot0 + (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
   const bool stopped = stop_requested(st.stop, st.stop_gen) || (blockIdx.x == 0 && relay_stop(st));
-  const float4 rb = S.ray_b[slot];
+  const float4 rb = sld(S.ray_b + slot);
   const bool   live = !(__float_as_int(rb.w) & PF_DEAD);
   int  cls = OUT_DEAD;
   Path P;
   P.o = {0, 0, 0}, P.d = {0, 0, 0};
   if (live) {
-    const float4 ra = S.ray_a[slot], ha = S.hit_a[slot];
+    const float4 ra = sld(S.ray_a + slot), ha = sld(S.hit_a + slot);
     P.o             = {ra.x, ra.y, ra.z};
     P.d             = {ra.w, rb.x, rb.y};
     const int inst  = __float_as_int(ha.w);
-    P.isec          = {inst, S.hit_e[slot], ha.x, ha.y, ha.z, inst >= 0};
+    P.isec          = {inst, sld(S.hit_e + slot), ha.x, ha.y, ha.z, inst >= 0};
     if (inst < 0) P.isec = {-1, -1, 0, 0, 0, false};
     stream_load_rest(st, S, slot, P, rb);
     const int max_bounces = max_bounces_of<SAMPLER>(kp);
