@@ -605,8 +605,8 @@ typedef struct ythip_stream_info {
   int32_t generations;  /* generations that had rays queued */
   int32_t launched;     /* generations enqueued (the surplus returned at once) */
   int32_t bins;         /* bins of the counting sort (bounce-ray + camera-ray) */
-  int32_t groups;       /* chains of generations that ran side by side (1 or 2) */
-  int32_t path_slots;   /* paths in flight (= the tile grid's slots unless the pixel queue fed fewer) */
+  int32_t groups;       /* chains of generations that ran side by side */
+  int32_t path_slots;   /* paths in flight: one per slot of the slice's tile grid */
   int64_t rays;         /* profiling (ythip_set_profiling bit 0) only: rays walked by ks_extend ... */
   int64_t lane_steps;   /* ... the traversal steps they took ... */
   int64_t wave_steps;   /* ... and 64 x the longest lane of every wavefront: lane_steps / wave_steps = how even the walks are */
@@ -618,12 +618,10 @@ int ythip_set_scheduler(ythip_ctx* ctx, int mode);
  * phased 0 / 1 = ks_extend's majority-phase scene walk off / on (default: as the fused kernel — on for matte scenes with
  * area lights).  env YTHIP_STREAM_ORDER / _CELLS / _PHASED. */
 int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased);
-/* The shape of a streamed batch (0 / negative keeps): groups 1 | 2 = the path slots as one chain of generations or as two halves on
- * two streams (one half's shade / sort launches run while the other's extend launch drains); slot_fraction in (0, 1] = paths in
- * flight as a fraction of the frame's pixels — below 1 a slot whose pixel has had its batch takes the next pixel of a queue that
- * hands the tiles out most expensive first (costs: the previous batch's generations per pixel), so that a batch does not end
- * in a tail of nearly empty generations.  env YTHIP_STREAM_GROUPS / YTHIP_STREAM_SLOTS.  Results never depend on either. */
-int ythip_set_stream_shape(ythip_ctx* ctx, int groups, float slot_fraction);
+/* groups 1..8 (default 2): the pixels of the slice as that many runs, each a chain of generations of its own on its own stream —
+ * one run's shade / sort launches fill the machine while another's extend launch drains (frames too small for it run as
+ * fewer).  env YTHIP_STREAM_GROUPS.  Results never depend on it. */
+int ythip_set_stream_groups(ythip_ctx* ctx, int groups);
 int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info);
 /* Profiling (ythip_set_profiling bit 0 during the batch): the queue length of every generation of the last streamed batch,
  * up to `capacity` (and 8192) entries; *written = how many. */

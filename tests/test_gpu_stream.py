@@ -52,24 +52,20 @@ def test_streamed_path_equals_the_reference(scene):
 
 
 @pytest.mark.parametrize("scene", ["materials", "instances", "cornellbox"])
-def test_groups_and_the_pixel_queue_change_nothing(scene, monkeypatch):
-    """Two chains of generations on two streams, and fewer path slots than pixels fed by the pixel queue (tiles handed out by the
-    previous batch's costs): the same bytes, over several batches (the second one runs in cost order)."""
+def test_groups_change_nothing(scene, monkeypatch):
+    """One, two, five chains of generations on as many streams: the same bytes, over several batches."""
     monkeypatch.setenv("YTHIP_STREAM_MIN_SLOTS", "1024")
     flat = P.SCENES[scene]()
     params = yt.trace_params(sampler="path", resolution=200, samples=12, batch=4)
     want = want_state(flat, params)
-    full = None
-    for groups, frac in ((2, 1.0), (1, 0.3), (2, 0.45), (5, 1.0)):
+    for groups in (1, 2, 5):
         ctx = stream_context(flat)
-        ctx.set_stream_shape(groups, frac)
+        ctx.set_stream_groups(groups)
         got = P.gpu_render(ctx, flat, params)
         info = ctx.stream_info()
         ctx.close()
         assert info["ran"] == 1 and info["groups"] == groups, info
-        full = full or info["path_slots"]
-        assert (info["path_slots"] < full) == (frac < 1), info
-        P.assert_identical(want, got, f"{scene} streamed, {groups} groups, slot fraction {frac}")
+        P.assert_identical(want, got, f"{scene} streamed, {groups} groups")
 
 
 @pytest.mark.parametrize("kw", [dict(tentfilter=True), dict(nocaustics=True), dict(envhidden=True), dict(bounces=1), dict(bounces=3, clamp=2.0)])

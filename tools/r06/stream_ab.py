@@ -65,7 +65,7 @@ def main():
             groups, frac = (int(v[3]) if len(v) > 3 else 1), (v[4] if len(v) > 4 else 1.0)
             ctx.set_scheduler(1)
             ctx.set_stream_options(order=order, cell_bits=cells, phased=phased)
-            ctx.set_stream_shape(groups, frac)
+            ctx.set_stream_groups(groups)
             ms = timed(ctx, flat, p, launches)  # (the pixel queue's order comes from the warm-up batches' costs)
             info = ctx.stream_info()
             ctx.make_trace_state(flat, p)

@@ -29,7 +29,7 @@ def child(scene, spp, mode):
         ctx.set_scheduler(1)
         o, c = (int(x) for x in os.environ.get("VARIANT", "1:3").split(":"))
         ctx.set_stream_options(order=o, cell_bits=c)
-        ctx.set_stream_shape(1, 1.0)
+        ctx.set_stream_groups(1)
     ctx.make_trace_state(flat, p)
     ctx.trace_samples(p)
     ctx.trace_samples(p)

@@ -201,9 +201,8 @@ struct ythip_ctx {
   int                stream_slots     = 0;        // the slot count they were sized for (0: none)
   int                stream_cell_bits = 4, stream_order = 0, stream_phased = -1, stream_min_batch = 4;  // YTHIP_STREAM_CELLS / _ORDER / _PHASED / _MIN_BATCH
   int*               stream_counts_host = nullptr;  // pinned: {next queue length, generations run} per group
-  int                stream_groups = 1;           // chains of generations (1 or 2: YTHIP_STREAM_GROUPS)
-  double             stream_slot_frac = 1.0;      // path slots as a fraction of the tile grid's slots (< 1: the pixel queue feeds them)
-  int                stream_min_slots = 262144;   // never fewer paths in flight than this (the machine holds 4-5 k wavefronts); two groups from half of it each (YTHIP_STREAM_MIN_SLOTS: tests)
+  int                stream_groups = 2;           // chains of generations side by side (YTHIP_STREAM_GROUPS; 2 measured best)
+  int                stream_min_slots = 262144;   // a group holds at least a quarter of this many path slots (a chain of generations wants a few thousand wavefronts per launch; YTHIP_STREAM_MIN_SLOTS: tests)
   int                stream_bins_cap = 0;         // bins the hist / offs arrays hold per group
   hipStream_t        stream_side[YT_STREAM_MAX_GROUPS] = {};  // the further groups' streams ([0] unused: group 0 runs on `stream`)
   hipEvent_t         stream_ev[YT_STREAM_MAX_GROUPS] = {};

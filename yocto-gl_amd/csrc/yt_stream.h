@@ -40,13 +40,11 @@ constexpr int      YT_STREAM_MAX_GROUPS = 8;
 constexpr int      PF_DEAD   = 0x80;         // Path flag of such a slot (ray_b.w)
 
 struct DStream {
-  // path state, one record per PATH SLOT (SoA of 16-B pieces; WgState's layout, in HBM) — arrays shared by the groups
+  // path state, one record per slot of the tile grid = per pixel (SoA of 16-B pieces; WgState's layout, in HBM) — arrays shared by the groups
   float4 *    ray_a, *ray_b, *wgt, *rad;
   ulonglong2* rng;
   float4*     hit_a;  // u, v, distance, instance (-1: miss)
   int*        hit_e;  // element
-  int*        vslot;  // the slot of the tile grid whose pixel the path slot renders (Path::vslot; the slot itself without the pixel queue)
-  int*        gen0;   // the generation in which that pixel started its batch (tile costs for the queue's order)
   unsigned *  key, *rank;  // the next ray's sort key, its arrival number inside the key's bin
   // one GROUP of path slots = one chain of generations on one stream (two groups overlap each other's launch tails)
   int       slot0, nslots;  // the group's path slots [slot0, slot0 + nslots), a multiple of 64
@@ -85,46 +83,19 @@ YT_FN unsigned stream_key(const DStream& S, int slot, vec3f o, vec3f d, bool pri
   return S.order == 0 ? (octant << (3 * S.cell_bits)) | cell : (cell << 3) | octant;
 }
 
-// -DYT_STREAM_NT (development builds): the path state through non-temporal loads / stores — touched once per generation by
-// one wavefront each, 200 MB per generation that would otherwise wash the tree out of the L2s
-#ifdef YT_STREAM_NT
-template <typename T>
-YT_FN T sld(const T* p) { return __builtin_nontemporal_load(p); }
-template <typename T>
-YT_FN void sst(T* p, T v) { __builtin_nontemporal_store(v, p); }
-YT_FN float4 sld(const float4* p) {
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
-  return {v.x, v.y, v.z, v.w};
-}
-YT_FN void sst(float4* p, float4 a) {
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 v = {a.x, a.y, a.z, a.w};
-  __builtin_nontemporal_store(v, reinterpret_cast<v4*>(p));
-}
-YT_FN ulonglong2 sld(const ulonglong2* p) {
-  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
-  u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p));
-  return {v.x, v.y};
-}
-YT_FN void sst(ulonglong2* p, ulonglong2 a) {
-  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
-  u2 v = {a.x, a.y};
-  __builtin_nontemporal_store(v, reinterpret_cast<u2*>(p));
-}
-#else
+// the path state's loads / stores in one place (measured as non-temporal accesses — 200 MB per generation that wash the tree
+// out of the L2s —: -1 ... -3 %, docs/HISTORY.md)
 template <typename T>
 YT_FN T sld(const T* p) { return *p; }
 template <typename T>
 YT_FN void sst(T* p, T v) { *p = v; }
-#endif
 
 // a live slot's state <-> registers (load_path_rest / store_path of yt_kernels.h on the HBM arrays)
 YT_FN void stream_load_rest(const DState& st, const DStream& S, int slot, Path& P, float4 rb) {
   float4 w = sld(S.wgt + slot), r = sld(S.rad + slot);
   auto   g = sld(S.rng + slot);
   int    pi, pj;
-  P.vslot         = sld(S.vslot + slot);
+  P.vslot         = slot;
   P.pix           = slot_pixel(st, P.vslot, pi, pj);
   P.bounce        = __float_as_int(rb.z);
   int fw          = __float_as_int(rb.w);
@@ -142,7 +113,6 @@ YT_FN void stream_store(const DStream& S, int slot, const Path& P) {
   sst(S.ray_b + slot, float4{P.d.y, P.d.z, __int_as_float(P.bounce), __int_as_float(P.flags | (P.opbounce << 8))});
   sst(S.wgt + slot, float4{P.weight.x, P.weight.y, P.weight.z, P.max_roughness});
   sst(S.rad + slot, float4{P.radiance.x, P.radiance.y, P.radiance.z, __int_as_float(P.sidx)});
-  sst(S.vslot + slot, P.vslot);
 }
 
 // The slot's entry in the next generation's queue: key + histogram count; the returning atomic IS the rank inside the bin.
@@ -181,44 +151,21 @@ YT_FN void stream_emit(const DStream& S, int slot, const Path& P, int cls) {
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(YT_BLOCK) ks_init(DScene sc, DState st, KParams kp, DStream S) {
   const int slot = S.slot0 + (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
-  // the pixel of the path slot: the slot's own (every pixel in flight), or — with the pixel queue (DState::pool_next: fewer path
-  // slots than pixels) — entry `slot` of the queue: the tiles in launch order (most expensive first), 64 entries each; the queue's
-  // head starts behind these statically assigned entries (enqueue_stream)
-  int  vs = slot, i, j;
-  Path P;
+  int       i, j;
+  const int pix = slot_pixel(st, slot, i, j);
+  int       cls = OUT_DEAD;
+  Path      P;
   P.o = {0, 0, 0}, P.d = {0, 0, 0}, P.vslot = slot;
-  int pix = -1;
-  if (st.pool_next) {
-    int q = slot;
-    while (q < st.pool_total) {
-      int tile = q / YT_BLOCK;
-      if (st.tile_perm) tile = st.tile_perm[tile];
-      vs  = tile * YT_BLOCK + (q & (YT_BLOCK - 1));
-      pix = slot_pixel(st, vs, i, j);
-      if (pix >= 0) break;
-      // a slot of an edge tile outside the slice: the next entry of the queue (the lanes that are here together with one atomic)
-      const unsigned long long here = __ballot(1);
-      const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)here) - 1;
-      int       base = 0;
-      if (lane == leader) base = atomicAdd(st.pool_next, __popcll(here));
-      q = __shfl(base, leader) + __popcll(here & ((1ull << lane) - 1ull));
-    }
-  } else {
-    pix = slot_pixel(st, vs, i, j);
-  }
-  int cls = OUT_DEAD;
   if (pix >= 0) {
     auto r  = st.rngs[pix];
     P.rng   = {r.x, r.y};
     P.sidx  = 0;
     P.pix   = pix;
-    P.vslot = vs;
     start_sample(sc, st, kp, slot, P);
     stream_store(S, slot, P);
-    S.gen0[slot] = 0;
-    cls          = OUT_PRIMARY;
+    cls = OUT_PRIMARY;
   } else {
-    S.ray_b[slot] = {0, 0, 0, __int_as_float(PF_DEAD)};
+    S.ray_b[slot] = {0, 0, 0, __int_as_float(PF_DEAD)};  // a slot of an edge tile outside the slice
   }
   stream_emit(S, slot, P, cls);
 }
@@ -378,16 +325,8 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DSce
         step = step_tail(P);
       }
     }
-    const int pixel_before = P.vslot;
     cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
     if (cls == OUT_DEAD) P.flags |= PF_DEAD;
-    if (st.tile_cost && (cls == OUT_DEAD || P.vslot != pixel_before)) {
-      // the pixel has had its batch: the generations it took go to its tile's cost — the next batch's queue hands the tiles out
-      // most expensive first (yt_order.hip), so that the batch does not end in a long tail of a few slow pixels
-      const int gen = S.counts[1];
-      atomicAdd(&st.tile_cost[pixel_before / YT_BLOCK], (unsigned)(gen - S.gen0[slot] + 1));
-      S.gen0[slot] = gen + 1;
-    }
     stream_store(S, slot, P);
   }
   stream_emit(S, slot, P, cls);

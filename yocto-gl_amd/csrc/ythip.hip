@@ -127,12 +127,9 @@ void harvest_events(ythip_ctx* ctx) {
 // read-back of the next queue's length says zero.  The first `batch` generations are enqueued blind (a sample is at least
 // one generation), the rest in chunks; a chunk's surplus generations return at once on the device.  Blocks until the batch
 // is done (the queue length has to come home), watching the caller's stop flag meanwhile.
-//   * groups (YTHIP_STREAM_GROUPS, default 1): the path slots in 2 halves, each a chain of generations of its own on its own
-//     stream — one group's shade / sort launches fill the machine while the other's extend launch drains;
-//   * the pixel queue (YTHIP_STREAM_SLOTS = fraction of the tile grid's slots, default 1 = every pixel in flight): fewer path
-//     slots than pixels; a slot whose pixel has had its batch takes the next pixel of a queue that hands the tiles out most
-//     expensive first (the tile costs of the previous batch: generations per pixel) — resolve_step's pixel pool, so that a
-//     batch does not end in a long tail of generations with a few slow pixels left.
+//   * groups (YTHIP_STREAM_GROUPS, default 2): the path slots in runs, each a chain of generations of its own on its own
+//     stream — one group's shade / sort launches fill the machine while another's extend launch drains (2 groups: +8 ... +25 %
+//     over one; 4 and more lose again: profiles/r06_stream_ab_groups.txt).
 int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp, int lp, int cls, const volatile int32_t* stop) {
   auto& st = ctx->st;
   auto& S  = ctx->ss;
@@ -147,7 +144,7 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     const size_t nb = (((size_t)(8 << (3 * 5)) + (size_t)S.nprim_bins + 4095) / 4096 + 1) * 4096;  // (room for the finest cell grid, padded to ks_scan's tiles)
 #define AL(field, count) \
   if ((rc = dalloc(ctx, ctx->state_allocs, &S.field, (size_t)(count)))) return rc;
-    AL(ray_a, ns) AL(ray_b, ns) AL(wgt, ns) AL(rad, ns) AL(rng, ns) AL(hit_a, ns) AL(hit_e, ns) AL(vslot, ns) AL(gen0, ns) AL(key, ns) AL(rank, ns)
+    AL(ray_a, ns) AL(ray_b, ns) AL(wgt, ns) AL(rad, ns) AL(rng, ns) AL(hit_a, ns) AL(hit_e, ns) AL(key, ns) AL(rank, ns)
     AL(queue, ns) AL(hist, MAX_GROUPS * nb) AL(offs, MAX_GROUPS * nb) AL(counts, MAX_GROUPS * 16) AL(stats, MAX_GROUPS * 8 * 64)
     AL(gen_rays, MAX_GROUPS * YT_STREAM_GEN_LOG)
 #undef AL
@@ -165,32 +162,10 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
   auto        scale = [&](float a, float b) { return (b > a && std::isfinite(b - a)) ? cells / (b - a) : 0.0f; };
   S.cell_lo    = lo;
   S.cell_scale = {scale(lo.x, hi.x), scale(lo.y, hi.y), scale(lo.z, hi.z)};
-  // path slots: all of the tile grid's, or a fraction of them fed by the pixel queue (at least 256 k where the grid has them)
-  int  pslots = st.nslots;
-  if (ctx->stream_slot_frac > 0 && ctx->stream_slot_frac < 1) {
-    pslots = (int)((double)st.nslots * ctx->stream_slot_frac);
-    pslots = std::max(pslots, std::min(st.nslots, ctx->stream_min_slots));
-    pslots = std::min(st.nslots, (pslots + 127) / 128 * 128);
-  }
-  const bool pool   = pslots < st.nslots;
+  const int pslots = st.nslots;  // every pixel in flight (fewer slots fed by a pixel queue: measured, -17 ... -40 %, docs/HISTORY.md)
   int groups = std::min(std::max(ctx->stream_groups, 1), MAX_GROUPS);
   while (groups > 1 && pslots / groups < ctx->stream_min_slots / 4) groups--;  // (a chain of generations wants a few thousand wavefronts per launch)
   st.tile_perm = nullptr, st.tile_cost = nullptr, st.pool_next = nullptr, st.pool_total = 0;
-  if (ctx->d_tile_cost && ctx->lpt > 0) {  // tile costs: generations per pixel, summed per tile (ks_shade) — the next batch's queue order
-    if (pool && ctx->have_tile_costs) {
-      if (ctx->lpt_age % 16 == 0)
-        HIPCHECK(ctx, ytorder::order_by_cost(ctx->stream, ctx->d_tile_cost, st.nblocks, ctx->d_tile_perm, ctx->d_sort_temp, ctx->sort_temp_bytes));
-      ctx->lpt_age++;
-      st.tile_perm = ctx->d_tile_perm;
-    }
-    HIPCHECK(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)st.nblocks * sizeof(unsigned), ctx->stream));
-    st.tile_cost = ctx->d_tile_cost;
-  }
-  if (pool) {
-    if (!ctx->d_pool_next) HIPCHECK(ctx, hipMalloc((void**)&ctx->d_pool_next, 64));
-    st.pool_next = ctx->d_pool_next, st.pool_total = st.nblocks * YT_BLOCK;
-    HIPCHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->d_pool_next, pslots, 16, ctx->stream));
-  }
   const bool prof = (ctx->prof_mode & 1) != 0;
   if (prof) HIPCHECK(ctx, hipMemsetAsync(S.stats, 0, MAX_GROUPS * 8 * 64 * sizeof(unsigned long long), ctx->stream));
   HIPCHECK(ctx, hipMemsetAsync(S.counts, 0, MAX_GROUPS * 16 * sizeof(int), ctx->stream));
@@ -260,7 +235,6 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     }
   }
   HIPCHECK(ctx, hipGetLastError());
-  if (st.tile_cost) ctx->have_tile_costs = true;
   ctx->stream_info             = {};
   ctx->stream_info.ran         = 1;
   for (int g = 0; g < groups; g++) ctx->stream_info.generations = std::max(ctx->stream_info.generations, ctx->stream_counts_host[16 * g + 1]);
@@ -277,7 +251,6 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
       ctx->stream_info.rays += (int64_t)h[8 * b + 3];
     }
   }
-  st.tile_perm = nullptr, st.tile_cost = nullptr, st.pool_next = nullptr, st.pool_total = 0;
   return YTHIP_OK;
 }
 
@@ -525,7 +498,6 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_BATCH")) ctx->stream_min_batch = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_GROUPS")) ctx->stream_groups = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_SLOTS")) ctx->stream_min_slots = std::max(128, std::atoi(e));
-  if (const char* e = std::getenv("YTHIP_STREAM_SLOTS")) ctx->stream_slot_frac = std::atof(e);
   {
     hipDeviceProp_t prop;
     ctx->pool_blocks = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount * 16 : 4096;
@@ -1654,10 +1626,9 @@ int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phase
   if (phased >= 0) ctx->stream_phased = phased;
   return YTHIP_OK;
 }
-int ythip_set_stream_shape(ythip_ctx* ctx, int groups, float slot_fraction) {
-  if (!ctx || groups > YT_STREAM_MAX_GROUPS || groups == 0 || slot_fraction > 1) return fail(ctx, YTHIP_ERR_INVALID, "stream shape: groups 1..%d, slot_fraction (0, 1]", YT_STREAM_MAX_GROUPS);
-  if (groups > 0) ctx->stream_groups = groups;
-  if (slot_fraction > 0) ctx->stream_slot_frac = slot_fraction;
+int ythip_set_stream_groups(ythip_ctx* ctx, int groups) {
+  if (!ctx || groups < 1 || groups > YT_STREAM_MAX_GROUPS) return fail(ctx, YTHIP_ERR_INVALID, "stream groups: 1..%d", YT_STREAM_MAX_GROUPS);
+  ctx->stream_groups = groups;
   return YTHIP_OK;
 }
 int ythip_get_stream_generations(ythip_ctx* ctx, int32_t* rays, int32_t capacity, int32_t* written) {

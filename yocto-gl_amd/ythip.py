@@ -516,7 +516,7 @@ _SIGNATURES = {
     "ythip_set_scheduler": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_get_stream_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_set_stream_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
-    "ythip_set_stream_shape": (C.c_int, [C.c_void_p, C.c_int, C.c_float]),
+    "ythip_set_stream_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_get_stream_generations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "ythip_last_launch_fastmath": (C.c_int, [C.c_void_p]),
     "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
@@ -776,9 +776,9 @@ class Context:
         2 unsorted, cell_bits 1..5, phased 0 / 1."""
         self._check(self.lib.ythip_set_stream_options(self.h, int(order), int(cell_bits), int(phased)), "set_stream_options")
 
-    def set_stream_shape(self, groups=0, slot_fraction=0.0):
-        """groups 1 | 2 chains of generations; slot_fraction (0, 1] paths in flight per pixel of the frame (ythip_set_stream_shape)."""
-        self._check(self.lib.ythip_set_stream_shape(self.h, int(groups), float(slot_fraction)), "set_stream_shape")
+    def set_stream_groups(self, groups):
+        """1..8 chains of generations side by side (default 2) — ythip_set_stream_groups."""
+        self._check(self.lib.ythip_set_stream_groups(self.h, int(groups)), "set_stream_groups")
 
     def stream_generations(self):
         """Queue length of every generation of the last streamed batch (profiling mode 1 during the batch)."""
