@@ -32,6 +32,40 @@ __global__ void __launch_bounds__(YT_BLOCK) k_gather_tinst(const DInstanceT* tin
 }
 
 
+// The quad records as the walk reads them (yt_bvh.h: YT_WIDE7): the bake kernels and the host assembly write the plain layout — per
+// slot {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axes}, which k_own_compress also reads —, this puts a record's boxes and
+// refs into its first seven float4 and the three axes into bits 26-27 of refs a, b, d.  In place, one thread per record.
+namespace {
+__global__ void __launch_bounds__(YT_BLOCK) k_quads_repack(float4* quads, long long n) {
+  const long long k = (long long)blockIdx.x * YT_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  float4*      Q = quads + 8 * k;
+  const float4 a0 = Q[0], a1 = Q[1], b0 = Q[2], b1 = Q[3], c0 = Q[4], c1 = Q[5], d0 = Q[6], d1 = Q[7];
+  const int    axes = __float_as_int(a1.w);
+  int          ra = __float_as_int(a1.z), rb = __float_as_int(b1.z), rc = __float_as_int(c1.z), rd = __float_as_int(d1.z);
+  ra = (ra & ~(3 << WIDE_AXIS_SHIFT)) | ((axes & 3) << WIDE_AXIS_SHIFT);                               // (slot a is never empty)
+  if (rb != REF_NONE) rb = (rb & ~(3 << WIDE_AXIS_SHIFT)) | (((axes >> 2) & 3) << WIDE_AXIS_SHIFT);  // child 0's axis: only when it has children
+  if (rd != REF_NONE) rd = (rd & ~(3 << WIDE_AXIS_SHIFT)) | (((axes >> 4) & 3) << WIDE_AXIS_SHIFT);
+  Q[0] = a0;
+  Q[1] = {a1.x, a1.y, b1.x, b1.y};
+  Q[2] = b0;
+  Q[3] = c0;
+  Q[4] = {c1.x, c1.y, d1.x, d1.y};
+  Q[5] = d0;
+  Q[6] = {__int_as_float(ra), __int_as_float(rb), __int_as_float(rc), __int_as_float(rd)};
+  Q[7] = {0, 0, 0, 0};
+}
+}  // namespace
+int repack_quads(ythip_ctx* ctx) {
+#if YT_WIDE7
+  if (ctx->num_pairs > 0 && ctx->wide_stack_ok)
+    hipLaunchKernelGGL(k_quads_repack, dim3(grid_for(ctx->num_pairs)), dim3(YT_BLOCK), 0, ctx->stream, const_cast<float4*>(ctx->ds.wide),
+        (long long)ctx->num_pairs);
+  HIPCHECK(ctx, hipGetLastError());
+#endif
+  return YTHIP_OK;
+}
+
 int bake_bvh(ythip_ctx* ctx) {
   auto& b        = ctx->h_bvh;
   int   nshapes  = (int)ctx->h_shapes.size();
@@ -351,6 +385,18 @@ int bake_bvh(ythip_ctx* ctx) {
     ti.leaf_bias = (int)(leaf_base[s] - b.prim_offset[s] * strides[s]);
     ti.shape     = s;
   }
+  // all instances of one shape: the per-shape half of their records as launch constants (yt_bvh.h: load_instance_record)
+  ctx->ds.one_shape = 0;
+  if (!tinst.empty()) {
+    bool one = true;
+    for (auto& ti : tinst) one = one && ti.shape == tinst[0].shape;
+    if (one) {
+      const auto& t0 = tinst[0];
+      ctx->ds.one_shape = 1, ctx->ds.one_root = t0.root_ref, ctx->ds.one_kind = t0.kind, ctx->ds.one_leaf_bias = t0.leaf_bias;
+      ctx->ds.one_bmin = {t0.root_bmin[0], t0.root_bmin[1], t0.root_bmin[2]};
+      ctx->ds.one_bmax = {t0.root_bmax[0], t0.root_bmax[1], t0.root_bmax[2]};
+    }
+  }
   ctx->ds.tlas_ref  = roots[nshapes].ref;
   ctx->ds.tlas_bmin = {roots[nshapes].bmin[0], roots[nshapes].bmin[1], roots[nshapes].bmin[2]};
   ctx->ds.tlas_bmax = {roots[nshapes].bmax[0], roots[nshapes].bmax[1], roots[nshapes].bmax[2]};
@@ -381,6 +427,12 @@ int bake_bvh(ythip_ctx* ctx) {
     HIPCHECK(ctx, hipGetLastError());
     ctx->ds.tinst_leaf = d_tl;
   }
+#if YT_WIDE7
+  // the seven-load quad records carry the split axes in bits 26-27 of their refs (yt_bvh.h): internal nodes and primitives are
+  // capped at 2^26 each; a larger scene is walked binary (as a tree too deep for the wide walk's stack is)
+  if (npairs >= (1ll << 26) || b.prim_offset[ntrees] >= (1ll << 26)) ctx->wide_stack_ok = false;
+#endif
+  if (!ctx->bake_plain_quads && (rc = repack_quads(ctx))) return rc;
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   ctx->have_bvh = true;
   return YTHIP_OK;
@@ -476,14 +528,16 @@ int build_own_bvh(ythip_ctx* ctx, const ythip_scene& sc) {
   const int64_t keep_largest = ctx->largest_tree, keep_pairs = ctx->num_pairs, keep_leaf4 = ctx->num_leaf4;
   ctx->h_bvh = ythost::flat_bvh{};
   ctx->d_trees.clear(), ctx->d_tree_on_host.clear(), ctx->bvh_allocs.clear();
+  ctx->bake_plain_quads = true;  // (k_own_compress reads the plain layout; the records are repacked behind it)
   int rc = build_bvh_mixed(ctx, sc, true, ctx->bvh_builder != 0);
+  ctx->bake_plain_quads = false;
   if (rc == YTHIP_OK) {
     uint4* d_own = nullptr;
     rc           = dalloc(ctx, ctx->bvh_allocs, &d_own, (size_t)ctx->num_pairs * 4 + 4);
     if (rc == YTHIP_OK && ctx->num_pairs > 0) {
       hipLaunchKernelGGL(k_own_compress, dim3(grid_for(ctx->num_pairs)), dim3(YT_BLOCK), 0, ctx->stream, ctx->ds.wide,
           (long long)ctx->num_pairs, d_own);
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+      if (hipGetLastError() != hipSuccess || repack_quads(ctx) != YTHIP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess)
         rc = fail(ctx, YTHIP_ERR_HIP, "own-tree compression failed");
     }
     if (rc == YTHIP_OK) {

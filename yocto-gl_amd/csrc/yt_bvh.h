@@ -112,6 +112,7 @@ struct Hit {
   int   instance, element;
   float u, v, distance;
   bool  hit;
+  int   leaf;  // float4 index of the hit primitive's record in DScene::leafdata (its vertices, as the walk read them: yt_scene.h TriPos)
 };
 
 struct Counters {
@@ -261,6 +262,29 @@ YT_FN bool slab_rec(vec3f o, vec3f dinv, float tmin, float4 r0, float4 r1, float
   return slab<true>(o, dinv, tmin, {r0.x, r0.y, r1.x}, {r0.z, r0.w, r1.y}, t0);
 }
 
+// The grandchildren ("quad") records of the wide walk, as SEVEN 16-B loads (round 6; until round 5: eight — per slot
+// {min.x, min.y, max.x, max.y} {min.z, max.z, ref, axes}, the axes word in slot a only, three words unused).  The record keeps its
+// 128-B stride and alignment; its first 112 B hold everything a step reads:
+//     q0 = a {min.x, min.y, max.x, max.y}    q1 = {a.min.z, a.max.z, b.min.z, b.max.z}    q2 = b {min.x, min.y, max.x, max.y}
+//     q3 = c {min.x, ...}                    q4 = {c.min.z, c.max.z, d.min.z, d.max.z}    q5 = d {min.x, ...}
+//     q6 = {ref a, ref b, ref c, ref d}
+// and the three split axes travel in bits 26-27 of three of the refs: the node's own axis in ref a, child 0's in ref b, child 1's
+// in ref d (slot b / d is empty exactly when child 0 / 1 is a leaf, whose axis nobody asks for; an empty slot's ref is REF_NONE
+// as before).  A ref keeps those two bits wherever it travels (`cur`, the stack): they are masked off where a ref is USED — the
+// record address of an internal node (WIDE_REF_MASK), the first primitive of a leaf (LEAF_FIRST_MASK) — so the bake caps internal
+// nodes and primitives at 2^26 each (bake_bvh: larger scenes are walked binary).  One wave-level load less per node step on a
+// path that is bound by the vector-memory address unit.  k_quads_repack (yt_bake.hip) makes this layout from the
+// plain one the bake kernels write.
+#ifndef YT_WIDE7
+#define YT_WIDE7 1
+#endif
+constexpr int WIDE_AXIS_SHIFT = 26;
+constexpr int WIDE_REF_MASK   = YT_WIDE7 ? 0x03ffffff : 0x3fffffff;  // record index of an internal ref
+constexpr int LEAF_FIRST_MASK = YT_WIDE7 ? 0x03ffffff : 0x0fffffff;  // first primitive of a leaf ref
+YT_FN bool slab_rec7(vec3f o, vec3f dinv, float tmin, float4 xy, float zmin, float zmax, float& t0) {
+  return slab<true>(o, dinv, tmin, {xy.x, xy.y, zmin}, {xy.z, xy.w, zmax}, t0);
+}
+
 // Wavefront-uniform reads through the SCALAR cache (round 4).  The vector-memory address path is this kernel's co-bound
 // (profiles/r04_traversal.txt §5: a wave-level 16-B-per-lane load keeps the CU's texture addresser busy ~16-20 cycles
 // however many lanes are active).  When every lane that executes a load asks for the SAME record — camera rays of a tile
@@ -273,8 +297,14 @@ YT_FN float4 ldc4(const void* p, int k) {  // float4 #k at the (uniform) address
   const v4f_ v = ((cv4f*)p)[k];
   return float4{v.x, v.y, v.z, v.w};
 }
-// the 96-B traversal record #idx of `base` (sc.tinst or sc.tinst_leaf)
-YT_FN void load_instance_record(const DInstanceT* base, int idx, float4& m0, float4& m1, float4& m2, float4& m3, float4& m4, int4& m5) {
+// the 96-B traversal record #idx of `base` (sc.tinst or sc.tinst_leaf).  In a scene whose instances all refer to one shape
+// (DScene::one_shape) the per-shape half — root box, root ref, kind, leaf bias: m3, m4, m5.x — is a launch constant and only the
+// per-instance half is fetched: the inverse frame (3 of the 6 float4) and, where the caller uses it, the instance id (m5.z; one
+// dword) — half the vector loads of a TLAS-leaf entry on BASELINE configs[3].  Same values either way.
+#ifndef YT_ONE_SHAPE
+#define YT_ONE_SHAPE 1
+#endif
+YT_FN void load_instance_record(const DScene& sc, const DInstanceT* base, int idx, float4& m0, float4& m1, float4& m2, float4& m3, float4& m4, int4& m5) {
   int u;
   if (SCALAR_LOADS && wave_uniform(idx, u)) {
     const DInstanceT* r = base + u;
@@ -284,9 +314,17 @@ YT_FN void load_instance_record(const DInstanceT* base, int idx, float4& m0, flo
     return;
   }
   const float4* ti = reinterpret_cast<const float4*>(base + idx);
+  if (YT_ONE_SHAPE && sc.one_shape) {
+    m0 = ti[0], m1 = ti[1], m2 = ti[2];
+    m3 = {sc.one_bmin.x, sc.one_bmin.y, sc.one_bmin.z, sc.one_bmax.x};
+    m4 = {sc.one_bmax.y, sc.one_bmax.z, __int_as_float(sc.one_root), __int_as_float(sc.one_kind)};
+    m5 = {sc.one_leaf_bias, 0, reinterpret_cast<const int*>(ti)[22], 0};  // ([22]: DInstanceT::instance)
+    return;
+  }
   m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
   m5 = reinterpret_cast<const int4*>(ti)[5];
 }
+static_assert(offsetof(DInstanceT, instance) == 22 * 4, "load_instance_record reads the instance id as dword 22");
 
 // The traversal.  `only_instance` < 0: intersect_scene_bvh (yocto_bvh.cpp:554-617);
 // otherwise intersect_instance_bvh of that instance (yocto_bvh.cpp:619-628).
@@ -345,7 +383,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   auto enter = [&](const DInstanceT* base, int idx, int inst, bool tested = false) -> int {
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-    load_instance_record(base, idx, m0, m1, m2, m3, m4, m5);
+    load_instance_record(sc, base, idx, m0, m1, m2, m3, m4, m5);
     int root = __float_as_int(m4.z);
     if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
@@ -390,7 +428,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   auto pretest = [&](int k, float& t0) -> bool {
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-    load_instance_record(sc.tinst_leaf, k, m0, m1, m2, m3, m4, m5);
+    load_instance_record(sc, sc.tinst_leaf, k, m0, m1, m2, m3, m4, m5);
     t0 = 0;
     if (__float_as_int(m4.z) == REF_NONE) return false;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
@@ -425,8 +463,8 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
     cur = sc.tlas_ref;
   }
 
-  auto accept = [&](int element, const PrimHit& h) {
-    best     = {cur_inst, element, h.u, h.v, h.t, true};
+  auto accept = [&](int element, const PrimHit& h, int leaf = 0) {
+    best     = {cur_inst, element, h.u, h.v, h.t, true, leaf};
     tmax     = h.t;
     tmaxk    = h.t * BBOX_K;
     weird    = weird || (h.t != h.t);
@@ -457,6 +495,24 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         // reference's walk reaches them, each pushed with its own pop-time test
         cnt.steps++;
         // (the step on a record given by value: the wavefront-uniform form below hands it scalar registers)
+#if YT_WIDE7
+        auto wide_step = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float4 q4, const float4 q5,
+                             const float4 q6) __attribute__((always_inline)) {
+          float ta, tb, tc, td;
+          bool  fa = slab_rec7(o, dinv, tmin, q0, q1.x, q1.y, ta);
+          bool  fb = slab_rec7(o, dinv, tmin, q2, q1.z, q1.w, tb);
+          bool  fc = slab_rec7(o, dinv, tmin, q3, q4.x, q4.y, tc);
+          bool  fd = slab_rec7(o, dinv, tmin, q5, q4.z, q4.w, td);
+          const int wa = __float_as_int(q6.x), wb = __float_as_int(q6.y), wc = __float_as_int(q6.z), wd = __float_as_int(q6.w);
+          // slots: a, b = children of child 0 (or child 0 itself, then b is empty); c, d likewise for child 1
+          int ra = (fa && ta <= tmaxk) ? wa : REF_NONE;
+          int rb = (fb && tb <= tmaxk) ? wb : REF_NONE;
+          int rc = (fc && tc <= tmaxk) ? wc : REF_NONE;
+          int rd = (fd && td <= tmaxk) ? wd : REF_NONE;
+          // node axis in ref a, child 0's axis in ref b, child 1's in ref d (bits 26-27)
+          const bool hs = ((sign >> ((wa >> WIDE_AXIS_SHIFT) & 3)) & 1) != 0, ls = ((sign >> ((wb >> WIDE_AXIS_SHIFT) & 3)) & 1) != 0,
+                     rs = ((sign >> ((wd >> WIDE_AXIS_SHIFT) & 3)) & 1) != 0;
+#else
         auto wide_step = [&](const float4 a0, const float4 a1, const float4 b0, const float4 b1, const float4 c0, const float4 c1,
                              const float4 d0, const float4 d1) __attribute__((always_inline)) {
           float ta, tb, tc, td;
@@ -473,6 +529,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           const int  axes = __float_as_int(a1.w);  // node axis | child 0's axis << 2 | child 1's axis << 4
           const bool hs = ((sign >> (axes & 3)) & 1) != 0, ls = ((sign >> ((axes >> 2) & 3)) & 1) != 0,
                      rs = ((sign >> ((axes >> 4) & 3)) & 1) != 0;
+#endif
           // within each half: ray_dsign[child.axis] → its child 1 first (yocto_bvh.cpp:498-504)
           int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
           float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
@@ -502,19 +559,27 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         // address path — and the slab tests take the box as scalar operands.  Same arithmetic: configs[1] +8.4 %, the
         // rest +0 ... +3 %, bit-identical (profiles/r04_traversal.txt §7).
         if (int ucur; SCALAR_LOADS && wave_uniform(cur, ucur)) {
-          const float4* Qs = sc.wide + 8 * (int64_t)ucur;
+          const float4* Qs = sc.wide + 8 * (int64_t)(ucur & WIDE_REF_MASK);
+#if YT_WIDE7
+          wide_step(ldc4(Qs, 0), ldc4(Qs, 1), ldc4(Qs, 2), ldc4(Qs, 3), ldc4(Qs, 4), ldc4(Qs, 5), ldc4(Qs, 6));
+#else
           wide_step(ldc4(Qs, 0), ldc4(Qs, 1), ldc4(Qs, 2), ldc4(Qs, 3), ldc4(Qs, 4), ldc4(Qs, 5), ldc4(Qs, 6), ldc4(Qs, 7));
+#endif
           continue;
         }
-        const float4* Qp = sc.wide + 8 * (int64_t)cur;
+        const float4* Qp = sc.wide + 8 * (int64_t)(cur & WIDE_REF_MASK);
         {
+#if YT_WIDE7
+          float4 q0 = Qp[0], q1 = Qp[1], q2 = Qp[2], q3 = Qp[3], q4 = Qp[4], q5 = Qp[5], q6 = Qp[6];
+          asm volatile("" : "+v"(q6.x));  // (the loads whole and where they are: hipcc otherwise narrows them and sinks a ref behind the tests)
+          wide_step(q0, q1, q2, q3, q4, q5, q6);
+#else
           float4 q0 = Qp[0], q1 = Qp[1], q2 = Qp[2], q3 = Qp[3], q4 = Qp[4], q5 = Qp[5], q6 = Qp[6], q7 = Qp[7];
           asm volatile("" : "+v"(q1.z));
           wide_step(q0, q1, q2, q3, q4, q5, q6, q7);
+#endif
           continue;
         }
-        wide_step(Qp[0], Qp[1], Qp[2], Qp[3], Qp[4], Qp[5], Qp[6], Qp[7]);
-        continue;
       }
       // internal node: its two children in the reference's visit order
       // (near-first along the split axis — yocto_bvh.cpp:498-504, 592-598)
@@ -575,7 +640,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
       if (cur_inst < 0 && find_any && cur_last && best.hit) done = true;
       continue;
     }
-    const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+    const int first = cur & LEAF_FIRST_MASK, num = (cur >> 28) & 7;
     if (cur_inst < 0) {
       // TLAS leaf: instances are walked in order, each to completion
       // (yocto_bvh.cpp:600-609) → continuation entries in reverse, first one now.
@@ -603,7 +668,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           if (k >= num) continue;
           float4 m0, m1, m2, m3, m4;
           int4   m5;
-          load_instance_record(sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
+          load_instance_record(sc, sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
           if (__float_as_int(m4.z) == REF_NONE) continue;
           frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
           vec3f   io   = transform_point(inv, wo);
@@ -624,7 +689,9 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
             done = true;
             continue;
           }
-          const int4 m5 = reinterpret_cast<const int4*>(sc.tinst_leaf + (first + ck))[5];
+          int4 m5;
+          if (YT_ONE_SHAPE && sc.one_shape) m5 = {sc.one_leaf_bias, 0, reinterpret_cast<const int*>(sc.tinst_leaf + (first + ck))[22], 0};
+          else m5 = reinterpret_cast<const int4*>(sc.tinst_leaf + (first + ck))[5];
           cur_inst      = m5.z;
           o = co, d = cd, dinv = cdinv;
           tame     = true;
@@ -661,11 +728,11 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
         }
         if (COUNT) cnt.triangles++;
         auto h = intersect_triangle(o, d, tmin, tmax, {a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x});
-        if (h.hit) accept(__float_as_int(c0.y), h);
+        if (h.hit) accept(__float_as_int(c0.y), h, leafbias + first * 3 + 3 * k0);
         if (k0 + 1 < num) {
           if (COUNT) cnt.triangles++;
           h = intersect_triangle(o, d, tmin, tmax, {a1.x, a1.y, a1.z}, {a1.w, b1.x, b1.y}, {b1.z, b1.w, c1.x});
-          if (h.hit) accept(__float_as_int(c1.y), h);
+          if (h.hit) accept(__float_as_int(c1.y), h, leafbias + first * 3 + 3 * k0 + 3);
         }
       }
     } else if (TRI != 1 && kind == KIND_QUADS) {
@@ -731,7 +798,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
   auto enter = [&](const DInstanceT* base, int idx, int inst) -> int {  // (as in traverse())
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-    load_instance_record(base, idx, m0, m1, m2, m3, m4, m5);
+    load_instance_record(sc, base, idx, m0, m1, m2, m3, m4, m5);
     int root = __float_as_int(m4.z);
     if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
@@ -756,8 +823,8 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
     push(REF_EXIT, 0);
     return root;
   };
-  auto accept = [&](int element, const PrimHit& h) {
-    best  = {cur_inst, element, h.u, h.v, h.t, true};
+  auto accept = [&](int element, const PrimHit& h, int leaf = 0) {
+    best  = {cur_inst, element, h.u, h.v, h.t, true, leaf};
     tmax  = h.t;
     tmaxk = h.t * BBOX_K;
   };
@@ -796,7 +863,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
         }
         if (cur < 0 && cur_inst < 0) {
           // TLAS leaf: its instances in order, each to completion (yocto_bvh.cpp:600-609)
-          const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+          const int first = cur & LEAF_FIRST_MASK, num = (cur >> 28) & 7;
           for (int k = num - 1; k >= 1; k--) push(REF_INST + (((first + k) << 1) | (k == num - 1 ? 1 : 0)), 0);
           cur = num > 0 ? REF_INST + ((first << 1) | (num == 1 ? 1 : 0)) : REF_NONE;
           continue;
@@ -817,10 +884,24 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
 #endif
     if (nW > 0 && nW * YT_PHASE_W >= nW + nL + nE) {
       if (wantW) {
-        const float4* Qp = sc.wide + 8 * (int64_t)cur;
-        float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
+        const float4* Qp = sc.wide + 8 * (int64_t)(cur & WIDE_REF_MASK);
         cnt.steps++;
         float ta, tb, tc, td;
+#if YT_WIDE7
+        float4 q0 = Qp[0], q1 = Qp[1], q2 = Qp[2], q3 = Qp[3], q4 = Qp[4], q5 = Qp[5], q6 = Qp[6];
+        bool  fa = slab_rec7(o, dinv, tmin, q0, q1.x, q1.y, ta);
+        bool  fb = slab_rec7(o, dinv, tmin, q2, q1.z, q1.w, tb);
+        bool  fc = slab_rec7(o, dinv, tmin, q3, q4.x, q4.y, tc);
+        bool  fd = slab_rec7(o, dinv, tmin, q5, q4.z, q4.w, td);
+        const int wa = __float_as_int(q6.x), wb = __float_as_int(q6.y), wc = __float_as_int(q6.z), wd = __float_as_int(q6.w);
+        int   ra = (fa && ta <= tmaxk) ? wa : REF_NONE;
+        int   rb = (fb && tb <= tmaxk) ? wb : REF_NONE;
+        int   rc = (fc && tc <= tmaxk) ? wc : REF_NONE;
+        int   rd = (fd && td <= tmaxk) ? wd : REF_NONE;
+        const bool hs = ((sign >> ((wa >> WIDE_AXIS_SHIFT) & 3)) & 1) != 0, ls = ((sign >> ((wb >> WIDE_AXIS_SHIFT) & 3)) & 1) != 0,
+                   rs = ((sign >> ((wd >> WIDE_AXIS_SHIFT) & 3)) & 1) != 0;
+#else
+        float4 a0 = Qp[0], a1 = Qp[1], b0 = Qp[2], b1 = Qp[3], c0 = Qp[4], c1 = Qp[5], d0 = Qp[6], d1 = Qp[7];
         bool  fa = slab_rec(o, dinv, tmin, a0, a1, ta);
         bool  fb = slab_rec(o, dinv, tmin, b0, b1, tb);
         bool  fc = slab_rec(o, dinv, tmin, c0, c1, tc);
@@ -832,6 +913,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
         const int  axes = __float_as_int(a1.w);
         const bool hs = ((sign >> (axes & 3)) & 1) != 0, ls = ((sign >> ((axes >> 2) & 3)) & 1) != 0,
                    rs = ((sign >> ((axes >> 4) & 3)) & 1) != 0;
+#endif
         int   l0r = ls ? rb : ra, l1r = ls ? ra : rb, r0r = rs ? rd : rc, r1r = rs ? rc : rd;
         float l0t = ls ? tb : ta, l1t = ls ? ta : tb, r0t = rs ? td : tc, r1t = rs ? tc : td;
         int   v0r = hs ? r0r : l0r, v1r = hs ? r1r : l1r, v2r = hs ? l0r : r0r, v3r = hs ? l1r : r1r;
@@ -855,7 +937,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
       }
     } else if (nL > 0 && nL * YT_PHASE_L >= nL + nE) {
       if (wantL) {
-        const int first = cur & 0x0fffffff, num = (cur >> 28) & 7;
+        const int first = cur & LEAF_FIRST_MASK, num = (cur >> 28) & 7;
         cur = REF_NONE;
         cnt.steps++;
         if (TRI == 1 || kind == KIND_TRIANGLES) {
@@ -864,10 +946,10 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
             float4 a0 = L[3 * k0], b0 = L[3 * k0 + 1], c0 = L[3 * k0 + 2];
             float4 a1 = L[3 * k0 + 3], b1 = L[3 * k0 + 4], c1 = L[3 * k0 + 5];
             auto h = intersect_triangle(o, d, tmin, tmax, {a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x});
-            if (h.hit) accept(__float_as_int(c0.y), h);
+            if (h.hit) accept(__float_as_int(c0.y), h, leafbias + first * 3 + 3 * k0);
             if (k0 + 1 < num) {
               h = intersect_triangle(o, d, tmin, tmax, {a1.x, a1.y, a1.z}, {a1.w, b1.x, b1.y}, {b1.z, b1.w, c1.x});
-              if (h.hit) accept(__float_as_int(c1.y), h);
+              if (h.hit) accept(__float_as_int(c1.y), h, leafbias + first * 3 + 3 * k0 + 3);
             }
           }
         } else if (TRI != 1 && kind == KIND_QUADS) {

@@ -216,7 +216,9 @@ struct Surface {
 };
 
 // TRI: what the caller knows about the scene's shapes (as traverse(): 1 triangle meshes only, 2 triangle and quad meshes only)
-template <int TRI = 0>
+// LEAF: the caller has the hit triangle's vertices from the leaf record (TriPos): the element's indices are then only needed
+// for vertex normals / colours (an untextured class: no texcoords either)
+template <int TRI = 0, bool LEAF = false>
 YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv) {
   // The instance, shape and material records through the scalar cache whenever the lanes that shade together agree on
   // them (wave_uniform, yt_bvh.h): one instance per scene, or thousands of instances of one shape with one material, are
@@ -234,7 +236,8 @@ YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv
   if (int u; SCALAR_LOADS && wave_uniform(inst.material, u)) s.mat = ldc_record(sc.materials + u);
   else s.mat = YT_LD_RECORD(sc.materials + inst.material);
 #undef YT_LD_RECORD
-  s.e     = load_element(sc, s.shc, element);
+  if (LEAF && s.shc.normals < 0 && s.shc.colors < 0) s.e = {0, 0, 0, 0};
+  else s.e = load_element(sc, s.shc, element);
   s.uv    = uv;
   return s;
 }
@@ -293,9 +296,16 @@ YT_FN float sample_lights_pdf(const DScene& sc, vec3f position, vec3f direction,
           Hit   isec = traverse<COUNT, false, TRI>(sc, ray, light.instance, false, *st, *cnt);  // (counts only in the counting launch)
 #endif
           if (!isec.hit) break;
-          auto e         = load_element(sc, sh, isec.element);
-          auto lposition = eval_position(sc, frame, sh, e, {isec.u, isec.v});
-          auto lnormal   = eval_element_normal(sc, frame, sh, e);
+          vec3f lposition, lnormal;
+          if constexpr (TRI == 1 && YT_LEAF_SHADE) {  // every shape a triangle mesh: the light's triangle as the walk read it
+            const TriPos tp = load_tripos(sc, isec.leaf);
+            lposition       = eval_position(sc, frame, sh, elem4{0, 0, 0, 0}, {isec.u, isec.v}, &tp);
+            lnormal         = eval_element_normal(sc, frame, sh, elem4{0, 0, 0, 0}, &tp);
+          } else {
+            auto e    = load_element(sc, sh, isec.element);
+            lposition = eval_position(sc, frame, sh, e, {isec.u, isec.v});
+            lnormal   = eval_element_normal(sc, frame, sh, e);
+          }
           lpdf += div_(distance_squared(lposition, position), fabs_(dot(lnormal, direction)) * area);
           next_position = lposition + direction * 1e-3f;
         }
@@ -413,8 +423,11 @@ YT_FN int step_tail(Path& P) {
 // every material matte, glossy or reflective (nothing transmits: no volumes), textures only in the
 // color and normal slots, triangle and quad meshes only: the scenes of the reference's own test
 // corpus (materials1 / materials3 / shapes1 / instances1 / arealights1 / environments1).
-template <int SAMPLER, int LP, int CLS = 0>
+// LEAFPOS (class 1 of the fused kernel, where the hit record comes straight from the walk): the shading point's position and
+// geometric normal from the hit's leaf record (yt_scene.h: TriPos)
+template <int SAMPLER, int LP, int CLS = 0, bool LEAFPOS = false>
 YT_FN int step_path(ShadeEnv& E, Path& P) {
+  static_assert(!LEAFPOS || CLS == 1, "leaf-record shading: triangle scenes");
   constexpr bool MATTE = CLS == 1, NOTEX = CLS == 1 || CLS == 2, OPAQUE = CLS == 3;
   constexpr int  PRIMS = MATTE ? 1 : (OPAQUE ? 2 : 0);
   const auto& sc = E.sc;
@@ -450,9 +463,12 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
   if (!in_volume) {
     // prepare shading point
     auto outgoing = -P.d;
-    auto s        = load_surface<PRIMS>(sc, isec.instance, isec.element, {isec.u, isec.v});
-    auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv);
-    auto normal   = eval_shading_normal<NOTEX>(sc, s.frame, s.shc, s.mat, s.e, s.uv, outgoing);
+    TriPos        tri;
+    const TriPos* tp = nullptr;
+    if constexpr (LEAFPOS) tri = load_tripos(sc, isec.leaf), tp = &tri;
+    auto s        = load_surface<PRIMS, LEAFPOS>(sc, isec.instance, isec.element, {isec.u, isec.v});
+    auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv, tp);
+    auto normal   = eval_shading_normal<NOTEX>(sc, s.frame, s.shc, s.mat, s.e, s.uv, outgoing, tp);
     auto material = eval_material<NOTEX, OPAQUE>(sc, s.shc, s.mat, s.e, s.uv);
     count_shade(E.st);
 #ifdef YT_TIMING
@@ -1198,7 +1214,8 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_WAVES_PER_EU)
         ShadeEnv E = {sc, st, kp, slot};
         if constexpr (SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST ||
                       SAMPLER == YTHIP_SAMPLER_PATHDIRECT || SAMPLER == YTHIP_SAMPLER_PATHMIS) {
-          step = step_path<SAMPLER, LP, CLS>(E, P);
+          constexpr bool LEAFPOS = YT_LEAF_SHADE && CLS == 1 && !MIS;  // (pathmis re-uses hit records kept in HBM without the leaf index)
+          step = step_path<SAMPLER, LP, CLS, LEAFPOS>(E, P);
           if constexpr (MIS) {
             // pathmis re-tests the SAME next_intersection against `opacity` with a fresh random
             // number until it passes (yocto_trace.cpp:794-796 with :830-836; up to 128 times):

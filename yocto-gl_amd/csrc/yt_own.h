@@ -151,7 +151,7 @@ YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, S
   auto enter = [&](const DInstanceT* base, int idx, int inst, bool tested) -> int {
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-    load_instance_record(base, idx, m0, m1, m2, m3, m4, m5);
+    load_instance_record(sc, base, idx, m0, m1, m2, m3, m4, m5);
     const int root = __float_as_int(m4.z);
     if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
@@ -176,8 +176,8 @@ YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, S
     if (!(own_box(o, idir, tmin, sc.tlas_bmin, sc.tlas_bmax, t0) && t0 <= tmax)) return best;
     cur = sc.tlas_ref;
   }
-  auto accept = [&](int element, const PrimHit& h) {
-    best = {cur_inst, element, h.u, h.v, h.t, true};
+  auto accept = [&](int element, const PrimHit& h, int leaf = 0) {
+    best = {cur_inst, element, h.u, h.v, h.t, true, leaf};
     tmax = h.t;
   };
 
@@ -273,7 +273,7 @@ R                 = (T0 <= __builtin_fminf(far_, tmax)) ? (int)(REF) : REF_NONE;
       if (k >= num) continue;
       float4 m0, m1, m2, m3, m4;
       int4   m5;
-      load_instance_record(sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
+      load_instance_record(sc, sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
       if (__float_as_int(m4.z) == REF_NONE) continue;
       const frame3f inv   = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
       const vec3f   io    = transform_point(inv, wo);
@@ -308,10 +308,10 @@ R                 = (T0 <= __builtin_fminf(far_, tmax)) ? (int)(REF) : REF_NONE;
           a1 = L[3 * k0 + 3], b1 = L[3 * k0 + 4], c1 = L[3 * k0 + 5];
         }
         auto h = own_triangle(o, d, tmin, tmax, {a0.x, a0.y, a0.z}, {a0.w, b0.x, b0.y}, {b0.z, b0.w, c0.x});
-        if (h.hit) accept(__float_as_int(c0.y), h);
+        if (h.hit) accept(__float_as_int(c0.y), h, leafbias + first * 3 + 3 * k0);
         if (k0 + 1 < num) {
           h = own_triangle(o, d, tmin, tmax, {a1.x, a1.y, a1.z}, {a1.w, b1.x, b1.y}, {b1.z, b1.w, c1.x});
-          if (h.hit) accept(__float_as_int(c1.y), h);
+          if (h.hit) accept(__float_as_int(c1.y), h, leafbias + first * 3 + 3 * k0 + 3);
         }
       }
     } else if (TRI != 1 && kind == KIND_QUADS) {

@@ -78,6 +78,13 @@ struct DScene {
   const DInstanceT* tinst_leaf; // the same records gathered in TLAS-leaf order (tinst[tlas_prims[k]], with .instance set)
   int               tlas_ref;   // ref of the TLAS root, REF_NONE if empty
   vec3f             tlas_bmin, tlas_bmax;
+  // Every instance of the scene refers to ONE shape (thousands of instances of one mesh: BASELINE configs[3]): the per-shape half
+  // of the instances' traversal records — the BLAS root's box and ref, the kind, the leaf bias — is then the same in all of them
+  // and travels here, as launch constants in scalar registers; a record fetch is the per-instance half only (round 6,
+  // yt_bvh.h: load_instance_record).  0: the records are read whole.
+  int               one_shape;
+  vec3f             one_bmin, one_bmax;
+  int               one_root, one_kind, one_leaf_bias;
   const uint4*      own;        // fastmath = 2 only: compressed 64-B nodes of the own tree (yt_own.h), same ids as `wide`; null otherwise
   // lights
   const DLight* lights;
@@ -325,11 +332,29 @@ YT_FN elem4 load_element(const DScene& sc, const DShape& sh, int element) {
   }
 }
 
+// The vertices of a hit triangle as the walk read them: the leaf record of the hit (Hit::leaf — DScene::leafdata holds every
+// primitive's vertices pre-gathered in leaf order, bit-identical copies of `positions`).  The shading point's position and
+// geometric normal then come from three contiguous 16-B loads that depend on nothing but the hit, instead of the element's index
+// triple and three gathers behind it (yocto_scene.cpp:288-336 read shape.triangles[element] -> shape.positions[]); a triangle
+// mesh without vertex normals or colours needs no index fetch at all (round 6).  Null: read through the indices.
+struct TriPos {
+  vec3f p0, p1, p2;
+};
+#ifndef YT_LEAF_SHADE
+#define YT_LEAF_SHADE 1
+#endif
+YT_FN TriPos load_tripos(const DScene& sc, int leaf) {
+  const float4* L = sc.leafdata + leaf;
+  const float4  a = L[0], b = L[1], c = L[2];
+  return {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}};
+}
 // shape-local position (yocto_shape.cpp:63-82 for points; interpolation otherwise)
-YT_FN vec3f eval_position_local(const DScene& sc, const DShape& sh, elem4 e, vec2f uv) {
+YT_FN vec3f eval_position_local(const DScene& sc, const DShape& sh, elem4 e, vec2f uv, const TriPos* tp = nullptr) {
   auto P = sc.positions + 3 * (int64_t)sh.positions;
   switch (sh.kind_eval) {
-    case KIND_TRIANGLES: return interpolate_triangle(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z), uv);
+    case KIND_TRIANGLES:
+      if (tp) return interpolate_triangle(tp->p0, tp->p1, tp->p2, uv);
+      return interpolate_triangle(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z), uv);
     case KIND_QUADS:
       return interpolate_quad(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z), ld3(P, e.w), uv);
     case KIND_LINES: return interpolate_line(ld3(P, e.x), ld3(P, e.y), uv.x);
@@ -338,15 +363,16 @@ YT_FN vec3f eval_position_local(const DScene& sc, const DShape& sh, elem4 e, vec
   }
 }
 // eval_position — yocto_scene.cpp:288-311
-YT_FN vec3f eval_position(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e, vec2f uv) {
+YT_FN vec3f eval_position(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e, vec2f uv, const TriPos* tp = nullptr) {
   if (sh.kind_eval == KIND_NONE) return {0, 0, 0};
-  return transform_point(frame, eval_position_local(sc, sh, e, uv));
+  return transform_point(frame, eval_position_local(sc, sh, e, uv, tp));
 }
 // eval_element_normal — yocto_scene.cpp:314-336
-YT_FN vec3f eval_element_normal(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e) {
+YT_FN vec3f eval_element_normal(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e, const TriPos* tp = nullptr) {
   auto P = sc.positions + 3 * (int64_t)sh.positions;
   switch (sh.kind_eval) {
     case KIND_TRIANGLES:
+      if (tp) return transform_normal(frame, triangle_normal(tp->p0, tp->p1, tp->p2));
       return transform_normal(frame, triangle_normal(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z)));
     case KIND_QUADS:
       return transform_normal(frame, quad_normal(ld3(P, e.x), ld3(P, e.y), ld3(P, e.z), ld3(P, e.w)));
@@ -356,8 +382,8 @@ YT_FN vec3f eval_element_normal(const DScene& sc, const frame3f& frame, const DS
   }
 }
 // eval_normal — yocto_scene.cpp:339-366
-YT_FN vec3f eval_normal(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e, vec2f uv) {
-  if (sh.normals < 0) return eval_element_normal(sc, frame, sh, e);
+YT_FN vec3f eval_normal(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e, vec2f uv, const TriPos* tp = nullptr) {
+  if (sh.normals < 0) return eval_element_normal(sc, frame, sh, e, tp);
   auto N = sc.normals + 3 * (int64_t)sh.normals;
   switch (sh.kind_eval) {
     case KIND_TRIANGLES:
@@ -454,9 +480,9 @@ YT_FN vec3f eval_normalmap(const DScene& sc, const frame3f& frame, const DShape&
 // eval_shading_position — yocto_scene.cpp:469-482 (points: shape-local, a
 // reference quirk kept for parity)
 YT_FN vec3f eval_shading_position(const DScene& sc, const frame3f& frame, const DShape& sh, elem4 e,
-    vec2f uv) {
+    vec2f uv, const TriPos* tp = nullptr) {
   if (sh.kind_eval == KIND_TRIANGLES || sh.kind_eval == KIND_QUADS || sh.kind_eval == KIND_LINES) {
-    return eval_position(sc, frame, sh, e, uv);
+    return eval_position(sc, frame, sh, e, uv, tp);
   } else if (sh.kind_eval == KIND_POINTS) {
     return eval_position_local(sc, sh, e, uv);
   }
@@ -465,9 +491,9 @@ YT_FN vec3f eval_shading_position(const DScene& sc, const frame3f& frame, const 
 // eval_shading_normal — yocto_scene.cpp:485-505
 template <bool NOTEX = false>
 YT_FN vec3f eval_shading_normal(const DScene& sc, const frame3f& frame, const DShape& sh,
-    const ythip_material& material, elem4 e, vec2f uv, vec3f outgoing) {
+    const ythip_material& material, elem4 e, vec2f uv, vec3f outgoing, const TriPos* tp = nullptr) {
   if (sh.kind_eval == KIND_TRIANGLES || sh.kind_eval == KIND_QUADS) {
-    auto normal = eval_normal(sc, frame, sh, e, uv);
+    auto normal = eval_normal(sc, frame, sh, e, uv, tp);
     if (!NOTEX && material.normal_tex != YTHIP_INVALIDID) normal = eval_normalmap(sc, frame, sh, material, e, uv);
     if (material.type == YTHIP_REFRACTIVE) return normal;
     return dot(normal, outgoing) >= 0 ? normal : -normal;
