@@ -113,6 +113,16 @@ def progress(msg):
         print(f"[bench +{time.time() - _T0:5.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
+MODE_NAMES = ["bit-exact (the reference's trace_state, byte for byte)",
+              "tolerance (ythip_params::fastmath = 1): statistically equal image, exact hit records",
+              "own-tree (ythip_params::fastmath = 2): statistically equal image, the library's own SAH tree in 64-B nodes of 8-bit boxes",
+              "stream (ythip_set_scheduler 1): bit-exact; every pixel in flight, per bounce a counting sort of the rays by direction "
+              "octant and origin cell + a traversal-only extend kernel + a shade kernel in pixel order, two chains side by side",
+              "pathdirect: bit-exact, sampler pathdirect (yocto_trace.cpp:599-722), scene-class kernel",
+              "pathmis: bit-exact, sampler pathmis (yocto_trace.cpp:725-934), scene-class kernel"]
+MODE_SAMPLER = {4: "pathdirect", 5: "pathmis"}
+
+
 def run_workload(name, device, steps, warmup, count=True, fastmath=0):
     """One workload in one mode through the C ABI (see run_workload_modes)."""
     return run_workload_modes(name, device, steps, warmup, [int(fastmath)], count)[0]
@@ -136,9 +146,13 @@ def run_workload_modes(name, device, steps, warmup, modes, count=True):
         if mode == 2:  # the own-tree mode walks the library's own tree (built next to the reference tree)
             ctx.make_own_bvh(flat)
             own_info = ctx.own_bvh_info()
-        progress(f"workload {name}: launches (fastmath = {mode})")
-        p = yt.trace_params(sampler="path", resolution=w["resolution"], bounces=8, clamp=10.0,
-                            samples=1 << 30, batch=w["spp"], fastmath=mode)
+        # modes 3-5 (round 6) are bit-exact like mode 0: 3 = `path` on the streaming scheduler (csrc/yt_stream.h), 4 / 5 = the
+        # next-event-estimation samplers pathdirect / pathmis (since round 6 by scene class, as `path`)
+        sampler = MODE_SAMPLER.get(mode, "path")
+        ctx.set_scheduler(1 if mode == 3 else 0)
+        progress(f"workload {name}: launches (mode {mode}: {MODE_NAMES[mode].split(' ')[0]})")
+        p = yt.trace_params(sampler=sampler, resolution=w["resolution"], bounces=8, clamp=10.0,
+                            samples=1 << 30, batch=w["spp"], fastmath=mode if mode <= 2 else 0)
         width, height = ctx.make_trace_state(flat, p)
         if count and cnt is None:
             ctx.set_profiling(2)
@@ -156,10 +170,13 @@ def run_workload_modes(name, device, steps, warmup, modes, count=True):
         ctx.set_profiling(0)
         pool = ctx.pixel_pool_info()
         ms = st["trace_ms"] / max(st["trace_launches"], 1)
-        out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"],
-               "fastmath": int(ctx.last_launch_fastmath()),
+        out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"], "sampler": sampler,
+               "fastmath": int(ctx.last_launch_fastmath()), "streamed": int(ctx.stream_info()["ran"]),
                "ms_per_launch": ms, "launches": st["trace_launches"], "samples_per_launch": width * height * w["spp"]}
-        if cnt is not None:
+        if mode == 3:
+            info = ctx.stream_info()
+            out["stream"] = {k: info[k] for k in ("generations", "launched", "groups", "path_slots", "bins")}
+        if cnt is not None and sampler == "path":  # (the counted work is `path`'s)
             nsamp = max(cnt["samples"], 1)
             out["bytes_per_sample"] = yt.algorithmic_bytes(cnt) / nsamp
             out["per_sample"] = {k: round(cnt[k] / nsamp, 3) for k in
@@ -407,8 +424,9 @@ def other_workloads(device, args, calib):
     # (ythip_params::fastmath: statistically equal images, tests/test_gpu_fastmath.py) — what bit-exactness costs
     every = ["configs1", "cfg2b", "configs3", "configs4", "cornell9m", "materials1", "features1"]
     runs = []
+    extra = {"cfg2b": [3, 4, 5], "configs3": [3], "configs4": [3], "cornell9m": [3]}  # (round 6: streamed / the NEE samplers, bit-exact)
     for name in every:  # one worker process per workload: scene, context and trees once, then mode after mode
-        modes = [1, 2] if name == "configs1" else [0, 1, 2]  # (the primary line IS the bit-exact configs[1])
+        modes = ([1, 2] if name == "configs1" else [0, 1, 2]) + extra.get(name, [])  # (the primary line IS the bit-exact configs[1])
         try:
             runs += run_workload_isolated(name, device, modes=modes)
         except Exception as ex:  # reported, never required
@@ -416,32 +434,32 @@ def other_workloads(device, args, calib):
     for run in sorted(runs, key=lambda r: r["mode_asked"]):  # (all bit-exact entries, then tolerance, then own-tree)
         name = run["name"]
         e = {"workload": f"{run['label']}, {run['width']}x{run['height']}x{run['spp']}spp, "
-                         f"sampler=path bounces=8 clamp=10",
+                         f"sampler={run.get('sampler', 'path')} bounces=8 clamp=10",
              "name": name,
-             "mode": ["bit-exact (the reference's trace_state, byte for byte)",
-                      "tolerance (ythip_params::fastmath = 1): statistically equal image, exact hit records",
-                      "own-tree (ythip_params::fastmath = 2): statistically equal image, the library's own SAH tree in "
-                      "64-B nodes of 8-bit boxes"][run["mode_asked"]],
-             "fastmath_ran": int(run.get("fastmath", 0)),
+             "mode": MODE_NAMES[run["mode_asked"]],
+             "fastmath_ran": int(run.get("fastmath", 0)), "streamed": int(run.get("streamed", 0)),
              "value": round(run["samples_per_launch"] / run["ms_per_launch"] / 1e3, 3), "unit": "Msamples/s",
              "ms_per_step": round(run["ms_per_launch"], 3), "steps": run["launches"],
-             "bytes_per_sample": round(run["bytes_per_sample"], 1), "per_sample": run["per_sample"],
              "roofline": roofline_of(run, None, None, calib)}
+        if "bytes_per_sample" in run:
+            e["bytes_per_sample"], e["per_sample"] = round(run["bytes_per_sample"], 1), run["per_sample"]
+        if "stream" in run:
+            e["stream"] = run["stream"]
         if "baked_bytes" in run:
             e["baked_bvh_bytes"] = run["baked_bytes"]
         if "own_tree" in run:
             e["own_tree"] = run["own_tree"]
         e["pixel_pool"] = run.get("pixel_pool")
         res.append(e)
-        if not run["mode_asked"] or args.tolerance_counters:  # (the other modes' counter passes are opt-in)
+        if not run["mode_asked"] or (args.tolerance_counters and run["mode_asked"] <= 2):  # (the other modes' counter passes are opt-in)
             deferred.append((name, run, e))
     # what the tolerance mode buys, per workload
     res.sort(key=lambda e: 0 if "error" not in e else 1)
     exact = {e["name"]: e["value"] for e in res if "value" in e and e["mode"].startswith("bit-exact")}
     exact["configs1"] = args.primary_value  # (the primary line is the bit-exact configs[1])
     for e in res:
-        if "value" in e and not e["mode"].startswith("bit-exact") and e["name"] in exact:
-            e["speedup_over_bit_exact"] = round(e["value"] / exact[e["name"]], 3)
+        if "value" in e and not e["mode"].startswith(("bit-exact", "pathdirect", "pathmis")) and e["name"] in exact:
+            e["speedup_over_bit_exact"] = round(e["value"] / exact[e["name"]], 3)  # (over the fused kernel's bit-exact `path`)
     return res, deferred
 
 
@@ -502,8 +520,10 @@ def compact_line(out, detail_path):
                 short.append({"name": o.get("name"), "error": o["error"][:80]})
                 continue
             r = o.get("roofline", {})
-            mode = o["mode"].split(" ")[0]  # "bit-exact" / "tolerance" / "own-tree"
-            e = {"name": o["name"], "mode": mode, "value": round(o["value"], 1), "ms_per_step": round(o["ms_per_step"], 2)}
+            mode = o["mode"].split(" ")[0].rstrip(":")  # "bit-exact" / "tolerance" / "own-tree" / "stream" / "pathdirect" / "pathmis"
+            e = {"name": o["name"], "mode": mode, "value": round(o["value"], 1)}
+            if mode in ("bit-exact", "pathdirect", "pathmis"):  # (the others carry their ratio to the bit-exact entry)
+                e["ms_per_step"] = round(o["ms_per_step"], 2)
             if r.get("bound"):  # (entries whose counter passes are opt-in carry no fractions)
                 e.update(bound=r["bound"], frac=round(r["frac"], 3), lanes=round(r.get("lane_utilisation") or 0, 3))
             if "speedup_over_bit_exact" in o:

@@ -44,7 +44,7 @@ def test_default_line_carries_the_contract(tmp_path):
     assert "counters_per_launch" not in lr
     for o in line["other_configs"]:
         assert set(o) <= {"name", "mode", "value", "ms_per_step", "bound", "frac", "lanes", "x"}, o
-        assert o["value"] > 0 and o["mode"] in ("bit-exact", "tolerance", "own-tree")
+        assert o["value"] > 0 and o["mode"] in ("bit-exact", "tolerance", "own-tree", "stream", "pathdirect", "pathmis")
         if o["mode"] == "bit-exact":
             assert o["bound"] in ("hbm", "l2", "valu", "ta") and 0 < o["frac"] <= 1 and 0 < o["lanes"] <= 1
     lb = line["cpu_baseline"]
@@ -101,6 +101,14 @@ def test_default_line_carries_the_contract(tmp_path):
     assert all(o["roofline"]["kernel"].startswith("yt::k_trace") for o in exact)
     assert all(o["fastmath_ran"] == 1 for o in fast)  # the tolerance-mode unit really ran
     assert all(0.9 < o["speedup_over_bit_exact"] < 2 for o in fast)
+    # round 6: `path` on the streaming scheduler (bit-exact) on the workloads it was measured on, and the NEE samplers on cfg2b
+    streamed = [o for o in j["other_configs"] if o.get("mode", "").startswith("stream")]
+    assert [o["name"] for o in streamed] == ["cfg2b", "configs3", "configs4", "cornell9m"]
+    assert all(o["streamed"] == 1 and o["stream"]["groups"] == 2 and o["stream"]["generations"] >= 64 for o in streamed)
+    assert all(0.5 < o["speedup_over_bit_exact"] < 2 for o in streamed)
+    nee = [o for o in j["other_configs"] if o.get("mode", "").startswith("path")]
+    assert [(o["name"], o["mode"].split(":")[0]) for o in nee] == [("cfg2b", "pathdirect"), ("cfg2b", "pathmis")]
+    assert all("sampler=" + o["mode"].split(":")[0] in o["workload"] and o["streamed"] == 0 for o in nee)
     own = [o for o in j["other_configs"] if o.get("mode", "").startswith("own-tree")]
     assert [o["name"] for o in own] == [o["name"] for o in fast]
     assert all(o["fastmath_ran"] == 2 and o["own_tree"]["nodes"] > 0 for o in own)  # ... and so did the own-tree unit, on its tree

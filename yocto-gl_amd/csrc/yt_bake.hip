@@ -385,18 +385,6 @@ int bake_bvh(ythip_ctx* ctx) {
     ti.leaf_bias = (int)(leaf_base[s] - b.prim_offset[s] * strides[s]);
     ti.shape     = s;
   }
-  // all instances of one shape: the per-shape half of their records as launch constants (yt_bvh.h: load_instance_record)
-  ctx->ds.one_shape = 0;
-  if (!tinst.empty()) {
-    bool one = true;
-    for (auto& ti : tinst) one = one && ti.shape == tinst[0].shape;
-    if (one) {
-      const auto& t0 = tinst[0];
-      ctx->ds.one_shape = 1, ctx->ds.one_root = t0.root_ref, ctx->ds.one_kind = t0.kind, ctx->ds.one_leaf_bias = t0.leaf_bias;
-      ctx->ds.one_bmin = {t0.root_bmin[0], t0.root_bmin[1], t0.root_bmin[2]};
-      ctx->ds.one_bmax = {t0.root_bmax[0], t0.root_bmax[1], t0.root_bmax[2]};
-    }
-  }
   ctx->ds.tlas_ref  = roots[nshapes].ref;
   ctx->ds.tlas_bmin = {roots[nshapes].bmin[0], roots[nshapes].bmin[1], roots[nshapes].bmin[2]};
   ctx->ds.tlas_bmax = {roots[nshapes].bmax[0], roots[nshapes].bmax[1], roots[nshapes].bmax[2]};

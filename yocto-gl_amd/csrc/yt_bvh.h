@@ -297,14 +297,10 @@ YT_FN float4 ldc4(const void* p, int k) {  // float4 #k at the (uniform) address
   const v4f_ v = ((cv4f*)p)[k];
   return float4{v.x, v.y, v.z, v.w};
 }
-// the 96-B traversal record #idx of `base` (sc.tinst or sc.tinst_leaf).  In a scene whose instances all refer to one shape
-// (DScene::one_shape) the per-shape half — root box, root ref, kind, leaf bias: m3, m4, m5.x — is a launch constant and only the
-// per-instance half is fetched: the inverse frame (3 of the 6 float4) and, where the caller uses it, the instance id (m5.z; one
-// dword) — half the vector loads of a TLAS-leaf entry on BASELINE configs[3].  Same values either way.
-#ifndef YT_ONE_SHAPE
-#define YT_ONE_SHAPE 1
-#endif
-YT_FN void load_instance_record(const DScene& sc, const DInstanceT* base, int idx, float4& m0, float4& m1, float4& m2, float4& m3, float4& m4, int4& m5) {
+// the 96-B traversal record #idx of `base` (sc.tinst or sc.tinst_leaf).  (Round 6 measured the per-shape half of the record —
+// root box, root ref, kind, leaf bias — as launch constants for scenes whose instances all refer to ONE shape, half the vector
+// loads of a TLAS-leaf entry on BASELINE configs[3]: -0.8 %, tools/experiments/r06_one_shape_records.patch.)
+YT_FN void load_instance_record(const DInstanceT* base, int idx, float4& m0, float4& m1, float4& m2, float4& m3, float4& m4, int4& m5) {
   int u;
   if (SCALAR_LOADS && wave_uniform(idx, u)) {
     const DInstanceT* r = base + u;
@@ -314,17 +310,9 @@ YT_FN void load_instance_record(const DScene& sc, const DInstanceT* base, int id
     return;
   }
   const float4* ti = reinterpret_cast<const float4*>(base + idx);
-  if (YT_ONE_SHAPE && sc.one_shape) {
-    m0 = ti[0], m1 = ti[1], m2 = ti[2];
-    m3 = {sc.one_bmin.x, sc.one_bmin.y, sc.one_bmin.z, sc.one_bmax.x};
-    m4 = {sc.one_bmax.y, sc.one_bmax.z, __int_as_float(sc.one_root), __int_as_float(sc.one_kind)};
-    m5 = {sc.one_leaf_bias, 0, reinterpret_cast<const int*>(ti)[22], 0};  // ([22]: DInstanceT::instance)
-    return;
-  }
   m0 = ti[0], m1 = ti[1], m2 = ti[2], m3 = ti[3], m4 = ti[4];
   m5 = reinterpret_cast<const int4*>(ti)[5];
 }
-static_assert(offsetof(DInstanceT, instance) == 22 * 4, "load_instance_record reads the instance id as dword 22");
 
 // The traversal.  `only_instance` < 0: intersect_scene_bvh (yocto_bvh.cpp:554-617);
 // otherwise intersect_instance_bvh of that instance (yocto_bvh.cpp:619-628).
@@ -383,7 +371,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   auto enter = [&](const DInstanceT* base, int idx, int inst, bool tested = false) -> int {
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-    load_instance_record(sc, base, idx, m0, m1, m2, m3, m4, m5);
+    load_instance_record(base, idx, m0, m1, m2, m3, m4, m5);
     int root = __float_as_int(m4.z);
     if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
@@ -428,7 +416,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   auto pretest = [&](int k, float& t0) -> bool {
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-    load_instance_record(sc, sc.tinst_leaf, k, m0, m1, m2, m3, m4, m5);
+    load_instance_record(sc.tinst_leaf, k, m0, m1, m2, m3, m4, m5);
     t0 = 0;
     if (__float_as_int(m4.z) == REF_NONE) return false;
     frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
@@ -668,7 +656,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
           if (k >= num) continue;
           float4 m0, m1, m2, m3, m4;
           int4   m5;
-          load_instance_record(sc, sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
+          load_instance_record(sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
           if (__float_as_int(m4.z) == REF_NONE) continue;
           frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
           vec3f   io   = transform_point(inv, wo);
@@ -689,9 +677,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
             done = true;
             continue;
           }
-          int4 m5;
-          if (YT_ONE_SHAPE && sc.one_shape) m5 = {sc.one_leaf_bias, 0, reinterpret_cast<const int*>(sc.tinst_leaf + (first + ck))[22], 0};
-          else m5 = reinterpret_cast<const int4*>(sc.tinst_leaf + (first + ck))[5];
+          const int4 m5 = reinterpret_cast<const int4*>(sc.tinst_leaf + (first + ck))[5];
           cur_inst      = m5.z;
           o = co, d = cd, dinv = cdinv;
           tame     = true;
@@ -798,7 +784,7 @@ YT_FN Hit traverse_phased(const DScene& sc, const ray3f& wray, int only_instance
   auto enter = [&](const DInstanceT* base, int idx, int inst) -> int {  // (as in traverse())
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-    load_instance_record(sc, base, idx, m0, m1, m2, m3, m4, m5);
+    load_instance_record(base, idx, m0, m1, m2, m3, m4, m5);
     int root = __float_as_int(m4.z);
     if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;

@@ -67,23 +67,17 @@ struct BvhView {
   int               tlas_ref = 0x7ffffffe;  // REF_NONE
   vec3f             tlas_bmin = {0, 0, 0}, tlas_bmax = {0, 0, 0};
   const uint4*      own = nullptr;
-  int               one_shape = 0, one_root = 0, one_kind = 0, one_leaf_bias = 0;  // (DScene::one_shape ...: the trees' roots differ)
-  vec3f             one_bmin = {0, 0, 0}, one_bmax = {0, 0, 0};
   static BvhView    of(const DScene& d) {
     BvhView v;
     v.pairs = d.pairs, v.wide = d.wide, v.leafdata = d.leafdata, v.tlas_prims = d.tlas_prims;
     v.tinst = d.tinst, v.tinst_leaf = d.tinst_leaf, v.tlas_ref = d.tlas_ref, v.tlas_bmin = d.tlas_bmin, v.tlas_bmax = d.tlas_bmax;
     v.own = d.own;
-    v.one_shape = d.one_shape, v.one_root = d.one_root, v.one_kind = d.one_kind, v.one_leaf_bias = d.one_leaf_bias;
-    v.one_bmin = d.one_bmin, v.one_bmax = d.one_bmax;
     return v;
   }
   void apply(DScene& d) const {
     d.pairs = pairs, d.wide = wide, d.leafdata = leafdata, d.tlas_prims = tlas_prims;
     d.tinst = tinst, d.tinst_leaf = tinst_leaf, d.tlas_ref = tlas_ref, d.tlas_bmin = tlas_bmin, d.tlas_bmax = tlas_bmax;
     d.own = own;
-    d.one_shape = one_shape, d.one_root = one_root, d.one_kind = one_kind, d.one_leaf_bias = one_leaf_bias;
-    d.one_bmin = one_bmin, d.one_bmax = one_bmax;
   }
 };
 

@@ -98,7 +98,8 @@ inline bool header(const uint8_t* data, size_t size, Info& info, std::string& wh
     const uint8_t* v = data + at;
     at += len;
     if (name == "compression") {
-      if (len < 1 || v[0] > 4) return why = v[0] == 128 ? "ZFP compression is not supported" : "unknown EXR compression type " + std::to_string((int)v[0]) + " (NONE, RLE, ZIPS, ZIP and PIZ are read)", false;
+      if (len < 1) return why = "corrupt EXR: failed to read attribute", false;  // (an empty "string"-typed value got here and v[0] was read past it)
+      if (v[0] > 4) return why = v[0] == 128 ? "ZFP compression is not supported" : "unknown EXR compression type " + std::to_string((int)v[0]) + " (NONE, RLE, ZIPS, ZIP and PIZ are read)", false;
       info.compression = v[0], has[0] = true;
     } else if (name == "channels") {
       size_t p = 0;
@@ -291,9 +292,11 @@ inline bool decode(const std::vector<uint64_t>& hcode, const uint8_t* in, int nB
       for (uint64_t k = 0; k < (1ull << (FAST - e.len)); k++) fast[(size_t)(base + k)] = (int32_t)((e.sym << 6) | e.len);
     }
   const uint8_t* end = in + (nBits + 7) / 8;
-  uint64_t       c   = 0;
-  int            lc  = 0;
-  int64_t        bits_left = nBits;
+  // (the bit window is 128 bits wide: codes are up to 58 bits long and the window is refilled by whole bytes, so with 57 bits
+  //  in it the next byte would push the oldest valid bit out of a 64-bit word — ADVICE r5)
+  unsigned __int128 c  = 0;
+  int               lc = 0;
+  int64_t           bits_left = nBits;
   int            o   = 0;
   auto           fill = [&](int n) {
     while (lc < n) {
@@ -329,7 +332,7 @@ inline bool decode(const std::vector<uint64_t>& hcode, const uint8_t* in, int nB
     for (int l = 1; l <= 58 && l <= bits_left; l++) {
       if (by_len[(size_t)l].empty()) continue;
       fill(l);
-      const uint64_t code = (c >> (lc - l)) & ((1ull << l) - 1);
+      const uint64_t code = (uint64_t)(c >> (lc - l)) & ((1ull << l) - 1);
       auto&          v    = by_len[(size_t)l];
       auto           it   = std::lower_bound(v.begin(), v.end(), std::make_pair(code, -1));
       if (it != v.end() && it->first == code) {

@@ -216,8 +216,8 @@ struct Surface {
 };
 
 // TRI: what the caller knows about the scene's shapes (as traverse(): 1 triangle meshes only, 2 triangle and quad meshes only)
-// LEAF: the caller has the hit triangle's vertices from the leaf record (TriPos): the element's indices are then only needed
-// for vertex normals / colours (an untextured class: no texcoords either)
+// LEAF (class 1: untextured triangle meshes): a mesh without vertex normals and colours is shaded from the hit's leaf record alone
+// (TriPos, yt_scene.h) — its element's indices are not fetched; any other mesh goes through its indices as before
 template <int TRI = 0, bool LEAF = false>
 YT_FN Surface load_surface(const DScene& sc, int instance, int element, vec2f uv) {
   // The instance, shape and material records through the scalar cache whenever the lanes that shade together agree on
@@ -463,10 +463,13 @@ YT_FN int step_path(ShadeEnv& E, Path& P) {
   if (!in_volume) {
     // prepare shading point
     auto outgoing = -P.d;
+    auto s        = load_surface<PRIMS, LEAFPOS>(sc, isec.instance, isec.element, {isec.u, isec.v});
     TriPos        tri;
     const TriPos* tp = nullptr;
-    if constexpr (LEAFPOS) tri = load_tripos(sc, isec.leaf), tp = &tri;
-    auto s        = load_surface<PRIMS, LEAFPOS>(sc, isec.instance, isec.element, {isec.u, isec.v});
+    if constexpr (LEAFPOS) {
+      // (a mesh with vertex normals fetches its indices anyway: three more 16-B loads would only add to them — configs[3] -0.5 %)
+      if (s.shc.normals < 0 && s.shc.colors < 0) tri = load_tripos(sc, isec.leaf), tp = &tri;
+    }
     auto position = eval_shading_position(sc, s.frame, s.shc, s.e, s.uv, tp);
     auto normal   = eval_shading_normal<NOTEX>(sc, s.frame, s.shc, s.mat, s.e, s.uv, outgoing, tp);
     auto material = eval_material<NOTEX, OPAQUE>(sc, s.shc, s.mat, s.e, s.uv);

@@ -151,7 +151,7 @@ YT_FN Hit traverse_own(const DScene& sc, const ray3f& wray, int only_instance, S
   auto enter = [&](const DInstanceT* base, int idx, int inst, bool tested) -> int {
     float4 m0, m1, m2, m3, m4;
     int4   m5;
-    load_instance_record(sc, base, idx, m0, m1, m2, m3, m4, m5);
+    load_instance_record(base, idx, m0, m1, m2, m3, m4, m5);
     const int root = __float_as_int(m4.z);
     if (inst < 0) inst = m5.z;
     if (root == REF_NONE) return REF_NONE;
@@ -273,7 +273,7 @@ R                 = (T0 <= __builtin_fminf(far_, tmax)) ? (int)(REF) : REF_NONE;
       if (k >= num) continue;
       float4 m0, m1, m2, m3, m4;
       int4   m5;
-      load_instance_record(sc, sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
+      load_instance_record(sc.tinst_leaf, first + k, m0, m1, m2, m3, m4, m5);
       if (__float_as_int(m4.z) == REF_NONE) continue;
       const frame3f inv   = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
       const vec3f   io    = transform_point(inv, wo);

@@ -78,13 +78,6 @@ struct DScene {
   const DInstanceT* tinst_leaf; // the same records gathered in TLAS-leaf order (tinst[tlas_prims[k]], with .instance set)
   int               tlas_ref;   // ref of the TLAS root, REF_NONE if empty
   vec3f             tlas_bmin, tlas_bmax;
-  // Every instance of the scene refers to ONE shape (thousands of instances of one mesh: BASELINE configs[3]): the per-shape half
-  // of the instances' traversal records — the BLAS root's box and ref, the kind, the leaf bias — is then the same in all of them
-  // and travels here, as launch constants in scalar registers; a record fetch is the per-instance half only (round 6,
-  // yt_bvh.h: load_instance_record).  0: the records are read whole.
-  int               one_shape;
-  vec3f             one_bmin, one_bmax;
-  int               one_root, one_kind, one_leaf_bias;
   const uint4*      own;        // fastmath = 2 only: compressed 64-B nodes of the own tree (yt_own.h), same ids as `wide`; null otherwise
   // lights
   const DLight* lights;

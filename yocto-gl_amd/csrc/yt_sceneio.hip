@@ -1218,13 +1218,21 @@ static int scene_open_impl(const char* path, ythip_scene_file** out, ythip_scene
     if (tf.kind != TEX_HDR && tf.kind != TEX_EXR) {
       static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
       auto                 starts     = [&](const char* t) { return count >= std::strlen(t) && std::memcmp(bytes, t, std::strlen(t)) == 0; };
+      // stb_image's jpeg test reads the SOI through its get_marker, which skips 0xFF fill bytes in front of the marker code:
+      // FF FF D8 is a JPEG to the reference
+      auto jpeg_soi = [](const uint8_t* b, size_t n) {
+        if (n < 2 || b[0] != 0xff) return false;
+        size_t i = 1;
+        while (i < n && b[i] == 0xff) i++;
+        return i < n && b[i] == 0xd8;
+      };
       const char*          other      = nullptr;
       if (count >= 8 && std::memcmp(bytes, png_sig, 8) == 0) tf.kind = TEX_PNG;
       else if (ytimg::bmp::test(bytes, count)) tf.kind = TEX_BMP;
       else if (starts("GIF87a") || starts("GIF89a")) other = "GIF";
       else if (starts("8BPS")) other = "PSD";
       else if (count >= 4 && bytes[0] == 0x53 && bytes[1] == 0x80 && bytes[2] == 0xf6 && bytes[3] == 0x34) other = "Softimage PIC";
-      else if (count >= 2 && bytes[0] == 0xff && bytes[1] == 0xd8) tf.kind = TEX_JPG;
+      else if (jpeg_soi(bytes, count)) tf.kind = TEX_JPG;
       else if (starts("P5") || starts("P6")) other = "PNM";
       else if (starts("#?RADIANCE\n") || starts("#?RGBE\n")) other = "Radiance HDR (as an 8-bit texture)";
       else if (ytimg::tga::test(bytes, count)) tf.kind = TEX_TGA;

@@ -264,6 +264,8 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   if (params->camera < 0 || params->camera >= ctx->num_cameras)
     return fail(ctx, YTHIP_ERR_INVALID, "camera index %d out of range [0,%d)", params->camera, ctx->num_cameras);
   if (params->batch < 1) return fail(ctx, YTHIP_ERR_INVALID, "batch must be >= 1");
+  if (params->fastmath < 0 || params->fastmath > 2)  // (any other value used to render exact without a word)
+    return fail(ctx, YTHIP_ERR_INVALID, "fastmath must be 0 (bit-exact), 1 (tolerance) or 2 (own tree), not %d", params->fastmath);
   ctx->have_denoised = false;
   if (only_pix < 0 && ctx->samples >= params->samples) return YTHIP_OK;  // yocto_trace.cpp:1598
   if (stop && *stop) return fail(ctx, YTHIP_ERR_CANCELLED, "cancelled");
