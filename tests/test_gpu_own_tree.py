@@ -32,9 +32,13 @@ HIT_IDENTICAL = 0.99    # rays whose own-tree hit record names the reference's (
                         # scenes, 0.9987 on the Cornell box — its blocks stand ON the floor —, 0.9962 on the hair: consecutive
                         # segments of a strand share an end point, and a ray that meets the joint meets both at one distance) ...
 HIT_AGREEMENT = 0.9999  # ... or another primitive at exactly the reference's distance (coincident faces, shared edges)
-HIT_IDENTICAL_BY_SCENE = {"cfg5": 0.975}  # the hair with the one-reciprocal line test (own_line): 0.9841 identical, 17 811 ties of
-                                          # 1.12 M rays — a strand's joints again, now also where rounding decides between two
-                                          # segments at distances one ulp apart; identical-or-tie stays 0.99996
+HIT_IDENTICAL_BY_SCENE = {"cfg5": 0.98}  # the hair with the one-reciprocal line test (own_line): 0.9841 identical; what is not is
+                                         # classified below — JOINT ties: the neighbouring segment of the same strand (element +-1)
+                                         # at the reference's distance, a ray that meets the shared end point of two segments —
+                                         # and identical + joint must reach HIT_IDENTICAL again
+FAR_OFF_MAX = {"cfg5": 12}  # rays that name ANOTHER surface (distance off by > 1e-3 rel).  Triangle / quad scenes: none since the
+                            # edge rule of own_triangle (round 6: 60 of 2.27 M leaked through cracks on cfg4 before); the hair's
+                            # are grazes of 1 mm-thin segments (9 of 1.12 M)
 
 
 def statistical_gate(what, ref, other_seed, got, w, h, ratio):
@@ -59,7 +63,7 @@ def statistical_gate(what, ref, other_seed, got, w, h, ratio):
     return dict(rel_mean=rel_mean, err=err, spread=spread, same_rng=same_rng, hits_differ=hits_differ)
 
 
-def hit_agreement(what, own, exact, identical_min=HIT_IDENTICAL):
+def hit_agreement(what, own, exact, identical_min=HIT_IDENTICAL, far_off_max=0):
     """Own-tree hit records against the reference's (= the exact walk's): the share of rays that name the same (hit,
     instance, element), and the share that does so OR names another primitive at the same distance (an exact tie:
     coincident faces — the Cornell box's blocks stand ON the floor —, shared edges; which of the two wins depends on the
@@ -71,16 +75,20 @@ def hit_agreement(what, own, exact, identical_min=HIT_IDENTICAL):
     d_own, d_ex = own["distance"].astype(np.float64), exact["distance"].astype(np.float64)
     rel = np.where(both, np.abs(d_own - d_ex) / np.maximum(np.abs(d_ex), 1e-6), 0.0)
     tie = both & ~same_prim & (rel <= 1e-5)
+    # a strand's joint: the neighbouring segment (consecutive elements of one shape's line list) at the same distance
+    joint = tie & (own["instance"] == exact["instance"]) & (np.abs(own["element"].astype(np.int64) - exact["element"]) == 1)
     identical = (same_flag & (~both | same_prim)).mean()
+    identical_or_joint = (same_flag & (~both | same_prim | joint)).mean()
     identical_or_tie = (same_flag & (~both | same_prim | tie)).mean()
     far_off = int((rel > 1e-3).sum())   # a different surface altogether
     flips = int((~same_flag).sum())     # hit here, miss there: a graze of a box / triangle edge
     print(f"[hits] {what}: {n} rays, identical (hit, instance, element) {identical:.6f}; identical or an exact tie "
-          f"{identical_or_tie:.6f} ({int(tie.sum())} ties); hit / miss flips {flips}; another surface (distance off by > 1e-3 rel) "
-          f"{far_off}")
+          f"{identical_or_tie:.6f} ({int(tie.sum())} ties, {int(joint.sum())} of them the neighbouring segment of a strand: identical or "
+          f"joint {identical_or_joint:.6f}); hit / miss flips {flips}; another surface (distance off by > 1e-3 rel) {far_off}")
     assert identical >= identical_min, (what, identical)
+    assert identical_or_joint >= HIT_IDENTICAL, (what, identical_or_joint)
     assert identical_or_tie >= HIT_AGREEMENT, (what, identical_or_tie)
-    assert far_off <= max(2, n // 20000), (what, far_off)
+    assert far_off <= far_off_max, (what, far_off)
     assert flips <= max(2, n // 5000), (what, flips)
     return identical
 
@@ -123,7 +131,7 @@ def test_own_walk_names_the_references_hits(scenes, name):
     rays = np.concatenate([ctx.camera_rays(p), P.random_rays(flat, 200_000, seed=23)])
     exact = ctx.intersect_batch(rays)  # (== the reference's records: tests/test_gpu_baseline_configs.py, test_gpu_parity.py)
     own = ctx.intersect_batch_own(rays)
-    hit_agreement(name, own, exact, HIT_IDENTICAL_BY_SCENE.get(name, HIT_IDENTICAL))
+    hit_agreement(name, own, exact, HIT_IDENTICAL_BY_SCENE.get(name, HIT_IDENTICAL), FAR_OFF_MAX.get(name, 0))
     # ... and the exact entry is what it was (the own tree is built NEXT TO the reference tree)
     assert ctx.intersect_batch(rays).tobytes() == exact.tobytes()
     if name == "cornellbox" and P.have_ref():
@@ -132,7 +140,8 @@ def test_own_walk_names_the_references_hits(scenes, name):
     if len(flat.instances) > 1:  # intersect_instance_bvh: one instance per ray
         inst = np.random.default_rng(5).integers(0, len(flat.instances), 50_000).astype("i4")
         rr = P.random_rays(flat, 50_000, seed=29)
-        hit_agreement(name + " (per-instance walks)", ctx.intersect_batch_own(rr, inst), ctx.intersect_instance_batch(inst, rr))
+        hit_agreement(name + " (per-instance walks)", ctx.intersect_batch_own(rr, inst), ctx.intersect_instance_batch(inst, rr),
+                      far_off_max=FAR_OFF_MAX.get(name, 0))
 
 
 @pytest.mark.parametrize("name", list(BASELINE))
@@ -141,9 +150,7 @@ def test_own_tree_and_tolerance_mode_at_baseline_size_against_the_reference(scen
     Without the compiled reference on the box the exact HIP render stands in (it is the reference's bytes:
     tests/test_gpu_baseline_configs.py asserts that at these very sizes)."""
     flat, ctx = scenes(name)
-    _, res, spp = BASELINE[name]
-    if name == "cfg4":
-        spp = 64  # (the gate needs three exact-size renders and one CPU render: a quarter of configs[3]'s 256 spp)
+    _, res, spp = BASELINE[name]  # (configs[3] at its 256 spp since round 6: the CPU render is cached per session)
     kw = dict(sampler="path", resolution=res, samples=spp, batch=spp)
     exact = P.gpu_render(ctx, flat, yt.trace_params(**kw))
     assert ctx.last_launch_fastmath() == 0
@@ -164,14 +171,20 @@ def test_own_tree_and_tolerance_mode_at_baseline_size_against_the_reference(scen
 
 @pytest.mark.parametrize("sampler", ["pathdirect", "pathmis", "naive", "eyelight", "pathtest"])
 def test_own_tree_mode_of_the_other_samplers(scenes, sampler):
+    """The other samplers through the same gate as `path` (round 6: directly against oracle/_ref, 640 px, the same block ratio —
+    round 5 gated them against the HIP exact render at 192 x 108 with ratio 1.0)."""
     flat, ctx = scenes("materials")
-    kw = dict(sampler=sampler, resolution=192, samples=32, batch=32)
+    kw = dict(sampler=sampler, resolution=640, samples=32, batch=32)
     exact = P.gpu_render(ctx, flat, yt.trace_params(**kw))
     w, h = ctx.width, ctx.height
+    ref = exact
+    if P.have_ref():
+        ref = P.ref_render_cached(("materials", sampler, 640, 32), flat, yt.trace_params(**kw))
+        P.assert_identical(exact, ref, f"materials {sampler}: exact render vs oracle/_ref")
     other = P.gpu_render(ctx, flat, yt.trace_params(seed=20240917, **kw))
     own = P.gpu_render(ctx, flat, yt.trace_params(fastmath=2, **kw))
     assert ctx.last_launch_fastmath() == 2
-    statistical_gate(f"materials {sampler} own tree", exact, other, own, w, h, 1.0)  # (192 x 108 x 32 spp: few blocks, loose ratio)
+    statistical_gate(f"materials {sampler} {w}x{h}x32 own tree vs reference", ref, other, own, w, h, OWN_BLOCK_RATIO)
 
 
 def test_own_tree_must_be_built_is_dropped_by_edits_and_leaves_the_exact_mode_alone():

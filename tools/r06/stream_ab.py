@@ -62,17 +62,17 @@ def main():
         for v in variants:
             order, cells = int(v[0]), int(v[1])
             phased = int(v[2]) if len(v) > 2 else -1
-            groups, frac = (int(v[3]) if len(v) > 3 else 1), (v[4] if len(v) > 4 else 1.0)
+            groups = int(v[3]) if len(v) > 3 else 2
             ctx.set_scheduler(1)
             ctx.set_stream_options(order=order, cell_bits=cells, phased=phased)
             ctx.set_stream_groups(groups)
-            ms = timed(ctx, flat, p, launches)  # (the pixel queue's order comes from the warm-up batches' costs)
+            ms = timed(ctx, flat, p, launches)
             info = ctx.stream_info()
             ctx.make_trace_state(flat, p)
             ctx.trace_samples(p)
             d = digest(ctx)
             even = info["lane_steps"] / max(1, info["wave_steps"])
-            print(f"{name:10s} stream order {order} cells {cells} phased {phased:2d} groups {info['groups']} slots {info['path_slots'] / 1e3:.0f}k {ms:9.3f} ms {npix * spp / ms / 1e3:9.1f} Msamples/s  x{ms0 / ms:.3f}  "
+            print(f"{name:10s} stream order {order} cells {cells} phased {phased:2d} groups {info['groups']} {ms:9.3f} ms {npix * spp / ms / 1e3:9.1f} Msamples/s  x{ms0 / ms:.3f}  "
                   f"state {d} {'OK' if d == d0 else 'DIFFERENT'}  generations {info['generations']} (+{info['launched'] - info['generations']} empty)  "
                   f"rays {info['rays'] / 1e6:.1f} M  walk evenness {even:.3f}", flush=True)
         ctx.close()

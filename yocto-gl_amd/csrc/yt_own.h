@@ -63,7 +63,13 @@ YT_FN bool own_box(vec3f o, vec3f idir, float tmin, vec3f bmin, vec3f bmax, floa
   return t0 <= far * BBOX_K;
 }
 
-// Möller–Trumbore, one reciprocal, fused multiply-adds (yocto_geometry.h:794-825 is the exact walk's)
+// Möller–Trumbore, one reciprocal, fused multiply-adds (yocto_geometry.h:794-825 is the exact walk's).
+// Edge rule (round 6): the barycentric tests take a tolerance of OWN_EDGE_EPS.  Two triangles that share an edge evaluate it from
+// different vertices and edge vectors, and with a reciprocal and fused products both can put a ray that passes ON the edge a few
+// 1e-8 OUTSIDE: the ray then slips between them and hits whatever lies behind (60 of 2.27 M rays on the 10 k-sphere scene named
+// "another surface", 9 on the hair: profiles/r05_own_tree_gates.txt).  With the tolerance both neighbours take such a ray — the
+// nearer hit wins as always — and the returned coordinates are clamped into the triangle.
+constexpr float OWN_EDGE_EPS = 9.5367431640625e-7f;  // 2^-20
 YT_FN PrimHit own_triangle(vec3f o, vec3f d, float tmin, float tmax, vec3f p0, vec3f p1, vec3f p2) {
   const vec3f e1 = {p1.x - p0.x, p1.y - p0.y, p1.z - p0.z}, e2 = {p2.x - p0.x, p2.y - p0.y, p2.z - p0.z};
   const vec3f pv = {d.y * e2.z - d.z * e2.y, d.z * e2.x - d.x * e2.z, d.x * e2.y - d.y * e2.x};
@@ -72,13 +78,13 @@ YT_FN PrimHit own_triangle(vec3f o, vec3f d, float tmin, float tmax, vec3f p0, v
   const float inv = __builtin_amdgcn_rcpf(det);
   const vec3f tv  = {o.x - p0.x, o.y - p0.y, o.z - p0.z};
   const float u   = (tv.x * pv.x + tv.y * pv.y + tv.z * pv.z) * inv;
-  if (u < 0 || u > 1) return {0, 0, flt_max, false};
+  if (!(u >= -OWN_EDGE_EPS && u <= 1 + OWN_EDGE_EPS)) return {0, 0, flt_max, false};
   const vec3f qv = {tv.y * e1.z - tv.z * e1.y, tv.z * e1.x - tv.x * e1.z, tv.x * e1.y - tv.y * e1.x};
   const float v  = (d.x * qv.x + d.y * qv.y + d.z * qv.z) * inv;
-  if (v < 0 || u + v > 1) return {0, 0, flt_max, false};
+  if (!(v >= -OWN_EDGE_EPS && u + v <= 1 + OWN_EDGE_EPS)) return {0, 0, flt_max, false};
   const float t = (e2.x * qv.x + e2.y * qv.y + e2.z * qv.z) * inv;
   if (!(t >= tmin && t <= tmax)) return {0, 0, flt_max, false};
-  return {u, v, t, true};
+  return {__builtin_fmaxf(u, 0.0f), __builtin_fmaxf(v, 0.0f), t, true};
 }
 
 // intersect_line / intersect_point (yocto_geometry.h:716-757, :697-713) on reciprocals and fused multiply-adds; `dd2` = |d|^2
