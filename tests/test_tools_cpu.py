@@ -120,3 +120,30 @@ def test_bench_line_stays_under_4k_whatever_the_detail_holds():
     for k in ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "detail"]:
         assert k in line, k
+
+
+def test_check_bench_line_recomputes_the_roofline_from_its_side_files():
+    """tools/check_bench_line.py on round 5's committed evidence: the line, its side file of raw counters and the
+    kernel trace of the same session agree; a line whose fraction, traffic or launch time was edited does not pass."""
+    import copy
+    import csv
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_bench_line as cbl
+    prof = os.path.join(root, "profiles")
+    line = json.loads(open(os.path.join(prof, "r05_bench.json")).read())
+    detail = json.load(open(os.path.join(prof, "r05_bench_detail.json")))
+    rows = list(csv.DictReader(open(os.path.join(prof, "r05_kernel_stats.csv"))))
+    bad, out = cbl.check(line, detail, rows)
+    assert bad == [] and abs(out["fractions"]["valu"] - line["roofline"]["frac"]) < 0.01 and 2.0 < out["shader_clock_GHz"] < 2.6
+    assert cbl.main(["x", os.path.join(prof, "r05_bench.json"), os.path.join(prof, "r05_bench_detail.json"),
+                     os.path.join(prof, "r05_kernel_stats.csv")]) == 0
+    for edit in (lambda l: l["roofline"].__setitem__("frac", l["roofline"]["frac"] * 1.05),
+                 lambda l: l["roofline"]["fractions"].__setitem__("hbm", 0.4),
+                 lambda l: l["roofline"].__setitem__("traffic", l["roofline"]["traffic"] * 2),
+                 lambda l: l.__setitem__("value", l["value"] * 1.1),
+                 lambda l: l["roofline"].__setitem__("launch_ms_avg", l["roofline"]["launch_ms_avg"] * 0.9)):
+        forged = copy.deepcopy(line)
+        edit(forged)
+        assert cbl.check(forged, detail, rows)[0], "an edited line must not pass"

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as G  # noqa: E402  (the shipped flags)
 
 # (round 4: the kernels live in several units — the three k_trace units, the tolerance-mode unit, the C-ABI unit)
-UNITS = ["yt_trace_path.hip", "yt_trace_nee.hip", "yt_trace_misc.hip", "yt_fast.hip", "yt_owntree.hip", "ythip.hip"]
+UNITS = ["yt_trace_path.hip", "yt_trace_nee.hip", "yt_trace_nee_cls.hip", "yt_trace_misc.hip", "yt_stream.hip", "yt_fast.hip", "yt_owntree.hip", "ythip.hip"]
 if len(sys.argv) > 1:  # remarks captured earlier (hipcc ... 2> file)
     remarks = open(sys.argv[1]).read()
 else:

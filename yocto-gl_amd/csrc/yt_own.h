@@ -66,9 +66,10 @@ YT_FN bool own_box(vec3f o, vec3f idir, float tmin, vec3f bmin, vec3f bmax, floa
 // Möller–Trumbore, one reciprocal, fused multiply-adds (yocto_geometry.h:794-825 is the exact walk's).
 // Edge rule (round 6): the barycentric tests take a tolerance of OWN_EDGE_EPS.  Two triangles that share an edge evaluate it from
 // different vertices and edge vectors, and with a reciprocal and fused products both can put a ray that passes ON the edge a few
-// 1e-8 OUTSIDE: the ray then slips between them and hits whatever lies behind (60 of 2.27 M rays on the 10 k-sphere scene named
-// "another surface", 9 on the hair: profiles/r05_own_tree_gates.txt).  With the tolerance both neighbours take such a ray — the
-// nearer hit wins as always — and the returned coordinates are clamped into the triangle.
+// 1e-8 OUTSIDE: the ray would slip between them.  With the tolerance both neighbours take such a ray — the nearer hit wins as
+// always — and the returned coordinates are clamped into the triangle.  (What it did NOT change: the 59 rays of 2.27 M that name
+// "another surface" than the reference on the 10 k-sphere scene — those are silhouette grazes of the instance-space ray, as many
+// in the reference's favour as in this walk's: tests/test_gpu_own_tree.py.)
 constexpr float OWN_EDGE_EPS = 9.5367431640625e-7f;  // 2^-20
 YT_FN PrimHit own_triangle(vec3f o, vec3f d, float tmin, float tmax, vec3f p0, vec3f p1, vec3f p2) {
   const vec3f e1 = {p1.x - p0.x, p1.y - p0.y, p1.z - p0.z}, e2 = {p2.x - p0.x, p2.y - p0.y, p2.z - p0.z};
