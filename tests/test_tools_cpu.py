@@ -51,17 +51,18 @@ def test_kernel_resources_tool_parses_compiler_remarks(tmp_path):
 
 
 def test_bench_table_tool_renders_the_committed_line():
-    """tools/bench_table.py on profiles/r05_bench_detail.json (the side file of the committed line): DESIGN.md §5's table is this
+    """tools/bench_table.py on profiles/r06_bench_detail.json (the side file of the committed line): DESIGN.md §5's table is this
     output, so the table and the bench line are one run."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = os.path.join(root, "profiles", "r05_bench_detail.json")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_table.py"), line, os.path.join(root, "profiles", "r04_bench.json")],
+    line = os.path.join(root, "profiles", "r06_bench_detail.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_table.py"), line, os.path.join(root, "profiles", "r05_bench_detail.json")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     rows = [l for l in r.stdout.splitlines() if l.startswith("| ")]
-    assert len(rows) == 1 + 7 + 7 + 7  # header, seven workloads bit-exact, in the tolerance mode, on the own tree (the rule row starts "|-")
+    # header, seven workloads bit-exact, in the tolerance mode, on the own tree, four streamed, two NEE samplers (the rule row starts "|-")
+    assert len(rows) == 1 + 7 + 7 + 7 + 4 + 2
     import json
     j = json.load(open(line))
     assert f"**{j['value']:,.0f}**" in rows[1] and "configs[1]" in rows[1]

@@ -2,7 +2,7 @@
 """The workload table of DESIGN.md §5 from ONE bench.py line (the tables and the driver line used to be
 different runs):   python tools/bench_table.py profiles/r04_bench.json  [previous.json]
 Prints a markdown table: Msamples/s (previous round in parentheses), ms / step, the four fractions, lane utilisation,
-wait share, L2 hit rate, TA cycles per wave-level load; bit-exact rows first, then the tolerance-mode rows, then the own-tree rows."""
+wait share, L2 hit rate, TA cycles per wave-level load; bit-exact rows first, then the tolerance-mode rows, the own-tree rows, the streamed rows and the NEE samplers."""
 import json
 import sys
 
@@ -25,7 +25,8 @@ def row(name, value, ms, r, mode, speed=None):
     was = f" ({prev[name]:,.0f})" if mode == "exact" and name in prev else ""
     sp = f" ×{speed:.2f}" if speed else ""
     bound = max(f, key=f.get) if f else "-"
-    cells = [NAMES.get(name, name) + {"exact": "", "fast": " — tolerance mode", "own": " — own tree"}[mode], f"**{value:,.0f}**{was}{sp}", f"{ms:.2f}"]
+    cells = [NAMES.get(name, name) + {"exact": "", "fast": " — tolerance mode", "own": " — own tree", "stream": " — streaming scheduler (bit-exact)",
+                                         "pathdirect": " — sampler pathdirect (bit-exact)", "pathmis": " — sampler pathmis (bit-exact)"}[mode], f"**{value:,.0f}**{was}{sp}", f"{ms:.2f}"]
     cells += [("**%.2f**" % f[k]) if k == bound else ("%.2f" % f[k]) if k in f else "-" for k in ("hbm", "l2", "valu", "ta")]
     cells += ["%.2f" % r["lane_utilisation"] if "lane_utilisation" in r else "-", "%.2f" % r["wave_wait_share"] if "wave_wait_share" in r else "-",
               "%d %%" % round(100 * r["l2_hit_rate"]) if "l2_hit_rate" in r else "-",
@@ -36,10 +37,10 @@ def row(name, value, ms, r, mode, speed=None):
 print("| workload | Msamples/s (previous round) | ms / step | hbm | l2 | valu | ta | lanes | waiting | L2 hit | TA cycles / wave load |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 print(row("configs1", j["value"], j["ms_per_step"], j.get("roofline", {}), "exact"))
-for mode in ("bit-exact", "tolerance", "own-tree"):
+for mode in ("bit-exact", "tolerance", "own-tree", "stream", "pathdirect", "pathmis"):
     for e in j.get("other_configs", []):
         if "value" in e and e["mode"].startswith(mode):
-            print(row(e["name"], e["value"], e["ms_per_step"], e["roofline"], {"bit-exact": "exact", "tolerance": "fast", "own-tree": "own"}[mode],
+            print(row(e["name"], e["value"], e["ms_per_step"], e["roofline"], {"bit-exact": "exact", "tolerance": "fast", "own-tree": "own"}.get(mode, mode),
                       e.get("speedup_over_bit_exact")))
 c = j.get("cpu_baseline") or {}
 if "value" in c:
