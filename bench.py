@@ -119,7 +119,9 @@ MODE_NAMES = ["bit-exact (the reference's trace_state, byte for byte)",
               "stream (ythip_set_scheduler 1): bit-exact; every pixel in flight, per bounce a counting sort of the rays by direction "
               "octant and origin cell + a traversal-only extend kernel + a shade kernel in pixel order, two chains side by side",
               "pathdirect: bit-exact, sampler pathdirect (yocto_trace.cpp:599-722), scene-class kernel",
-              "pathmis: bit-exact, sampler pathmis (yocto_trace.cpp:725-934), scene-class kernel"]
+              "pathmis: bit-exact, sampler pathmis (yocto_trace.cpp:725-934), scene-class kernel",
+              "own-stream (fastmath = 2 on ythip_set_scheduler 1): the own tree's walk in the streaming scheduler's extend kernel; equal to "
+              "the own-tree entry byte for byte"]
 MODE_SAMPLER = {4: "pathdirect", 5: "pathmis"}
 
 
@@ -140,19 +142,22 @@ def run_workload_modes(name, device, steps, warmup, modes, count=True):
     progress(f"workload {name}: upload + bvh")
     ctx = open_context(device, flat)
     sizes = ctx.bvh_baked_sizes()
-    cnt, outs = None, []
+    cnt, outs, own_built = None, [], None
     for mode in modes:
         own_info = None
-        if mode == 2:  # the own-tree mode walks the library's own tree (built next to the reference tree)
-            ctx.make_own_bvh(flat)
-            own_info = ctx.own_bvh_info()
+        if mode in (2, 6):  # the own-tree mode walks the library's own tree (built next to the reference tree)
+            if own_built is None:
+                ctx.make_own_bvh(flat)
+                own_built = ctx.own_bvh_info()
+            own_info = own_built
         # modes 3-5 (round 6) are bit-exact like mode 0: 3 = `path` on the streaming scheduler (csrc/yt_stream.h), 4 / 5 = the
-        # next-event-estimation samplers pathdirect / pathmis (since round 6 by scene class, as `path`)
+        # next-event-estimation samplers pathdirect / pathmis (since round 6 by scene class, as `path`); 6 = the own-tree mode on the
+        # streaming scheduler
         sampler = MODE_SAMPLER.get(mode, "path")
-        ctx.set_scheduler(1 if mode == 3 else 0)
+        ctx.set_scheduler(1 if mode in (3, 6) else 0)
         progress(f"workload {name}: launches (mode {mode}: {MODE_NAMES[mode].split(' ')[0]})")
         p = yt.trace_params(sampler=sampler, resolution=w["resolution"], bounces=8, clamp=10.0,
-                            samples=1 << 30, batch=w["spp"], fastmath=mode if mode <= 2 else 0)
+                            samples=1 << 30, batch=w["spp"], fastmath=mode if mode <= 2 else 2 if mode == 6 else 0)
         width, height = ctx.make_trace_state(flat, p)
         if count and cnt is None:
             ctx.set_profiling(2)
@@ -173,7 +178,7 @@ def run_workload_modes(name, device, steps, warmup, modes, count=True):
         out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"], "sampler": sampler,
                "fastmath": int(ctx.last_launch_fastmath()), "streamed": int(ctx.stream_info()["ran"]),
                "ms_per_launch": ms, "launches": st["trace_launches"], "samples_per_launch": width * height * w["spp"]}
-        if mode == 3:
+        if mode in (3, 6):
             info = ctx.stream_info()
             out["stream"] = {k: info[k] for k in ("generations", "launched", "groups", "path_slots", "bins")}
         if cnt is not None and sampler == "path":  # (the counted work is `path`'s)
@@ -424,7 +429,8 @@ def other_workloads(device, args, calib):
     # (ythip_params::fastmath: statistically equal images, tests/test_gpu_fastmath.py) — what bit-exactness costs
     every = ["configs1", "cfg2b", "configs3", "configs4", "cornell9m", "materials1", "features1"]
     runs = []
-    extra = {"cfg2b": [3, 4, 5], "configs3": [3], "configs4": [3], "cornell9m": [3]}  # (round 6: streamed / the NEE samplers, bit-exact)
+    # (round 6: streamed / the NEE samplers, bit-exact; the own tree on the streaming scheduler where the scheduler wins)
+    extra = {"cfg2b": [3, 4, 5, 6], "configs3": [3, 6], "configs4": [3], "cornell9m": [3, 6]}
     for name in every:  # one worker process per workload: scene, context and trees once, then mode after mode
         modes = ([1, 2] if name == "configs1" else [0, 1, 2]) + extra.get(name, [])  # (the primary line IS the bit-exact configs[1])
         try:
@@ -520,7 +526,7 @@ def compact_line(out, detail_path):
                 short.append({"name": o.get("name"), "error": o["error"][:80]})
                 continue
             r = o.get("roofline", {})
-            mode = o["mode"].split(" ")[0].rstrip(":")  # "bit-exact" / "tolerance" / "own-tree" / "stream" / "pathdirect" / "pathmis"
+            mode = o["mode"].split(" ")[0].rstrip(":")  # "bit-exact" / "tolerance" / "own-tree" / "stream" / "pathdirect" / "pathmis" / "own-stream"
             e = {"name": o["name"], "mode": mode, "value": round(o["value"], 1)}
             if mode in ("bit-exact", "pathdirect", "pathmis"):  # (the others carry their ratio to the bit-exact entry)
                 e["ms_per_step"] = round(o["ms_per_step"], 2)

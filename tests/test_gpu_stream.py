@@ -125,7 +125,7 @@ def test_what_the_scheduler_does_not_serve_runs_fused():
     flat = P.SCENES["cornellbox"]()
     ctx = stream_context(flat)
     for kw in (dict(sampler="pathdirect", batch=4), dict(sampler="path", batch=1), dict(sampler="path", batch=4, bounces=0),
-               dict(sampler="path", batch=4, fastmath=1)):
+               dict(sampler="pathmis", batch=4, fastmath=1)):
         params = yt.trace_params(resolution=64, samples=4, **kw)
         got = P.gpu_render(ctx, flat, params)
         assert ctx.stream_info()["ran"] == 0, kw
@@ -135,6 +135,37 @@ def test_what_the_scheduler_does_not_serve_runs_fused():
     params = yt.trace_params(sampler="path", resolution=64, samples=4, batch=4)
     P.assert_identical(want_state(flat, params), P.gpu_render(ctx, flat, params), "fused fallback, binary walk")
     assert ctx.stream_info()["ran"] == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_streamed_tolerance_and_own_tree_modes_equal_their_fused_kernels(scene, mode):
+    """fastmath = 1 / 2 on the streaming scheduler: the tolerance and the own-tree unit carry their own build of the stream
+    kernels (csrc/yt_stream_unit.h).  The scheduler changes which wavefront walks a ray, never what a pixel computes, so a streamed
+    batch equals the FUSED batch of the same mode byte for byte (what those modes are gated against is the reference, elsewhere:
+    tests/test_gpu_fastmath.py, test_gpu_own_tree.py)."""
+    flat = P.SCENES[scene]()
+    params = yt.trace_params(sampler="path", resolution=144, samples=12, batch=6, fastmath=mode)
+    out = []
+    for stream in (0, 1):
+        ctx = P.gpu_context(flat)
+        ctx.set_traversal("wide")
+        if mode == 2:
+            ctx.make_own_bvh(flat)
+        ctx.set_scheduler(stream)
+        out.append(P.gpu_render(ctx, flat, params))
+        assert ctx.stream_info()["ran"] == stream and ctx.last_launch_fastmath() == mode, (ctx.stream_info(), ctx.last_launch_fastmath())
+        ctx.close()
+    P.assert_identical(out[0], out[1], f"{scene} fastmath {mode}: streamed vs fused")
+
+
+def test_own_tree_mode_without_its_tree_fails_on_the_streaming_scheduler_too():
+    flat = P.SCENES["cornellbox"]()
+    ctx = stream_context(flat)
+    params = yt.trace_params(sampler="path", resolution=64, samples=4, batch=4, fastmath=2)
+    with pytest.raises(yt.YthipError, match="own tree"):
+        P.gpu_render(ctx, flat, params)
     ctx.close()
 
 

@@ -5,6 +5,7 @@ Per workload: the fused kernel's time + whole-state digest, then the streaming s
 the walks of a wavefront are (sum of lane steps / 64 x longest lane; the fused kernel's figure is in profiles/r03_traversal_experiments.txt).
 
   SCENES=cfg2b,configs4 SPP=64 VARIANTS=0:4,1:4,2:4 LAUNCHES=2 python tools/r06/stream_ab.py
+FASTMATH=1 / 2: both sides in the tolerance / own-tree mode (the scheduler's kernels of yt_fast.hip / yt_owntree.hip).
 """
 import hashlib
 import os
@@ -50,7 +51,10 @@ def main():
         spp = int(os.environ.get("SPP", w["spp"]))
         res = int(os.environ.get("RES", w["resolution"]))
         ctx = bench.open_context(0, flat)
-        p = yt.trace_params(sampler=os.environ.get("SAMPLER", "path"), resolution=res, samples=1 << 30, batch=spp)
+        fm = int(os.environ.get("FASTMATH", "0"))
+        if fm == 2:
+            ctx.make_own_bvh(flat)
+        p = yt.trace_params(sampler=os.environ.get("SAMPLER", "path"), resolution=res, samples=1 << 30, batch=spp, fastmath=fm)
         ctx.set_scheduler(0)
         ms0 = timed(ctx, flat, p, launches)
         # the digest of a fixed number of batches from a fresh state
@@ -58,7 +62,7 @@ def main():
         ctx.trace_samples(p)
         d0 = digest(ctx)
         npix = ctx.npixels
-        print(f"{name:10s} {res}x{spp}spp fused            {ms0:9.3f} ms {npix * spp / ms0 / 1e3:9.1f} Msamples/s  state {d0}", flush=True)
+        print(f"{name:10s} {res}x{spp}spp fastmath {fm} fused            {ms0:9.3f} ms {npix * spp / ms0 / 1e3:9.1f} Msamples/s  state {d0}", flush=True)
         for v in variants:
             order, cells = int(v[0]), int(v[1])
             phased = int(v[2]) if len(v) > 2 else -1

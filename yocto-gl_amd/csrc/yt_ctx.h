@@ -218,6 +218,11 @@ struct ythip_ctx {
 extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds, const void* st, const void* kp, int lp, int cls);
 // yt_owntree.hip: the same kernels once more over the own tree (-DYT_FAST -DYT_OWN_TREE, own namespace; yt_own.h)
 extern "C" int ythip_own_launch(void* stream, int blocks, const void* ds, const void* st, const void* kp, int lp, int cls);
+// the two units' builds of the streaming scheduler's launches (yt_stream_unit.h); `launch`: a ytl::StreamLaunch
+extern "C" void ythip_fast_stream_begin(const void* launch);
+extern "C" void ythip_fast_stream_generation(const void* launch);
+extern "C" void ythip_own_stream_begin(const void* launch);
+extern "C" void ythip_own_stream_generation(const void* launch);
 extern "C" int ythip_own_intersect(void* stream, const void* ds, const void* rays, const int* instances, long long n, void* hits);
 
 inline void drop_staging_views(ythip_ctx* ctx) {

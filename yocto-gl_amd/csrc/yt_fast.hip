@@ -28,9 +28,12 @@
 #include "../../include/ythip.h"
 
 #define YT_FAST 1
+#define YT_STREAM_KERNELS 1  // this unit's build of the streaming scheduler (yt_stream_unit.h)
+#define ytl ytl_fast
 #define yt yt_fast
 #define ytm ytm_fast
 #include "yt_kernels.h"
+#include "yt_stream_unit.h"
 
 using namespace yt_fast;
 
@@ -79,3 +82,8 @@ extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds_, cons
     default: return 1;  // diagram / falsecolor: debug views, no tolerance build
   }
 }
+
+// the streaming scheduler in this mode (ythip_set_scheduler 1 with fastmath = 1): `l` points at the caller's ytl::StreamLaunch — the
+// same struct under this unit's namespaces
+extern "C" void ythip_fast_stream_begin(const void* l) { ytl::stream_begin(*static_cast<const ytl::StreamLaunch*>(l)); }
+extern "C" void ythip_fast_stream_generation(const void* l) { ytl::stream_generation(*static_cast<const ytl::StreamLaunch*>(l)); }

@@ -16,11 +16,14 @@
 #include "../../include/ythip.h"
 
 #define YT_FAST 1
+#define YT_STREAM_KERNELS 1  // this unit's build of the streaming scheduler (yt_stream_unit.h)
+#define ytl ytl_own
 #define YT_OWN_TREE 1
 #define yt yt_own
 #define ytm ytm_own
 #include "yt_kernels.h"
 #include "yt_own.h"
+#include "yt_stream_unit.h"
 
 using namespace yt_own;
 
@@ -79,3 +82,8 @@ extern "C" int ythip_own_intersect(void* stream, const void* ds_, const void* ra
       (unsigned long long*)nullptr);
   return 0;
 }
+
+// the streaming scheduler in this mode (ythip_set_scheduler 1 with fastmath = 2): `l` points at the caller's ytl::StreamLaunch — the
+// same struct under this unit's namespaces, its DScene the one with the own tree's bvh fields swapped in
+extern "C" void ythip_own_stream_begin(const void* l) { ytl::stream_begin(*static_cast<const ytl::StreamLaunch*>(l)); }
+extern "C" void ythip_own_stream_generation(const void* l) { ytl::stream_generation(*static_cast<const ytl::StreamLaunch*>(l)); }

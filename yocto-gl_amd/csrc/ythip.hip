@@ -130,7 +130,15 @@ void harvest_events(ythip_ctx* ctx) {
 //   * groups (YTHIP_STREAM_GROUPS, default 2): the path slots in runs, each a chain of generations of its own on its own
 //     stream — one group's shade / sort launches fill the machine while another's extend launch drains (2 groups: +8 ... +25 %
 //     over one; 4 and more lose again: profiles/r06_stream_ab_groups.txt).
-int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp, int lp, int cls, const volatile int32_t* stop) {
+//   * mode (ythip_params::fastmath): 0 = the bit-exact kernels (yt_stream.hip), 1 = the tolerance mode's (yt_fast.hip), 2 = the own
+//     tree's (yt_owntree.hip; `ds` is then the scene with the own tree's bvh fields swapped in).  The same schedule of the same
+//     per-pixel operations as the mode's fused kernel: a streamed batch equals the fused batch of its mode byte for byte.
+int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp, int lp, int cls, const volatile int32_t* stop, int mode,
+    const DScene& ds) {
+  auto begin      = [&](const ytl::StreamLaunch& l) { mode == 2 ? ythip_own_stream_begin(&l) : mode == 1 ? ythip_fast_stream_begin(&l) : ytl::stream_begin(l); };
+  auto generation = [&](const ytl::StreamLaunch& l) {
+    mode == 2 ? ythip_own_stream_generation(&l) : mode == 1 ? ythip_fast_stream_generation(&l) : ytl::stream_generation(l);
+  };
   auto& st = ctx->st;
   auto& S  = ctx->ss;
   int   rc;
@@ -157,7 +165,7 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
   S.cell_bits = std::min(std::max(ctx->stream_cell_bits, 1), 5);
   S.nbins     = 8 << (3 * S.cell_bits);
   // the cell grid of the sort keys: the scene's root box
-  const vec3f lo = ctx->ds.tlas_bmin, hi = ctx->ds.tlas_bmax;
+  const vec3f lo = ds.tlas_bmin, hi = ds.tlas_bmax;
   const float cells = (float)(1 << S.cell_bits);
   auto        scale = [&](float a, float b) { return (b > a && std::isfinite(b - a)) ? cells / (b - a) : 0.0f; };
   S.cell_lo    = lo;
@@ -192,7 +200,7 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     G[g].counts   = S.counts + 16 * g;
     G[g].stats    = prof ? S.stats + 8 * 64 * g : nullptr;
     G[g].gen_rays = prof ? S.gen_rays + YT_STREAM_GEN_LOG * g : nullptr;
-    L[g]          = {streams[g], &ctx->ds, &ctx->st, &kp, &G[g], lp, cls, phased};
+    L[g]          = {streams[g], &ds, &ctx->st, &kp, &G[g], lp, cls, phased};
   }
   ctx->stream_cancelled = false;
   int launched = 0;
@@ -202,12 +210,12 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
       HIPCHECK(ctx, hipEventRecord(ctx->stream_ev[0], ctx->stream));
       for (int g = 1; g < groups; g++) HIPCHECK(ctx, hipStreamWaitEvent(streams[g], ctx->stream_ev[0], 0));
     }
-    for (int g = 0; g < groups; g++) ytl::stream_begin(L[g]);
+    for (int g = 0; g < groups; g++) begin(L[g]);
     int chunk = std::max(1, params->batch);
     if (!ctx->done_event) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->done_event, hipEventDisableTiming));
     while (true) {
       for (int k = 0; k < chunk; k++)
-        for (int g = 0; g < groups; g++) ytl::stream_generation(L[g]);
+        for (int g = 0; g < groups; g++) generation(L[g]);
       launched += chunk;
       for (int g = 1; g < groups; g++) {  // the main stream (and with it the read-back, and whatever the caller enqueues next) waits for the side streams
         HIPCHECK(ctx, hipEventRecord(ctx->stream_ev[g], streams[g]));
@@ -321,17 +329,23 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
       if (l.instance != YTHIP_INVALIDID) lp = LP_DEFER;
   }
 
-  // the streaming scheduler (ythip_set_scheduler 1): `path`, bit-exact mode, scenes the wide walk serves, real batches
+  // the streaming scheduler (ythip_set_scheduler 1): `path`, scenes the mode's wide walk serves, real batches.  In the mode the
+  // caller asked for (round 6: the tolerance and own-tree units carry their own build of the kernels); a mode whose fused kernel
+  // would not run either (no own tree: an error below; a tree the tolerance unit's walk cannot serve) is left to the fused path.
   ctx->last_launch_stream = false;
   ctx->stream_info.ran    = 0;
-  if (ctx->scheduler == 1 && only_pix < 0 && !count && params->fastmath == 0 && ctx->use_wide() && params->batch >= ctx->stream_min_batch) {
-    const int cls = ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
+  if (ctx->scheduler == 1 && only_pix < 0 && !count && params->batch >= ctx->stream_min_batch) {
+    const int  mode = params->fastmath;
+    const bool served = mode == 0 ? ctx->use_wide() : mode == 1 ? (ctx->wide_stack_ok && ctx->traversal_mode != 0) : (ctx->have_own && ctx->own_stack_ok);
+    const int  cls  = ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
     ytl::StreamLaunch probe = {ctx->stream, &ctx->ds, &ctx->st, &kp, &ctx->ss, lp, cls, false};
-    if (ytl::stream_supported(probe)) {
+    if (served && ytl::stream_supported(probe)) {
       ctx->st.tile_perm = nullptr, ctx->st.tile_cost = nullptr, ctx->st.pool_next = nullptr, ctx->st.pool_total = 0;
-      int rc = enqueue_stream(ctx, params, kp, lp, cls, stop);
+      DScene d = ctx->ds;  // (mode 2: only the bvh part is the own tree's — launch_trace_any)
+      if (mode == 2) ctx->own.apply(d);
+      int rc = enqueue_stream(ctx, params, kp, lp, cls, stop, mode, d);
       if (rc) return rc;
-      ctx->last_launch_fast = false, ctx->last_launch_mode = 0, ctx->last_launch_stream = true;
+      ctx->last_launch_fast = mode != 0, ctx->last_launch_mode = mode, ctx->last_launch_stream = true;
       ctx->samples += params->batch;
       return YTHIP_OK;
     }
