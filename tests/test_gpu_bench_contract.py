@@ -44,7 +44,7 @@ def test_default_line_carries_the_contract(tmp_path):
     assert "counters_per_launch" not in lr
     for o in line["other_configs"]:
         assert set(o) <= {"name", "mode", "value", "ms_per_step", "bound", "frac", "lanes", "x"}, o
-        assert o["value"] > 0 and o["mode"] in ("bit-exact", "tolerance", "own-tree", "stream", "pathdirect", "pathmis")
+        assert o["value"] > 0 and o["mode"] in ("bit-exact", "tolerance", "own-tree", "stream", "pathdirect", "pathmis", "own-stream")
         if o["mode"] == "bit-exact":
             assert o["bound"] in ("hbm", "l2", "valu", "ta") and 0 < o["frac"] <= 1 and 0 < o["lanes"] <= 1
     lb = line["cpu_baseline"]
@@ -113,6 +113,11 @@ def test_default_line_carries_the_contract(tmp_path):
     assert [o["name"] for o in own] == [o["name"] for o in fast]
     assert all(o["fastmath_ran"] == 2 and o["own_tree"]["nodes"] > 0 for o in own)  # ... and so did the own-tree unit, on its tree
     assert all(0.8 < o["speedup_over_bit_exact"] < 4 for o in own)
+    # ... and the own tree on the streaming scheduler (the scheduler's kernels of the own-tree unit), where the scheduler pays
+    own_streamed = [o for o in j["other_configs"] if o.get("mode", "").startswith("own-stream")]
+    assert [o["name"] for o in own_streamed] == ["cfg2b", "configs3", "cornell9m"]
+    assert all(o["fastmath_ran"] == 2 and o["streamed"] == 1 and o["stream"]["groups"] == 2 for o in own_streamed)
+    assert all(0.8 < o["speedup_over_bit_exact"] < 4 for o in own_streamed)
     assert "800,000 line segments" in exact[2]["workload"]
     assert exact[4]["roofline"]["kernel"].endswith("3>") and exact[5]["roofline"]["kernel"].endswith("0>")  # opaque-textured / general class
     big = exact[3]
@@ -123,6 +128,17 @@ def test_slice_run_and_flags():
     j = run_bench("--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--as-rank", "3/8")
     assert j["config"]["pixels_per_rank"] == 1280 * 720 // 8 and "roofline" not in j and "cpu_baseline" not in j
     assert abs(j["value"] - j["config"]["pixels_per_rank"] * 64 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
+
+
+def test_gather_path_over_rccl_with_one_rank():
+    """The N > 1 code path of bench.py on the backend the driver's launch uses — init_process_group("nccl") = RCCL, the frame
+    gathered by all_gather on device tensors, the barrier, the max-over-ranks all_reduce — with the one rank a 1-GPU box has
+    (--rehearse-gather).  What it cannot show is a transfer between two devices; what it does show is that RCCL comes up in this
+    image and that the collective runs on the kernel's stream."""
+    j = run_bench("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-other-configs", "--rehearse-gather")
+    assert j["n_gpus"] == 1 and j["config"]["collective"] == {"backend": "nccl", "ranks": 1}
+    assert abs(j["value"] - 1280 * 720 * 64 / j["ms_per_step"] / 1e3) <= 1e-3 * j["value"]
+    assert j["value"] > 5000  # (the gather of one rank is a device copy: the step stays the kernel)
 
 
 def test_two_rank_launch_rehearsed_with_gloo():

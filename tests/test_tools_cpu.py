@@ -16,18 +16,21 @@ def test_fuzz_scenes_are_reproducible_and_always_lit():
     light the reference's make_trace_lights would find (the reference reads out of bounds in
     sample_lights otherwise)."""
     import fuzz_parity as F
-    samplers = set()
+    samplers, streamed = set(), 0
     for seed in range(60):
-        a, pa, ha = F.random_scene(seed)
-        b, pb, hb = F.random_scene(seed)
-        assert pa == pb and ha == hb
+        a, pa, ha, sa = F.random_scene(seed)
+        b, pb, hb, sb = F.random_scene(seed)
+        assert pa == pb and ha == hb and sa == sb
+        if sa:  # (round 6) a case for the streaming scheduler: `path`, real batches
+            streamed += 1
+            assert pa["sampler"] == "path" and pa["batch"] >= 4 and pa["samples"] % pa["batch"] == 0
         assert a.positions.tobytes() == b.positions.tobytes() and a.materials.tobytes() == b.materials.tobytes()
         samplers.add(pa["sampler"])
         lit = len(a.environments) > 0 or any(
             np.any(a.materials["emission"][i["material"]] > 0) and
             (a.shapes[i["shape"]]["num_triangles"] > 0 or a.shapes[i["shape"]]["num_quads"] > 0) for i in a.instances)
         assert lit, seed
-    assert len(samplers) >= 6
+    assert len(samplers) >= 6 and streamed >= 2
 
 
 def test_kernel_resources_tool_parses_compiler_remarks(tmp_path):

@@ -133,7 +133,15 @@ def random_scene(seed):
              bounces=int(r.choice([0, 1, 2, 4, 8])), clamp=float(r.choice([10.0, 1.0, 100.0])),
              nocaustics=int(r.random() < 0.3), envhidden=int(r.random() < 0.3), tentfilter=int(r.random() < 0.3),
              seed=int(r.integers(1, 1 << 30)), falsecolor=int(r.integers(0, 18)))
-    return sc, p, bool(r.random() < 0.25)
+    # round 6: some `path` cases run on the streaming scheduler (csrc/yt_stream.h) — wide walk forced (the scheduler has no binary
+    # walk), batches of >= 4 samples, random sort order / cell grid / number of chains; drawn AFTER everything else, so the scenes
+    # and parameters of a seed are what they were in rounds 2-5
+    stream = None
+    if sampler == "path" and p["bounces"] > 0 and r.random() < 0.6:
+        spp = int(r.integers(4, 9))
+        p["samples"], p["batch"] = spp * int(r.integers(1, 3)), spp
+        stream = dict(order=int(r.integers(0, 3)), cell_bits=int(r.integers(1, 6)), groups=int(r.choice([1, 2, 3])))
+    return sc, p, bool(r.random() < 0.25), stream
 
 
 def main():
@@ -142,11 +150,21 @@ def main():
     fails = 0
     t0 = time.time()
     for seed in range(first, first + count):
-        flat, pk, hq = random_scene(seed)
+        flat, pk, hq, stream = random_scene(seed)
         p = yt.trace_params(**pk)
+        ran = ""
         try:
             ctx = P.gpu_context(flat, highquality=hq)
+            if stream:
+                os.environ["YTHIP_STREAM_MIN_SLOTS"] = "1024"  # (small frames: let two or three chains form)
+                ctx.set_traversal("wide")
+                ctx.set_scheduler(1)
+                ctx.set_stream_options(order=stream["order"], cell_bits=stream["cell_bits"])
+                ctx.set_stream_groups(stream["groups"])
             gpu = P.gpu_render(ctx, flat, p)
+            if stream:
+                info = ctx.stream_info()
+                ran = f" streamed {info['ran']} ({info['generations']} generations, {info['groups']} chains, order {stream['order']}, {stream['cell_bits']} cell bits)"
             ctx.close()
             ref = P.RefBundle(flat, highquality=hq).render(p)
         except Exception as e:  # a scene one side refuses: report, go on
@@ -165,7 +183,7 @@ def main():
             extra = f" differing: {bad}, image pixels {nd}/{len(a)}"
         print(f"seed {seed}: {tag} {pk['sampler']:10s} res {pk['resolution']:3d} spp {pk['samples']} bounces {pk['bounces']} "
               f"hq {int(hq)} shapes {len(flat.shapes)} inst {len(flat.instances)} mats {len(flat.materials)} "
-              f"tex {len(flat.textures)} env {len(flat.environments)}{extra}", flush=True)
+              f"tex {len(flat.textures)} env {len(flat.environments)}{ran}{extra}", flush=True)
     print(f"{count} cases, {fails} failures, {time.time() - t0:.0f} s")
     return 1 if fails else 0
 

@@ -24,7 +24,10 @@ def child(scene, spp, mode):
     w = bench._workloads()[scene]
     flat = w["make"]()
     ctx = bench.open_context(0, flat)
-    p = yt.trace_params(sampler="path", resolution=w["resolution"], samples=1 << 30, batch=spp)
+    fm = int(os.environ.get("FASTMATH", "0"))  # 1 / 2: the tolerance / own-tree units' kernels (yt_fast:: / yt_own::)
+    if fm == 2:
+        ctx.make_own_bvh(flat)
+    p = yt.trace_params(sampler="path", resolution=w["resolution"], samples=1 << 30, batch=spp, fastmath=fm)
     if mode == "stream":
         ctx.set_scheduler(1)
         o, c = (int(x) for x in os.environ.get("VARIANT", "1:3").split(":"))
@@ -54,7 +57,7 @@ def collect(scene, spp, mode):
         for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                if not name.startswith(("yt::k_trace", "yt::ks_")):
+                if not name.startswith(("yt::k_trace", "yt::ks_", "yt_own::k_trace", "yt_own::ks_", "yt_fast::k_trace", "yt_fast::ks_")):
                     continue
                 c = row["Counter_Name"] + ("#2" if k == 1 and row["Counter_Name"] == "GRBM_GUI_ACTIVE" else "")
                 d = tot.setdefault(name, {})
