@@ -641,6 +641,13 @@ def main():
     if args.worker:
         return worker_main(args)
     sys.path.insert(0, os.path.join(ROOT, "yocto-gl_amd"))
+    # stdout carries ONE line.  Libraries below us write to file descriptor 1 on their own — RCCL prints a five-line banner
+    # ("RCCL version : ... / Hostname : ... / Librccl path : ...") from C stdio when a communicator comes up, which is how round 6's
+    # single-rank RCCL test found out — so descriptor 1 is pointed at stderr for the life of the process and the line is written to
+    # a private duplicate of the real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import ythip as yt
@@ -915,7 +922,7 @@ def main():
             detail = os.path.relpath(args.detail, ROOT) if args.detail.startswith(ROOT) else args.detail
         except OSError as e:
             progress(f"could not write {args.detail}: {e}")
-        print(compact_line(out, detail), flush=True)
+        os.write(real_stdout, (compact_line(out, detail) + "\n").encode())
     if gathering:
         dist.destroy_process_group()
 
