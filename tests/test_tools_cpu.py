@@ -64,8 +64,9 @@ def test_bench_table_tool_renders_the_committed_line():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     rows = [l for l in r.stdout.splitlines() if l.startswith("| ")]
-    # header, seven workloads bit-exact, in the tolerance mode, on the own tree, four streamed, two NEE samplers (the rule row starts "|-")
-    assert len(rows) == 1 + 7 + 7 + 7 + 4 + 2
+    # header, seven workloads bit-exact, in the tolerance mode, on the own tree, four streamed, two NEE samplers, three own-tree streamed
+    # (the rule row starts "|-")
+    assert len(rows) == 1 + 7 + 7 + 7 + 4 + 2 + 3
     import json
     j = json.load(open(line))
     assert f"**{j['value']:,.0f}**" in rows[1] and "configs[1]" in rows[1]
