@@ -202,7 +202,7 @@ enum {
  *             ythip_intersect_batch is not affected by this field: hit indices of a ray batch stay bit-exact.
  * The struct is 80 bytes (the reference's trace_params + fastmath): a caller built against another layout must not
  * pass it — check ythip_abi_version() == YTHIP_ABI_VERSION and ythip_params_size() == sizeof(ythip_params). */
-#define YTHIP_ABI_VERSION 5
+#define YTHIP_ABI_VERSION 6
 typedef struct ythip_params {
   int32_t  camera, resolution, sampler, falsecolor, samples, bounces;
   float    clamp;
@@ -612,7 +612,20 @@ typedef struct ythip_stream_info {
   int64_t rays;         /* profiling (ythip_set_profiling bit 0) only: rays walked by ks_extend ... */
   int64_t lane_steps;   /* ... the traversal steps they took ... */
   int64_t wave_steps;   /* ... and 64 x the longest lane of every wavefront: lane_steps / wave_steps = how even the walks are */
+  int64_t finish_rays;  /* queue entries handed to ks_finish (ythip_set_stream_finish): the paths that left the generations for the tail kernel */
+  /* ythip_set_scheduler(ctx, 2), the measured choice: 0 a fused batch is timed next (once the fused path has settled: tile costs
+   * known, pixel pool decided), 1 a streamed batch runs next untimed (the scheduler's buffers and first launches), 2 a streamed
+   * batch is timed next, 3 waiting for the two times, 4 decided */
+  int32_t choice_state;
+  int32_t choice_streamed;      /* the decision (state 4): 1 = this state / sampler / mode / batch size is served streamed */
+  float   fused_ms_per_sample;  /* the two timed batches, per sample per pixel (state 4) */
+  float   stream_ms_per_sample;
 } ythip_stream_info;
+/* mode 0: the fused persistent kernel (default).  1: the streaming scheduler wherever it serves the batch.  2: a MEASURED CHOICE,
+ * as for the pixel pool — on a batch the streaming scheduler serves (and of >= 8 samples), once the fused path has settled, one
+ * batch is timed fused, the next two run streamed (the second timed), and whichever took less time per sample (the streamed one by 3 % at least) serves
+ * the state from then on; measured again for a new trace_state, sampler, mode, bounce limit or batch size.  The two schedulers
+ * produce the same bytes, so the choice is invisible in the results.  env YTHIP_SCHEDULER. */
 int ythip_set_scheduler(ythip_ctx* ctx, int mode);
 /* Tuning of the streaming scheduler's sort (a negative argument keeps the current value; results never depend on it):
  * order 0 = direction octant major, origin cell minor (default), 1 = cell major, 2 = no sort (the queue in pixel order: the
@@ -624,6 +637,12 @@ int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phase
  * one run's shade / sort launches fill the machine while another's extend launch drains (frames too small for it run as
  * fewer).  env YTHIP_STREAM_GROUPS.  Results never depend on it. */
 int ythip_set_stream_groups(ythip_ctx* ctx, int groups);
+/* The tail of a streamed batch: once a group's queue has shrunk to `permille` thousandths of its path slots (default 250), the
+ * group stops running generations and ONE launch (ks_finish: a lane per queue entry, extend and shade in turn on the same HBM
+ * state) carries the paths still queued to the end of their pixels' batch — the last third of a batch's generations holds 2-4 %
+ * of its rays.  0 = never (generations until the queue is empty), 1000 = from the first ray on (tests).  env YTHIP_STREAM_FINISH.
+ * Results never depend on it. */
+int ythip_set_stream_finish(ythip_ctx* ctx, int permille);
 int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info);
 /* Profiling (ythip_set_profiling bit 0 during the batch): the queue length of every generation of the last streamed batch,
  * up to `capacity` (and 8192) entries; *written = how many. */

@@ -68,6 +68,53 @@ def test_groups_change_nothing(scene, monkeypatch):
         P.assert_identical(want, got, f"{scene} streamed, {groups} groups")
 
 
+@pytest.mark.parametrize("scene", SCENES)
+def test_the_tail_kernel_changes_nothing(scene, monkeypatch):
+    """ythip_set_stream_finish: the paths still queued when a group's queue has shrunk to a fraction of its slots finish their
+    pixels' batch in ONE launch (ks_finish: extend and shade in turn, a lane per queue entry) instead of further generations —
+    never (0), late, early, and from the first ray on (1000: the whole batch in ks_finish): the reference's bytes each time."""
+    monkeypatch.setenv("YTHIP_STREAM_MIN_SLOTS", "1024")
+    flat = P.SCENES[scene]()
+    params = yt.trace_params(sampler="path", resolution=160, samples=12, batch=6)
+    want = want_state(flat, params)
+    for permille, groups in ((0, 2), (250, 1), (250, 2), (700, 2), (1000, 1), (1000, 3)):
+        ctx = stream_context(flat)
+        ctx.set_stream_finish(permille)
+        ctx.set_stream_groups(groups)
+        got = P.gpu_render(ctx, flat, params)
+        info = ctx.stream_info()
+        ctx.close()
+        assert info["ran"] == 1 and info["groups"] == groups, info
+        if permille == 0:
+            assert info["finish_rays"] == 0, info
+        if permille >= 700 and scene != "plane":  # (the open plane's queue is full or empty: every sample is one generation)
+            assert info["finish_rays"] > 0, info
+        if permille == 1000:
+            assert info["generations"] <= 1 and info["finish_rays"] == info["path_slots"], info  # (the scan behind ks_init counts as one)
+        P.assert_identical(want, got, f"{scene} streamed, finish at {permille} / 1000, {groups} groups")
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_the_tail_kernel_in_the_other_modes(mode):
+    flat = P.SCENES["materials"]()
+    params = yt.trace_params(sampler="path", resolution=144, samples=8, batch=8, fastmath=mode)
+    out = []
+    for stream, permille in ((0, 0), (1, 500), (1, 1000)):
+        ctx = P.gpu_context(flat)
+        ctx.set_traversal("wide")
+        if mode == 2:
+            ctx.make_own_bvh(flat)
+        ctx.set_scheduler(stream)
+        ctx.set_stream_finish(permille)
+        out.append(P.gpu_render(ctx, flat, params))
+        assert ctx.stream_info()["ran"] == stream and ctx.last_launch_fastmath() == mode
+        if permille == 1000:
+            assert ctx.stream_info()["finish_rays"] > 0
+        ctx.close()
+    P.assert_identical(out[0], out[1], f"fastmath {mode}: streamed with a tail kernel vs fused")
+    P.assert_identical(out[0], out[2], f"fastmath {mode}: the whole batch in the tail kernel vs fused")
+
+
 @pytest.mark.parametrize("kw", [dict(tentfilter=True), dict(nocaustics=True), dict(envhidden=True), dict(bounces=1), dict(bounces=3, clamp=2.0)])
 def test_streamed_params_variants(kw):
     flat = P.SCENES["materials"]()
@@ -160,6 +207,41 @@ def test_streamed_tolerance_and_own_tree_modes_equal_their_fused_kernels(scene, 
     P.assert_identical(out[0], out[1], f"{scene} fastmath {mode}: streamed vs fused")
 
 
+def test_the_measured_choice_of_scheduler():
+    """ythip_set_scheduler(ctx, 2): once the fused path has settled one batch is timed fused, the next two run streamed (the second timed), and the faster
+    serves the state from then on; a new state / batch size is measured again; the render is the reference's whichever ran."""
+    flat = P.SCENES["cornellbox"]()
+    params = yt.trace_params(sampler="path", resolution=256, samples=96, batch=8)
+    want = want_state(flat, params)
+    ctx = P.gpu_context(flat)
+    ctx.set_traversal("wide")
+    ctx.set_scheduler(2)
+    ctx.make_trace_state(flat, params)
+    ran, states = [], []
+    for _ in range(params.samples // params.batch):
+        ctx.trace_samples(params)
+        info = ctx.stream_info()
+        ran.append(info["ran"]), states.append(info["choice_state"])
+    got = ctx.download_state()
+    P.assert_identical(want, got, "measured choice of scheduler")
+    assert states[-1] == 4 and sum(ran) >= 2, (ran, states)  # decided; two batches were the streamed probes (more if streaming won)
+    k = states.index(3)  # the timed streamed batch; the one before it streamed too (untimed), the one before that was the timed fused one
+    assert ran[k] == 1 and ran[k - 1] == 1 and ran[k - 2] == 0, (ran, states)
+    info = ctx.stream_info()
+    assert info["fused_ms_per_sample"] > 0 and info["stream_ms_per_sample"] > 0
+    assert all(r == info["choice_streamed"] for r in ran[k + 1:]), (ran, info)
+    # another batch size: measured again
+    q = yt.trace_params(sampler="path", resolution=256, samples=1000, batch=16)
+    ctx.trace_samples(q)
+    assert ctx.stream_info()["choice_state"] < 4
+    # batches too short to time run fused and leave the choice open
+    ctx.set_scheduler(2)
+    r = yt.trace_params(sampler="path", resolution=256, samples=1000, batch=4)
+    ctx.trace_samples(r)
+    assert ctx.stream_info()["ran"] == 0 and ctx.stream_info()["choice_state"] == 0
+    ctx.close()
+
+
 def test_own_tree_mode_without_its_tree_fails_on_the_streaming_scheduler_too():
     flat = P.SCENES["cornellbox"]()
     ctx = stream_context(flat)
@@ -192,10 +274,29 @@ def test_cancel_inside_a_streamed_batch():
     ctx.close()
 
 
+def test_cancel_inside_the_tail_kernel():
+    """ks_finish polls the stop word once per bounce: a batch that runs entirely inside it stops at sample boundaries too."""
+    flat = P.SCENES["cornellbox"]()
+    ctx = stream_context(flat)
+    ctx.set_stream_finish(1000)
+    p = yt.trace_params(sampler="path", resolution=512, samples=100000, batch=4096)
+    ctx.make_trace_state(flat, p)
+    stop = np.zeros(1, np.int32)
+    threading.Timer(0.05, lambda: stop.__setitem__(0, 1)).start()
+    t0 = time.time()
+    with pytest.raises(yt.YthipError, match="cancelled"):
+        ctx.trace_samples(p, stop=stop)
+    assert time.time() - t0 < 5.0
+    st = ctx.download_state()
+    assert st["samples"] == 0 and np.isfinite(st["image"]).all() and 0 < st["hits"].max() < 4096
+    ctx.close()
+
+
 def test_profiling_reports_the_walks_evenness():
     flat = P.SCENES["cornellbox"]()
     ctx = stream_context(flat)
     ctx.set_profiling(1)
+    ctx.set_stream_finish(0)  # (every ray through ks_extend, which does the counting)
     p = yt.trace_params(sampler="path", resolution=128, samples=8, batch=8)
     P.gpu_render(ctx, flat, p)
     info = ctx.stream_info()

@@ -17,6 +17,8 @@ p = yt.trace_params(sampler="path", resolution=w["resolution"], samples=1 << 30,
 ctx.set_scheduler(1)
 o, c = (int(x) for x in os.environ.get("VARIANT", "1:3").split(":"))
 ctx.set_stream_options(order=o, cell_bits=c)
+if os.environ.get("GROUPS"): ctx.set_stream_groups(int(os.environ["GROUPS"]))
+if os.environ.get("FINISH"): ctx.set_stream_finish(int(os.environ["FINISH"]))
 ctx.make_trace_state(flat, p)
 ctx.trace_samples(p)
 ctx.set_profiling(1); ctx.reset_stats()

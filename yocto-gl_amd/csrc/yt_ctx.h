@@ -197,12 +197,21 @@ struct ythip_ctx {
   const int*         stop_host_dev = nullptr;  // ... and its device address (the kernels relay it into d_stop)
   ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
   // the streaming scheduler (yt_stream.h; ythip_set_scheduler): generations of extend / shade launches over SoA path state in HBM
-  int                scheduler        = 0;        // 0 the fused persistent kernel (k_trace), 1 streaming generations
+  int                scheduler        = 0;        // 0 the fused persistent kernel (k_trace), 1 streaming generations, 2 measured choice between the two
+  // scheduler 2: as for the pixel pool — once the fused path has settled (tile costs known, pool decided), one batch is timed fused,
+  // the next two run streamed (the second timed), and whichever took less time per sample serves this state / sampler / mode from then on (same bytes either way)
+  int                sched_tune       = 0;        // 0 time a fused batch next, 1 a streamed batch next (untimed: buffers, first launches), 2 time a streamed batch next, 3 waiting for both, 4 decided
+  bool               sched_on         = false;    // the decision: streamed
+  long long          sched_key        = -1;       // what it was taken for (sampler, mode, bounces, batch)
+  hipEvent_t         sched_ev[4]      = {nullptr, nullptr, nullptr, nullptr};  // fused begin / end, streamed begin / end
+  double             sched_samples[2] = {0, 0};
+  float              sched_ms[2]      = {0, 0};
   DStream            ss               = {};       // its arrays live in state_allocs (they go with the state)
   int                stream_slots     = 0;        // the slot count they were sized for (0: none)
   int                stream_cell_bits = 4, stream_order = 0, stream_phased = -1, stream_min_batch = 4;  // YTHIP_STREAM_CELLS / _ORDER / _PHASED / _MIN_BATCH
   int*               stream_counts_host = nullptr;  // pinned: {next queue length, generations run} per group
   int                stream_groups = 2;           // chains of generations side by side (YTHIP_STREAM_GROUPS; 2 measured best)
+  int                stream_finish = 250;         // a group leaves the generations for ks_finish once its queue is this many thousandths of its path slots (YTHIP_STREAM_FINISH; 0: never)
   int                stream_min_slots = 262144;   // a group holds at least a quarter of this many path slots (a chain of generations wants a few thousand wavefronts per launch; YTHIP_STREAM_MIN_SLOTS: tests)
   int                stream_bins_cap = 0;         // bins the hist / offs arrays hold per group
   hipStream_t        stream_side[YT_STREAM_MAX_GROUPS] = {};  // the further groups' streams ([0] unused: group 0 runs on `stream`)
@@ -221,8 +230,10 @@ extern "C" int ythip_own_launch(void* stream, int blocks, const void* ds, const 
 // the two units' builds of the streaming scheduler's launches (yt_stream_unit.h); `launch`: a ytl::StreamLaunch
 extern "C" void ythip_fast_stream_begin(const void* launch);
 extern "C" void ythip_fast_stream_generation(const void* launch);
+extern "C" void ythip_fast_stream_finish(const void* launch);
 extern "C" void ythip_own_stream_begin(const void* launch);
 extern "C" void ythip_own_stream_generation(const void* launch);
+extern "C" void ythip_own_stream_finish(const void* launch);
 extern "C" int ythip_own_intersect(void* stream, const void* ds, const void* rays, const int* instances, long long n, void* hits);
 
 inline void drop_staging_views(ythip_ctx* ctx) {

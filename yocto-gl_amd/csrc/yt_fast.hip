@@ -87,3 +87,4 @@ extern "C" int ythip_fast_launch(void* stream, int blocks, const void* ds_, cons
 // same struct under this unit's namespaces
 extern "C" void ythip_fast_stream_begin(const void* l) { ytl::stream_begin(*static_cast<const ytl::StreamLaunch*>(l)); }
 extern "C" void ythip_fast_stream_generation(const void* l) { ytl::stream_generation(*static_cast<const ytl::StreamLaunch*>(l)); }
+extern "C" void ythip_fast_stream_finish(const void* l) { ytl::stream_finish(*static_cast<const ytl::StreamLaunch*>(l)); }

@@ -87,3 +87,4 @@ extern "C" int ythip_own_intersect(void* stream, const void* ds_, const void* ra
 // same struct under this unit's namespaces, its DScene the one with the own tree's bvh fields swapped in
 extern "C" void ythip_own_stream_begin(const void* l) { ytl::stream_begin(*static_cast<const ytl::StreamLaunch*>(l)); }
 extern "C" void ythip_own_stream_generation(const void* l) { ytl::stream_generation(*static_cast<const ytl::StreamLaunch*>(l)); }
+extern "C" void ythip_own_stream_finish(const void* l) { ytl::stream_finish(*static_cast<const ytl::StreamLaunch*>(l)); }

@@ -173,10 +173,13 @@ __global__ void __launch_bounds__(YT_BLOCK) ks_init(DScene sc, DState st, KParam
 // ---------------------------------------------------------------------------------------------------------------------
 // the counting sort between two generations
 // ---------------------------------------------------------------------------------------------------------------------
-// One workgroup: offs = exclusive prefix of hist, hist = 0, counts[0] = total.  The bins in tiles of 4096 (one uint4 per
-// thread, coalesced), a running carry from tile to tile.  (4 k - 40 k bins: 1 - 10 tiles.  The first version gave every
-// thread a contiguous run of bins — strided, uncoalesced reads: 50 us per launch at 37 k bins, 460 us at 278 k.)
-constexpr int YT_SCAN_THREADS = 1024;
+// One workgroup: offs = exclusive prefix of hist, hist = 0, counts[0] = total.  The bins in tiles of 4096 (16 consecutive bins
+// per thread as four uint4), a running carry from tile to tile.  (4 k - 40 k bins: 1 - 10 tiles.  The first version gave every
+// thread a contiguous run of ALL its bins — strided, uncoalesced reads: 50 us per launch at 37 k bins, 460 us at 278 k.)
+// FOUR wavefronts, not sixteen: the scan sits on its chain's critical path while the other chain's extend launch fills the
+// machine, and a 1024-thread workgroup has to wait for one CU with sixteen free wave slots — it averaged 51 us per launch
+// in a cfg2b batch (12 us alone); four slots are free somewhere at once.
+constexpr int YT_SCAN_THREADS = 256;
 __global__ void __launch_bounds__(YT_SCAN_THREADS) ks_scan(DStream S) {
   __shared__ unsigned s_wave[YT_SCAN_THREADS / 64];
   __shared__ unsigned s_carry;
@@ -184,15 +187,21 @@ __global__ void __launch_bounds__(YT_SCAN_THREADS) ks_scan(DStream S) {
   const int tid = (int)threadIdx.x;
   if (tid == 0) s_carry = 0;
   __syncthreads();
-  for (int t0 = 0; t0 < nb; t0 += 4 * YT_SCAN_THREADS) {
-    const int   b = t0 + 4 * tid;
-    uint4       c = reinterpret_cast<const uint4*>(S.hist + b)[0];
-    if (b + 0 >= nb) c.x = 0;
-    if (b + 1 >= nb) c.y = 0;
-    if (b + 2 >= nb) c.z = 0;
-    if (b + 3 >= nb) c.w = 0;
-    const unsigned sum = c.x + c.y + c.z + c.w;
-    unsigned       x   = sum;  // inclusive scan over the workgroup: shuffles inside a wavefront, LDS across
+  for (int t0 = 0; t0 < nb; t0 += 16 * YT_SCAN_THREADS) {
+    const int b = t0 + 16 * tid;
+    uint4     c[4];
+    unsigned  part[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      c[j] = reinterpret_cast<const uint4*>(S.hist + b)[j];
+      if (b + 4 * j + 0 >= nb) c[j].x = 0;
+      if (b + 4 * j + 1 >= nb) c[j].y = 0;
+      if (b + 4 * j + 2 >= nb) c[j].z = 0;
+      if (b + 4 * j + 3 >= nb) c[j].w = 0;
+      part[j] = sum;
+      sum += c[j].x + c[j].y + c[j].z + c[j].w;
+    }
+    unsigned x = sum;  // inclusive scan over the workgroup: shuffles inside a wavefront, LDS across
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       unsigned y = (unsigned)__shfl_up((int)x, off);
@@ -206,9 +215,13 @@ __global__ void __launch_bounds__(YT_SCAN_THREADS) ks_scan(DStream S) {
       if (w < (tid >> 6)) before += s_wave[w];
       total += s_wave[w];
     }
-    const unsigned run = before + x - sum;
-    reinterpret_cast<uint4*>(S.offs + b)[0] = {run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z};
-    reinterpret_cast<uint4*>(S.hist + b)[0] = {0, 0, 0, 0};
+    const unsigned run0 = before + x - sum;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned run = run0 + part[j];
+      reinterpret_cast<uint4*>(S.offs + b)[j] = {run, run + c[j].x, run + c[j].x + c[j].y, run + c[j].x + c[j].y + c[j].z};
+      reinterpret_cast<uint4*>(S.hist + b)[j] = {0, 0, 0, 0};
+    }
     __syncthreads();
     if (tid == 0) s_carry += total;
     __syncthreads();
@@ -287,11 +300,42 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_EXTEND_WAVES) ks_extend(DS
 #ifndef YT_STREAM_SHADE_WAVES
 #define YT_STREAM_SHADE_WAVES 4
 #endif
-template <int SAMPLER, int LP, int CLS, bool WIDE>
-__global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DScene sc, DState st, KParams kp, DStream S) {
+// one live slot through one iteration of the bounce loop: state in, state out (stored), the slot's queue class returned
+template <int SAMPLER, int LP, int CLS>
+YT_FN int stream_shade_slot(const DScene& sc, const DState& st, const KParams& kp, const DStream& S, int slot, float4 rb, bool stopped, Stack stack,
+    Path& P) {
   constexpr bool MATTE = CLS == 1;
   constexpr int  PRIMS = MATTE ? 1 : (CLS == 3 ? 2 : 0);
   constexpr bool PEEK  = SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST || SAMPLER == YTHIP_SAMPLER_NAIVE;
+  const float4   ra = sld(S.ray_a + slot), ha = sld(S.hit_a + slot);
+  P.o               = {ra.x, ra.y, ra.z};
+  P.d               = {ra.w, rb.x, rb.y};
+  const int inst    = __float_as_int(ha.w);
+  P.isec            = {inst, sld(S.hit_e + slot), ha.x, ha.y, ha.z, inst >= 0};
+  if (inst < 0) P.isec = {-1, -1, 0, 0, 0, false};
+  stream_load_rest(st, S, slot, P, rb);
+  const int max_bounces = max_bounces_of<SAMPLER>(kp);
+  ShadeEnv  E           = {sc, st, kp, slot};
+  int       step;
+  if constexpr (SAMPLER == YTHIP_SAMPLER_NAIVE) step = step_naive<SAMPLER>(E, P);
+  else step = step_path<SAMPLER, LP, CLS>(E, P);
+  if constexpr (LP == LP_DEFER) {
+    if (step == STEP_DEFER) {  // the rest of the loop body behind the light pdf's instance walks (k_trace's walk stage)
+      Counters     cnt  = {0, 0, 0, 0, 0, 0, 0, 0};
+      const float4 pd   = st.pend[slot];
+      const float  lpdf = sample_lights_pdf<2, false, PRIMS>(sc, P.o, P.d, &stack, &cnt);
+      P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
+      step = step_tail(P);
+    }
+  }
+  const int cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
+  if (cls == OUT_DEAD) P.flags |= PF_DEAD;
+  stream_store(S, slot, P);
+  return cls;
+}
+
+template <int SAMPLER, int LP, int CLS, bool WIDE>
+__global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DScene sc, DState st, KParams kp, DStream S) {
   __shared__ StackEntry s_stack[LP == LP_DEFER ? YT_LDS_DEPTH : 1][YT_BLOCK];
   if (S.counts[0] == 0) return;  // nothing was queued for this generation: the batch is done
   const int  slot    = S.slot0 + (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
@@ -302,34 +346,57 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DSce
   Path P;
   P.o = {0, 0, 0}, P.d = {0, 0, 0};
   if (live) {
-    const float4 ra = sld(S.ray_a + slot), ha = sld(S.hit_a + slot);
-    P.o             = {ra.x, ra.y, ra.z};
-    P.d             = {ra.w, rb.x, rb.y};
-    const int inst  = __float_as_int(ha.w);
-    P.isec          = {inst, sld(S.hit_e + slot), ha.x, ha.y, ha.z, inst >= 0};
-    if (inst < 0) P.isec = {-1, -1, 0, 0, 0, false};
-    stream_load_rest(st, S, slot, P, rb);
-    const int max_bounces = max_bounces_of<SAMPLER>(kp);
-    ShadeEnv  E           = {sc, st, kp, slot};
-    int       step;
-    if constexpr (SAMPLER == YTHIP_SAMPLER_NAIVE) step = step_naive<SAMPLER>(E, P);
-    else step = step_path<SAMPLER, LP, CLS>(E, P);
-    if constexpr (LP == LP_DEFER) {
-      if (step == STEP_DEFER) {  // the rest of the loop body behind the light pdf's instance walks (k_trace's walk stage)
-        Stack stack;
-        YT_STACK_INIT(stack, s_stack);
-        Counters     cnt  = {0, 0, 0, 0, 0, 0, 0, 0};
-        const float4 pd   = st.pend[slot];
-        const float  lpdf = sample_lights_pdf<2, false, PRIMS>(sc, P.o, P.d, &stack, &cnt);
-        P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
-        step = step_tail(P);
-      }
-    }
-    cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
-    if (cls == OUT_DEAD) P.flags |= PF_DEAD;
-    stream_store(S, slot, P);
+    Stack stack;
+    YT_STACK_INIT(stack, s_stack);
+    cls = stream_shade_slot<SAMPLER, LP, CLS>(sc, st, kp, S, slot, rb, stopped, stack, P);
   }
   stream_emit(S, slot, P, cls);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// finish: the tail of a batch without generations.  Once the queue is a fraction of the path slots (the pixels still short of
+// their batch are few and scattered), every further generation is four launches and a drain for a handful of wavefronts, and
+// waits for the slowest walk among them — 90-110 of the 270-320 generations of a 64-spp batch on the closed box / the hair hold
+// 2-4 % of its rays and take 12-16 % of its time.  ks_finish takes the LAST sorted queue instead: one lane per entry carries its
+// path slot through extend and shade, iteration after iteration, until the slot's pixel has taken its batch — the same two
+// bodies as ks_extend / ks_shade on the same HBM state (the state goes through memory between them on purpose: the kernel then
+// needs the registers of the larger body, not of both), no sort, no launches, no generation waiting for anybody.  Per-pixel
+// order untouched: still bit for bit the fused kernel's batch.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef YT_STREAM_FINISH_WAVES
+#define YT_STREAM_FINISH_WAVES 4
+#endif
+template <int SAMPLER, int LP, int CLS, bool WIDE, int TRI, bool PHASED>
+__global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_FINISH_WAVES) ks_finish(DScene sc, DState st, KParams kp, DStream S) {
+  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
+  const int n = S.counts[0];
+  const int i = (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
+  if (i >= n) return;
+  const int slot = S.queue[i];
+  Stack     stack;
+  YT_STACK_INIT(stack, s_stack);
+  for (unsigned iter = 0;; iter++) {
+    {  // extend (ks_extend's body)
+      Counters     cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+      const float4 ra = sld(S.ray_a + slot), rb = sld(S.ray_b + slot);
+      const ray3f  ray = make_ray({ra.x, ra.y, ra.z}, {ra.w, rb.x, rb.y});
+      const Hit    h   = traverse_any<false, WIDE, TRI, PHASED>(sc, ray, -1, false, stack, cnt);
+      sst(S.hit_a + slot, float4{h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)});
+      sst(S.hit_e + slot, h.element);
+    }
+    asm volatile("" ::: "memory");  // (the hit record and the path state are re-read, not carried in registers across the walk)
+    bool stopped = stop_requested(st.stop, st.stop_gen);
+    if (blockIdx.x == 0 && (iter & 15) == 0 && st.stop_host &&
+        __hip_atomic_load(st.stop_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == st.stop_gen) {  // relay_stop, by whichever lanes are left
+      __hip_atomic_store(st.stop, st.stop_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      stopped = true;
+    }
+    Path         P;
+    const float4 rb  = sld(S.ray_b + slot);
+    const int    cls = stream_shade_slot<SAMPLER, LP, CLS>(sc, st, kp, S, slot, rb, stopped, stack, P);
+    if (cls == OUT_DEAD) break;
+    asm volatile("" ::: "memory");
+  }
 }
 
 }  // namespace yt

@@ -19,5 +19,6 @@ struct StreamLaunch {
 bool stream_supported(const StreamLaunch& l);
 void stream_begin(const StreamLaunch& l);       // ks_init + the first scan of the group l.ss, on l.stream
 void stream_generation(const StreamLaunch& l);  // scatter, extend, shade, scan
+void stream_finish(const StreamLaunch& l);      // scatter, then ks_finish: every queued path slot to the end of its pixel's batch
 
 }  // namespace ytl

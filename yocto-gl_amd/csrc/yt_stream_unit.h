@@ -25,6 +25,16 @@ void stream_extend(const StreamLaunch& l) {
   else
     hipLaunchKernelGGL((ks_extend<true, TRI, false>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.ss);
 }
+template <int LP, int CLS, int TRI>
+void stream_finish_launch(const StreamLaunch& l) {
+  using namespace yt;
+  if (l.phased)
+    hipLaunchKernelGGL((ks_finish<YTHIP_SAMPLER_PATH, LP, CLS, true, TRI, true>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.st,
+        *l.kp, *l.ss);
+  else
+    hipLaunchKernelGGL((ks_finish<YTHIP_SAMPLER_PATH, LP, CLS, true, TRI, false>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.st,
+        *l.kp, *l.ss);
+}
 }  // namespace
 
 bool stream_supported(const StreamLaunch& l) { return l.kp->sampler == YTHIP_SAMPLER_PATH && l.kp->bounces > 0; }
@@ -53,6 +63,20 @@ void stream_generation(const StreamLaunch& l) {
     default: defer ? stream_shade<LP_DEFER, 0>(l) : stream_shade<LP_NONE, 0>(l); break;
   }
   hipLaunchKernelGGL(ks_scan, dim3(1), dim3(YT_SCAN_THREADS), 0, l.stream, *l.ss);
+}
+
+// the tail of the group's batch in one launch: the queue the last scan sized, sorted once more, then every entry's path slot carried
+// to the end of its pixel's batch by one lane (ks_finish).  `blocks` covers the queue length the host read back.
+void stream_finish(const StreamLaunch& l) {
+  using namespace yt;
+  const bool defer = l.lp == LP_DEFER;
+  hipLaunchKernelGGL(ks_scatter, dim3((l.ss->nslots + 255) / 256), dim3(256), 0, l.stream, *l.ss);
+  switch (l.cls) {
+    case 1: defer ? stream_finish_launch<LP_DEFER, 1, 1>(l) : stream_finish_launch<LP_NONE, 1, 1>(l); break;
+    case 2: defer ? stream_finish_launch<LP_DEFER, 2, 0>(l) : stream_finish_launch<LP_NONE, 2, 0>(l); break;
+    case 3: defer ? stream_finish_launch<LP_DEFER, 3, 2>(l) : stream_finish_launch<LP_NONE, 3, 2>(l); break;
+    default: defer ? stream_finish_launch<LP_DEFER, 0, 0>(l) : stream_finish_launch<LP_NONE, 0, 0>(l); break;
+  }
 }
 
 }  // namespace ytl

@@ -139,6 +139,7 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
   auto generation = [&](const ytl::StreamLaunch& l) {
     mode == 2 ? ythip_own_stream_generation(&l) : mode == 1 ? ythip_fast_stream_generation(&l) : ytl::stream_generation(l);
   };
+  auto finish = [&](const ytl::StreamLaunch& l) { mode == 2 ? ythip_own_stream_finish(&l) : mode == 1 ? ythip_fast_stream_finish(&l) : ytl::stream_finish(l); };
   auto& st = ctx->st;
   auto& S  = ctx->ss;
   int   rc;
@@ -203,7 +204,8 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     L[g]          = {streams[g], &ds, &ctx->st, &kp, &G[g], lp, cls, phased};
   }
   ctx->stream_cancelled = false;
-  int launched = 0;
+  int     launched    = 0;
+  int64_t finish_rays = 0;
   {
     EvScope ev(ctx, 0);
     if (groups > 1) {  // the side streams start behind everything the main stream has been given so far
@@ -211,12 +213,23 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
       for (int g = 1; g < groups; g++) HIPCHECK(ctx, hipStreamWaitEvent(streams[g], ctx->stream_ev[0], 0));
     }
     for (int g = 0; g < groups; g++) begin(L[g]);
+    // A group whose queue has shrunk to `finish` thousandths of its path slots leaves the generations: ks_finish carries what is
+    // queued to the end of the batch in one launch (yt_stream.h).  1000: from the first ray on (tests: the whole batch in ks_finish).
+    const int permille = std::min(std::max(ctx->stream_finish, 0), 1000);
+    bool      fin[MAX_GROUPS] = {}, idle[MAX_GROUPS] = {};
+    if (permille >= 1000)
+      for (int g = 0; g < groups; g++) finish(L[g]), fin[g] = true, finish_rays += G[g].nslots;
     int chunk = std::max(1, params->batch);
     if (!ctx->done_event) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->done_event, hipEventDisableTiming));
     while (true) {
-      for (int k = 0; k < chunk; k++)
-        for (int g = 0; g < groups; g++) generation(L[g]);
-      launched += chunk;
+      bool work = false;
+      for (int g = 0; g < groups; g++) work = work || !(fin[g] || idle[g]);
+      if (work) {
+        for (int k = 0; k < chunk; k++)
+          for (int g = 0; g < groups; g++)
+            if (!(fin[g] || idle[g])) generation(L[g]);
+        launched += chunk;
+      }
       for (int g = 1; g < groups; g++) {  // the main stream (and with it the read-back, and whatever the caller enqueues next) waits for the side streams
         HIPCHECK(ctx, hipEventRecord(ctx->stream_ev[g], streams[g]));
         HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->stream_ev[g], 0));
@@ -235,9 +248,16 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
         }
       }
       HIPCHECK(ctx, hipEventSynchronize(ctx->done_event));
-      bool any = false;
-      for (int g = 0; g < groups; g++) any = any || ctx->stream_counts_host[16 * g] != 0;
-      if (!any) break;
+      if (!work) break;  // (this round only waited for the ks_finish launches of the last one)
+      bool any = false, finishing = false;
+      for (int g = 0; g < groups; g++) {
+        if (fin[g] || idle[g]) continue;
+        const int n = ctx->stream_counts_host[16 * g];
+        if (n == 0) idle[g] = true;
+        else if ((int64_t)n * 1000 <= (int64_t)permille * G[g].nslots) finish(L[g]), fin[g] = finishing = true, finish_rays += n;
+        else any = true;
+      }
+      if (!any && !finishing) break;
       // what is left: the live paths' remaining bounces — a few generations at a time (each surplus one costs four empty launches)
       chunk = std::max(4, std::min(chunk, 16));
     }
@@ -250,6 +270,7 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
   ctx->stream_info.bins        = S.nbins + S.nprim_bins;
   ctx->stream_info.groups      = groups;
   ctx->stream_info.path_slots  = pslots;
+  ctx->stream_info.finish_rays = finish_rays;
   if (prof) {
     std::vector<unsigned long long> h(MAX_GROUPS * 8 * 64);
     HIPCHECK(ctx, hipMemcpy(h.data(), S.stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -334,17 +355,51 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   // would not run either (no own tree: an error below; a tree the tolerance unit's walk cannot serve) is left to the fused path.
   ctx->last_launch_stream = false;
   ctx->stream_info.ran    = 0;
-  if (ctx->scheduler == 1 && only_pix < 0 && !count && params->batch >= ctx->stream_min_batch) {
+  // pixel pool: only where there are more tiles than resident workgroups, and once the tile costs of a plain launch
+  // order the queue (the first batch / the probe launch runs plain and records them)
+  // (bounces <= 0: k_trace finishes such a batch in its prologue, tile by tile, without ever reaching the queue)
+  const bool pool_ok = ctx->pixel_pool && only_pix < 0 && !count && ctx->st.nblocks > ctx->pool_blocks && params->bounces > 0 &&
+                       (ctx->have_tile_costs || !ctx->d_tile_cost || ctx->pixel_pool >= 2);
+  int sched_timed = -1;  // scheduler 2: 0 = this batch is the timed fused one, 1 = the timed streamed one
+  if (ctx->scheduler != 0 && only_pix < 0 && !count && params->batch >= ctx->stream_min_batch) {
     const int  mode = params->fastmath;
     const bool served = mode == 0 ? ctx->use_wide() : mode == 1 ? (ctx->wide_stack_ok && ctx->traversal_mode != 0) : (ctx->have_own && ctx->own_stack_ok);
     const int  cls  = ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
     ytl::StreamLaunch probe = {ctx->stream, &ctx->ds, &ctx->st, &kp, &ctx->ss, lp, cls, false};
-    if (served && ytl::stream_supported(probe)) {
+    bool stream = served && ytl::stream_supported(probe);
+    if (stream && ctx->scheduler == 2) {  // the measured choice
+      const long long key = (long long)params->sampler | ((long long)mode << 8) | ((long long)(params->bounces & 0xffff) << 16) | ((long long)params->batch << 32);
+      if (key != ctx->sched_key) ctx->sched_key = key, ctx->sched_tune = 0, ctx->sched_on = false;
+      if (ctx->sched_tune == 3 && hipEventQuery(ctx->sched_ev[1]) == hipSuccess && hipEventQuery(ctx->sched_ev[3]) == hipSuccess) {
+        if (hipEventElapsedTime(&ctx->sched_ms[0], ctx->sched_ev[0], ctx->sched_ev[1]) == hipSuccess &&
+            hipEventElapsedTime(&ctx->sched_ms[1], ctx->sched_ev[2], ctx->sched_ev[3]) == hipSuccess)
+          ctx->sched_on = ctx->sched_ms[1] / ctx->sched_samples[1] < 0.97 * ctx->sched_ms[0] / ctx->sched_samples[0];
+        ctx->sched_tune = 4;
+      }
+      if (ctx->sched_tune == 4) stream = ctx->sched_on;
+      else if (params->batch < 8 || ctx->sched_tune == 3) stream = false;  // (too short a batch for its time to mean something: fused, undecided)
+      else {
+        // the fused path first has to be the one the streamed batch competes with: tile costs known, the pixel pool decided
+        const bool pool_pending = ctx->pixel_pool == 1 && ctx->pool_tune < 3 && ctx->st.nblocks > ctx->pool_blocks && params->bounces > 0;
+        const bool settled      = (ctx->have_tile_costs || !ctx->d_tile_cost) && !pool_pending;
+        for (auto& e : ctx->sched_ev)
+          if (!e) HIPCHECK(ctx, hipEventCreate(&e));
+        if (ctx->sched_tune == 0) stream = false, sched_timed = settled ? 0 : -1;
+        else if (ctx->sched_tune == 1) ctx->sched_tune = 2;  // this batch streamed, untimed: the scheduler's buffers, streams and first launches
+        else sched_timed = 1;                                // (tune 2: this batch streamed, timed)
+      }
+    }
+    if (stream) {
       ctx->st.tile_perm = nullptr, ctx->st.tile_cost = nullptr, ctx->st.pool_next = nullptr, ctx->st.pool_total = 0;
       DScene d = ctx->ds;  // (mode 2: only the bvh part is the own tree's — launch_trace_any)
       if (mode == 2) ctx->own.apply(d);
+      if (sched_timed == 1) HIPCHECK(ctx, hipEventRecord(ctx->sched_ev[2], ctx->stream));
       int rc = enqueue_stream(ctx, params, kp, lp, cls, stop, mode, d);
       if (rc) return rc;
+      if (sched_timed == 1) {
+        HIPCHECK(ctx, hipEventRecord(ctx->sched_ev[3], ctx->stream));
+        ctx->sched_samples[1] = params->batch, ctx->sched_tune = 3;
+      }
       ctx->last_launch_fast = mode != 0, ctx->last_launch_mode = mode, ctx->last_launch_stream = true;
       ctx->samples += params->batch;
       return YTHIP_OK;
@@ -354,11 +409,6 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   // until its pixels have taken `batch` samples (k_trace)
   ctx->st.tile_perm = nullptr, ctx->st.tile_cost = nullptr;
   ctx->st.pool_next = nullptr, ctx->st.pool_total = 0;
-  // pixel pool: only where there are more tiles than resident workgroups, and once the tile costs of a plain launch
-  // order the queue (the first batch / the probe launch runs plain and records them)
-  // (bounces <= 0: k_trace finishes such a batch in its prologue, tile by tile, without ever reaching the queue)
-  const bool pool_ok = ctx->pixel_pool && only_pix < 0 && !count && ctx->st.nblocks > ctx->pool_blocks && params->bounces > 0 &&
-                       (ctx->have_tile_costs || !ctx->d_tile_cost || ctx->pixel_pool >= 2);
   bool pool = false;
   int  timed = -1;  // 0: this launch is the timed plain batch, 1: the timed pool batch
   if (params->fastmath != ctx->pool_mode) {  // (the plain / pool choice was measured on another kernel family)
@@ -402,8 +452,13 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   {
     EvScope ev(ctx, 0);
     if (timed >= 0) HIPCHECK(ctx, hipEventRecord(ctx->pool_ev[2 * timed], ctx->stream));
+    if (sched_timed == 0) HIPCHECK(ctx, hipEventRecord(ctx->sched_ev[0], ctx->stream));
     int rc = launch_trace_any(ctx, kp, lp, count, params->fastmath);
     if (rc) return rc;
+    if (sched_timed == 0) {
+      HIPCHECK(ctx, hipEventRecord(ctx->sched_ev[1], ctx->stream));
+      ctx->sched_samples[0] = params->batch, ctx->sched_tune = 1;
+    }
     if (timed >= 0) {
       HIPCHECK(ctx, hipEventRecord(ctx->pool_ev[2 * timed + 1], ctx->stream));
       ctx->pool_samples[timed] = params->batch, ctx->pool_tune = timed + 1;
@@ -507,12 +562,13 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_LPT")) ctx->lpt = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_LPT_PROBE")) ctx->lpt_probe = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_PIXEL_POOL")) ctx->pixel_pool = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_SCHEDULER")) ctx->scheduler = std::atoi(e) == 1 ? 1 : 0;
+  if (const char* e = std::getenv("YTHIP_SCHEDULER")) ctx->scheduler = std::min(std::max(std::atoi(e), 0), 2);
   if (const char* e = std::getenv("YTHIP_STREAM_CELLS")) ctx->stream_cell_bits = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_ORDER")) ctx->stream_order = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_PHASED")) ctx->stream_phased = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_BATCH")) ctx->stream_min_batch = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_GROUPS")) ctx->stream_groups = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_STREAM_FINISH")) ctx->stream_finish = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_SLOTS")) ctx->stream_min_slots = std::max(128, std::atoi(e));
   {
     hipDeviceProp_t prop;
@@ -1278,6 +1334,7 @@ int ythip_state_create_striped(ythip_ctx* ctx, int width, int height, int row_be
   }
   ctx->lpt_age = 0;  // (the order is recomputed from the kept costs at the first launch)
   ctx->pool_tune = 0, ctx->pool_on = false;  // (a new state: the pixel pool is measured again)
+  ctx->sched_tune = 0, ctx->sched_on = false;  // (... and so is the scheduler, where it is a measured choice)
   return YTHIP_OK;
 }
 
@@ -1613,6 +1670,7 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volati
 int ythip_set_pixel_pool(ythip_ctx* ctx, int mode, int workgroups) {
   if (!ctx || mode < 0 || mode > 2) return fail(ctx, YTHIP_ERR_INVALID, "pixel pool mode must be 0, 1 or 2");
   ctx->pixel_pool = mode, ctx->pool_tune = 0, ctx->pool_on = false;
+  ctx->sched_tune = 0, ctx->sched_on = false;
   if (workgroups > 0) ctx->pool_blocks = workgroups;
   return YTHIP_OK;
 }
@@ -1631,8 +1689,8 @@ int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info) {
 }
 
 int ythip_set_scheduler(ythip_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 1) return fail(ctx, YTHIP_ERR_INVALID, "scheduler must be 0 (fused kernel) or 1 (streaming)");
-  ctx->scheduler = mode;
+  if (!ctx || mode < 0 || mode > 2) return fail(ctx, YTHIP_ERR_INVALID, "scheduler must be 0 (fused kernel), 1 (streaming) or 2 (measured choice)");
+  ctx->scheduler = mode, ctx->sched_tune = 0, ctx->sched_on = false;
   return YTHIP_OK;
 }
 int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased) {
@@ -1645,6 +1703,11 @@ int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phase
 int ythip_set_stream_groups(ythip_ctx* ctx, int groups) {
   if (!ctx || groups < 1 || groups > YT_STREAM_MAX_GROUPS) return fail(ctx, YTHIP_ERR_INVALID, "stream groups: 1..%d", YT_STREAM_MAX_GROUPS);
   ctx->stream_groups = groups;
+  return YTHIP_OK;
+}
+int ythip_set_stream_finish(ythip_ctx* ctx, int permille) {
+  if (!ctx || permille < 0 || permille > 1000) return fail(ctx, YTHIP_ERR_INVALID, "stream finish: 0..1000 thousandths of the path slots");
+  ctx->stream_finish = permille;
   return YTHIP_OK;
 }
 int ythip_get_stream_generations(ythip_ctx* ctx, int32_t* rays, int32_t capacity, int32_t* written) {
@@ -1660,6 +1723,12 @@ int ythip_get_stream_generations(ythip_ctx* ctx, int32_t* rays, int32_t capacity
 int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info) {
   if (!ctx || !info) return fail(ctx, YTHIP_ERR_INVALID, "null argument");
   *info = ctx->stream_info;
+  info->choice_state = ctx->scheduler == 2 ? ctx->sched_tune : 0;
+  info->choice_streamed = ctx->scheduler == 2 && ctx->sched_tune == 4 && ctx->sched_on;
+  if (ctx->scheduler == 2 && ctx->sched_tune == 4 && ctx->sched_samples[0] > 0 && ctx->sched_samples[1] > 0) {
+    info->fused_ms_per_sample  = (float)(ctx->sched_ms[0] / ctx->sched_samples[0]);
+    info->stream_ms_per_sample = (float)(ctx->sched_ms[1] / ctx->sched_samples[1]);
+  }
   return YTHIP_OK;
 }
 

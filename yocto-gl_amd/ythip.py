@@ -222,7 +222,9 @@ class CPoolInfo(C.Structure):
 
 class CStreamInfo(C.Structure):
     _fields_ = [("ran", C.c_int32), ("generations", C.c_int32), ("launched", C.c_int32), ("bins", C.c_int32),
-                ("groups", C.c_int32), ("path_slots", C.c_int32), ("rays", C.c_int64), ("lane_steps", C.c_int64), ("wave_steps", C.c_int64)]
+                ("groups", C.c_int32), ("path_slots", C.c_int32), ("rays", C.c_int64), ("lane_steps", C.c_int64), ("wave_steps", C.c_int64),
+                ("finish_rays", C.c_int64), ("choice_state", C.c_int32), ("choice_streamed", C.c_int32),
+                ("fused_ms_per_sample", C.c_float), ("stream_ms_per_sample", C.c_float)]
 
 
 class CBuildInfo(C.Structure):
@@ -517,6 +519,7 @@ _SIGNATURES = {
     "ythip_get_stream_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_set_stream_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ythip_set_stream_groups": (C.c_int, [C.c_void_p, C.c_int]),
+    "ythip_set_stream_finish": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_get_stream_generations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "ythip_last_launch_fastmath": (C.c_int, [C.c_void_p]),
     "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
@@ -602,7 +605,7 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
-ABI_VERSION = 5  # include/ythip.h: YTHIP_ABI_VERSION
+ABI_VERSION = 6  # include/ythip.h: YTHIP_ABI_VERSION
 
 
 def load_library(path=LIB_PATH):
@@ -768,7 +771,8 @@ class Context:
         return {k: getattr(info, k) for k, _ in CPoolInfo._fields_}
 
     def set_scheduler(self, mode):
-        """0 the fused persistent kernel (default), 1 the streaming scheduler (csrc/yt_stream.h) — ythip_set_scheduler."""
+        """0 the fused persistent kernel (default), 1 the streaming scheduler (csrc/yt_stream.h), 2 a measured choice between the
+        two per trace_state / sampler / mode / batch size — ythip_set_scheduler."""
         self._check(self.lib.ythip_set_scheduler(self.h, int(mode)), "set_scheduler")
 
     def set_stream_options(self, order=-1, cell_bits=-1, phased=-1):
@@ -779,6 +783,11 @@ class Context:
     def set_stream_groups(self, groups):
         """1..8 chains of generations side by side (default 2) — ythip_set_stream_groups."""
         self._check(self.lib.ythip_set_stream_groups(self.h, int(groups)), "set_stream_groups")
+
+    def set_stream_finish(self, permille):
+        """A group's queue at `permille` thousandths of its path slots goes to the tail kernel (default 250; 0 never,
+        1000 the whole batch) — ythip_set_stream_finish."""
+        self._check(self.lib.ythip_set_stream_finish(self.h, int(permille)), "set_stream_finish")
 
     def stream_generations(self):
         """Queue length of every generation of the last streamed batch (profiling mode 1 during the batch)."""
