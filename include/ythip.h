@@ -643,10 +643,21 @@ int ythip_set_stream_groups(ythip_ctx* ctx, int groups);
  * of its rays.  0 = never (generations until the queue is empty), 1000 = from the first ray on (tests).  env YTHIP_STREAM_FINISH.
  * Results never depend on it. */
 int ythip_set_stream_finish(ythip_ctx* ctx, int permille);
+/* Eviction of a wavefront's last walkers: ks_extend's wavefronts end once fewer than `lanes` (1..32; 0 = off, the default) of their
+ * 64 lanes still walk (and at least `steps` traversal steps have been taken; 0 keeps the current value, default 8).  The unfinished
+ * walks — node, stack, best hit — are written out and go on in a second launch, 64 to a wavefront, which evicts once more into a
+ * third that walks to the end.  A walk resumed takes exactly the steps it would have taken: hit records, and with them the whole
+ * trace_state, do not depend on it.  Serves the wide walk of the bit-exact and the tolerance mode (not its majority-phase form,
+ * not the own tree).  env YTHIP_STREAM_EVICT. */
+int ythip_set_stream_eviction(ythip_ctx* ctx, int lanes, int steps);
 int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info);
 /* Profiling (ythip_set_profiling bit 0 during the batch): the queue length of every generation of the last streamed batch,
  * up to `capacity` (and 8192) entries; *written = how many. */
 int ythip_get_stream_generations(ythip_ctx* ctx, int32_t* rays, int32_t capacity, int32_t* written);
+/* Profiling: the traversal steps (+ 1) of every ray of ONE generation of a streamed batch, in queue order per group (a group's
+ * entries start at its first path slot; entries beyond the generation's queue length keep what an earlier batch left).  Call with
+ * steps = NULL before the batch to choose the generation (-1: off), with a buffer of >= path_slots entries after it. */
+int ythip_get_stream_walk_steps(ythip_ctx* ctx, int generation, int32_t* steps, int32_t capacity);
 
 /* The mode the last trace_samples / trace_sample launch of this context ran: 0 the bit-exact kernels, 1 the
  * tolerance-mode kernels, 2 the own-tree kernels (ythip_params::fastmath asked for it AND such a kernel exists for the

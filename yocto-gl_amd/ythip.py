@@ -520,7 +520,9 @@ _SIGNATURES = {
     "ythip_set_stream_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ythip_set_stream_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_set_stream_finish": (C.c_int, [C.c_void_p, C.c_int]),
+    "ythip_set_stream_eviction": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ythip_get_stream_generations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "ythip_get_stream_walk_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]),
     "ythip_last_launch_fastmath": (C.c_int, [C.c_void_p]),
     "ythip_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "ythip_ply_read": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 9),
@@ -788,6 +790,21 @@ class Context:
         """A group's queue at `permille` thousandths of its path slots goes to the tail kernel (default 250; 0 never,
         1000 the whole batch) — ythip_set_stream_finish."""
         self._check(self.lib.ythip_set_stream_finish(self.h, int(permille)), "set_stream_finish")
+
+    def set_stream_eviction(self, lanes, steps=0):
+        """ks_extend's wavefronts end below `lanes` walking lanes (0 off), not before `steps` steps; the walks go on regrouped
+        in two more launches — ythip_set_stream_eviction."""
+        self._check(self.lib.ythip_set_stream_eviction(self.h, int(lanes), int(steps)), "set_stream_eviction")
+
+    def stream_walk_steps(self, generation, fetch=False):
+        """Profiling: choose the generation whose per-ray walk lengths the next profiled streamed batch logs (fetch=False), or
+        fetch them (int32 per path slot, queue order per group) — ythip_get_stream_walk_steps."""
+        if not fetch:
+            self._check(self.lib.ythip_get_stream_walk_steps(self.h, int(generation), None, 0), "get_stream_walk_steps")
+            return None
+        out = np.zeros(self.stream_info()["path_slots"], "i4")
+        self._check(self.lib.ythip_get_stream_walk_steps(self.h, int(generation), _ptr(out), len(out)), "get_stream_walk_steps")
+        return out
 
     def stream_generations(self):
         """Queue length of every generation of the last streamed batch (profiling mode 1 during the batch)."""
