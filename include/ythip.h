@@ -630,8 +630,8 @@ int ythip_set_scheduler(ythip_ctx* ctx, int mode);
 /* Tuning of the streaming scheduler's sort (a negative argument keeps the current value; results never depend on it):
  * order 0 = direction octant major, origin cell minor (default), 1 = cell major, 2 = no sort (the queue in pixel order: the
  * baseline the sort is measured against); cell_bits 1..5 = the scene's root box cut into 2^bits cells per axis (default 4);
- * phased 0 / 1 = ks_extend's majority-phase scene walk off / on (default: as the fused kernel — on for matte scenes with
- * area lights).  env YTHIP_STREAM_ORDER / _CELLS / _PHASED. */
+ * phased 0 / 1 = ks_extend's majority-phase scene walk off / on (default off: sorted wavefronts mostly want the same
+ * step kind; the fused kernel's default on matte scenes with area lights is on).  env YTHIP_STREAM_ORDER / _CELLS / _PHASED. */
 int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased);
 /* groups 1..8 (default 2): the pixels of the slice as that many runs, each a chain of generations of its own on its own stream —
  * one run's shade / sort launches fill the machine while another's extend launch drains (frames too small for it run as
@@ -643,17 +643,6 @@ int ythip_set_stream_groups(ythip_ctx* ctx, int groups);
  * of its rays.  0 = never (generations until the queue is empty), 1000 = from the first ray on (tests).  env YTHIP_STREAM_FINISH.
  * Results never depend on it. */
 int ythip_set_stream_finish(ythip_ctx* ctx, int permille);
-/* Eviction of a wavefront's last walkers: ks_extend's wavefronts end once fewer than `lanes` (1..32; 0 = off, the default) of their
- * 64 lanes still walk (and at least `steps` traversal steps have been taken; 0 keeps the current value, default 8).  The unfinished
- * walks — node, stack, best hit — are written out and go on in a second launch, 64 to a wavefront, which evicts once more into a
- * third that walks to the end.  A walk resumed takes exactly the steps it would have taken: hit records, and with them the whole
- * trace_state, do not depend on it.  Serves the wide walk of the bit-exact and the tolerance mode (not its majority-phase form,
- * not the own tree).  env YTHIP_STREAM_EVICT. */
-int ythip_set_stream_eviction(ythip_ctx* ctx, int lanes, int steps);
-int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info);
-/* Profiling (ythip_set_profiling bit 0 during the batch): the queue length of every generation of the last streamed batch,
- * up to `capacity` (and 8192) entries; *written = how many. */
-int ythip_get_stream_generations(ythip_ctx* ctx, int32_t* rays, int32_t capacity, int32_t* written);
 /* Profiling: the traversal steps (+ 1) of every ray of ONE generation of a streamed batch, in queue order per group (a group's
  * entries start at its first path slot; entries beyond the generation's queue length keep what an earlier batch left).  Call with
  * steps = NULL before the batch to choose the generation (-1: off), with a buffer of >= path_slots entries after it. */

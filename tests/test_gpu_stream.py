@@ -94,46 +94,6 @@ def test_the_tail_kernel_changes_nothing(scene, monkeypatch):
         P.assert_identical(want, got, f"{scene} streamed, finish at {permille} / 1000, {groups} groups")
 
 
-@pytest.mark.parametrize("scene", SCENES)
-def test_evicting_the_last_walkers_changes_nothing(scene, monkeypatch):
-    """ythip_set_stream_eviction: a wavefront of ks_extend ends once fewer than `lanes` of its lanes still walk; their walks — node,
-    stack, best hit — are written out and resumed, regrouped, by ks_extend_more (twice).  A resumed walk takes the steps it would
-    have taken: the reference's bytes, for every threshold incl. "evict at once" (steps 1, lanes 32: nearly every walk is cut twice)."""
-    monkeypatch.setenv("YTHIP_STREAM_MIN_SLOTS", "1024")
-    flat = P.SCENES[scene]()
-    params = yt.trace_params(sampler="path", resolution=160, samples=12, batch=6)
-    want = want_state(flat, params)
-    for lanes, steps, groups, phased in ((16, 8, 2, 0), (32, 1, 1, 0), (32, 2, 3, 0), (24, 4, 2, -1)):
-        ctx = stream_context(flat)
-        ctx.set_stream_eviction(lanes, steps)
-        ctx.set_stream_groups(groups)
-        ctx.set_stream_options(phased=phased)
-        got = P.gpu_render(ctx, flat, params)
-        info = ctx.stream_info()
-        ctx.close()
-        assert info["ran"] == 1, info
-        P.assert_identical(want, got, f"{scene} streamed, eviction below {lanes} lanes after {steps} steps, {groups} groups")
-
-
-def test_eviction_in_the_tolerance_mode_and_not_on_the_own_tree():
-    flat = P.SCENES["instances"]()
-    for mode in (1, 2):
-        params = yt.trace_params(sampler="path", resolution=144, samples=8, batch=8, fastmath=mode)
-        out = []
-        for stream, lanes in ((0, 0), (1, 32)):
-            ctx = P.gpu_context(flat)
-            ctx.set_traversal("wide")
-            if mode == 2:
-                ctx.make_own_bvh(flat)
-            ctx.set_scheduler(stream)
-            ctx.set_stream_eviction(lanes, 1)
-            ctx.set_stream_options(phased=0)
-            out.append(P.gpu_render(ctx, flat, params))
-            assert ctx.stream_info()["ran"] == stream
-            ctx.close()
-        P.assert_identical(out[0], out[1], f"fastmath {mode}: streamed with eviction vs fused")
-
-
 @pytest.mark.parametrize("mode", [1, 2])
 def test_the_tail_kernel_in_the_other_modes(mode):
     flat = P.SCENES["materials"]()

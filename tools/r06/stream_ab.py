@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Round 6: the streaming scheduler (csrc/yt_stream.h) against the fused kernel on bench.py's workloads.
 Per workload: the fused kernel's time + whole-state digest, then the streaming scheduler in the variants of VARIANTS
-(order:cells[:phased[:groups[:finish[:evict lanes[:evict steps]]]]]; order 0 octant major, 1 cell major, 2 unsorted) — time, digest (must equal), generations, and how even
+(order:cells[:phased[:groups[:finish]]]; order 0 octant major, 1 cell major, 2 unsorted) — time, digest (must equal), generations, and how even
 the walks of a wavefront are (sum of lane steps / 64 x longest lane; the fused kernel's figure is in profiles/r03_traversal_experiments.txt).
 
   SCENES=cfg2b,configs4 SPP=64 VARIANTS=0:4,1:4,2:4 LAUNCHES=2 python tools/r06/stream_ab.py
@@ -69,8 +69,6 @@ def main():
             groups = int(v[3]) if len(v) > 3 else 2
             finish = int(v[4]) if len(v) > 4 else 250  # the tail kernel's threshold, thousandths of the path slots (0: off)
             ctx.set_stream_finish(finish)
-            evict = int(v[5]) if len(v) > 5 else 0  # ks_extend's wavefronts end below this many walking lanes (0: off)
-            ctx.set_stream_eviction(evict, int(v[6]) if len(v) > 6 else 0)
             ctx.set_scheduler(1)
             ctx.set_stream_options(order=order, cell_bits=cells, phased=phased)
             ctx.set_stream_groups(groups)
@@ -80,7 +78,7 @@ def main():
             ctx.trace_samples(p)
             d = digest(ctx)
             even = info["lane_steps"] / max(1, info["wave_steps"])
-            print(f"{name:10s} stream order {order} cells {cells} phased {phased:2d} groups {info['groups']} finish {finish:4d} ({info['finish_rays'] / 1e3:.0f} k) evict {evict:2d} {ms:9.3f} ms {npix * spp / ms / 1e3:9.1f} Msamples/s  x{ms0 / ms:.3f}  "
+            print(f"{name:10s} stream order {order} cells {cells} phased {phased:2d} groups {info['groups']} finish {finish:4d} ({info['finish_rays'] / 1e3:.0f} k) {ms:9.3f} ms {npix * spp / ms / 1e3:9.1f} Msamples/s  x{ms0 / ms:.3f}  "
                   f"state {d} {'OK' if d == d0 else 'DIFFERENT'}  generations {info['generations']} (+{info['launched'] - info['generations']} empty)  "
                   f"rays {info['rays'] / 1e6:.1f} M  walk evenness {even:.3f}", flush=True)
         ctx.close()

@@ -318,37 +318,14 @@ YT_FN void load_instance_record(const DInstanceT* base, int idx, float4& m0, flo
 // otherwise intersect_instance_bvh of that instance (yocto_bvh.cpp:619-628).
 constexpr int HIT_ABORT = -2;  // Hit::instance of a wide walk that met an irregular ray: redo it binary
 
-// Suspending and resuming a walk (the streaming scheduler's eviction of a wavefront's last walkers, yt_stream.h): a lane's walk is
-// (node to process, stack, level being walked, best hit so far); written out at the top of the walk's outer loop and read back there
-// by another lane of another launch it goes on with exactly the steps it would have taken.  Entry i of a buffer: three int4 of
-// head ([3][cap]) and up to WALK_CONT_DEPTH stack entries ([depth][cap]: coalesced across the lanes that are evicted together).
-constexpr int WALK_CONT_DEPTH = 40;  // (a deeper stack at the moment of eviction: the lane walks on)
-struct WalkCont {
-  int4*       head;
-  StackEntry* stack;
-  int*        count;  // entries written (may run past cap: readers clamp)
-  int         cap;
-};
-struct WalkCtl {
-  bool     resume = false;  // resume entry in_idx of `in` (false: a fresh walk)
-  WalkCont in     = {};
-  int      in_idx = 0;
-  bool     evict  = false;  // evict into `out` once fewer than min_lanes lanes of the wavefront still walk ...
-  WalkCont out    = {};
-  int      min_lanes = 0, min_steps = 0;  // ... and this launch has walked min_steps steps with them
-  int      tag       = 0;      // the caller's word, kept in the entry (the path slot)
-  bool     suspended = false;  // result: the walk was evicted; there is no hit record yet
-};
-
 // LDSD: stack entries per lane kept in the LDS column of `st` (the rest, up to the
 // reference's 128, in scratch).  0 = a walk that leaves the LDS stack alone.
 // TRI: what is known about the scene's shapes — 0 nothing, 1 every shape is a triangle mesh, 2 triangle and quad meshes only
 // (checked at upload; tells the compiler which intersectors can be reached, the arithmetic of the live ones is the same)
-template <bool COUNT, bool WIDE = false, int TRI = 0, int LDSD = YT_LDS_DEPTH, bool CTL = false>
+template <bool COUNT, bool WIDE = false, int TRI = 0, int LDSD = YT_LDS_DEPTH>
 YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool find_any, Stack& st,
-    Counters& cnt, WalkCtl* ctl = nullptr) {
+    Counters& cnt) {
   constexpr int LDS_LEVELS = LDSD, SPILL_LEVELS = 128 - LDSD;
-  static_assert(!CTL || WIDE, "suspend / resume is the wide walk's");
   static_assert(!(COUNT && WIDE), "work counters follow the reference's binary walk");
   Hit best = {-1, -1, 0, 0, 0, false};
 
@@ -461,40 +438,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
   };
 
   int cur = REF_NONE;  // node to process next, REF_NONE = pop one
-  bool resumed = false;
-  if constexpr (CTL) resumed = ctl->resume;
-  if (CTL && resumed) {
-    // the walk goes on where it was evicted: node, stack, best hit; the level's ray is recomputed from the instance's record
-    // (the same transform_ray on the same operands as when the level was entered)
-    const WalkCont& C  = ctl->in;
-    const int4      h0 = C.head[ctl->in_idx], h1 = C.head[C.cap + ctl->in_idx], h2 = C.head[2 * C.cap + ctl->in_idx];
-    cur = h0.y, sp = h0.z;
-    const int inst = h0.w;
-    best  = {h1.x, h1.y, __int_as_float(h2.x), __int_as_float(h2.y), __int_as_float(h2.z), (h1.w & 1) != 0, h1.z};
-    weird = (h1.w & 2) != 0;
-    if (best.hit) tmax = best.distance, tmaxk = best.distance * BBOX_K;
-    for (int k = 0; k < sp; k++) {
-      const StackEntry e = C.stack[(size_t)k * C.cap + ctl->in_idx];
-      if (k < LDS_LEVELS) lds[k * YT_BLOCK].ref = e.ref, lds[k * YT_BLOCK].t0 = e.t0;
-      else spill[k - LDS_LEVELS] = e;
-    }
-    if (inst >= 0) {
-      float4 m0, m1, m2, m3, m4;
-      int4   m5;
-      load_instance_record(sc.tinst, inst, m0, m1, m2, m3, m4, m5);
-      frame3f inv = {{m0.x, m0.y, m0.z}, {m0.w, m1.x, m1.y}, {m1.z, m1.w, m2.x}, {m2.y, m2.z, m2.w}};
-      o = transform_point(inv, wo), d = transform_vector(inv, wd);
-      dinv = {1 / d.x, 1 / d.y, 1 / d.z};
-      tame = true;  // (the wide walk enters no level its ray is irregular at)
-      sign = ((dinv.x < 0) ? 1 : 0) | ((dinv.y < 0) ? 2 : 0) | ((dinv.z < 0) ? 4 : 0);
-      cur_inst = inst;
-      kind     = TRI == 1 ? KIND_TRIANGLES : __float_as_int(m4.w);
-      if (TRI == 2 && kind != KIND_TRIANGLES) kind = KIND_QUADS;
-      leafbias = m5.x;
-      blas_hit = (h1.w & 4) != 0;
-      cur_last = true;
-    }
-  } else if (only_instance >= 0) {
+  if (only_instance >= 0) {
     cur_last = true;
     cur      = enter(sc.tinst, only_instance, only_instance);
     if (WIDE && abort) return Hit{HIT_ABORT, -1, 0, 0, 0, false};
@@ -517,40 +461,7 @@ YT_FN Hit traverse(const DScene& sc, const ray3f& wray, int only_instance, bool 
 
   const float4* pairs = sc.pairs;
   bool          done  = false;
-  int           rounds = 0;  // (CTL) iterations of the outer loop: the same number for every lane that still walks
   while (!done) {
-    if constexpr (CTL) {
-      // eviction: the lanes here are the wavefront's lanes that still walk.  Once they are few (and have had min_steps rounds of
-      // descend + leaf in this launch) they write their walks out and the wavefront ends; a later launch regroups such walks 64 to a wavefront.
-      if (ctl->evict && rounds++ >= ctl->min_steps) {
-        const unsigned long long here = __ballot(1);
-        if (__popcll(here) < ctl->min_lanes) {
-          const WalkCont&          C     = ctl->out;
-          const bool               fits  = sp <= WALK_CONT_DEPTH;
-          const unsigned long long going = __ballot(fits);
-          if (fits) {
-            const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)going) - 1;
-            int       base = 0;
-            if (lane == leader) base = atomicAdd(C.count, __popcll(going));
-            base          = __shfl(base, leader);
-            const int idx = base + __popcll(going & ((1ull << lane) - 1ull));
-            if (idx < C.cap) {
-              C.head[idx]             = {ctl->tag, cur, sp, cur_inst};
-              C.head[C.cap + idx]     = {best.instance, best.element, best.leaf, (best.hit ? 1 : 0) | (weird ? 2 : 0) | (blas_hit ? 4 : 0)};
-              C.head[2 * C.cap + idx] = {__float_as_int(best.u), __float_as_int(best.v), __float_as_int(best.distance), 0};
-              for (int k = 0; k < sp; k++) {
-                StackEntry e;
-                if (k < LDS_LEVELS) e.ref = lds[k * YT_BLOCK].ref, e.t0 = lds[k * YT_BLOCK].t0;
-                else e = spill[k - LDS_LEVELS];
-                C.stack[(size_t)k * C.cap + idx] = e;
-              }
-              ctl->suspended = true;
-              break;
-            }
-          }
-        }
-      }
-    }
     // ---- (1) descend: until this lane holds a leaf / instance entry ----------
     while (true) {
       if (cur == REF_NONE) {
@@ -1085,21 +996,6 @@ YT_FN Hit traverse_any(const DScene& sc, const ray3f& wray, int only_instance, b
     }
   }
   return traverse<COUNT, false, TRI>(sc, wray, only_instance, find_any, st, cnt);
-}
-
-// traverse_any for a walk that may be evicted / is resumed (WalkCtl): the wide walk only.  An irregular ray (HIT_ABORT) is redone
-// binary from its start whether it had been resumed or not; units whose walk has no suspend / resume (the majority-phase walk, the
-// own tree) take ctl as "never evict" — nothing is ever resumed there because nothing was evicted.
-template <int TRI, bool PHASED = false>
-YT_FN Hit traverse_any_ctl(const DScene& sc, const ray3f& wray, Stack& st, Counters& cnt, WalkCtl& ctl) {
-#ifndef YT_OWN_TREE
-  if constexpr (!PHASED) {
-    Hit h = traverse<false, true, TRI, YT_LDS_DEPTH, true>(sc, wray, -1, false, st, cnt, &ctl);
-    if (ctl.suspended || h.instance != HIT_ABORT) return h;
-    return traverse<false, false, TRI>(sc, wray, -1, false, st, cnt);
-  }
-#endif
-  return traverse_any<false, true, TRI, PHASED>(sc, wray, -1, false, st, cnt);
 }
 
 }  // namespace yt

@@ -211,9 +211,6 @@ struct ythip_ctx {
   int                stream_cell_bits = 4, stream_order = 0, stream_phased = -1, stream_min_batch = 4;  // YTHIP_STREAM_CELLS / _ORDER / _PHASED / _MIN_BATCH
   int*               stream_counts_host = nullptr;  // pinned: {next queue length, generations run} per group
   int                stream_groups = 2;           // chains of generations side by side (YTHIP_STREAM_GROUPS; 2 measured best)
-  int                stream_evict_lanes = 0, stream_evict_steps = 3;  // ks_extend's wavefronts end below this many walking lanes (0: off), not before this many steps (YTHIP_STREAM_EVICT)
-  int4*              stream_cont_head[2]  = {nullptr, nullptr};     // the evicted walks (WalkCont, yt_bvh.h), two buffers: pass 0 -> 1, pass 1 -> 2
-  yt::StackEntry*    stream_cont_stack[2] = {nullptr, nullptr};
   int                stream_log_gen = -1;         // profiling: the generation whose per-ray walk lengths ks_extend logs (ythip_get_stream_walk_steps)
   int                stream_finish = 250;         // a group leaves the generations for ks_finish once its queue is this many thousandths of its path slots (YTHIP_STREAM_FINISH; 0: never)
   int                stream_min_slots = 262144;   // a group holds at least a quarter of this many path slots (a chain of generations wants a few thousand wavefronts per launch; YTHIP_STREAM_MIN_SLOTS: tests)

@@ -55,10 +55,6 @@ struct DStream {
   int*      step_log;       // profiling: the traversal steps of every queue entry of generation log_gen (null: off)
   int       log_gen;
   unsigned long long* stats;  // optional (profiling): [0] sum of lane steps, [1] 64 x longest lane per wavefront, [2] wavefronts, [3] rays
-  // eviction (ythip_set_stream_eviction): ks_extend's wavefronts end when fewer than evict_lanes lanes still walk; the walks go on in
-  // ks_extend_more, regrouped 64 to a wavefront, from cont[0], and what is evicted there once more from cont[1] (to the end)
-  WalkCont cont[2];
-  int      evict_lanes, evict_steps;  // 0: off (cont unset)
   int   nbins;        // bounce-ray bins: 8 octants x 2^(3 cell_bits) cells
   int   nprim_bins;   // camera-ray bins (groups of neighbouring tiles), after the bounce-ray bins
   int   cell_bits, prim_shift;
@@ -234,7 +230,6 @@ __global__ void __launch_bounds__(YT_SCAN_THREADS) ks_scan(DStream S) {
   }
   if (tid == 0) {
     const unsigned total = s_carry;
-    if (S.evict_lanes) *S.cont[0].count = 0, *S.cont[1].count = 0;
     S.counts[0]          = (int)total;
     if (total) {
       const int g = S.counts[1];
@@ -280,8 +275,7 @@ YT_FN void stream_walk_stats(const DStream& S, unsigned steps) {
   }
 }
 
-// EVICT: the wavefront's last walkers leave for ks_extend_more (WalkCtl, yt_bvh.h)
-template <bool WIDE, int TRI, bool PHASED, bool EVICT = false>
+template <bool WIDE, int TRI, bool PHASED>
 __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_EXTEND_WAVES) ks_extend(DScene sc, DStream S) {
   __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
   const int n = S.counts[0];
@@ -295,51 +289,11 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_EXTEND_WAVES) ks_extend(DS
     const int    slot = S.queue[i];
     const float4 ra = sld(S.ray_a + slot), rb = sld(S.ray_b + slot);
     const ray3f  ray = make_ray({ra.x, ra.y, ra.z}, {ra.w, rb.x, rb.y});
-    Hit          h;
-    bool         evicted = false;
-    if constexpr (EVICT) {
-      WalkCtl ctl;
-      ctl.evict = true, ctl.out = S.cont[0], ctl.min_lanes = S.evict_lanes, ctl.min_steps = S.evict_steps, ctl.tag = slot;
-      h       = traverse_any_ctl<TRI, PHASED>(sc, ray, stack, cnt, ctl);
-      evicted = ctl.suspended;
-    } else {
-      h = traverse_any<false, WIDE, TRI, PHASED>(sc, ray, -1, false, stack, cnt);
-    }
-    if (!evicted) {
-      sst(S.hit_a + slot, float4{h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)});
-      sst(S.hit_e + slot, h.element);
-    }
+    const Hit    h   = traverse_any<false, WIDE, TRI, PHASED>(sc, ray, -1, false, stack, cnt);
+    sst(S.hit_a + slot, float4{h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)});
+    sst(S.hit_e + slot, h.element);
     steps = cnt.steps + 1;
     if (S.step_log && S.counts[1] - 1 == S.log_gen) S.step_log[i] = (int)steps;
-  }
-  if (S.stats) stream_walk_stats(S, steps);
-}
-
-// the evicted walks of pass PASS - 1, 64 to a wavefront; PASS 1 evicts once more (into cont[1]), PASS 2 walks to the end
-template <int TRI, int PASS>
-__global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_EXTEND_WAVES) ks_extend_more(DScene sc, DStream S) {
-  __shared__ StackEntry s_stack[YT_LDS_DEPTH][YT_BLOCK];
-  const WalkCont& C = S.cont[PASS - 1];
-  const int       n = min_(*C.count, C.cap);
-  const int       i = (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
-  if ((int)blockIdx.x * YT_BLOCK >= n) return;
-  unsigned steps = 0;
-  if (i < n) {
-    Stack stack;
-    YT_STACK_INIT(stack, s_stack);
-    Counters     cnt  = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int    slot = C.head[i].x;
-    const float4 ra = sld(S.ray_a + slot), rb = sld(S.ray_b + slot);
-    const ray3f  ray = make_ray({ra.x, ra.y, ra.z}, {ra.w, rb.x, rb.y});
-    WalkCtl      ctl;
-    ctl.resume = true, ctl.in = C, ctl.in_idx = i, ctl.tag = slot;
-    if constexpr (PASS == 1) ctl.evict = true, ctl.out = S.cont[1], ctl.min_lanes = S.evict_lanes, ctl.min_steps = S.evict_steps;
-    const Hit h = traverse_any_ctl<TRI, false>(sc, ray, stack, cnt, ctl);
-    if (!ctl.suspended) {
-      sst(S.hit_a + slot, float4{h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)});
-      sst(S.hit_e + slot, h.element);
-    }
-    steps = cnt.steps + 1;
   }
   if (S.stats) stream_walk_stats(S, steps);
 }

@@ -20,12 +20,6 @@ void stream_shade(const StreamLaunch& l) {
 template <int TRI>
 void stream_extend(const StreamLaunch& l) {
   using namespace yt;
-  if (l.ss->evict_lanes) {  // (the host loop sets it only where the unit's walk can be suspended: not phased, not the own tree)
-    hipLaunchKernelGGL((ks_extend<true, TRI, false, true>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.ss);
-    hipLaunchKernelGGL((ks_extend_more<TRI, 1>), dim3((l.ss->cont[0].cap + YT_BLOCK - 1) / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.ss);
-    hipLaunchKernelGGL((ks_extend_more<TRI, 2>), dim3((l.ss->cont[1].cap + YT_BLOCK - 1) / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.ss);
-    return;
-  }
   if (l.phased)
     hipLaunchKernelGGL((ks_extend<true, TRI, true>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.ss);
   else

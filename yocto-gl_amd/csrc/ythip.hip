@@ -147,7 +147,6 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
   if (ctx->stream_slots != st.nslots) {
     const size_t ns = (size_t)st.nslots;
     S               = DStream{};
-    ctx->stream_cont_head[0] = ctx->stream_cont_head[1] = nullptr, ctx->stream_cont_stack[0] = ctx->stream_cont_stack[1] = nullptr;
     S.prim_shift    = 8;  // camera rays: bins of 4 neighbouring tiles
     while (((st.nslots >> S.prim_shift) > 16384)) S.prim_shift++;
     S.nprim_bins = std::max(1, (st.nslots + (1 << S.prim_shift) - 1) >> S.prim_shift);
@@ -179,17 +178,10 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
   const bool prof = (ctx->prof_mode & 1) != 0;
   if (prof) HIPCHECK(ctx, hipMemsetAsync(S.stats, 0, MAX_GROUPS * 8 * 64 * sizeof(unsigned long long), ctx->stream));
   HIPCHECK(ctx, hipMemsetAsync(S.counts, 0, MAX_GROUPS * 16 * sizeof(int), ctx->stream));
-  const bool phased = ctx->stream_phased >= 0 ? ctx->stream_phased != 0 : (cls == 1 && lp == LP_DEFER);
-  // eviction of a wavefront's last walkers (ythip_set_stream_eviction): where the unit's walk can be suspended — the wide walk,
-  // not its majority-phase form, not the own tree's
-  const bool evict = ctx->stream_evict_lanes > 0 && !phased && mode != 2;
-  const size_t cont_cap_all = (size_t)st.nslots / 2 + 64 * MAX_GROUPS;  // (fewer than half of a wavefront's lanes are ever evicted)
-  if (evict && !ctx->stream_cont_head[0]) {
-    for (int b = 0; b < 2; b++) {
-      if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->stream_cont_head[b], 3 * cont_cap_all))) return rc;
-      if ((rc = dalloc(ctx, ctx->state_allocs, &ctx->stream_cont_stack[b], (size_t)WALK_CONT_DEPTH * cont_cap_all))) return rc;
-    }
-  }
+  // (the majority-phase walk — the fused kernel's choice on matte scenes with area lights, where a wavefront's lanes want different step
+  //  kinds at any moment — is OFF by default here: ks_extend's wavefronts are sorted rays that mostly want the same; cfg2b 62.2 -> 53.6 ms,
+  //  the 9M box 19.2 -> 18.3 ms, profiles/r06_stream_ab_eviction.txt)
+  const bool phased = ctx->stream_phased > 0;
   DStream           G[MAX_GROUPS];
   ytl::StreamLaunch L[MAX_GROUPS];
   hipStream_t       streams[MAX_GROUPS];
@@ -212,14 +204,6 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     G[g].counts   = S.counts + 16 * g;
     G[g].stats    = prof ? S.stats + 8 * 64 * g : nullptr;
     G[g].gen_rays = prof ? S.gen_rays + YT_STREAM_GEN_LOG * g : nullptr;
-    G[g].evict_lanes = evict ? std::min(ctx->stream_evict_lanes, 32) : 0;
-    G[g].evict_steps = std::max(ctx->stream_evict_steps, 1);
-    if (evict) {
-      const int    cap = G[g].nslots / 2;
-      const size_t off = (size_t)G[g].slot0 / 2 + 64 * (size_t)g;
-      for (int b = 0; b < 2; b++)
-        G[g].cont[b] = {ctx->stream_cont_head[b] + 3 * off, ctx->stream_cont_stack[b] + (size_t)WALK_CONT_DEPTH * off, G[g].counts + 4 + b, cap};
-    }
     G[g].step_log = prof && ctx->stream_log_gen >= 0 ? S.step_log + G[g].slot0 : nullptr;
     G[g].log_gen  = ctx->stream_log_gen;
     L[g]          = {streams[g], &ds, &ctx->st, &kp, &G[g], lp, cls, phased};
@@ -590,7 +574,6 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_BATCH")) ctx->stream_min_batch = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_GROUPS")) ctx->stream_groups = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_FINISH")) ctx->stream_finish = std::atoi(e);
-  if (const char* e = std::getenv("YTHIP_STREAM_EVICT")) ctx->stream_evict_lanes = std::min(std::max(std::atoi(e), 0), 32);
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_SLOTS")) ctx->stream_min_slots = std::max(128, std::atoi(e));
   {
     hipDeviceProp_t prop;
@@ -1734,12 +1717,6 @@ int ythip_get_stream_walk_steps(ythip_ctx* ctx, int generation, int32_t* steps, 
   if (!ctx->stream_slots || capacity < ctx->stream_slots) return fail(ctx, YTHIP_ERR_STATE, "no streamed batch to report / capacity below the path slots");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   HIPCHECK(ctx, hipMemcpy(steps, ctx->ss.step_log, (size_t)ctx->stream_slots * sizeof(int), hipMemcpyDeviceToHost));
-  return YTHIP_OK;
-}
-int ythip_set_stream_eviction(ythip_ctx* ctx, int lanes, int steps) {
-  if (!ctx || lanes < 0 || lanes > 32 || steps < 0) return fail(ctx, YTHIP_ERR_INVALID, "stream eviction: lanes 0..32, steps >= 0");
-  ctx->stream_evict_lanes = lanes;
-  if (steps > 0) ctx->stream_evict_steps = steps;
   return YTHIP_OK;
 }
 int ythip_set_stream_finish(ythip_ctx* ctx, int permille) {

@@ -520,7 +520,6 @@ _SIGNATURES = {
     "ythip_set_stream_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ythip_set_stream_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_set_stream_finish": (C.c_int, [C.c_void_p, C.c_int]),
-    "ythip_set_stream_eviction": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ythip_get_stream_generations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "ythip_get_stream_walk_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]),
     "ythip_last_launch_fastmath": (C.c_int, [C.c_void_p]),
@@ -790,11 +789,6 @@ class Context:
         """A group's queue at `permille` thousandths of its path slots goes to the tail kernel (default 250; 0 never,
         1000 the whole batch) — ythip_set_stream_finish."""
         self._check(self.lib.ythip_set_stream_finish(self.h, int(permille)), "set_stream_finish")
-
-    def set_stream_eviction(self, lanes, steps=0):
-        """ks_extend's wavefronts end below `lanes` walking lanes (0 off), not before `steps` steps; the walks go on regrouped
-        in two more launches — ythip_set_stream_eviction."""
-        self._check(self.lib.ythip_set_stream_eviction(self.h, int(lanes), int(steps)), "set_stream_eviction")
 
     def stream_walk_steps(self, generation, fetch=False):
         """Profiling: choose the generation whose per-ray walk lengths the next profiled streamed batch logs (fetch=False), or
