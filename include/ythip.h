@@ -643,6 +643,10 @@ int ythip_set_stream_groups(ythip_ctx* ctx, int groups);
  * of its rays.  0 = never (generations until the queue is empty), 1000 = from the first ray on (tests).  env YTHIP_STREAM_FINISH.
  * Results never depend on it. */
 int ythip_set_stream_finish(ythip_ctx* ctx, int permille);
+int ythip_get_stream_info(ythip_ctx* ctx, ythip_stream_info* info);
+/* Profiling (ythip_set_profiling bit 0 during the batch): the queue length of every generation of the last streamed batch,
+ * up to `capacity` (and 8192) entries; *written = how many. */
+int ythip_get_stream_generations(ythip_ctx* ctx, int32_t* rays, int32_t capacity, int32_t* written);
 /* Profiling: the traversal steps (+ 1) of every ray of ONE generation of a streamed batch, in queue order per group (a group's
  * entries start at its first path slot; entries beyond the generation's queue length keep what an earlier batch left).  Call with
  * steps = NULL before the batch to choose the generation (-1: off), with a buffer of >= path_slots entries after it. */
