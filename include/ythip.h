@@ -627,6 +627,7 @@ typedef struct ythip_stream_info {
  * the state from then on; measured again for a new trace_state, sampler, mode, bounce limit or batch size.  The two schedulers
  * produce the same bytes, so the choice is invisible in the results.  env YTHIP_SCHEDULER. */
 int ythip_set_scheduler(ythip_ctx* ctx, int mode);
+int ythip_get_scheduler(ythip_ctx* ctx); /* the mode set (0 for a null context) */
 /* Tuning of the streaming scheduler's sort (a negative argument keeps the current value; results never depend on it):
  * order 0 = direction octant major, origin cell minor (default), 1 = cell major, 2 = no sort (the queue in pixel order: the
  * baseline the sort is measured against); cell_bits 1..5 = the scene's root box cut into 2^bits cells per axis (default 4);

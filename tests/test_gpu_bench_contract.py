@@ -104,7 +104,7 @@ def test_default_line_carries_the_contract(tmp_path):
     # round 6: `path` on the streaming scheduler (bit-exact) on the workloads it was measured on, and the NEE samplers on cfg2b
     streamed = [o for o in j["other_configs"] if o.get("mode", "").startswith("stream")]
     assert [o["name"] for o in streamed] == ["cfg2b", "configs3", "configs4", "cornell9m"]
-    assert all(o["streamed"] == 1 and o["stream"]["groups"] == 2 and o["stream"]["generations"] >= 64 for o in streamed)
+    assert all(o["streamed"] == 1 and o["stream"]["groups"] == 2 and o["stream"]["generations"] >= 16 for o in streamed)  # (>= the batch's samples; the tail kernel takes the rest)
     assert all(0.5 < o["speedup_over_bit_exact"] < 2 for o in streamed)
     nee = [o for o in j["other_configs"] if o.get("mode", "").startswith("path")]
     assert [(o["name"], o["mode"].split(":")[0]) for o in nee] == [("cfg2b", "pathdirect"), ("cfg2b", "pathmis")]

@@ -645,6 +645,19 @@ def test_cpp_dropin_sharded_over_two_ranks():
     assert "dropin_test: OK" in r.stdout and "devices: 2" in r.stdout
 
 
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dropin_test did not travel")
+@pytest.mark.parametrize("devices", ["0", "0,0"])
+def test_cpp_dropin_on_the_streaming_scheduler(devices):
+    """... and with the streaming scheduler as the library's default (YTHIP_SCHEDULER=1; the wide walk forced so that the small test
+    scenes are served): `path` batches of 4 and of 256 samples and a cancelled render run streamed, on one rank and on two — where
+    ythip_multi launches the ranks from a thread each, since a streamed batch returns when it is done.  Same comparisons."""
+    import subprocess
+    env = dict(os.environ, YOCTO_HIP_DEVICES=devices, YTHIP_SCHEDULER="1", YTHIP_TRAVERSAL="1", YTHIP_STREAM_MIN_SLOTS="1024")
+    r = subprocess.run([DROPIN], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "dropin_test: OK" in r.stdout
+
+
 YTRACE_CPU = os.path.join(os.path.dirname(DROPIN), "ytrace_cpu")
 YTRACE_HIP = os.path.join(os.path.dirname(DROPIN), "ytrace_hip")
 
@@ -684,6 +697,30 @@ def test_unmodified_ytrace_app_on_both_backends(tmp_path, scene, args, exact):
     a, b = out[YTRACE_CPU], out[YTRACE_HIP]
     assert a.shape == b.shape and a.shape[0] > 0
     assert a.tobytes() == b.tobytes()  # the saved images are the same files, whatever the sampler
+
+
+@pytest.mark.skipif(not (os.path.exists(YTRACE_CPU) and os.path.exists(YTRACE_HIP) and P.have_ref()),
+                    reason="oracle/_ref/ytrace_{cpu,hip} did not travel")
+@pytest.mark.parametrize("scheduler", ["1", "2"])
+def test_unmodified_ytrace_app_on_the_streaming_scheduler(tmp_path, scheduler):
+    """The drop-in takes the library's defaults from the environment: YTHIP_SCHEDULER=1 (streamed wherever served) / 2 (the
+    measured choice: fused, fused timed, streamed, streamed timed, then the faster) under the unmodified ytrace — the same
+    .hdr as the CPU build's, byte for byte.  (YTHIP_TRAVERSAL=1: the test scene's trees are tiny and would be walked binary,
+    which the scheduler does not serve.)"""
+    import subprocess
+    sc = ry.RefScene.from_flat(P.SCENES["cornellbox"]())
+    fn = tmp_path / "cornellbox" / "cornellbox.json"
+    os.makedirs(fn.parent, exist_ok=True)
+    sc.save(fn)
+    args = ["--sampler", "path", "--samples", "96", "--batch", "8", "--resolution", "128"]
+    out = {}
+    for exe in [YTRACE_CPU, YTRACE_HIP]:
+        o = tmp_path / (os.path.basename(exe) + ".hdr")
+        env = dict(os.environ, YTHIP_SCHEDULER=scheduler, YTHIP_TRAVERSAL="1", YTHIP_STREAM_MIN_SLOTS="1024")
+        r = subprocess.run([exe, "--scene", str(fn), "--output", str(o)] + args, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[exe] = ry.load_image(o)
+    assert out[YTRACE_CPU].tobytes() == out[YTRACE_HIP].tobytes()
 
 
 def test_no_device_memory_leak_over_context_and_state_cycles():

@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -292,18 +293,54 @@ int ythip_multi_trace_samples(ythip_multi* m, const ythip_params* params, const 
   std::vector<int> samples_before(m->n, 0);
   for (int r = 0; r < m->n; r++)
     if (m->lwidth[r]) (void)ythip_state_get_samples(m->ctx[r], &samples_before[r]);
-  for (int r = 0; r < m->n; r++) {
-    if (m->lwidth[r] == 0) continue;
-    int rc = ythip_trace_samples_async(m->ctx[r], params);
-    if (rc) {  // all ranks or none: the ranks that did launch finish their batch and take it back
-      for (int q = 0; q < r; q++) {
-        (void)ythip_sync(m->ctx[q]);
-        if (m->lwidth[q]) (void)ythip_state_set_samples(m->ctx[q], samples_before[q]);
+  bool cancelled = false;
+  // A rank on the streaming scheduler (ythip_set_scheduler 1 / 2) runs its batch as generations enqueued by a host loop that
+  // returns when the batch is done: such ranks launch from a thread each — or they would render one after the other, and nobody
+  // would relay `stop` meanwhile.
+  bool streaming = false;
+  for (int r = 0; r < m->n; r++) streaming = streaming || (m->lwidth[r] && ythip_get_scheduler(m->ctx[r]) != 0);
+  if (streaming) {  // (one rank too: somebody has to watch `stop` while the rank's host loop runs)
+    std::vector<int>         rcs(m->n, 0);
+    std::vector<std::thread> threads;
+    std::atomic<int>         left{0};
+    for (int r = 0; r < m->n; r++) {
+      if (m->lwidth[r] == 0) continue;
+      left++;
+      threads.emplace_back([&, r] {
+        rcs[r] = ythip_trace_samples_async(m->ctx[r], params);
+        left--;
+      });
+    }
+    while (left.load() > 0) {
+      if (stop && *stop && !cancelled) {
+        for (int q = 0; q < m->n; q++) (void)ythip_cancel(m->ctx[q]);
+        cancelled = true;
       }
-      return rank_fail(m, r, rc);
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    for (auto& t : threads) t.join();
+    for (int r = 0; r < m->n; r++) {
+      if (!rcs[r] || (cancelled && rcs[r] == YTHIP_ERR_CANCELLED)) continue;
+      for (int q = 0; q < m->n; q++) {  // all ranks or none: the ranks that did run take their batch back
+        if (q == r || !m->lwidth[q]) continue;
+        (void)ythip_sync(m->ctx[q]);
+        (void)ythip_state_set_samples(m->ctx[q], samples_before[q]);
+      }
+      return rank_fail(m, r, rcs[r]);
+    }
+  } else {
+    for (int r = 0; r < m->n; r++) {
+      if (m->lwidth[r] == 0) continue;
+      int rc = ythip_trace_samples_async(m->ctx[r], params);
+      if (rc) {  // all ranks or none: the ranks that did launch finish their batch and take it back
+        for (int q = 0; q < r; q++) {
+          (void)ythip_sync(m->ctx[q]);
+          if (m->lwidth[q]) (void)ythip_state_set_samples(m->ctx[q], samples_before[q]);
+        }
+        return rank_fail(m, r, rc);
+      }
     }
   }
-  bool cancelled = false;
   if (stop) {
     for (int r = 0; r < m->n && !cancelled; r++)
       while (ythip_poll(m->ctx[r]) == 0) {

@@ -21,6 +21,9 @@ std::string& ythip_thread_error() { return g_error; }
 
 namespace {
 
+bool stop_raised(ythip_ctx* ctx) {  // ythip_cancel (any thread) has asked this batch to stop
+  return ctx->stop_host && __atomic_load_n(ctx->stop_host, __ATOMIC_ACQUIRE) == ctx->stop_gen.load();
+}
 void raise_stop_word(ythip_ctx* ctx) {  // (what ythip_cancel does: the batch's number into the pinned word the kernels relay)
   __atomic_store_n(ctx->stop_host, ctx->stop_gen.load(), __ATOMIC_RELEASE);
 }
@@ -224,7 +227,10 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     bool      fin[MAX_GROUPS] = {}, idle[MAX_GROUPS] = {};
     if (permille >= 1000)
       for (int g = 0; g < groups; g++) finish(L[g]), fin[g] = true, finish_rays += G[g].nslots;
-    int chunk = std::max(1, params->batch);
+    // the first `batch` generations need no look at the queue (a sample is at least one generation) — but what is enqueued cannot be
+    // taken back: a cancelled batch still pays for every launch queued behind it (2.5 us each, returning at once).  64 at a time keeps
+    // a cancel under 2 ms of empty launches whatever the batch (a 4096-sample batch enqueued blind: 90 ms).
+    int chunk = std::min(std::max(1, params->batch), 64), blind = std::max(1, params->batch);
     if (!ctx->done_event) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->done_event, hipEventDisableTiming));
     while (true) {
       bool work = false;
@@ -263,8 +269,11 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
         else any = true;
       }
       if (!any && !finishing) break;
-      // what is left: the live paths' remaining bounces — a few generations at a time (each surplus one costs four empty launches)
-      chunk = std::max(4, std::min(chunk, 16));
+      // inside the first `batch` generations: 64 at a time; behind them what is left are the live paths' remaining bounces — a few
+      // generations at a time (each surplus one costs four empty launches)
+      blind -= chunk;
+      chunk = blind > 0 ? std::min(blind, 64) : 16;
+      if (ctx->stream_cancelled || stop_raised(ctx)) chunk = 4;
     }
   }
   HIPCHECK(ctx, hipGetLastError());
@@ -568,6 +577,7 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_LPT_PROBE")) ctx->lpt_probe = std::atoi(e) != 0;
   if (const char* e = std::getenv("YTHIP_PIXEL_POOL")) ctx->pixel_pool = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_SCHEDULER")) ctx->scheduler = std::min(std::max(std::atoi(e), 0), 2);
+  if (const char* e = std::getenv("YTHIP_TRAVERSAL")) ctx->traversal_mode = std::min(std::max(std::atoi(e), 0), 2);  // (ythip_set_traversal)
   if (const char* e = std::getenv("YTHIP_STREAM_CELLS")) ctx->stream_cell_bits = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_ORDER")) ctx->stream_order = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_PHASED")) ctx->stream_phased = std::atoi(e);
@@ -1698,6 +1708,7 @@ int ythip_set_scheduler(ythip_ctx* ctx, int mode) {
   ctx->scheduler = mode, ctx->sched_tune = 0, ctx->sched_on = false;
   return YTHIP_OK;
 }
+int ythip_get_scheduler(ythip_ctx* ctx) { return ctx ? ctx->scheduler : 0; }
 int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased) {
   if (!ctx || order > 2 || cell_bits == 0 || cell_bits > 5 || phased > 1) return fail(ctx, YTHIP_ERR_INVALID, "stream options: order 0..2, cell_bits 1..5, phased 0..1");
   if (order >= 0) ctx->stream_order = order;
