@@ -688,6 +688,7 @@ def main():
     ctx.make_trace_bvh(flat)
     ctx.make_trace_lights(flat)
     ctx.set_traversal(args.traversal)
+    ctx.set_scheduler(0)  # the headline is the fused kernel's (the library's measured choice — its default — picks it on configs[1] as well)
     setup_s = time.time() - t0
     build_info = ctx.bvh_build_info()
     dev = torch.device("cuda", local)

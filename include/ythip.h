@@ -601,7 +601,7 @@ int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info);
  * >= 4 samples, in every ythip_params::fastmath mode (0: the reference's bytes; 1 / 2: the bytes of that mode's fused kernel —
  * the tolerance and own-tree units carry their own build of the scheduler's kernels); anything else runs on the fused kernel
  * (ythip_get_stream_info says which ran, ythip_last_launch_fastmath which mode).
- * env YTHIP_SCHEDULER=1 makes it the default of new contexts. */
+ * env YTHIP_SCHEDULER=0 / 1 / 2 sets the mode of new contexts (default 2: ythip_set_scheduler). */
 typedef struct ythip_stream_info {
   int32_t ran;          /* the last batch ran on the streaming scheduler */
   int32_t generations;  /* generations that had rays queued */
@@ -621,11 +621,13 @@ typedef struct ythip_stream_info {
   float   fused_ms_per_sample;  /* the two timed batches, per sample per pixel (state 4) */
   float   stream_ms_per_sample;
 } ythip_stream_info;
-/* mode 0: the fused persistent kernel (default).  1: the streaming scheduler wherever it serves the batch.  2: a MEASURED CHOICE,
+/* mode 0: the fused persistent kernel.  1: the streaming scheduler wherever it serves the batch.  2 (default): a MEASURED CHOICE,
  * as for the pixel pool — on a batch the streaming scheduler serves (and of >= 8 samples), once the fused path has settled, one
  * batch is timed fused, the next two run streamed (the second timed), and whichever took less time per sample (the streamed one by 3 % at least) serves
  * the state from then on; measured again for a new trace_state, sampler, mode, bounce limit or batch size.  The two schedulers
- * produce the same bytes, so the choice is invisible in the results.  env YTHIP_SCHEDULER. */
+ * produce the same bytes, so the choice is invisible in the results.  A streamed batch is enqueued by a host loop that returns when
+ * the batch is done: ythip_trace_samples_async then blocks like ythip_trace_samples (ythip_multi launches such ranks from a thread
+ * each); a caller that needs the call to return at once sets mode 0.  env YTHIP_SCHEDULER. */
 int ythip_set_scheduler(ythip_ctx* ctx, int mode);
 int ythip_get_scheduler(ythip_ctx* ctx); /* the mode set (0 for a null context) */
 /* Tuning of the streaming scheduler's sort (a negative argument keeps the current value; results never depend on it):

@@ -197,7 +197,7 @@ struct ythip_ctx {
   const int*         stop_host_dev = nullptr;  // ... and its device address (the kernels relay it into d_stop)
   ytx::Bounce        xfer;  // every host <-> device byte goes through pinned memory the library owns (yt_xfer.h)
   // the streaming scheduler (yt_stream.h; ythip_set_scheduler): generations of extend / shade launches over SoA path state in HBM
-  int                scheduler        = 0;        // 0 the fused persistent kernel (k_trace), 1 streaming generations, 2 measured choice between the two
+  int                scheduler        = 2;        // 0 the fused persistent kernel (k_trace), 1 streaming generations, 2 (default) measured choice between the two
   // scheduler 2: as for the pixel pool — once the fused path has settled (tile costs known, pool decided), one batch is timed fused,
   // the next two run streamed (the second timed), and whichever took less time per sample serves this state / sampler / mode from then on (same bytes either way)
   int                sched_tune       = 0;        // 0 time a fused batch next, 1 a streamed batch next (untimed: buffers, first launches), 2 time a streamed batch next, 3 waiting for both, 4 decided

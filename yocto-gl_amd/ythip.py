@@ -773,7 +773,7 @@ class Context:
         return {k: getattr(info, k) for k, _ in CPoolInfo._fields_}
 
     def set_scheduler(self, mode):
-        """0 the fused persistent kernel (default), 1 the streaming scheduler (csrc/yt_stream.h), 2 a measured choice between the
+        """0 the fused persistent kernel, 1 the streaming scheduler (csrc/yt_stream.h), 2 (default) a measured choice between the
         two per trace_state / sampler / mode / batch size — ythip_set_scheduler."""
         self._check(self.lib.ythip_set_scheduler(self.h, int(mode)), "set_scheduler")
 
