@@ -140,7 +140,8 @@ def random_scene(seed):
     if sampler == "path" and p["bounces"] > 0 and r.random() < 0.6:
         spp = int(r.integers(4, 9))
         p["samples"], p["batch"] = spp * int(r.integers(1, 3)), spp
-        stream = dict(order=int(r.integers(0, 3)), cell_bits=int(r.integers(1, 6)), groups=int(r.choice([1, 2, 3])))
+        stream = dict(order=int(r.integers(0, 3)), cell_bits=int(r.integers(1, 6)), groups=int(r.choice([1, 2, 3])),
+                      finish=int(r.choice([0, 100, 250, 500, 800, 1000])), phased=int(r.integers(0, 2)))  # (round 6, last session: the tail kernel)
     return sc, p, bool(r.random() < 0.25), stream
 
 
@@ -161,10 +162,12 @@ def main():
                 ctx.set_scheduler(1)
                 ctx.set_stream_options(order=stream["order"], cell_bits=stream["cell_bits"])
                 ctx.set_stream_groups(stream["groups"])
+                ctx.set_stream_finish(stream["finish"])
+                ctx.set_stream_options(phased=stream["phased"])
             gpu = P.gpu_render(ctx, flat, p)
             if stream:
                 info = ctx.stream_info()
-                ran = f" streamed {info['ran']} ({info['generations']} generations, {info['groups']} chains, order {stream['order']}, {stream['cell_bits']} cell bits)"
+                ran = f" streamed {info['ran']} ({info['generations']} generations, {info['groups']} chains, order {stream['order']}, {stream['cell_bits']} cell bits, tail kernel at {stream['finish']}: {info['finish_rays']} rays, phased {stream['phased']})"
             ctx.close()
             ref = P.RefBundle(flat, highquality=hq).render(p)
         except Exception as e:  # a scene one side refuses: report, go on
