@@ -121,8 +121,10 @@ MODE_NAMES = ["bit-exact (the reference's trace_state, byte for byte)",
               "pathdirect: bit-exact, sampler pathdirect (yocto_trace.cpp:599-722), scene-class kernel",
               "pathmis: bit-exact, sampler pathmis (yocto_trace.cpp:725-934), scene-class kernel",
               "own-stream (fastmath = 2 on ythip_set_scheduler 1): the own tree's walk in the streaming scheduler's extend kernel; equal to "
-              "the own-tree entry byte for byte"]
-MODE_SAMPLER = {4: "pathdirect", 5: "pathmis"}
+              "the own-tree entry byte for byte",
+              "direct-stream (sampler pathdirect on ythip_set_scheduler 1): bit-exact; the path rays through the sorted extend stage, the NEE "
+              "ray of a bounce walked in the shade stage; x = over the fused pathdirect entry"]
+MODE_SAMPLER = {4: "pathdirect", 5: "pathmis", 7: "pathdirect"}
 
 
 def run_workload(name, device, steps, warmup, count=True, fastmath=0):
@@ -154,7 +156,7 @@ def run_workload_modes(name, device, steps, warmup, modes, count=True):
         # next-event-estimation samplers pathdirect / pathmis (since round 6 by scene class, as `path`); 6 = the own-tree mode on the
         # streaming scheduler
         sampler = MODE_SAMPLER.get(mode, "path")
-        ctx.set_scheduler(1 if mode in (3, 6) else 0)
+        ctx.set_scheduler(1 if mode in (3, 6, 7) else 0)
         progress(f"workload {name}: launches (mode {mode}: {MODE_NAMES[mode].split(' ')[0]})")
         p = yt.trace_params(sampler=sampler, resolution=w["resolution"], bounces=8, clamp=10.0,
                             samples=1 << 30, batch=w["spp"], fastmath=mode if mode <= 2 else 2 if mode == 6 else 0)
@@ -178,7 +180,7 @@ def run_workload_modes(name, device, steps, warmup, modes, count=True):
         out = {"name": name, "label": w["label"], "width": width, "height": height, "spp": w["spp"], "sampler": sampler,
                "fastmath": int(ctx.last_launch_fastmath()), "streamed": int(ctx.stream_info()["ran"]),
                "ms_per_launch": ms, "launches": st["trace_launches"], "samples_per_launch": width * height * w["spp"]}
-        if mode in (3, 6):
+        if mode in (3, 6, 7):
             info = ctx.stream_info()
             out["stream"] = {k: info[k] for k in ("generations", "launched", "groups", "path_slots", "bins")}
         if cnt is not None and sampler == "path":  # (the counted work is `path`'s)
@@ -430,7 +432,7 @@ def other_workloads(device, args, calib):
     every = ["configs1", "cfg2b", "configs3", "configs4", "cornell9m", "materials1", "features1"]
     runs = []
     # (round 6: streamed / the NEE samplers, bit-exact; the own tree on the streaming scheduler where the scheduler wins)
-    extra = {"cfg2b": [3, 4, 5, 6], "configs3": [3, 6], "configs4": [3], "cornell9m": [3, 6]}
+    extra = {"cfg2b": [3, 4, 5, 6, 7], "configs3": [3, 6], "configs4": [3], "cornell9m": [3, 6]}
     for name in every:  # one worker process per workload: scene, context and trees once, then mode after mode
         modes = ([1, 2] if name == "configs1" else [0, 1, 2]) + extra.get(name, [])  # (the primary line IS the bit-exact configs[1])
         try:
@@ -464,8 +466,12 @@ def other_workloads(device, args, calib):
     exact = {e["name"]: e["value"] for e in res if "value" in e and e["mode"].startswith("bit-exact")}
     exact["configs1"] = args.primary_value  # (the primary line is the bit-exact configs[1])
     for e in res:
-        if "value" in e and not e["mode"].startswith(("bit-exact", "pathdirect", "pathmis")) and e["name"] in exact:
+        if "value" in e and not e["mode"].startswith(("bit-exact", "pathdirect", "pathmis", "direct-stream")) and e["name"] in exact:
             e["speedup_over_bit_exact"] = round(e["value"] / exact[e["name"]], 3)  # (over the fused kernel's bit-exact `path`)
+    direct = {e["name"]: e["value"] for e in res if "value" in e and e["mode"].startswith("pathdirect")}
+    for e in res:  # (the streamed pathdirect over the fused pathdirect of the same workload)
+        if "value" in e and e["mode"].startswith("direct-stream") and e["name"] in direct:
+            e["speedup_over_bit_exact"] = round(e["value"] / direct[e["name"]], 3)
     return res, deferred
 
 
@@ -526,7 +532,7 @@ def compact_line(out, detail_path):
                 short.append({"name": o.get("name"), "error": o["error"][:80]})
                 continue
             r = o.get("roofline", {})
-            mode = o["mode"].split(" ")[0].rstrip(":")  # "bit-exact" / "tolerance" / "own-tree" / "stream" / "pathdirect" / "pathmis" / "own-stream"
+            mode = o["mode"].split(" ")[0].rstrip(":")  # "bit-exact" / "tolerance" / "own-tree" / "stream" / "pathdirect" / "pathmis" / "own-stream" / "direct-stream"
             e = {"name": o["name"], "mode": mode, "value": round(o["value"], 1)}
             if mode in ("bit-exact", "pathdirect", "pathmis"):  # (the others carry their ratio to the bit-exact entry)
                 e["ms_per_step"] = round(o["ms_per_step"], 2)

@@ -44,7 +44,7 @@ def test_default_line_carries_the_contract(tmp_path):
     assert "counters_per_launch" not in lr
     for o in line["other_configs"]:
         assert set(o) <= {"name", "mode", "value", "ms_per_step", "bound", "frac", "lanes", "x"}, o
-        assert o["value"] > 0 and o["mode"] in ("bit-exact", "tolerance", "own-tree", "stream", "pathdirect", "pathmis", "own-stream")
+        assert o["value"] > 0 and o["mode"] in ("bit-exact", "tolerance", "own-tree", "stream", "pathdirect", "pathmis", "own-stream", "direct-stream")
         if o["mode"] == "bit-exact":
             assert o["bound"] in ("hbm", "l2", "valu", "ta") and 0 < o["frac"] <= 1 and 0 < o["lanes"] <= 1
     lb = line["cpu_baseline"]
@@ -109,6 +109,9 @@ def test_default_line_carries_the_contract(tmp_path):
     nee = [o for o in j["other_configs"] if o.get("mode", "").startswith("path")]
     assert [(o["name"], o["mode"].split(":")[0]) for o in nee] == [("cfg2b", "pathdirect"), ("cfg2b", "pathmis")]
     assert all("sampler=" + o["mode"].split(":")[0] in o["workload"] and o["streamed"] == 0 for o in nee)
+    ds = [o for o in j["other_configs"] if o.get("mode", "").startswith("direct-stream")]  # (round 6, last session: pathdirect streamed)
+    assert [o["name"] for o in ds] == ["cfg2b"] and ds[0]["streamed"] == 1 and "sampler=pathdirect" in ds[0]["workload"]
+    assert 0.8 < ds[0]["speedup_over_bit_exact"] < 3
     own = [o for o in j["other_configs"] if o.get("mode", "").startswith("own-tree")]
     assert [o["name"] for o in own] == [o["name"] for o in fast]
     assert all(o["fastmath_ran"] == 2 and o["own_tree"]["nodes"] > 0 for o in own)  # ... and so did the own-tree unit, on its tree

@@ -94,6 +94,43 @@ def test_the_tail_kernel_changes_nothing(scene, monkeypatch):
         P.assert_identical(want, got, f"{scene} streamed, finish at {permille} / 1000, {groups} groups")
 
 
+@pytest.mark.parametrize("scene", SCENES)
+def test_streamed_pathdirect_equals_the_reference(scene, monkeypatch):
+    """Sampler `pathdirect` (yocto_trace.cpp:599-722) on the streaming scheduler: the path rays through the sorted extend stage, the
+    NEE half of a bounce — light pdf walks, the NEE ray, its emission — in the shade stage, as k_trace's deferred stage does it.
+    The reference's bytes, with and without the tail kernel, in every mode's unit."""
+    monkeypatch.setenv("YTHIP_STREAM_MIN_SLOTS", "1024")
+    flat = P.SCENES[scene]()
+    params = yt.trace_params(sampler="pathdirect", resolution=144, samples=12, batch=6)
+    want = want_state(flat, params)
+    for order, groups, permille in ((0, 2, 250), (2, 1, 0), (1, 3, 1000)):
+        ctx = stream_context(flat)
+        ctx.set_stream_options(order=order)
+        ctx.set_stream_groups(groups)
+        ctx.set_stream_finish(permille)
+        got = P.gpu_render(ctx, flat, params)
+        assert ctx.stream_info()["ran"] == 1
+        ctx.close()
+        P.assert_identical(want, got, f"{scene} pathdirect streamed, order {order}, {groups} chains, tail kernel at {permille}")
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_streamed_pathdirect_in_the_other_modes(mode):
+    flat = P.SCENES["materials"]()
+    params = yt.trace_params(sampler="pathdirect", resolution=128, samples=8, batch=8, fastmath=mode)
+    out = []
+    for stream in (0, 1):
+        ctx = P.gpu_context(flat)
+        ctx.set_traversal("wide")
+        if mode == 2:
+            ctx.make_own_bvh(flat)
+        ctx.set_scheduler(stream)
+        out.append(P.gpu_render(ctx, flat, params))
+        assert ctx.stream_info()["ran"] == stream and ctx.last_launch_fastmath() == mode
+        ctx.close()
+    P.assert_identical(out[0], out[1], f"pathdirect fastmath {mode}: streamed vs fused")
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_the_tail_kernel_in_the_other_modes(mode):
     flat = P.SCENES["materials"]()
@@ -171,7 +208,7 @@ def test_slices_batches_and_scheduler_changes_in_one_render():
 def test_what_the_scheduler_does_not_serve_runs_fused():
     flat = P.SCENES["cornellbox"]()
     ctx = stream_context(flat)
-    for kw in (dict(sampler="pathdirect", batch=4), dict(sampler="path", batch=1), dict(sampler="path", batch=4, bounces=0),
+    for kw in (dict(sampler="naive", batch=4), dict(sampler="path", batch=1), dict(sampler="path", batch=4, bounces=0),
                dict(sampler="pathmis", batch=4, fastmath=1)):
         params = yt.trace_params(resolution=64, samples=4, **kw)
         got = P.gpu_render(ctx, flat, params)

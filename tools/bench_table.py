@@ -26,7 +26,7 @@ def row(name, value, ms, r, mode, speed=None):
     sp = f" ×{speed:.2f}" if speed else ""
     bound = max(f, key=f.get) if f else "-"
     cells = [NAMES.get(name, name) + {"exact": "", "fast": " — tolerance mode", "own": " — own tree", "stream": " — streaming scheduler (bit-exact)",
-                                         "pathdirect": " — sampler pathdirect (bit-exact)", "pathmis": " — sampler pathmis (bit-exact)", "own-stream": " — own tree on the streaming scheduler"}[mode], f"**{value:,.0f}**{was}{sp}", f"{ms:.2f}"]
+                                         "pathdirect": " — sampler pathdirect (bit-exact)", "pathmis": " — sampler pathmis (bit-exact)", "own-stream": " — own tree on the streaming scheduler", "direct-stream": " — sampler pathdirect on the streaming scheduler (bit-exact; × over the fused pathdirect)"}[mode], f"**{value:,.0f}**{was}{sp}", f"{ms:.2f}"]
     cells += [("**%.2f**" % f[k]) if k == bound else ("%.2f" % f[k]) if k in f else "-" for k in ("hbm", "l2", "valu", "ta")]
     cells += ["%.2f" % r["lane_utilisation"] if "lane_utilisation" in r else "-", "%.2f" % r["wave_wait_share"] if "wave_wait_share" in r else "-",
               "%d %%" % round(100 * r["l2_hit_rate"]) if "l2_hit_rate" in r else "-",
@@ -37,7 +37,7 @@ def row(name, value, ms, r, mode, speed=None):
 print("| workload | Msamples/s (previous round) | ms / step | hbm | l2 | valu | ta | lanes | waiting | L2 hit | TA cycles / wave load |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 print(row("configs1", j["value"], j["ms_per_step"], j.get("roofline", {}), "exact"))
-for mode in ("bit-exact", "tolerance", "own-tree", "stream", "pathdirect", "pathmis", "own-stream"):
+for mode in ("bit-exact", "tolerance", "own-tree", "stream", "pathdirect", "pathmis", "own-stream", "direct-stream"):
     for e in j.get("other_configs", []):
         if "value" in e and e["mode"].startswith(mode):
             print(row(e["name"], e["value"], e["ms_per_step"], e["roofline"], {"bit-exact": "exact", "tolerance": "fast", "own-tree": "own"}.get(mode, mode),

@@ -313,6 +313,7 @@ YT_FN int stream_shade_slot(const DScene& sc, const DState& st, const KParams& k
   constexpr bool MATTE = CLS == 1;
   constexpr int  PRIMS = MATTE ? 1 : (CLS == 3 ? 2 : 0);
   constexpr bool PEEK  = SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST || SAMPLER == YTHIP_SAMPLER_NAIVE;
+  static_assert(SAMPLER != YTHIP_SAMPLER_PATHDIRECT || LP == LP_DEFER, "pathdirect runs its walks in the deferred part");
   const float4   ra = sld(S.ray_a + slot), ha = sld(S.hit_a + slot);
   P.o               = {ra.x, ra.y, ra.z};
   P.d               = {ra.w, rb.x, rb.y};
@@ -327,11 +328,34 @@ YT_FN int stream_shade_slot(const DScene& sc, const DState& st, const KParams& k
   else step = step_path<SAMPLER, LP, CLS>(E, P);
   if constexpr (LP == LP_DEFER) {
     if (step == STEP_DEFER) {  // the rest of the loop body behind the light pdf's instance walks (k_trace's walk stage)
-      Counters     cnt  = {0, 0, 0, 0, 0, 0, 0, 0};
-      const float4 pd   = st.pend[slot];
-      const float  lpdf = sample_lights_pdf<2, false, PRIMS>(sc, P.o, P.d, &stack, &cnt);
-      P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
-      step = step_tail(P);
+      Counters cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+      int      nee = 0;
+      if constexpr (SAMPLER == YTHIP_SAMPLER_PATHDIRECT) {
+        // the NEE half of the loop body (yocto_trace.cpp:670-693) for the light direction step_path drew: pdf walks, the NEE
+        // ray — walked right here, in slot order: neighbouring pixels' NEE rays aim at the same few lights and are coherent as they
+        // come (a sort + extend launch of their own was measured: +-4 %, tools/experiments/r06_stream_pathdirect_two_stage.patch) —,
+        // the emission it finds
+        const float4 na = st.nee_a[slot];
+        nee             = __float_as_int(na.w);
+        if (nee) {
+          const float4 nb  = st.nee_b[slot];
+          const vec3f  inc = {na.x, na.y, na.z}, bsdfcos = {nb.x, nb.y, nb.z};
+          const float  pdf = sample_lights_pdf<2, false, PRIMS>(sc, P.o, inc, &stack, &cnt);
+          if (bsdfcos != vec3f{0, 0, 0} && pdf > 0) {
+            const ray3f nray     = make_ray(P.o, inc);
+            const Hit   nisec    = traverse_any<false, true, PRIMS>(sc, nray, -1, false, stack, cnt);
+            const auto  emission = nee_emission<CLS>(sc, nisec, inc);
+            P.radiance += P.weight * bsdfcos * emission / pdf;
+          }
+        }
+      }
+      step = STEP_END;
+      if (nee != 2) {
+        const float4 pd   = st.pend[slot];
+        const float  lpdf = sample_lights_pdf<2, false, PRIMS>(sc, P.o, P.d, &stack, &cnt);
+        P.weight *= vec3f{pd.x, pd.y, pd.z} / (0.5f * pd.w + 0.5f * lpdf);
+        step = step_tail(P);
+      }
     }
   }
   const int cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);

@@ -14,6 +14,13 @@ namespace {
 template <int LP, int CLS>
 void stream_shade(const StreamLaunch& l) {
   using namespace yt;
+  if constexpr (LP == LP_DEFER) {
+    if (l.kp->sampler == YTHIP_SAMPLER_PATHDIRECT) {
+      hipLaunchKernelGGL((ks_shade<YTHIP_SAMPLER_PATHDIRECT, LP, CLS, true>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.st,
+          *l.kp, *l.ss);
+      return;
+    }
+  }
   hipLaunchKernelGGL((ks_shade<YTHIP_SAMPLER_PATH, LP, CLS, true>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.st, *l.kp,
       *l.ss);
 }
@@ -28,6 +35,13 @@ void stream_extend(const StreamLaunch& l) {
 template <int LP, int CLS, int TRI>
 void stream_finish_launch(const StreamLaunch& l) {
   using namespace yt;
+  if constexpr (LP == LP_DEFER) {
+    if (l.kp->sampler == YTHIP_SAMPLER_PATHDIRECT) {  // (never the majority-phase walk)
+      hipLaunchKernelGGL((ks_finish<YTHIP_SAMPLER_PATHDIRECT, LP, CLS, true, TRI, false>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream,
+          *l.ds, *l.st, *l.kp, *l.ss);
+      return;
+    }
+  }
   if (l.phased)
     hipLaunchKernelGGL((ks_finish<YTHIP_SAMPLER_PATH, LP, CLS, true, TRI, true>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.st,
         *l.kp, *l.ss);
@@ -37,7 +51,9 @@ void stream_finish_launch(const StreamLaunch& l) {
 }
 }  // namespace
 
-bool stream_supported(const StreamLaunch& l) { return l.kp->sampler == YTHIP_SAMPLER_PATH && l.kp->bounces > 0; }
+bool stream_supported(const StreamLaunch& l) {
+  return (l.kp->sampler == YTHIP_SAMPLER_PATH || l.kp->sampler == YTHIP_SAMPLER_PATHDIRECT) && l.kp->bounces > 0;
+}
 
 void stream_begin(const StreamLaunch& l) {
   using namespace yt;

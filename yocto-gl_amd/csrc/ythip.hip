@@ -363,6 +363,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
     for (auto& l : ctx->h_lights.lights)
       if (l.instance != YTHIP_INVALIDID) lp = LP_DEFER;
   }
+  const int stream_lp = params->sampler == YTHIP_SAMPLER_PATHDIRECT ? LP_DEFER : lp;  // (the NEE samplers always run their walks deferred)
 
   // the streaming scheduler (ythip_set_scheduler 1): `path`, scenes the mode's wide walk serves, real batches.  In the mode the
   // caller asked for (round 6: the tolerance and own-tree units carry their own build of the kernels); a mode whose fused kernel
@@ -379,7 +380,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
     const int  mode = params->fastmath;
     const bool served = mode == 0 ? ctx->use_wide() : mode == 1 ? (ctx->wide_stack_ok && ctx->traversal_mode != 0) : (ctx->have_own && ctx->own_stack_ok);
     const int  cls  = ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
-    ytl::StreamLaunch probe = {ctx->stream, &ctx->ds, &ctx->st, &kp, &ctx->ss, lp, cls, false};
+    ytl::StreamLaunch probe = {ctx->stream, &ctx->ds, &ctx->st, &kp, &ctx->ss, stream_lp, cls, false};
     bool stream = served && ytl::stream_supported(probe);
     if (stream && ctx->scheduler == 2) {  // the measured choice
       const long long key = (long long)params->sampler | ((long long)mode << 8) | ((long long)(params->bounces & 0xffff) << 16) | ((long long)params->batch << 32);
@@ -408,7 +409,7 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
       DScene d = ctx->ds;  // (mode 2: only the bvh part is the own tree's — launch_trace_any)
       if (mode == 2) ctx->own.apply(d);
       if (sched_timed == 1) HIPCHECK(ctx, hipEventRecord(ctx->sched_ev[2], ctx->stream));
-      int rc = enqueue_stream(ctx, params, kp, lp, cls, stop, mode, d);
+      int rc = enqueue_stream(ctx, params, kp, stream_lp, cls, stop, mode, d);
       if (rc) return rc;
       if (sched_timed == 1) {
         HIPCHECK(ctx, hipEventRecord(ctx->sched_ev[3], ctx->stream));
