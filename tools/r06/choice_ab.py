@@ -13,7 +13,7 @@ for name in (os.environ.get("SCENES") or "configs1,cfg2b,configs3,configs4,corne
     flat = w["make"]()
     spp = int(os.environ.get("SPP", w["spp"]))
     fm = int(os.environ.get("FASTMATH", "0"))
-    p = yt.trace_params(sampler="path", resolution=w["resolution"], samples=1 << 30, batch=spp, fastmath=fm)
+    p = yt.trace_params(sampler=os.environ.get("SAMPLER", "path"), resolution=w["resolution"], samples=1 << 30, batch=spp, fastmath=fm)
     out = {}
     for sched in (0, 2):
         ctx = bench.open_context(0, flat)
@@ -32,6 +32,6 @@ for name in (os.environ.get("SCENES") or "configs1,cfg2b,configs3,configs4,corne
         out[sched] = (ms, digest(ctx), info)
         ctx.close()
     (ms0, d0, _), (ms2, d2, info) = out[0], out[2]
-    print(f"{name:10s} fastmath {fm} fused {ms0:9.3f} ms | choice: state {info['choice_state']} streamed {info['choice_streamed']} "
+    print(f"{name:10s} {os.environ.get('SAMPLER', 'path')} fastmath {fm} fused {ms0:9.3f} ms | choice: state {info['choice_state']} streamed {info['choice_streamed']} "
           f"(probes: fused {info['fused_ms_per_sample'] * spp:9.3f} ms, streamed {info['stream_ms_per_sample'] * spp:9.3f} ms) -> {ms2:9.3f} ms  x{ms0 / ms2:.3f}  "
           f"state {d2} {'OK' if d0 == d2 else 'DIFFERENT'}", flush=True)
