@@ -114,6 +114,16 @@ def test_render_at_baseline_size_vs_live_reference(cfg, name, res, spp):
     assert gpu["samples"] == ref["samples"] == spp
     assert int(gpu["hits"].max()) == spp
     P.assert_identical(gpu, ref, f"{name} at {res} x {spp} spp")
+    # ... and the same frame on the streaming scheduler (csrc/yt_stream.h: every pixel in flight, sorted extend stage, tail kernel),
+    # as two half batches: the same bytes
+    ctx.set_scheduler(1)
+    try:
+        half = yt.trace_params(sampler="path", resolution=res, samples=spp, batch=spp // 2)
+        streamed = P.gpu_render(ctx, flat, half)
+        assert ctx.stream_info()["ran"] == 1
+    finally:
+        ctx.set_scheduler(2)
+    P.assert_identical(streamed, ref, f"{name} at {res} x {spp} spp, streamed")
 
 
 def test_cfg2_full_size_properties(cfg):
