@@ -635,7 +635,7 @@ int ythip_get_scheduler(ythip_ctx* ctx); /* the mode set (0 for a null context) 
  * order 0 = direction octant major, origin cell minor (default), 1 = cell major, 2 = no sort (the queue in pixel order: the
  * baseline the sort is measured against); cell_bits 1..5 = the scene's root box cut into 2^bits cells per axis (default 4);
  * phased 0 / 1 = ks_extend's majority-phase scene walk off / on (default off: sorted wavefronts mostly want the same
- * step kind; the fused kernel's default on matte scenes with area lights is on).  env YTHIP_STREAM_ORDER / _CELLS / _PHASED. */
+ * step kind; the own-tree mode keeps the fused kernel's default, on for matte scenes with area lights).  env YTHIP_STREAM_ORDER / _CELLS / _PHASED. */
 int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased);
 /* groups 1..8 (default 2): the pixels of the slice as that many runs, each a chain of generations of its own on its own stream —
  * one run's shade / sort launches fill the machine while another's extend launch drains (frames too small for it run as

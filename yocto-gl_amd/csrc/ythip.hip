@@ -183,8 +183,9 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
   HIPCHECK(ctx, hipMemsetAsync(S.counts, 0, MAX_GROUPS * 16 * sizeof(int), ctx->stream));
   // (the majority-phase walk — the fused kernel's choice on matte scenes with area lights, where a wavefront's lanes want different step
   //  kinds at any moment — is OFF by default here: ks_extend's wavefronts are sorted rays that mostly want the same; cfg2b 62.2 -> 53.6 ms,
-  //  the 9M box 19.2 -> 18.3 ms, profiles/r06_stream_ab_eviction.txt)
-  const bool phased = ctx->stream_phased > 0;
+  //  the 9M box 19.2 -> 18.3 ms, profiles/r06_stream_ab_eviction.txt.
+  //  The own tree's walk keeps the fused kernel's rule: cfg2b 46.3 against 46.9 ms, the 9M box 14.1 against 14.8.)
+  const bool phased = ctx->stream_phased > 0 || (ctx->stream_phased < 0 && mode == 2 && cls == 1 && lp == LP_DEFER);
   DStream           G[MAX_GROUPS];
   ytl::StreamLaunch L[MAX_GROUPS];
   hipStream_t       streams[MAX_GROUPS];
