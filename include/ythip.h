@@ -631,6 +631,9 @@ typedef struct ythip_stream_info {
  * each); a caller that needs the call to return at once sets mode 0.  env YTHIP_SCHEDULER. */
 int ythip_set_scheduler(ythip_ctx* ctx, int mode);
 int ythip_get_scheduler(ythip_ctx* ctx); /* the mode set (0 for a null context) */
+/* 1 when the next batch with these parameters may run streamed (its enqueue call then returns only when the batch is done), 0 when it
+ * will run on the fused kernel; what ythip_multi asks before it launches its ranks from a thread each. */
+int ythip_may_stream(ythip_ctx* ctx, const ythip_params* params);
 /* Tuning of the streaming scheduler's sort (a negative argument keeps the current value; results never depend on it):
  * order 0 = direction octant major, origin cell minor (default), 1 = cell major, 2 = no sort (the queue in pixel order: the
  * baseline the sort is measured against); cell_bits 1..5 = the scene's root box cut into 2^bits cells per axis (default 4);

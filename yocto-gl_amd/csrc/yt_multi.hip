@@ -298,7 +298,7 @@ int ythip_multi_trace_samples(ythip_multi* m, const ythip_params* params, const 
   // returns when the batch is done: such ranks launch from a thread each — or they would render one after the other, and nobody
   // would relay `stop` meanwhile.
   bool streaming = false;
-  for (int r = 0; r < m->n; r++) streaming = streaming || (m->lwidth[r] && ythip_get_scheduler(m->ctx[r]) != 0);
+  for (int r = 0; r < m->n; r++) streaming = streaming || (m->lwidth[r] && ythip_may_stream(m->ctx[r], params));
   if (streaming) {  // (one rank too: somebody has to watch `stop` while the rank's host loop runs)
     std::vector<int>         rcs(m->n, 0);
     std::vector<std::thread> threads;

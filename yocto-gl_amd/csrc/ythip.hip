@@ -1711,6 +1711,21 @@ int ythip_set_scheduler(ythip_ctx* ctx, int mode) {
   return YTHIP_OK;
 }
 int ythip_get_scheduler(ythip_ctx* ctx) { return ctx ? ctx->scheduler : 0; }
+// May the next batch with these parameters run on the streaming scheduler (its enqueue call then returns only when the batch is done)?
+// Conservative: 1 whenever the scheduler might take it — under the measured choice also while the two times are still awaited; 0 for
+// what the fused kernel is sure to run (not served, the choice's fused probe, a decision for the fused kernel).
+int ythip_may_stream(ythip_ctx* ctx, const ythip_params* params) {
+  if (!ctx || !params || ctx->scheduler == 0) return 0;
+  if (params->batch < ctx->stream_min_batch || params->bounces <= 0) return 0;
+  if (params->sampler != YTHIP_SAMPLER_PATH && params->sampler != YTHIP_SAMPLER_PATHDIRECT) return 0;
+  if (ctx->scheduler == 2) {
+    if (params->batch < 8) return 0;
+    const long long key = (long long)params->sampler | ((long long)params->fastmath << 8) | ((long long)(params->bounces & 0xffff) << 16) | ((long long)params->batch << 32);
+    if (key == ctx->sched_key && ctx->sched_tune == 4 && !ctx->sched_on) return 0;
+    if (key != ctx->sched_key || ctx->sched_tune == 0) return 0;  // (the next batch is a fused one: timed, or waiting for the fused path to settle)
+  }
+  return 1;
+}
 int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased) {
   if (!ctx || order > 2 || cell_bits == 0 || cell_bits > 5 || phased > 1) return fail(ctx, YTHIP_ERR_INVALID, "stream options: order 0..2, cell_bits 1..5, phased 0..1");
   if (order >= 0) ctx->stream_order = order;

@@ -518,6 +518,7 @@ _SIGNATURES = {
     "ythip_set_scheduler": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_get_stream_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_get_scheduler": (C.c_int, [C.c_void_p]),
+    "ythip_may_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ythip_set_stream_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "ythip_set_stream_groups": (C.c_int, [C.c_void_p, C.c_int]),
     "ythip_set_stream_finish": (C.c_int, [C.c_void_p, C.c_int]),
