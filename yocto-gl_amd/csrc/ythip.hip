@@ -631,6 +631,8 @@ void ythip_destroy(ythip_ctx* ctx) {
   if (ctx->d_pool_next) (void)hipFree(ctx->d_pool_next);
   for (auto e : ctx->pool_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto e : ctx->sched_ev)
+    if (e) (void)hipEventDestroy(e);
   free_staging(ctx);
   free_all(ctx->denoise_allocs);
   free_all(ctx->order_allocs);
