@@ -627,8 +627,9 @@ typedef struct ythip_stream_info {
  * batch is timed fused, the next two run streamed (the second timed), and whichever took less time per sample (the streamed one by 3 % at least) serves
  * the state from then on; measured again for a new trace_state, sampler, mode, bounce limit or batch size.  The two schedulers
  * produce the same bytes, so the choice is invisible in the results.  A streamed batch is enqueued by a host loop that returns when
- * the batch is done: ythip_trace_samples_async then blocks like ythip_trace_samples (ythip_multi launches such ranks from a thread
- * each); a caller that needs the call to return at once sets mode 0.  env YTHIP_SCHEDULER. */
+ * the batch is done.  Under mode 2 only ythip_trace_samples — whose caller waits anyway — is ever streamed, and
+ * ythip_trace_samples_async keeps returning at once (its batches run fused and take no part in the choice); under mode 1 the async
+ * call blocks for a batch the scheduler serves.  ythip_multi launches ranks that may stream from a thread each.  env YTHIP_SCHEDULER. */
 int ythip_set_scheduler(ythip_ctx* ctx, int mode);
 int ythip_get_scheduler(ythip_ctx* ctx); /* the mode set (0 for a null context) */
 /* 1 when the next batch with these parameters may run streamed (its enqueue call then returns only when the batch is done), 0 when it

@@ -279,6 +279,27 @@ def test_the_measured_choice_of_scheduler():
     ctx.close()
 
 
+def test_the_measured_choice_leaves_the_async_call_alone():
+    """A streamed batch is enqueued by a host loop that returns when the batch is done, so under the default (the measured choice)
+    only ythip_trace_samples — whose caller waits anyway — is ever streamed: ythip_trace_samples_async keeps returning at once,
+    its batches run fused and take no part in the choice.  Mode 1 streams the async call's batches too (it then blocks)."""
+    flat = P.SCENES["cornellbox"]()
+    p = yt.trace_params(sampler="path", resolution=256, samples=1 << 20, batch=8)
+    ctx = P.gpu_context(flat)
+    ctx.set_traversal("wide")
+    assert ctx.lib.ythip_get_scheduler(ctx.h) == 2
+    ctx.make_trace_state(flat, p)
+    for _ in range(8):
+        ctx.trace_samples_async(p)
+        ctx.sync()
+        assert ctx.stream_info()["ran"] == 0 and ctx.stream_info()["choice_state"] == 0
+    ctx.set_scheduler(1)
+    ctx.trace_samples_async(p)
+    assert ctx.stream_info()["ran"] == 1
+    ctx.sync()
+    ctx.close()
+
+
 def test_own_tree_mode_without_its_tree_fails_on_the_streaming_scheduler_too():
     flat = P.SCENES["cornellbox"]()
     ctx = stream_context(flat)

@@ -200,6 +200,7 @@ struct ythip_ctx {
   int                scheduler        = 2;        // 0 the fused persistent kernel (k_trace), 1 streaming generations, 2 (default) measured choice between the two
   // scheduler 2: as for the pixel pool — once the fused path has settled (tile costs known, pool decided), one batch is timed fused,
   // the next two run streamed (the second timed), and whichever took less time per sample serves this state / sampler / mode from then on (same bytes either way)
+  bool               sync_call        = false;    // the batch being enqueued is ythip_trace_samples' (the caller waits for it): the measured choice may stream it
   int                sched_tune       = 0;        // 0 time a fused batch next, 1 a streamed batch next (untimed: buffers, first launches), 2 time a streamed batch next, 3 waiting for both, 4 decided
   bool               sched_on         = false;    // the decision: streamed
   long long          sched_key        = -1;       // what it was taken for (sampler, mode, bounces, batch)

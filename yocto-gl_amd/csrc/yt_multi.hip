@@ -307,7 +307,7 @@ int ythip_multi_trace_samples(ythip_multi* m, const ythip_params* params, const 
       if (m->lwidth[r] == 0) continue;
       left++;
       threads.emplace_back([&, r] {
-        rcs[r] = ythip_trace_samples_async(m->ctx[r], params);
+        rcs[r] = ythip_trace_samples(m->ctx[r], params, nullptr);  // (the waiting call: the one the measured choice may stream)
         left--;
       });
     }

@@ -377,7 +377,9 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   const bool pool_ok = ctx->pixel_pool && only_pix < 0 && !count && ctx->st.nblocks > ctx->pool_blocks && params->bounces > 0 &&
                        (ctx->have_tile_costs || !ctx->d_tile_cost || ctx->pixel_pool >= 2);
   int sched_timed = -1;  // scheduler 2: 0 = this batch is the timed fused one, 1 = the timed streamed one
-  if (ctx->scheduler != 0 && only_pix < 0 && !count && params->batch >= ctx->stream_min_batch) {
+  // (the measured choice only ever streams a batch whose caller waits for it anyway — ythip_trace_samples —: ythip_trace_samples_async keeps
+  //  returning at once under the default; mode 1 streams whatever it serves, and its async call returns when the batch is done)
+  if (ctx->scheduler != 0 && (ctx->scheduler == 1 || ctx->sync_call) && only_pix < 0 && !count && params->batch >= ctx->stream_min_batch) {
     const int  mode = params->fastmath;
     const bool served = mode == 0 ? ctx->use_wide() : mode == 1 ? (ctx->wide_stack_ok && ctx->traversal_mode != 0) : (ctx->have_own && ctx->own_stack_ok);
     const int  cls  = ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
@@ -1658,7 +1660,9 @@ int ythip_trace_samples(ythip_ctx* ctx, const ythip_params* params, const volati
   HIPCHECK(ctx, hipSetDevice(ctx->device));
   const int samples_before = ctx->samples;
   begin_batch(ctx);
+  ctx->sync_call           = true;
   int       rc             = enqueue_batch(ctx, params, stop);
+  ctx->sync_call           = false;
   if (rc) return rc;
   bool cancelled = ctx->last_launch_stream && ctx->stream_cancelled;  // (a streamed batch watched the flag itself)
   if (stop && !cancelled) {
