@@ -21,9 +21,9 @@ def test_fuzz_scenes_are_reproducible_and_always_lit():
         a, pa, ha, sa = F.random_scene(seed)
         b, pb, hb, sb = F.random_scene(seed)
         assert pa == pb and ha == hb and sa == sb
-        if sa:  # (round 6) a case for the streaming scheduler: `path`, real batches
+        if sa:  # (round 6) a case for the streaming scheduler: `path` / `pathdirect`, real batches
             streamed += 1
-            assert pa["sampler"] == "path" and pa["batch"] >= 4 and pa["samples"] % pa["batch"] == 0
+            assert pa["sampler"] in ("path", "pathdirect") and pa["batch"] >= 4 and pa["samples"] % pa["batch"] == 0
         assert a.positions.tobytes() == b.positions.tobytes() and a.materials.tobytes() == b.materials.tobytes()
         samplers.add(pa["sampler"])
         lit = len(a.environments) > 0 or any(
@@ -64,9 +64,9 @@ def test_bench_table_tool_renders_the_committed_line():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     rows = [l for l in r.stdout.splitlines() if l.startswith("| ")]
-    # header, seven workloads bit-exact, in the tolerance mode, on the own tree, four streamed, two NEE samplers, three own-tree streamed
+    # header, seven workloads bit-exact, in the tolerance mode, on the own tree, four streamed, two NEE samplers, three own-tree streamed, pathdirect streamed
     # (the rule row starts "|-")
-    assert len(rows) == 1 + 7 + 7 + 7 + 4 + 2 + 3
+    assert len(rows) == 1 + 7 + 7 + 7 + 4 + 2 + 3 + 1
     import json
     j = json.load(open(line))
     assert f"**{j['value']:,.0f}**" in rows[1] and "configs[1]" in rows[1]
