@@ -597,8 +597,8 @@ int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info);
  * and origin cell, a traversal-only extend kernel over the sorted queue, and a shade kernel in pixel order that accumulates,
  * regenerates and emits the next keys (csrc/yt_stream.h).  It schedules the SAME per-pixel operations — the parallel_for
  * over pixels of yocto_trace.cpp:1595-1619 says nothing about which worker runs a pixel — so the whole trace_state is the
- * megakernel's, bit for bit (tests/test_gpu_stream.py).  It serves the samplers `path` and `pathdirect` (the NEE ray of a bounce is
- * walked inside the shade stage, as k_trace's deferred stage walks it) on scenes the wide walk serves, batches of
+ * megakernel's, bit for bit (tests/test_gpu_stream.py).  It serves the samplers `path`, `pathdirect` (the NEE ray of a bounce is
+ * walked inside the shade stage, as k_trace's deferred stage walks it), `naive` and `pathtest` on scenes the wide walk serves, batches of
  * >= 4 samples, in every ythip_params::fastmath mode (0: the reference's bytes; 1 / 2: the bytes of that mode's fused kernel —
  * the tolerance and own-tree units carry their own build of the scheduler's kernels); anything else runs on the fused kernel
  * (ythip_get_stream_info says which ran, ythip_last_launch_fastmath which mode).

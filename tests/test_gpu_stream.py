@@ -114,10 +114,30 @@ def test_streamed_pathdirect_equals_the_reference(scene, monkeypatch):
         P.assert_identical(want, got, f"{scene} pathdirect streamed, order {order}, {groups} chains, tail kernel at {permille}")
 
 
+@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("sampler", ["naive", "pathtest"])
+def test_streamed_naive_and_pathtest_equal_the_reference(scene, sampler, monkeypatch):
+    """`naive` (yocto_trace.cpp:1032-1108) and `pathtest` (:937-1029) on the streaming scheduler — general-class shade kernels, as their
+    fused kernels are —: the reference's bytes (the tolerance / own-tree modes: test_streamed_nee_naive_pathtest_in_the_other_modes)."""
+    monkeypatch.setenv("YTHIP_STREAM_MIN_SLOTS", "1024")
+    flat = P.SCENES[scene]()
+    params = yt.trace_params(sampler=sampler, resolution=144, samples=12, batch=6)
+    want = want_state(flat, params)
+    for groups, permille in ((2, 250), (1, 1000)):
+        ctx = stream_context(flat)
+        ctx.set_stream_groups(groups)
+        ctx.set_stream_finish(permille)
+        got = P.gpu_render(ctx, flat, params)
+        assert ctx.stream_info()["ran"] == 1
+        ctx.close()
+        P.assert_identical(want, got, f"{scene} {sampler} streamed, {groups} chains, tail kernel at {permille}")
+
+
 @pytest.mark.parametrize("mode", [1, 2])
-def test_streamed_pathdirect_in_the_other_modes(mode):
+@pytest.mark.parametrize("sampler", ["pathdirect", "naive", "pathtest"])
+def test_streamed_nee_naive_pathtest_in_the_other_modes(mode, sampler):
     flat = P.SCENES["materials"]()
-    params = yt.trace_params(sampler="pathdirect", resolution=128, samples=8, batch=8, fastmath=mode)
+    params = yt.trace_params(sampler=sampler, resolution=128, samples=8, batch=8, fastmath=mode)
     out = []
     for stream in (0, 1):
         ctx = P.gpu_context(flat)
@@ -128,7 +148,7 @@ def test_streamed_pathdirect_in_the_other_modes(mode):
         out.append(P.gpu_render(ctx, flat, params))
         assert ctx.stream_info()["ran"] == stream and ctx.last_launch_fastmath() == mode
         ctx.close()
-    P.assert_identical(out[0], out[1], f"pathdirect fastmath {mode}: streamed vs fused")
+    P.assert_identical(out[0], out[1], f"{sampler} fastmath {mode}: streamed vs fused")
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -208,7 +228,7 @@ def test_slices_batches_and_scheduler_changes_in_one_render():
 def test_what_the_scheduler_does_not_serve_runs_fused():
     flat = P.SCENES["cornellbox"]()
     ctx = stream_context(flat)
-    for kw in (dict(sampler="naive", batch=4), dict(sampler="path", batch=1), dict(sampler="path", batch=4, bounces=0),
+    for kw in (dict(sampler="furnace", batch=4), dict(sampler="path", batch=1), dict(sampler="path", batch=4, bounces=0),
                dict(sampler="pathmis", batch=4, fastmath=1)):
         params = yt.trace_params(resolution=64, samples=4, **kw)
         got = P.gpu_render(ctx, flat, params)

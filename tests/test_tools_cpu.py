@@ -23,7 +23,7 @@ def test_fuzz_scenes_are_reproducible_and_always_lit():
         assert pa == pb and ha == hb and sa == sb
         if sa:  # (round 6) a case for the streaming scheduler: `path` / `pathdirect`, real batches
             streamed += 1
-            assert pa["sampler"] in ("path", "pathdirect") and pa["batch"] >= 4 and pa["samples"] % pa["batch"] == 0
+            assert pa["sampler"] in ("path", "pathdirect", "naive", "pathtest") and pa["batch"] >= 4 and pa["samples"] % pa["batch"] == 0
         assert a.positions.tobytes() == b.positions.tobytes() and a.materials.tobytes() == b.materials.tobytes()
         samplers.add(pa["sampler"])
         lit = len(a.environments) > 0 or any(

@@ -137,7 +137,7 @@ def random_scene(seed):
     # walk), batches of >= 4 samples, random sort order / cell grid / number of chains; drawn AFTER everything else, so the scenes
     # and parameters of a seed are what they were in rounds 2-5
     stream = None
-    if sampler in ("path", "pathdirect") and p["bounces"] > 0 and r.random() < 0.6:  # (pathdirect: since the round's last session)
+    if sampler in ("path", "pathdirect", "naive", "pathtest") and p["bounces"] > 0 and r.random() < 0.6:  # (pathdirect: since the round's last session)
         spp = int(r.integers(4, 9))
         p["samples"], p["batch"] = spp * int(r.integers(1, 3)), spp
         stream = dict(order=int(r.integers(0, 3)), cell_bits=int(r.integers(1, 6)), groups=int(r.choice([1, 2, 3])),

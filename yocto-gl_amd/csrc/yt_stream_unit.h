@@ -21,6 +21,19 @@ void stream_shade(const StreamLaunch& l) {
       return;
     }
   }
+  if constexpr (CLS == 0) {  // `naive` and `pathtest`: the general class, as their fused kernels (yt_trace_misc.hip, yt_trace_path.hip)
+    const dim3 grid(l.ss->nslots / YT_BLOCK), block(YT_BLOCK);
+    if (l.kp->sampler == YTHIP_SAMPLER_PATHTEST) {
+      hipLaunchKernelGGL((ks_shade<YTHIP_SAMPLER_PATHTEST, LP, 0, true>), grid, block, 0, l.stream, *l.ds, *l.st, *l.kp, *l.ss);
+      return;
+    }
+    if constexpr (LP == LP_NONE) {
+      if (l.kp->sampler == YTHIP_SAMPLER_NAIVE) {
+        hipLaunchKernelGGL((ks_shade<YTHIP_SAMPLER_NAIVE, LP_NONE, 0, true>), grid, block, 0, l.stream, *l.ds, *l.st, *l.kp, *l.ss);
+        return;
+      }
+    }
+  }
   hipLaunchKernelGGL((ks_shade<YTHIP_SAMPLER_PATH, LP, CLS, true>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.st, *l.kp,
       *l.ss);
 }
@@ -42,6 +55,19 @@ void stream_finish_launch(const StreamLaunch& l) {
       return;
     }
   }
+  if constexpr (CLS == 0) {
+    const dim3 grid(l.ss->nslots / YT_BLOCK), block(YT_BLOCK);
+    if (l.kp->sampler == YTHIP_SAMPLER_PATHTEST) {
+      hipLaunchKernelGGL((ks_finish<YTHIP_SAMPLER_PATHTEST, LP, 0, true, 0, false>), grid, block, 0, l.stream, *l.ds, *l.st, *l.kp, *l.ss);
+      return;
+    }
+    if constexpr (LP == LP_NONE) {
+      if (l.kp->sampler == YTHIP_SAMPLER_NAIVE) {
+        hipLaunchKernelGGL((ks_finish<YTHIP_SAMPLER_NAIVE, LP_NONE, 0, true, 0, false>), grid, block, 0, l.stream, *l.ds, *l.st, *l.kp, *l.ss);
+        return;
+      }
+    }
+  }
   if (l.phased)
     hipLaunchKernelGGL((ks_finish<YTHIP_SAMPLER_PATH, LP, CLS, true, TRI, true>), dim3(l.ss->nslots / YT_BLOCK), dim3(YT_BLOCK), 0, l.stream, *l.ds, *l.st,
         *l.kp, *l.ss);
@@ -52,7 +78,9 @@ void stream_finish_launch(const StreamLaunch& l) {
 }  // namespace
 
 bool stream_supported(const StreamLaunch& l) {
-  return (l.kp->sampler == YTHIP_SAMPLER_PATH || l.kp->sampler == YTHIP_SAMPLER_PATHDIRECT) && l.kp->bounces > 0;
+  return (l.kp->sampler == YTHIP_SAMPLER_PATH || l.kp->sampler == YTHIP_SAMPLER_PATHDIRECT || l.kp->sampler == YTHIP_SAMPLER_PATHTEST ||
+          l.kp->sampler == YTHIP_SAMPLER_NAIVE) &&
+         l.kp->bounces > 0;
 }
 
 void stream_begin(const StreamLaunch& l) {

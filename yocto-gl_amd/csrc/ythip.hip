@@ -382,7 +382,9 @@ int enqueue_samples(ythip_ctx* ctx, const ythip_params* params, const volatile i
   if (ctx->scheduler != 0 && (ctx->scheduler == 1 || ctx->sync_call) && only_pix < 0 && !count && params->batch >= ctx->stream_min_batch) {
     const int  mode = params->fastmath;
     const bool served = mode == 0 ? ctx->use_wide() : mode == 1 ? (ctx->wide_stack_ok && ctx->traversal_mode != 0) : (ctx->have_own && ctx->own_stack_ok);
-    const int  cls  = ctx->specialize ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
+    // (`naive` and `pathtest` have the general-class kernels only, as their fused kernels)
+    const bool plain = params->sampler == YTHIP_SAMPLER_NAIVE || params->sampler == YTHIP_SAMPLER_PATHTEST;
+    const int  cls  = (ctx->specialize && !plain) ? (ctx->all_matte ? 1 : ctx->no_textures ? 2 : ctx->opaque_textured ? 3 : 0) : 0;
     ytl::StreamLaunch probe = {ctx->stream, &ctx->ds, &ctx->st, &kp, &ctx->ss, stream_lp, cls, false};
     bool stream = served && ytl::stream_supported(probe);
     if (stream && ctx->scheduler == 2) {  // the measured choice
@@ -1723,7 +1725,9 @@ int ythip_get_scheduler(ythip_ctx* ctx) { return ctx ? ctx->scheduler : 0; }
 int ythip_may_stream(ythip_ctx* ctx, const ythip_params* params) {
   if (!ctx || !params || ctx->scheduler == 0) return 0;
   if (params->batch < ctx->stream_min_batch || params->bounces <= 0) return 0;
-  if (params->sampler != YTHIP_SAMPLER_PATH && params->sampler != YTHIP_SAMPLER_PATHDIRECT) return 0;
+  if (params->sampler != YTHIP_SAMPLER_PATH && params->sampler != YTHIP_SAMPLER_PATHDIRECT && params->sampler != YTHIP_SAMPLER_PATHTEST &&
+      params->sampler != YTHIP_SAMPLER_NAIVE)
+    return 0;
   if (ctx->scheduler == 2) {
     if (params->batch < 8) return 0;
     const long long key = (long long)params->sampler | ((long long)params->fastmath << 8) | ((long long)(params->bounces & 0xffff) << 16) | ((long long)params->batch << 32);
