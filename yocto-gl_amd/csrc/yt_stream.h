@@ -402,10 +402,14 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_FINISH_WAVES) ks_finish(DS
   const int n = S.counts[0];
   const int i = (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
   if (i >= n) return;
-  const int slot = S.queue[i];
-  Stack     stack;
+  int   slot = S.queue[i];
+  Stack stack;
   YT_STACK_INIT(stack, s_stack);
   for (unsigned iter = 0;; iter++) {
+    // (the slot made opaque once per phase: the compiler otherwise hoists every `array + slot` address of both bodies out of the loop
+    //  and keeps them alive across the walk: classes 1-3 spill 0-40 VGPRs instead of 7-55 without it, materials1 with the whole batch
+    //  in this kernel 82 -> 77 ms; the general class of `path` spills its 230-250 either way, and 3 waves per SIMD for it lost: 96 -> 104 ms)
+    asm volatile("" : "+v"(slot));
     {  // extend (ks_extend's body)
       Counters     cnt = {0, 0, 0, 0, 0, 0, 0, 0};
       const float4 ra = sld(S.ray_a + slot), rb = sld(S.ray_b + slot);
@@ -414,7 +418,7 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_FINISH_WAVES) ks_finish(DS
       sst(S.hit_a + slot, float4{h.u, h.v, h.distance, __int_as_float(h.hit ? h.instance : -1)});
       sst(S.hit_e + slot, h.element);
     }
-    asm volatile("" ::: "memory");  // (the hit record and the path state are re-read, not carried in registers across the walk)
+    asm volatile("" : "+v"(slot) : : "memory");  // (the hit record and the path state are re-read, not carried in registers across the walk)
     bool stopped = stop_requested(st.stop, st.stop_gen);
     if (blockIdx.x == 0 && (iter & 15) == 0 && st.stop_host &&
         __hip_atomic_load(st.stop_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == st.stop_gen) {  // relay_stop, by whichever lanes are left
