@@ -591,7 +591,7 @@ typedef struct ythip_pool_info {
 int ythip_set_pixel_pool(ythip_ctx* ctx, int mode, int workgroups); /* workgroups <= 0: keep (default 16 per CU) */
 int ythip_get_pixel_pool(ythip_ctx* ctx, ythip_pool_info* info);
 
-/* The scheduler of trace_samples (round 6).  0 (default): the fused persistent kernel — one wavefront owns a 16 x 4 pixel
+/* The scheduler of trace_samples (round 6).  0: the fused persistent kernel — one wavefront owns a 16 x 4 pixel
  * tile for the whole batch (k_trace).  1: the STREAMING scheduler north_star describes — every pixel in flight, SoA ray /
  * hit / path state in HBM, and per bounce ("generation") a counting sort of the live paths' next rays by direction octant
  * and origin cell, a traversal-only extend kernel over the sorted queue, and a shade kernel in pixel order that accumulates,
@@ -636,8 +636,8 @@ int ythip_get_scheduler(ythip_ctx* ctx); /* the mode set (0 for a null context) 
  * will run on the fused kernel; what ythip_multi asks before it launches its ranks from a thread each. */
 int ythip_may_stream(ythip_ctx* ctx, const ythip_params* params);
 /* Tuning of the streaming scheduler's sort (a negative argument keeps the current value; results never depend on it):
- * order 0 = direction octant major, origin cell minor (default), 1 = cell major, 2 = no sort (the queue in pixel order: the
- * baseline the sort is measured against); cell_bits 1..5 = the scene's root box cut into 2^bits cells per axis (default 4);
+ * order 0 = direction octant major, origin cell minor, 1 = cell major (default), 2 = no sort (the queue in pixel order: the
+ * baseline the sort is measured against); cell_bits 1..5 = the scene's root box cut into 2^bits cells per axis (default 3);
  * phased 0 / 1 = ks_extend's majority-phase scene walk off / on (default off: sorted wavefronts mostly want the same
  * step kind; the own-tree mode keeps the fused kernel's default, on for matte scenes with area lights).  env YTHIP_STREAM_ORDER / _CELLS / _PHASED. */
 int ythip_set_stream_options(ythip_ctx* ctx, int order, int cell_bits, int phased);

@@ -209,7 +209,7 @@ struct ythip_ctx {
   float              sched_ms[2]      = {0, 0};
   DStream            ss               = {};       // its arrays live in state_allocs (they go with the state)
   int                stream_slots     = 0;        // the slot count they were sized for (0: none)
-  int                stream_cell_bits = 4, stream_order = 0, stream_phased = -1, stream_min_batch = 4;  // YTHIP_STREAM_CELLS / _ORDER / _PHASED / _MIN_BATCH
+  int                stream_cell_bits = 3, stream_order = 1, stream_phased = -1, stream_min_batch = 4;  // YTHIP_STREAM_CELLS / _ORDER / _PHASED / _MIN_BATCH (cell major on 8^3 cells: = octant major on 16^3 on the closed boxes, +2 ... +4 % on the hair, the instances and the own tree)
   int*               stream_counts_host = nullptr;  // pinned: {next queue length, generations run} per group
   int                stream_groups = 2;           // chains of generations side by side (YTHIP_STREAM_GROUPS; 2 measured best)
   int                stream_log_gen = -1;         // profiling: the generation whose per-ray walk lengths ks_extend logs (ythip_get_stream_walk_steps)
