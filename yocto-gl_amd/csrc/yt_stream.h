@@ -21,6 +21,13 @@
 //                     accumulation and the regeneration; emits the next ray's sort key + histogram count;
 //   * dependent launches on one stream; a generation's kernels all return at once when nothing is queued, and the
 //     host stops enqueueing when a read-back of the queue length says zero.
+//   * the path slots run as two such chains of generations on two streams (one chain's shade / sort launches fill the machine
+//     while the other's extend launch drains), and once a chain's queue has shrunk to a quarter of its slots the rest of the
+//     batch — a few scattered pixels still short of their samples — runs in ONE launch: ks_finish, a lane per queue entry,
+//     extend and shade in turn on the same state.
+//   * samplers: `path` (ks_shade runs the deferred light-pdf walks of the lanes that deferred), `pathdirect` (and the NEE ray
+//     of a bounce, as k_trace's deferred stage does), `naive`, `pathtest`.  ythip_set_scheduler(ctx, 2) — the default — lets
+//     the library choose between this scheduler and k_trace per trace_state by timing a batch of each.
 //
 // Bit-exact by construction: the per-pixel sequence of operations is k_trace's (the same start_sample / step_path /
 // resolve_step / finish_sample on the same values) — only WHICH wavefront executes a ray's walk changes, and hit
