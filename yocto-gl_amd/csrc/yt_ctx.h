@@ -213,6 +213,7 @@ struct ythip_ctx {
   int*               stream_counts_host = nullptr;  // pinned: {next queue length, generations run} per group
   int                stream_groups = 2;           // chains of generations side by side (YTHIP_STREAM_GROUPS; 2 measured best)
   int                stream_log_gen = -1;         // profiling: the generation whose per-ray walk lengths ks_extend logs (ythip_get_stream_walk_steps)
+  int                stream_chunk_shift = 4;      // the groups' tiles are dealt round-robin in chunks of 2^this many tiles (YTHIP_STREAM_CHUNK; 0: tile by tile, 30: contiguous runs — round 6's first form: one chain got the sky, the other the scene)
   int                stream_finish = 250;         // a group leaves the generations for ks_finish once its queue is this many thousandths of its path slots (YTHIP_STREAM_FINISH; 0: never)
   int                stream_min_slots = 262144;   // a group holds at least a quarter of this many path slots (a chain of generations wants a few thousand wavefronts per launch; YTHIP_STREAM_MIN_SLOTS: tests)
   int                stream_bins_cap = 0;         // bins the hist / offs arrays hold per group

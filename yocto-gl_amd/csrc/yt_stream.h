@@ -54,7 +54,13 @@ struct DStream {
   int*        hit_e;  // element
   unsigned *  key, *rank;  // the next ray's sort key, its arrival number inside the key's bin
   // one GROUP of path slots = one chain of generations on one stream (two groups overlap each other's launch tails)
-  int       slot0, nslots;  // the group's path slots [slot0, slot0 + nslots), a multiple of 64
+  // The group's path slots: the grid's tiles (64 slots) dealt to the groups round-robin in chunks of 2^gshift tiles (16 by default),
+  // so that the chains carry the same work whatever the image's top and bottom look like.  (As contiguous runs — the first form —
+  // one chain of the corpus scenes got the sky and the other the scene: features1 306 -> 404 Msamples/s, materials1 392 -> 500 with
+  // the deal; cfg2b's tail kernel ran 13.5 ms for one half and 3.5 for the other.  Tile by tile costs the closed boxes 2 %: a chain's
+  // camera-ray bins and cells then span the whole image.)  slot0 = the group's offset into the per-group arrays (queue, step_log);
+  // nslots = its slot count, a multiple of 64.
+  int       slot0, nslots, gstride, goff, gshift;  // (chunks of 2^gshift tiles are dealt round-robin)
   unsigned *hist, *offs;    // per bin: count (zeroed by ks_scan), exclusive prefix
   int*      queue;          // the group's slots in key order
   int*      counts;         // [0] rays queued for the running generation (ks_scan), [1] generations run
@@ -68,6 +74,12 @@ struct DStream {
   int   order;        // 0: octant major, cell minor; 1: cell major, octant minor; 2: no sort (slot order)
   vec3f cell_lo, cell_scale;  // cell = (o - lo) * scale, the TLAS root box cut into 2^cell_bits cells per axis
 };
+
+// the k-th path slot of the group
+YT_FN int stream_slot(const DStream& S, int k) {
+  const int lt = k >> 6, lc = lt >> S.gshift, r = lt - (lc << S.gshift);  // the group's tile, its chunk of 2^gshift tiles, the tile inside it
+  return ((((lc * S.gstride + S.goff) << S.gshift) + r) << 6) | (k & 63);
+}
 
 YT_FN unsigned spread3(unsigned x) {  // 10 bits -> every third bit
   x &= 0x3ff;
@@ -159,7 +171,7 @@ YT_FN void stream_emit(const DStream& S, int slot, const Path& P, int cls) {
 // head of the batch: every pixel's first camera ray (k_trace's prologue)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(YT_BLOCK) ks_init(DScene sc, DState st, KParams kp, DStream S) {
-  const int slot = S.slot0 + (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
+  const int slot = stream_slot(S, (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x);
   int       i, j;
   const int pix = slot_pixel(st, slot, i, j);
   int       cls = OUT_DEAD;
@@ -250,7 +262,7 @@ __global__ void __launch_bounds__(256) ks_scatter(DStream S) {
   if (S.counts[0] == 0) return;
   const int k = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (k >= S.nslots) return;
-  const int      slot = S.slot0 + k;
+  const int      slot = stream_slot(S, k);
   const unsigned key  = S.key[slot];
   if (key != SKEY_DEAD) S.queue[S.offs[key] + S.rank[slot]] = slot;
 }
@@ -375,7 +387,7 @@ template <int SAMPLER, int LP, int CLS, bool WIDE>
 __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DScene sc, DState st, KParams kp, DStream S) {
   __shared__ StackEntry s_stack[LP == LP_DEFER ? YT_LDS_DEPTH : 1][YT_BLOCK];
   if (S.counts[0] == 0) return;  // nothing was queued for this generation: the batch is done
-  const int  slot    = S.slot0 + (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x;
+  const int  slot    = stream_slot(S, (int)blockIdx.x * YT_BLOCK + (int)threadIdx.x);
   const bool stopped = stop_requested(st.stop, st.stop_gen) || (blockIdx.x == 0 && relay_stop(st));
   const float4 rb = sld(S.ray_b + slot);
   const bool   live = !(__float_as_int(rb.w) & PF_DEAD);

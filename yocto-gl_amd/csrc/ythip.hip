@@ -196,12 +196,18 @@ int enqueue_stream(ythip_ctx* ctx, const ythip_params* params, const KParams& kp
     streams[g] = ctx->stream_side[g];
   }
   if (groups > 1 && !ctx->stream_ev[0]) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->stream_ev[0], hipEventDisableTiming));
-  // the path slots in `groups` runs of whole wavefronts
-  const int per = ((pslots / 64) + groups - 1) / groups * 64;
-  for (int g = 0; g < groups; g++) {
+  // the path slots in `groups` sets of whole wavefronts (tiles), interleaved tile by tile (yt_stream.h: stream_slot)
+  const int tiles = pslots / 64;
+  int gshift = std::min(std::max(ctx->stream_chunk_shift, 0), 30);
+  while (gshift > 0 && (long long)tiles < ((long long)groups << gshift)) gshift--;  // (every group gets tiles)
+  const int chunk = 1 << gshift;
+  for (int g = 0, off = 0; g < groups; g++) {
     G[g]          = S;
-    G[g].slot0    = std::min(g * per, pslots);
-    G[g].nslots   = std::min((g + 1) * per, pslots) - G[g].slot0;
+    G[g].gstride  = groups, G[g].goff = g, G[g].gshift = gshift;
+    G[g].slot0    = off;
+    const long long cycle = (long long)chunk * groups, rem = tiles % cycle;  // whole rounds of the deal + what the last one leaves this group
+    G[g].nslots   = (int)((tiles / cycle) * chunk + std::min<long long>(std::max<long long>(rem - (long long)g * chunk, 0), chunk)) * 64;
+    off += G[g].nslots;
     G[g].hist     = S.hist + (size_t)g * ctx->stream_bins_cap;
     G[g].offs     = S.offs + (size_t)g * ctx->stream_bins_cap;
     G[g].queue    = S.queue + G[g].slot0;
@@ -590,6 +596,7 @@ int ythip_create(int device, ythip_ctx** out) {
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_BATCH")) ctx->stream_min_batch = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_GROUPS")) ctx->stream_groups = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_FINISH")) ctx->stream_finish = std::atoi(e);
+  if (const char* e = std::getenv("YTHIP_STREAM_CHUNK")) ctx->stream_chunk_shift = std::atoi(e);
   if (const char* e = std::getenv("YTHIP_STREAM_MIN_SLOTS")) ctx->stream_min_slots = std::max(128, std::atoi(e));
   {
     hipDeviceProp_t prop;
