@@ -326,20 +326,13 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_EXTEND_WAVES) ks_extend(DS
 #define YT_STREAM_SHADE_WAVES 4
 #endif
 // one live slot through one iteration of the bounce loop: state in, state out (stored), the slot's queue class returned
+// ... on a path held in registers (P complete, isec = this iteration's hit): the iteration itself; returns the slot's queue class
 template <int SAMPLER, int LP, int CLS>
-YT_FN int stream_shade_slot(const DScene& sc, const DState& st, const KParams& kp, const DStream& S, int slot, float4 rb, bool stopped, Stack stack,
-    Path& P) {
+YT_FN int stream_shade_path(const DScene& sc, const DState& st, const KParams& kp, int slot, bool stopped, Stack stack, Path& P) {
   constexpr bool MATTE = CLS == 1;
   constexpr int  PRIMS = MATTE ? 1 : (CLS == 3 ? 2 : 0);
   constexpr bool PEEK  = SAMPLER == YTHIP_SAMPLER_PATH || SAMPLER == YTHIP_SAMPLER_PATHTEST || SAMPLER == YTHIP_SAMPLER_NAIVE;
   static_assert(SAMPLER != YTHIP_SAMPLER_PATHDIRECT || LP == LP_DEFER, "pathdirect runs its walks in the deferred part");
-  const float4   ra = sld(S.ray_a + slot), ha = sld(S.hit_a + slot);
-  P.o               = {ra.x, ra.y, ra.z};
-  P.d               = {ra.w, rb.x, rb.y};
-  const int inst    = __float_as_int(ha.w);
-  P.isec            = {inst, sld(S.hit_e + slot), ha.x, ha.y, ha.z, inst >= 0};
-  if (inst < 0) P.isec = {-1, -1, 0, 0, 0, false};
-  stream_load_rest(st, S, slot, P, rb);
   const int max_bounces = max_bounces_of<SAMPLER>(kp);
   ShadeEnv  E           = {sc, st, kp, slot};
   int       step;
@@ -377,7 +370,19 @@ YT_FN int stream_shade_slot(const DScene& sc, const DState& st, const KParams& k
       }
     }
   }
-  const int cls = resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
+  return resolve_step<PEEK>(sc, st, kp, slot, P, step, max_bounces, stopped);
+}
+template <int SAMPLER, int LP, int CLS>
+YT_FN int stream_shade_slot(const DScene& sc, const DState& st, const KParams& kp, const DStream& S, int slot, float4 rb, bool stopped, Stack stack,
+    Path& P) {
+  const float4 ra = sld(S.ray_a + slot), ha = sld(S.hit_a + slot);
+  P.o             = {ra.x, ra.y, ra.z};
+  P.d             = {ra.w, rb.x, rb.y};
+  const int inst  = __float_as_int(ha.w);
+  P.isec          = {inst, sld(S.hit_e + slot), ha.x, ha.y, ha.z, inst >= 0};
+  if (inst < 0) P.isec = {-1, -1, 0, 0, 0, false};
+  stream_load_rest(st, S, slot, P, rb);
+  const int cls = stream_shade_path<SAMPLER, LP, CLS>(sc, st, kp, slot, stopped, stack, P);
   if (cls == OUT_DEAD) P.flags |= PF_DEAD;
   stream_store(S, slot, P);
   return cls;
@@ -409,7 +414,8 @@ __global__ void __launch_bounds__(YT_BLOCK, YT_STREAM_SHADE_WAVES) ks_shade(DSce
 // 2-4 % of its rays and take 12-16 % of its time.  ks_finish takes the LAST sorted queue instead: one lane per entry carries its
 // path slot through extend and shade, iteration after iteration, until the slot's pixel has taken its batch — the same two
 // bodies as ks_extend / ks_shade on the same HBM state (the state goes through memory between them on purpose: the kernel then
-// needs the registers of the larger body, not of both), no sort, no launches, no generation waiting for anybody.  Per-pixel
+// needs the registers of the larger body, not of both; with the path held in registers instead — k_trace's inner loop on a lane — the
+// tail and a whole batch in this kernel take the same time), no sort, no launches, no generation waiting for anybody.  Per-pixel
 // order untouched: still bit for bit the fused kernel's batch.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef YT_STREAM_FINISH_WAVES
